@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pressure-field accumulate throughput on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of kernel 2
+(field_accum_k) that accumulates the complex pressure of `--foci-per-gpu` foci of a 256-element
+matrix array over a 256^3 grid -- BASELINE.json's metric configuration -- with the element table
+and the steering table already resident in HBM.  For N > 1 (launched by torch.distributed.run, one
+rank per GPU) each rank processes its own foci (weak scaling, no data-path collective in the
+compute) and the per-focus volumes are reassembled with an RCCL all-gather over xGMI on a side
+stream, overlapped with the next step's compute (north_star).  torch is used only for the
+rendezvous / barrier (gloo); the product path is ctypes -> HIP.
+
+Prints ONE JSON line (rank 0).  `value` = V * N_el * F_total / time [Mvoxel-elements/s].
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "openlifu-python_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# measured on MI355X by tools/ubench_valu.hip (profiles/ubench_valu_r01.txt), cycles per
+# wave-instruction per SIMD at 8 waves/SIMD: plain f32 VALU 2.45, v_sin/v_cos/v_rsq 8.17
+CYC_PLAIN, CYC_TRANS = 2.45, 8.17
+N_SIMD, CLK_GHZ = 1024, 2.4
+
+
+def synthetic_workload(grid_n: int, spacing_mm: float, el=(16, 16), pitch_mm=3.0, n_foci=1, seed=0):
+    """SURVEY 8(d) inputs: flat matrix array (gen_matrix_array semantics), cubic grid centred in x,y,
+    z from 5 mm, foci = Wheel(center, 5 mm) about (0,0,40) mm when n_foci > 1."""
+    import openlifu_amd as ol
+    arr = ol.Transducer.gen_matrix_array(nx=el[0], ny=el[1], pitch=pitch_mm, kerf=0.1 * pitch_mm, units="mm",
+                                         sensitivity=1e5)
+    half = (grid_n - 1) / 2 * spacing_mm
+    setup = ol.SimSetup(spacing=spacing_mm, x_extent=(-half, half), y_extent=(-half, half),
+                        z_extent=(5.0, 5.0 + (grid_n - 1) * spacing_mm))
+    target = ol.Point(position=(0, 0, 40), units="mm")
+    if n_foci == 1:
+        foci = [target]
+    else:
+        foci = ol.focal_patterns.Wheel(center=True, num_spokes=n_foci - 1, spoke_radius=5.0).get_targets(target)
+    if seed:  # distinct foci per rank
+        rng = np.random.default_rng(seed)
+        foci = [ol.Point(position=f.get_position(units="mm") + rng.uniform(-1, 1, 3), units="mm") for f in foci]
+    return arr, setup, foci
+
+
+def cpu_baseline(arr, setup, foci, budget_s: float):
+    """Times the fp64 NumPy oracle (oracle/field_oracle.py, kind "port": the reference has no NumPy
+    field code to time) on a bounded centred sub-cube of the same workload, single thread."""
+    from oracle import bf_oracle as bo, field_oracle as fo
+    pos_m, _, area, _, _ = arr.element_table()
+    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci[0].get_position(units="m"), 1500.0)
+    coords = [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+
+    def sub(n):
+        return [c[(len(c) - n) // 2:(len(c) - n) // 2 + n] for c in coords]
+
+    t = time.perf_counter()
+    fo.field_on_grid(*sub(16), pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    rate = 16 ** 3 * len(pos_m) / (time.perf_counter() - t)
+    n = int(min(len(coords[0]), max(16, round((budget_s * rate / len(pos_m)) ** (1 / 3)))))
+    t = time.perf_counter()
+    fo.field_on_grid(*sub(n), pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    dt = time.perf_counter() - t
+    return {"value": n ** 3 * len(pos_m) / dt / 1e6, "unit": "Mvoxel-elements/s", "cores": 1, "kind": "port",
+            "sample": f"fp64 NumPy oracle, centred {n}^3 sub-cube x {len(pos_m)} elements, 1 focus, {dt:.1f} s"}
+
+
+def cpu_baseline_c(arr, setup, foci, budget_s: float):
+    """Same definition in C + OpenMP on every host core (oracle/field_oracle.c)."""
+    from oracle import bf_oracle as bo, c_oracle as co
+    pos_m, _, area, _, _ = arr.element_table()
+    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci[0].get_position(units="m"), 1500.0)
+    coords = [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+    n = min(len(coords[0]), 64)
+    sub = [c[(len(c) - n) // 2:(len(c) - n) // 2 + n] for c in coords]
+    t = time.perf_counter()
+    co.field_on_grid(*sub, pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    rate = n ** 3 * len(pos_m) / (time.perf_counter() - t)
+    n2 = int(min(len(coords[0]), max(n, round((budget_s * rate / len(pos_m)) ** (1 / 3)))))
+    sub = [c[(len(c) - n2) // 2:(len(c) - n2) // 2 + n2] for c in coords]
+    t = time.perf_counter()
+    co.field_on_grid(*sub, pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    dt = time.perf_counter() - t
+    return {"value": n2 ** 3 * len(pos_m) / dt / 1e6, "unit": "Mvoxel-elements/s", "cores": co.max_threads(),
+            "kind": "port", "sample": f"fp64 C/OpenMP oracle, centred {n2}^3 sub-cube x {len(pos_m)} elements, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--foci-per-gpu", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--spacing-mm", type=float, default=0.25)
+    ap.add_argument("--elements", type=str, default="16x16")
+    ap.add_argument("--pitch-mm", type=float, default=3.0)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import openlifu_amd as ol  # loads libolx.so (system ROCm runtime) before any torch import
+    from openlifu_amd import _native as nat
+    from openlifu_amd.engine import grid_from_coords
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU); RCCL is driven by libolx
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    el = tuple(int(v) for v in args.elements.split("x"))
+    arr, setup, foci = synthetic_workload(args.grid, args.spacing_mm, el, args.pitch_mm, args.foci_per_gpu, seed=rank)
+    F, N = len(foci), arr.numelements()
+    eng = ol.get_engine(local_rank)
+    ctx = eng.ctx
+    eng.bind(arr)
+    ctx.bf_solve(np.array([f.get_position(units="m") for f in foci]), 1500.0)  # kernel 1: steering stays resident
+    gather = world > 1 and not args.no_gather
+    gather_note = None
+    if gather:
+        try:
+            import torch
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], world, rank)
+        except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
+            gather, gather_note = False, f"RCCL init failed: {e}"
+    origin, spacing, n = grid_from_coords(setup.get_coords())
+    ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+    V = int(np.prod(n))
+
+    def step():
+        ctx.field_launch()
+        if gather:
+            ctx.field_allgather()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ctx.profile_end()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        pairs_per_step = float(V) * N * F * world
+        value = pairs_per_step * args.steps / elapsed / 1e6
+        # roofline of the dominant kernel (field_accum_k): algorithmic HBM bytes per launch =
+        # 8 B per voxel per focus (|p| + intensity float32 outputs) + the 32 B/entry packed table
+        alg_bytes = 8.0 * V * F + 32.0 * N * F
+        k_ms = float(np.mean(kern_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            key = f"{args.elements}_{args.grid}_{F}"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        # VALU-issue ceiling of the exact per-pair formulation: 6 plain + 3
+        # transcendental wave-instructions per 64 pairs per SIMD
+        ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 / (6 * CYC_PLAIN + 3 * CYC_TRANS)
+        out = {
+            "metric": "Mvoxel-elements/s pressure-field accumulate", "value": value, "unit": "Mvoxel-elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N}-element {args.elements} matrix array x {args.grid}^3 grid "
+                                   f"({args.spacing_mm} mm), {F} focus/foci per GPU, |p|+intensity out",
+                       "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": 400e3,
+                       "kernel": ctx.field_variant(),
+                       "reassembly": ("rccl-allgather-overlapped" if gather else ("none" if world == 1 else "skipped")),
+                       **({"reassembly_note": gather_note} if gather_note else {})},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "exact per-pair formulation is VALU/transcendental-issue bound, not HBM bound "
+                                 "(SURVEY 8(d)); see valu_ceiling"},
+            "valu_ceiling": {"achieved_Mpairs_s": float(V) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
+                             "frac": float(V) * N * F / (k_ms * 1e-3) / ceil_pairs,
+                             "model": "6 plain VALU @2.45 cyc + 3 transcendental @8.17 cyc per 64 pairs per SIMD, "
+                                      "1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(arr, setup, foci, args.cpu_seconds)
+            out["cpu_baseline_c"] = cpu_baseline_c(arr, setup, foci, min(args.cpu_seconds, 10.0))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        if gather:
+            ctx.comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * olx.h -- C ABI of the MI355X-native openlifu beamforming + pressure-field path.
+ *
+ * Plain C types only, caller-allocated outputs, no callbacks, no torch types.
+ * Every entry point returns 0 on success and a negative OLX_E* code on failure;
+ * olx_last_error(ctx) then holds a human-readable message.  One caller thread
+ * per context (the reference is synchronous and single-threaded,
+ * src/openlifu/plan/protocol.py:318-339); different contexts are independent.
+ *
+ * The reference is pure Python, so "what its FFI for this path would bind" is
+ * the set of Python seams of SURVEY.md 8(b).  Each entry point cites the
+ * reference interface it stands in for (paths under /root/reference/src/openlifu).
+ * The ctypes binding a maintainer would add is shown in INTEGRATION.md and lives
+ * in openlifu-python_amd/openlifu_amd/_native.py.
+ *
+ * Units are SI throughout: metres, seconds, Hz, Pa, kg/m^3, m/s.  Arrays are
+ * C-order.  Field volumes are [nx, ny, nz] with z fastest -- the layout of the
+ * arrays run_simulation returns (sim/kwave_if.py:131-139).
+ */
+#ifndef OLX_H
+#define OLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLX_ABI_VERSION 1
+
+/* error codes */
+#define OLX_OK 0
+#define OLX_EINVAL (-1)  /* bad argument (NULL, non-positive size, shape mismatch) */
+#define OLX_ESTATE (-2)  /* call order: elements / steering / plan missing */
+#define OLX_EHIP (-3)    /* HIP runtime error (message has hipGetErrorString) */
+#define OLX_ENOMEM (-4)  /* device or host allocation failed */
+#define OLX_ECOMM (-5)   /* RCCL error or RCCL unavailable */
+
+/* apodization kinds: bf/apod_methods/{uniform,maxangle,piecewiselinear}.py */
+#define OLX_APOD_UNIFORM 0   /* p0 = value                              (uniform.py:21-22) */
+#define OLX_APOD_MAXANGLE 1  /* p0 = max angle [deg], inclusive <=      (maxangle.py:33-39) */
+#define OLX_APOD_PIECEWISE 2 /* p0 = zero angle, p1 = rolloff [deg]     (piecewiselinear.py:42-49) */
+#define OLX_APOD_RADIANS 0x10 /* OR-ed into the kind: p0 / p1 are radians (the methods' `units` field) */
+
+/* field output selection (olx_field_plan flags) */
+#define OLX_OUT_PMAG 1u      /* |p| [Pa]  -> p_max and p_min of kwave_if.py:131-139 */
+#define OLX_OUT_INTENSITY 2u /* 1e-4 |p|^2 / (2 rho c) [W/cm^2]  (kwave_if.py:140-144) */
+#define OLX_OUT_COMPLEX 4u   /* (re, im) interleaved, float32 */
+
+typedef struct olx_ctx olx_ctx;
+
+/* Regular grid = the three coordinate vectors of SimSetup.get_coords
+ * (sim/sim_setup.py:107-116): coord[a][i] = origin[a] + i * spacing[a]. */
+typedef struct olx_grid {
+    double origin[3];  /* metres, position of voxel (0,0,0) */
+    double spacing[3]; /* metres, > 0 */
+    int32_t n[3];      /* nx, ny, nz >= 1 */
+} olx_grid;
+
+/* Slab of a grid (multi-GPU sharding along x, the slowest axis): voxels
+ * [x_begin, x_begin + x_count) x ny x nz form one contiguous block. */
+typedef struct olx_slab {
+    int32_t x_begin;
+    int32_t x_count;
+} olx_slab;
+
+/* ---- library / context --------------------------------------------------------- */
+int olx_abi_version(void);
+/* Number of visible HIP devices (stands in for util/checkgpu.py:6-14 gpu_available,
+ * which is NVML-only and always False on AMD). */
+int olx_device_count(int *count);
+int olx_ctx_create(int device, olx_ctx **out);
+int olx_ctx_destroy(olx_ctx *ctx);
+const char *olx_last_error(const olx_ctx *ctx);
+int olx_sync(olx_ctx *ctx);
+
+/* ---- element table ------------------------------------------------------------------
+ * SoA flattening of Transducer.elements (xdc/element.py:33-59, xdc/transducer.py:203-207):
+ * pos_m[N*3] = Element.get_position(units="m"), normal[N*3] = column 2 of
+ * Element.get_matrix (element.py:200-214), area_m2[N] = Element.get_area("m")
+ * (element.py:181-184).  Order = Transducer.elements order (bit-exact indexing). */
+int olx_set_elements(olx_ctx *ctx, const double *pos_m, const double *normal,
+                     const double *area_m2, int n);
+
+/* ---- kernel 1: delay / apodization solve --------------------------------------------
+ * DelayMethod.calc_delays (bf/delay_methods/direct.py:28-38) and
+ * ApodizationMethod.calc_apodization for F foci in one launch; replaces the F x N
+ * Python loops of Protocol.beamform (plan/protocol.py:129-132, 318-320).
+ *   foci_m[F*3]  focus positions, metres (Point.get_position(units="m"))
+ *   M[16]        row-major 4x4 `transform` (NULL = identity); applied to the element
+ *                position for the distance (element.py:241-244) and to position and
+ *                normal for the angle (element.py:250-253)
+ *   c            speed of sound: params['sound_speed'].attrs['ref_value'] if params
+ *                else Direct.c0 (direct.py:29-32)
+ * Outputs (host, fp64, caller-allocated [F*N]): delays [s] = max(tof) - tof, apod.
+ * Either output pointer may be NULL.  The results also stay device-resident as the
+ * context's steering table (consumed by olx_field_*). */
+int olx_bf_solve(olx_ctx *ctx, const double *foci_m, int n_foci, const double *M, double c,
+                 int apod_kind, double p0, double p1, double *delays_out, double *apod_out);
+
+/* Upload externally computed delays / apodizations [F*N] as the steering table
+ * (run_simulation's `delays`, `apod` arguments, sim/kwave_if.py:81-83, 98-99). */
+int olx_set_steering(olx_ctx *ctx, const double *delays_s, const double *apod, int n_foci);
+
+/* ---- kernel 2: pressure-field accumulate --------------------------------------------
+ * Stands in for run_simulation (sim/kwave_if.py:80-146) at the seam
+ * plan/protocol.py:324-336.  Steady-state monochromatic point-source superposition
+ * (definition: oracle/field_oracle.py):
+ *   p_f(v) = sum_e a_ef P0 S_e / (lambda d) exp(j (k d + 2 pi f0 tau_ef)),
+ *   d = max(||r_v - r_e||, min(spacing)/2).
+ * plan: fixes grid / medium / outputs and allocates device buffers for n_foci volumes
+ *   (n_foci must equal the steering table's F).  p0_pa = amplitude * sensitivity
+ *   (xdc/transducer.py:105-106), rho/c = reference medium values (kwave_if.py:52-56).
+ * launch: asynchronous on the context's stream.  fetch: blocking D2H of one focus
+ *   volume into caller-owned host arrays [nx*ny*nz] (cplx: 2 floats per voxel); any
+ *   pointer may be NULL. */
+int olx_field_plan(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab /*NULL = whole grid*/,
+                   int n_foci, double freq, double c, double rho, double p0_pa, unsigned flags);
+int olx_field_launch(olx_ctx *ctx);
+int olx_field_fetch(olx_ctx *ctx, int focus, float *pmag, float *intensity, float *cplx);
+/* One-shot convenience: plan + launch + fetch of all foci ([F * slab voxels] each). */
+int olx_field(olx_ctx *ctx, const olx_grid *grid, int n_foci, double freq, double c, double rho,
+              double p0_pa, float *pmag_out, float *intensity_out);
+
+/* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
+ * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]
+ * floats each; intensity may be NULL.  Needs no element or steering table; olx_field_launch is
+ * refused afterwards until the next olx_field_plan. */
+int olx_field_upload(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab, int n_foci,
+                     const float *pmag, const float *intensity);
+
+/* Times `iters` back-to-back launches with HIP events on the context's stream
+ * (bench.py roofline leg); ms_each[iters] receives per-launch milliseconds. */
+int olx_field_time(olx_ctx *ctx, int iters, float *ms_each);
+/* In-stream kernel timing for bench.py: between begin and end every olx_field_launch is bracketed
+ * by a pair of HIP events recorded on the context's stream (the stream the kernel runs on), up to
+ * max_launches.  end synchronises the stream and returns the per-launch kernel durations [ms]. */
+int olx_profile_begin(olx_ctx *ctx, int max_launches);
+int olx_profile_end(olx_ctx *ctx, float *ms_each, int capacity, int *n_recorded);
+
+/* Name of the field kernel variant the current plan dispatches to (for profiles). */
+const char *olx_field_variant(const olx_ctx *ctx);
+
+/* ---- aggregation over foci (plan/protocol.py:382-387) ------------------------------
+ * p_agg = max_f |p_f|, I_agg = mean_f I_f over the planned volumes, on device;
+ * host outputs [slab voxels], either may be NULL. */
+int olx_field_aggregate(olx_ctx *ctx, float *pmag_max_out, float *intensity_mean_out);
+
+/* Per-focus in-place scaling (plan/solution.py:331-337): p_f *= s_f, I_f *= s_f^2. */
+int olx_field_scale(olx_ctx *ctx, const double *scale_per_focus, int n_foci);
+
+/* Per-focus masked peak (plan/solution_analysis.py:384-442 get_mask, consumed by
+ * Solution.analyze, plan/solution.py:205-262).  For focus f and voxel position r [m]:
+ *   q = A_f . [r, 1]   (A_f = first three rows of inv(get_focus_matrix(focus_f, origin_f)),
+ *                       solution_analysis.py:319-342; row-major, A[F*12])
+ *   dist = sqrt(sum_a (q_a / aspect[a])^2)
+ * the voxel is selected when `dist OP radius_m` (op 0 '<', 1 '<=', 2 '>', 3 '>=', 4 = no
+ * distance test) and, if use_zmin, its z coordinate > zmin_m.  peak_out[F] receives the max
+ * over selected voxels of |p_f| (which = 0) or intensity (which = 1); 0 when none selected. */
+int olx_field_masked_peak(olx_ctx *ctx, int which, const double *A, const double *aspect,
+                          double radius_m, int op, int use_zmin, double zmin_m, float *peak_out);
+
+/* ---- multi-GPU reassembly (RCCL over xGMI) -------------------------------------------
+ * One context per rank.  id_bytes = the 128-byte ncclUniqueId made by rank 0
+ * (olx_comm_unique_id) and distributed by the host launcher.  olx_field_allgather
+ * gathers every rank's planned |p| block (n_foci * slab voxels floats, equal on all
+ * ranks) into a device buffer of nranks blocks in rank order, asynchronously on a
+ * side stream ordered after the last olx_field_launch; olx_allgather_fetch copies
+ * rank r's block to the host. */
+#define OLX_UNIQUE_ID_BYTES 128
+int olx_comm_unique_id(olx_ctx *ctx, void *id_bytes);
+int olx_comm_init(olx_ctx *ctx, const void *id_bytes, int nranks, int rank);
+int olx_comm_destroy(olx_ctx *ctx);
+int olx_field_allgather(olx_ctx *ctx);
+int olx_allgather_fetch(olx_ctx *ctx, int rank, float *pmag_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OLX_H */

@@ -1,0 +1,663 @@
+// C-ABI of the MI355X-native openlifu hot path (declared in include/olx.h).
+// Host side: context, device buffers, launch logic, RCCL (dlopen) reassembly.
+#include "../../include/olx.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "olx_kernels.hip.h"
+
+using namespace olx;
+
+// ---- RCCL, bound at run time so that single-GPU use never loads it -------------------
+typedef struct { char internal[OLX_UNIQUE_ID_BYTES]; } olx_nccl_id;
+typedef void* olx_nccl_comm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(olx_nccl_id*) = nullptr;
+    int (*CommInitRank)(olx_nccl_comm*, int, olx_nccl_id, int) = nullptr;
+    int (*CommDestroy)(olx_nccl_comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int /*dtype*/, olx_nccl_comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
+
+struct olx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // element table (device fp64 SoA + host copy for variant decisions)
+    int n_el = 0;
+    double *d_pos = nullptr, *d_nrm = nullptr, *d_area = nullptr;
+    std::vector<double> h_pos;  // [3][N]
+    // steering
+    int n_foci = 0;
+    double *d_delays = nullptr, *d_apod = nullptr;
+    size_t steer_cap = 0;
+    double *d_foci = nullptr, *d_M = nullptr;
+    size_t foci_cap = 0;
+    unsigned long long steer_version = 0, packed_version = ~0ull;
+    // field plan
+    bool planned = false;
+    bool uploaded = false;  // volumes came from olx_field_upload: not launchable
+    olx_grid grid{};
+    olx_slab slab{};
+    int plan_foci = 0;
+    double freq = 0, c = 0, rho = 0, p0_pa = 0;
+    unsigned flags = 0;
+    FieldParams fp{};
+    bool flat = false, clamp = false;
+    float* d_tab = nullptr; size_t tab_cap = 0;
+    static constexpr int NBUF = 2;
+    float* d_pmag[NBUF] = {nullptr, nullptr};
+    float* d_inten = nullptr; float* d_cplx = nullptr;
+    float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
+    double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
+    size_t out_cap = 0; int nbuf = 1; int cur = 0;
+    std::string variant;
+    std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
+    // comm
+    RcclApi rccl; olx_nccl_comm comm = nullptr; int nranks = 1, rank = 0;
+    hipStream_t comm_stream = nullptr; hipEvent_t ev_field[NBUF] = {nullptr, nullptr};
+    hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
+    float* d_gather = nullptr; size_t gather_cap = 0;
+};
+
+static int fail(olx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail((c), e_ == hipErrorOutOfMemory ? OLX_ENOMEM : OLX_EHIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                          \
+    } while (0)
+
+template <typename T>
+static int ensure(olx_ctx* c, T** p, size_t* cap, size_t need) {
+    if (*cap >= need && *p) return OLX_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIPCHK(c, hipMalloc((void**)p, need * sizeof(T)));
+    *cap = need;
+    return OLX_OK;
+}
+
+extern "C" {
+
+int olx_abi_version(void) { return OLX_ABI_VERSION; }
+
+int olx_device_count(int* count) {
+    if (!count) return OLX_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return OLX_EHIP; }
+    *count = n;
+    return OLX_OK;
+}
+
+int olx_ctx_create(int device, olx_ctx** out) {
+    if (!out) return OLX_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OLX_EHIP;
+    olx_ctx* c = new (std::nothrow) olx_ctx();
+    if (!c) return OLX_ENOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return OLX_EHIP;
+    }
+    *out = c;
+    return OLX_OK;
+}
+
+int olx_comm_destroy(olx_ctx* c);
+
+int olx_ctx_destroy(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    olx_comm_destroy(c);
+    void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
+                    c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
+                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return OLX_OK;
+}
+
+const char* olx_last_error(const olx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int olx_sync(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    return OLX_OK;
+}
+
+// ---- element table ---------------------------------------------------------------------
+int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, const double* area_m2, int n) {
+    if (!c) return OLX_EINVAL;
+    if (!pos_m || !normal || !area_m2 || n <= 0) return fail(c, OLX_EINVAL, "olx_set_elements: null pointer or n <= 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n != c->n_el) {
+        for (double** p : {&c->d_pos, &c->d_nrm, &c->d_area}) { if (*p) hipFree(*p); *p = nullptr; }
+        HIPCHK(c, hipMalloc((void**)&c->d_pos, sizeof(double) * 3 * n));
+        HIPCHK(c, hipMalloc((void**)&c->d_nrm, sizeof(double) * 3 * n));
+        HIPCHK(c, hipMalloc((void**)&c->d_area, sizeof(double) * n));
+    }
+    // AoS [N][3] (the caller's natural layout) -> SoA [3][N] (coalesced on device)
+    std::vector<double> soa(3 * (size_t)n), nso(3 * (size_t)n);
+    for (int e = 0; e < n; ++e)
+        for (int a = 0; a < 3; ++a) {
+            soa[(size_t)a * n + e] = pos_m[3 * e + a];
+            nso[(size_t)a * n + e] = normal[3 * e + a];
+        }
+    HIPCHK(c, hipMemcpy(c->d_pos, soa.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_nrm, nso.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_area, area_m2, sizeof(double) * n, hipMemcpyHostToDevice));
+    c->h_pos.swap(soa);
+    c->n_el = n;
+    c->n_foci = 0;      // steering shape depends on N
+    c->planned = false;
+    c->steer_version++;
+    return OLX_OK;
+}
+
+// ---- kernel 1 -----------------------------------------------------------------------------
+int olx_bf_solve(olx_ctx* c, const double* foci_m, int n_foci, const double* M, double cs, int apod_kind,
+                 double p0, double p1, double* delays_out, double* apod_out) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_el <= 0) return fail(c, OLX_ESTATE, "olx_bf_solve: call olx_set_elements first");
+    if (!foci_m || n_foci <= 0) return fail(c, OLX_EINVAL, "olx_bf_solve: no foci");
+    if (!(cs > 0)) return fail(c, OLX_EINVAL, "olx_bf_solve: speed of sound must be > 0");
+    const double angle_scale = (apod_kind & OLX_APOD_RADIANS) ? 1.0 : (180.0 / 3.14159265358979323846);
+    apod_kind &= ~OLX_APOD_RADIANS;
+    if (apod_kind < 0 || apod_kind > 2) return fail(c, OLX_EINVAL, "olx_bf_solve: unknown apod_kind %d", apod_kind);
+    if (apod_kind == OLX_APOD_PIECEWISE && !(p1 < p0)) return fail(c, OLX_EINVAL, "olx_bf_solve: rolloff must be < zero angle");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t fn = (size_t)n_foci * c->n_el;
+    if (c->steer_cap < fn) {
+        for (double** p : {&c->d_delays, &c->d_apod}) { if (*p) hipFree(*p); *p = nullptr; }
+        c->steer_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_delays, sizeof(double) * fn));
+        HIPCHK(c, hipMalloc((void**)&c->d_apod, sizeof(double) * fn));
+        c->steer_cap = fn;
+    }
+    if (c->foci_cap < (size_t)n_foci) {
+        if (c->d_foci) hipFree(c->d_foci);
+        c->d_foci = nullptr; c->foci_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_foci, sizeof(double) * 3 * n_foci));
+        c->foci_cap = n_foci;
+    }
+    if (!c->d_M) HIPCHK(c, hipMalloc((void**)&c->d_M, sizeof(double) * 16));
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    HIPCHK(c, hipMemcpyAsync(c->d_foci, foci_m, sizeof(double) * 3 * n_foci, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_M, M ? M : I4, sizeof(double) * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bf_solve_k, dim3(n_foci), dim3(BF_THREADS), 0, c->stream, c->d_pos, c->d_nrm, c->n_el,
+                       c->d_foci, c->d_M, cs, apod_kind, angle_scale, p0, p1, c->d_delays, c->d_apod);
+    HIPCHK(c, hipGetLastError());
+    if (delays_out) HIPCHK(c, hipMemcpyAsync(delays_out, c->d_delays, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
+    if (apod_out) HIPCHK(c, hipMemcpyAsync(apod_out, c->d_apod, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_foci = n_foci;
+    c->steer_version++;
+    return OLX_OK;
+}
+
+int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int n_foci) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_el <= 0) return fail(c, OLX_ESTATE, "olx_set_steering: call olx_set_elements first");
+    if (!delays_s || !apod || n_foci <= 0) return fail(c, OLX_EINVAL, "olx_set_steering: null pointer or n_foci <= 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t fn = (size_t)n_foci * c->n_el;
+    if (c->steer_cap < fn) {
+        for (double** p : {&c->d_delays, &c->d_apod}) { if (*p) hipFree(*p); *p = nullptr; }
+        c->steer_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_delays, sizeof(double) * fn));
+        HIPCHK(c, hipMalloc((void**)&c->d_apod, sizeof(double) * fn));
+        c->steer_cap = fn;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_delays, delays_s, sizeof(double) * fn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_apod, apod, sizeof(double) * fn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_foci = n_foci;
+    c->steer_version++;
+    return OLX_OK;
+}
+
+// ---- kernel 2 -----------------------------------------------------------------------------
+static int pack_if_needed(olx_ctx* c) {
+    if (c->packed_version == c->steer_version) return OLX_OK;
+    const double lambda = c->c / c->freq;
+    dim3 g((c->n_el + 127) / 128, c->plan_foci);
+    hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
+                       c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
+                       c->p0_pa / lambda, c->d_tab);
+    HIPCHK(c, hipGetLastError());
+    c->packed_version = c->steer_version;
+    return OLX_OK;
+}
+
+int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_foci, double freq, double cs,
+                   double rho, double p0_pa, unsigned flags) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_el <= 0) return fail(c, OLX_ESTATE, "olx_field_plan: call olx_set_elements first");
+    if (c->n_foci <= 0) return fail(c, OLX_ESTATE, "olx_field_plan: no steering table (olx_bf_solve / olx_set_steering)");
+    if (!g) return fail(c, OLX_EINVAL, "olx_field_plan: null grid");
+    if (n_foci != c->n_foci) return fail(c, OLX_EINVAL, "olx_field_plan: n_foci %d != steering table foci %d", n_foci, c->n_foci);
+    for (int a = 0; a < 3; ++a)
+        if (g->n[a] < 1 || !(g->spacing[a] > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: bad grid axis %d", a);
+    if (!(freq > 0) || !(cs > 0) || !(rho > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: freq, c, rho must be > 0");
+    if (!(flags & (OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX))) return fail(c, OLX_EINVAL, "olx_field_plan: no outputs selected");
+    olx_slab s{0, g->n[0]};
+    if (slab) s = *slab;
+    if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_plan: slab outside grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->grid = *g; c->slab = s; c->plan_foci = n_foci;
+    c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags;
+    const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
+    const size_t total = (size_t)vox * n_foci;
+    c->nbuf = c->comm ? olx_ctx::NBUF : 1;
+    // outputs
+    if (c->out_cap < total || (c->nbuf == 2 && !c->d_pmag[1])) {
+        for (float** p : {&c->d_pmag[0], &c->d_pmag[1], &c->d_inten, &c->d_cplx, &c->d_agg_p, &c->d_agg_i}) { if (*p) hipFree(*p); *p = nullptr; }
+        c->out_cap = 0;
+    }
+    if (!c->d_pmag[0]) {
+        // |p| is always materialised (aggregate / allgather consume it)
+        for (int b = 0; b < c->nbuf; ++b) HIPCHK(c, hipMalloc((void**)&c->d_pmag[b], sizeof(float) * total));
+        c->out_cap = total;
+    }
+    if ((flags & OLX_OUT_INTENSITY) && !c->d_inten) HIPCHK(c, hipMalloc((void**)&c->d_inten, sizeof(float) * c->out_cap));
+    if ((flags & OLX_OUT_COMPLEX) && !c->d_cplx) HIPCHK(c, hipMalloc((void**)&c->d_cplx, sizeof(float) * 2 * c->out_cap));
+    const size_t tabn = (size_t)n_foci * c->n_el * TAB_STRIDE;
+    if (c->tab_cap < tabn) {
+        if (c->d_tab) hipFree(c->d_tab);
+        c->d_tab = nullptr; c->tab_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_tab, sizeof(float) * tabn));
+        c->tab_cap = tabn;
+    }
+    // kernel parameters.  Table origin = grid origin; slab start expressed relative to it.
+    FieldParams& P = c->fp;
+    P.nx = s.x_count; P.ny = g->n[1]; P.nz = g->n[2]; P.n_el = c->n_el;
+    P.x_begin = s.x_begin;
+    P.hx = (float)g->spacing[0]; P.hy = (float)g->spacing[1]; P.hz = (float)g->spacing[2];
+    P.rev_per_m = (float)(freq / cs);
+    const double dmin = 0.5 * std::min({g->spacing[0], g->spacing[1], g->spacing[2]});
+    P.dmin2 = (float)(dmin * dmin);
+    P.inten_scale = (float)(1e-4 / (2.0 * rho * cs));
+    P.vox = vox; P.flags = flags | OLX_OUT_PMAG;
+    // variant decisions from host copies (exact, fp64)
+    const int n = c->n_el;
+    const double* hz = c->h_pos.data() + 2 * (size_t)n;
+    c->flat = true;
+    for (int e = 1; e < n; ++e) if (hz[e] != hz[0]) { c->flat = false; break; }
+    P.flat_ez = (float)(hz[0] - g->origin[2]);
+    // clamp needed iff some element lies within dmin (+ fp32 slack) of the slab's bounding box
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a == 0) ? s.x_begin : 0;
+        const int cnt = (a == 0) ? s.x_count : g->n[a];
+        lo[a] = g->origin[a] + b * g->spacing[a];
+        hi[a] = g->origin[a] + (b + cnt - 1) * g->spacing[a];
+    }
+    c->clamp = false;
+    const double guard = 2.0 * dmin;
+    for (int e = 0; e < n && !c->clamp; ++e) {
+        double d2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double p = c->h_pos[(size_t)a * n + e];
+            const double d = p < lo[a] ? lo[a] - p : (p > hi[a] ? p - hi[a] : 0.0);
+            d2 += d * d;
+        }
+        if (d2 < guard * guard) c->clamp = true;
+    }
+    char nm[64];
+    snprintf(nm, sizeof nm, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    c->variant = nm;
+    c->packed_version = ~0ull;
+    c->planned = true; c->uploaded = false;
+    c->cur = 0;
+    return OLX_OK;
+}
+
+}  // extern "C"
+
+template <bool FLAT, bool CLAMP>
+static void launch_field(olx_ctx* c, float* pm) {
+    const FieldParams& P = c->fp;
+    constexpr int ZPL = 4;
+    const long long cpr = (P.nz + ZPL - 1) / ZPL;
+    const long long lanes = (long long)P.nx * P.ny * cpr;
+    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci);
+    hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm,
+                       c->d_inten, c->d_cplx, P);
+}
+
+extern "C" {
+
+int olx_field_launch(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_launch: call olx_field_plan first");
+    if (c->uploaded) return fail(c, OLX_ESTATE, "olx_field_launch: resident volumes were uploaded, not planned");
+    if (c->n_foci != c->plan_foci) return fail(c, OLX_ESTATE, "olx_field_launch: steering table changed shape since plan");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = pack_if_needed(c);
+    if (rc) return rc;
+    const int b = (c->nbuf == 2) ? (c->cur ^ 1) : 0;
+    if (c->gather_pending[b]) {  // the gather that read this buffer must be done before we overwrite it
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[b], 0));
+        c->gather_pending[b] = false;
+    }
+    float* pm = c->d_pmag[b];
+    const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
+    if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+    if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
+    else         { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }
+    HIPCHK(c, hipGetLastError());
+    if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
+    c->cur = b;
+    return OLX_OK;
+}
+
+int olx_profile_begin(olx_ctx* c, int max_launches) {
+    if (!c) return OLX_EINVAL;
+    if (max_launches < 1 || max_launches > (1 << 20)) return fail(c, OLX_EINVAL, "olx_profile_begin: bad max_launches");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (auto e : c->prof_ev) hipEventDestroy(e);
+    c->prof_ev.assign(2 * (size_t)max_launches, nullptr);
+    for (auto& e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
+    c->prof_n = 0; c->prof_on = true;
+    return OLX_OK;
+}
+
+int olx_profile_end(olx_ctx* c, float* ms_each, int capacity, int* n_recorded) {
+    if (!c) return OLX_EINVAL;
+    if (!ms_each || !n_recorded || capacity < 0) return fail(c, OLX_EINVAL, "olx_profile_end: null output");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = std::min(c->prof_n, capacity);
+    for (int i = 0; i < n; ++i) HIPCHK(c, hipEventElapsedTime(&ms_each[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    *n_recorded = n;
+    for (auto e : c->prof_ev) hipEventDestroy(e);
+    c->prof_ev.clear(); c->prof_n = 0; c->prof_on = false;
+    return OLX_OK;
+}
+
+int olx_field_fetch(olx_ctx* c, int focus, float* pmag, float* intensity, float* cplx) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_fetch: nothing planned");
+    if (focus < 0 || focus >= c->plan_foci) return fail(c, OLX_EINVAL, "olx_field_fetch: focus %d out of range", focus);
+    if (intensity && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_fetch: intensity not planned");
+    if (cplx && !(c->flags & OLX_OUT_COMPLEX)) return fail(c, OLX_ESTATE, "olx_field_fetch: complex output not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t vox = (size_t)c->fp.vox, off = vox * focus;
+    if (pmag) HIPCHK(c, hipMemcpyAsync(pmag, c->d_pmag[c->cur] + off, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
+    if (intensity) HIPCHK(c, hipMemcpyAsync(intensity, c->d_inten + off, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
+    if (cplx) HIPCHK(c, hipMemcpyAsync(cplx, c->d_cplx + 2 * off, sizeof(float) * 2 * vox, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+int olx_field(olx_ctx* c, const olx_grid* g, int n_foci, double freq, double cs, double rho, double p0_pa,
+              float* pmag_out, float* intensity_out) {
+    if (!c) return OLX_EINVAL;
+    unsigned flags = OLX_OUT_PMAG | (intensity_out ? OLX_OUT_INTENSITY : 0u);
+    int rc = olx_field_plan(c, g, nullptr, n_foci, freq, cs, rho, p0_pa, flags);
+    if (rc) return rc;
+    rc = olx_field_launch(c);
+    if (rc) return rc;
+    const size_t vox = (size_t)c->fp.vox;
+    for (int f = 0; f < n_foci; ++f) {
+        rc = olx_field_fetch(c, f, pmag_out ? pmag_out + vox * f : nullptr,
+                             intensity_out ? intensity_out + vox * f : nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return OLX_OK;
+}
+
+int olx_field_upload(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_foci, const float* pmag,
+                     const float* intensity) {
+    if (!c) return OLX_EINVAL;
+    if (!g || !pmag || n_foci < 1) return fail(c, OLX_EINVAL, "olx_field_upload: null grid / volume or n_foci < 1");
+    for (int a = 0; a < 3; ++a)
+        if (g->n[a] < 1 || !(g->spacing[a] > 0)) return fail(c, OLX_EINVAL, "olx_field_upload: bad grid axis %d", a);
+    olx_slab s{0, g->n[0]};
+    if (slab) s = *slab;
+    if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_upload: slab outside grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
+    const size_t total = (size_t)vox * n_foci;
+    if (c->out_cap < total) {
+        for (float** p : {&c->d_pmag[0], &c->d_pmag[1], &c->d_inten, &c->d_cplx, &c->d_agg_p, &c->d_agg_i}) { if (*p) hipFree(*p); *p = nullptr; }
+        c->out_cap = 0;
+    }
+    if (!c->d_pmag[0]) { HIPCHK(c, hipMalloc((void**)&c->d_pmag[0], sizeof(float) * total)); c->out_cap = total; }
+    if (intensity && !c->d_inten) HIPCHK(c, hipMalloc((void**)&c->d_inten, sizeof(float) * c->out_cap));
+    HIPCHK(c, hipMemcpy(c->d_pmag[0], pmag, sizeof(float) * total, hipMemcpyHostToDevice));
+    if (intensity) HIPCHK(c, hipMemcpy(c->d_inten, intensity, sizeof(float) * total, hipMemcpyHostToDevice));
+    c->grid = *g; c->slab = s; c->plan_foci = n_foci;
+    c->fp.nx = s.x_count; c->fp.ny = g->n[1]; c->fp.nz = g->n[2]; c->fp.vox = vox;
+    c->flags = OLX_OUT_PMAG | (intensity ? OLX_OUT_INTENSITY : 0u);
+    c->cur = 0; c->nbuf = 1;
+    c->planned = true; c->uploaded = true;
+    c->variant = "uploaded";
+    return OLX_OK;
+}
+
+int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
+    if (!c) return OLX_EINVAL;
+    if (iters < 1 || !ms_each) return fail(c, OLX_EINVAL, "olx_field_time: iters < 1 or null output");
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_time: nothing planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev(iters + 1);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    int rc = pack_if_needed(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    for (int i = 0; i < iters; ++i) {
+        rc = olx_field_launch(c);
+        if (rc) break;
+        HIPCHK(c, hipEventRecord(ev[i + 1], c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!rc)
+        for (int i = 0; i < iters; ++i) HIPCHK(c, hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+const char* olx_field_variant(const olx_ctx* c) { return (c && c->planned) ? c->variant.c_str() : ""; }
+
+int olx_field_aggregate(olx_ctx* c, float* pmax_out, float* imean_out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_aggregate: nothing planned");
+    if (imean_out && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_aggregate: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t vox = (size_t)c->fp.vox;
+    if (pmax_out && !c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+    if (imean_out && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+    hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, pmax_out ? c->d_pmag[c->cur] : nullptr,
+                       imean_out ? c->d_inten : nullptr, c->plan_foci, (long long)vox, pmax_out ? c->d_agg_p : nullptr,
+                       imean_out ? c->d_agg_i : nullptr);
+    HIPCHK(c, hipGetLastError());
+    if (pmax_out) HIPCHK(c, hipMemcpyAsync(pmax_out, c->d_agg_p, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
+    if (imean_out) HIPCHK(c, hipMemcpyAsync(imean_out, c->d_agg_i, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+int olx_field_scale(olx_ctx* c, const double* scale, int n_foci) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_scale: nothing planned");
+    if (!scale || n_foci != c->plan_foci) return fail(c, OLX_EINVAL, "olx_field_scale: need %d scale factors", c->plan_foci);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+    if (n_foci > 4096) return fail(c, OLX_EINVAL, "olx_field_scale: too many foci");
+    std::vector<float> s(n_foci);
+    for (int i = 0; i < n_foci; ++i) s[i] = (float)scale[i];
+    HIPCHK(c, hipMemcpyAsync(c->d_scale, s.data(), sizeof(float) * n_foci, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(field_scale_k, dim3(1024, n_foci), dim3(256), 0, c->stream, c->d_pmag[c->cur],
+                       (c->flags & OLX_OUT_INTENSITY) ? c->d_inten : nullptr,
+                       (c->flags & OLX_OUT_COMPLEX) ? c->d_cplx : nullptr, c->d_scale, c->fp.vox);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* aspect, double radius_m, int op,
+                          int use_zmin, double zmin_m, float* peak_out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_masked_peak: nothing planned");
+    if (!peak_out || !aspect || op < 0 || op > 4 || (op != 4 && !A)) return fail(c, OLX_EINVAL, "olx_field_masked_peak: bad arguments");
+    if (which == 1 && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_masked_peak: intensity not planned");
+    if (which != 0 && which != 1) return fail(c, OLX_EINVAL, "olx_field_masked_peak: which must be 0 or 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->plan_foci;
+    if (!c->d_peakA || c->peak_cap < (size_t)F) {
+        if (c->d_peakA) hipFree(c->d_peakA);
+        if (c->d_peak) hipFree(c->d_peak);
+        c->d_peakA = nullptr; c->d_peak = nullptr; c->peak_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_peakA, sizeof(double) * 12 * F));
+        HIPCHK(c, hipMalloc((void**)&c->d_peak, sizeof(unsigned) * F));
+        c->peak_cap = F;
+    }
+    if (A) HIPCHK(c, hipMemcpyAsync(c->d_peakA, A, sizeof(double) * 12 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_peak, 0, sizeof(unsigned) * F, c->stream));
+    PeakParams P;
+    P.nx = c->fp.nx; P.ny = c->fp.ny; P.nz = c->fp.nz;
+    P.ox = c->grid.origin[0] + c->slab.x_begin * c->grid.spacing[0]; P.oy = c->grid.origin[1]; P.oz = c->grid.origin[2];
+    P.hx = c->grid.spacing[0]; P.hy = c->grid.spacing[1]; P.hz = c->grid.spacing[2];
+    P.ia0 = 1.0 / aspect[0]; P.ia1 = 1.0 / aspect[1]; P.ia2 = 1.0 / aspect[2];
+    P.radius = radius_m; P.op = op; P.use_zmin = use_zmin; P.zmin = zmin_m; P.vox = c->fp.vox;
+    const long long want = (P.vox + 255) / 256;
+    dim3 grid((unsigned)std::min<long long>(want, 2048), F);
+    hipLaunchKernelGGL(field_masked_peak_k, grid, dim3(256), 0, c->stream, which == 0 ? c->d_pmag[c->cur] : c->d_inten,
+                       c->d_peakA, P, c->d_peak);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(peak_out, c->d_peak, sizeof(float) * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+// ---- RCCL reassembly ------------------------------------------------------------------------
+static int load_rccl(olx_ctx* c) {
+    RcclApi& r = c->rccl;
+    if (r.handle) return OLX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+    if (!r.handle) return fail(c, OLX_ECOMM, "RCCL not found: %s", dlerror());
+    r.GetUniqueId = (int (*)(olx_nccl_id*))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(olx_nccl_comm*, int, olx_nccl_id, int))dlsym(r.handle, "ncclCommInitRank");
+    r.CommDestroy = (int (*)(olx_nccl_comm))dlsym(r.handle, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllGather");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+        return fail(c, OLX_ECOMM, "RCCL symbols missing");
+    return OLX_OK;
+}
+#define NCCLCHK(c, call)                                                                              \
+    do {                                                                                              \
+        int r_ = (call);                                                                              \
+        if (r_ != 0) return fail((c), OLX_ECOMM, "%s: %s", #call, (c)->rccl.GetErrorString(r_));      \
+    } while (0)
+
+int olx_comm_unique_id(olx_ctx* c, void* id_bytes) {
+    if (!c || !id_bytes) return OLX_EINVAL;
+    int rc = load_rccl(c);
+    if (rc) return rc;
+    olx_nccl_id id;
+    NCCLCHK(c, c->rccl.GetUniqueId(&id));
+    memcpy(id_bytes, &id, sizeof id);
+    return OLX_OK;
+}
+
+int olx_comm_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
+    if (!c || !id_bytes) return OLX_EINVAL;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, OLX_EINVAL, "olx_comm_init: bad rank %d / %d", rank, nranks);
+    if (c->comm) return fail(c, OLX_ESTATE, "olx_comm_init: communicator already initialised");
+    int rc = load_rccl(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    olx_nccl_id id;
+    memcpy(&id, id_bytes, sizeof id);
+    NCCLCHK(c, c->rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->nranks = nranks; c->rank = rank;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int b = 0; b < olx_ctx::NBUF; ++b) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_field[b], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather[b], hipEventDisableTiming));
+    }
+    c->planned = false;  // re-plan to get double-buffered outputs
+    return OLX_OK;
+}
+
+int olx_comm_destroy(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    if (c->comm) { c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    for (int b = 0; b < olx_ctx::NBUF; ++b) {
+        if (c->ev_field[b]) { hipEventDestroy(c->ev_field[b]); c->ev_field[b] = nullptr; }
+        if (c->ev_gather[b]) { hipEventDestroy(c->ev_gather[b]); c->ev_gather[b] = nullptr; }
+        c->gather_pending[b] = false;
+    }
+    if (c->comm_stream) { hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    c->nranks = 1; c->rank = 0;
+    return OLX_OK;
+}
+
+int olx_field_allgather(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allgather: call olx_comm_init first");
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allgather: nothing planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t count = (size_t)c->fp.vox * c->plan_foci;
+    const size_t need = count * c->nranks;
+    if (c->gather_cap < need) {
+        HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+        if (c->d_gather) hipFree(c->d_gather);
+        c->d_gather = nullptr; c->gather_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_gather, sizeof(float) * need));
+        c->gather_cap = need;
+    }
+    const int b = c->cur;
+    HIPCHK(c, hipEventRecord(c->ev_field[b], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_field[b], 0));
+    NCCLCHK(c, c->rccl.AllGather(c->d_pmag[b], c->d_gather, count, kNcclFloat32, c->comm, c->comm_stream));
+    HIPCHK(c, hipEventRecord(c->ev_gather[b], c->comm_stream));
+    c->gather_pending[b] = true;
+    return OLX_OK;
+}
+
+int olx_allgather_fetch(olx_ctx* c, int rank, float* out) {
+    if (!c || !out) return OLX_EINVAL;
+    if (!c->d_gather) return fail(c, OLX_ESTATE, "olx_allgather_fetch: no gather issued");
+    if (rank < 0 || rank >= c->nranks) return fail(c, OLX_EINVAL, "olx_allgather_fetch: rank out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    const size_t count = (size_t)c->fp.vox * c->plan_foci;
+    HIPCHK(c, hipMemcpy(out, c->d_gather + count * rank, sizeof(float) * count, hipMemcpyDeviceToHost));
+    return OLX_OK;
+}
+
+}  // extern "C"

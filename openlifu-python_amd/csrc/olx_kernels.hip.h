@@ -1,0 +1,322 @@
+// Device kernels of the openlifu hot path for gfx950 (CDNA4, wave64).
+// Written for MI355X only: no other-architecture paths.
+//
+//  kernel 1  bf_solve_k        per-element geometric delay / apodization solve (fp64)
+//            steer_pack_k      fp64 steering + element table -> fp32 kernel-2 table
+//  kernel 2  field_accum_k     per-voxel complex pressure accumulate over elements (fp32)
+//            field_aggregate_k max / mean over foci;  field_scale_k  per-focus scaling
+//
+// Data layout in HBM is documented in DESIGN.md section 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// kernel 1: F blocks (one per focus) x 256 threads striding over elements.
+// Element table is SoA fp64 (pos[3][N], nrm[3][N]) so that lane e reads pos[a][e]:
+// consecutive lanes -> consecutive 8-byte words (coalesced).  The focus and the 4x4
+// transform are staged once per block in LDS and broadcast from there.
+// Restates  xdc/element.py:239-246 (distance), :248-260 (angle),
+//           bf/delay_methods/direct.py:36-38, bf/apod_methods/maxangle.py:37-38,
+//           bf/apod_methods/piecewiselinear.py:46-48.
+// ------------------------------------------------------------------------------------
+constexpr int BF_THREADS = 256;
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(BF_THREADS) void bf_solve_k(
+    const double* __restrict__ pos,  // [3][N]
+    const double* __restrict__ nrm,  // [3][N]
+    int n, const double* __restrict__ foci /*[F][3]*/, const double* __restrict__ M /*[16]*/,
+    double c, int apod_kind, double angle_scale, double p0, double p1,
+    double* __restrict__ delays /*[F][N]*/, double* __restrict__ apod /*[F][N]*/) {
+    __shared__ double s_focus[3];
+    __shared__ double s_M[16];
+    __shared__ double s_red[BF_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid < 3) s_focus[tid] = foci[3 * f + tid];
+    if (tid >= 64 && tid < 80) s_M[tid - 64] = M[tid - 64];
+    __syncthreads();
+    const double fx = s_focus[0], fy = s_focus[1], fz = s_focus[2];
+    double* dl = delays + (size_t)f * n;
+    double* ap = apod + (size_t)f * n;
+    double lmax = -1.0;
+    for (int e = tid; e < n; e += BF_THREADS) {
+        const double px = pos[e], py = pos[n + e], pz = pos[2 * n + e];
+        // gpos = (M . [p,1])[:3]
+        const double gx = s_M[0] * px + s_M[1] * py + s_M[2] * pz + s_M[3];
+        const double gy = s_M[4] * px + s_M[5] * py + s_M[6] * pz + s_M[7];
+        const double gz = s_M[8] * px + s_M[9] * py + s_M[10] * pz + s_M[11];
+        const double vx = fx - gx, vy = fy - gy, vz = fz - gz;
+        const double d = sqrt(vx * vx + vy * vy + vz * vz);
+        const double tof = d / c;
+        dl[e] = tof;
+        lmax = fmax(lmax, tof);
+        double a;
+        if (apod_kind == 0) {
+            a = p0;
+        } else {
+            const double nx0 = nrm[e], ny0 = nrm[n + e], nz0 = nrm[2 * n + e];
+            // v2 = (M . pose)[:3,2] = M[:3,:3] . normal
+            double wx = s_M[0] * nx0 + s_M[1] * ny0 + s_M[2] * nz0;
+            double wy = s_M[4] * nx0 + s_M[5] * ny0 + s_M[6] * nz0;
+            double wz = s_M[8] * nx0 + s_M[9] * ny0 + s_M[10] * nz0;
+            const double wn = sqrt(wx * wx + wy * wy + wz * wz);
+            wx /= wn; wy /= wn; wz /= wn;
+            const double ux = vx / d, uy = vy / d, uz = vz / d;
+            const double cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+            double sn = sqrt(cx * cx + cy * cy + cz * cz);
+            const double theta_deg = asin(sn) * angle_scale;  // 180/pi (np.degrees) or 1
+            if (apod_kind == 1) {
+                a = (theta_deg <= p0) ? 1.0 : 0.0;
+            } else {
+                const double fr = (p0 - theta_deg) / (p0 - p1);
+                a = fmax(0.0, fmin(1.0, fr));
+            }
+        }
+        ap[e] = a;
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) s_red[tid >> 6] = lmax;
+    __syncthreads();
+    double bmax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < BF_THREADS / 64; ++w) bmax = fmax(bmax, s_red[w]);
+    for (int e = tid; e < n; e += BF_THREADS) dl[e] = bmax - dl[e];  // same thread wrote dl[e]
+}
+
+// ------------------------------------------------------------------------------------
+// steering pack: fp64 (pos, area, delays, apod) -> the fp32 table kernel 2 streams through
+// the scalar cache.  Entry (f, e) = 8 floats (32 B, one s_load_dwordx8):
+//   { x_e - ox, y_e - oy, z_e - oz, w_ef, phi_ef, 0, 0, 0 }
+// w_ef = a_ef P0 S_e / lambda [Pa m];  phi_ef = frac(f0 tau_ef) [revolutions].
+// Differences and products are formed in fp64 and rounded once.
+// ------------------------------------------------------------------------------------
+constexpr int TAB_STRIDE = 8;
+
+__global__ void steer_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
+                             const double* __restrict__ delays, const double* __restrict__ apod,
+                             double ox, double oy, double oz, double freq, double p0_over_lambda,
+                             float* __restrict__ tab) {
+    const int f = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const size_t o = ((size_t)f * n + e);
+    const double cyc = freq * delays[o];
+    float* t = tab + o * TAB_STRIDE;
+    t[0] = (float)(pos[e] - ox);
+    t[1] = (float)(pos[n + e] - oy);
+    t[2] = (float)(pos[2 * n + e] - oz);
+    t[3] = (float)(apod[o] * area[e] * p0_over_lambda);
+    t[4] = (float)(cyc - floor(cyc));
+    t[5] = 0.f; t[6] = 0.f; t[7] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 2: pressure-field accumulate, exact per voxel-element pair, fp32.
+//
+// Work map: the [nx,ny,nz] slab is rows of nz voxels (z fastest).  A lane owns ZPL
+// consecutive z voxels of one row, so dx, dy and rho^2 = dx^2 + dy^2 are formed once per
+// (lane, element) and shared by its ZPL voxels; 64/ (nz/ZPL) rows per wave.  Lanes of a
+// wave write ZPL*4-byte pieces that tile whole rows: for nz = 256, ZPL = 4 a wave stores
+// one contiguous 1 KiB row with one dwordx4 store per lane.
+// Element data is wave-uniform: read with scalar loads (s_load_dwordx8) from the packed
+// table, served by the scalar cache -- no VGPR, LDS or vector-memory traffic in the loop.
+// Per pair: v_rsq_f32 (1/d), v_sin_f32 + v_cos_f32 on the phase in REVOLUTIONS
+// (t = d f/c + frac(f tau)), ~7 plain VALU.  Transcendental issue is the bound
+// (DESIGN.md section 5); HBM sees only the output stream.
+//   FLAT : every element has the same z -> (z_v - z_e)^2 hoisted out of the element loop.
+//   CLAMP: apply d >= dmin (needed only if a voxel can come within dmin of an element;
+//          decided on the host from the element / slab bounding boxes).
+// ------------------------------------------------------------------------------------
+struct FieldParams {
+    int nx, ny, nz;        // slab extent in voxels (nx = slab x_count)
+    int n_el;
+    int x_begin;           // slab start (global x index): coordinates are formed from GLOBAL indices so
+                           // that a slab launch is bit-identical to the same voxels of a whole-grid launch
+    float hx, hy, hz;      // spacing [m]
+    float rev_per_m;       // f0 / c
+    float dmin2;           // dmin^2 [m^2]
+    float inten_scale;     // 1e-4 / (2 rho c)
+    float flat_ez;         // common element z (FLAT only), relative to table origin
+    long long vox;         // voxels per focus volume (nx*ny*nz)
+    unsigned flags;        // OLX_OUT_*
+};
+
+constexpr int FIELD_THREADS = 256;
+
+template <int ZPL, bool FLAT, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
+    const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
+    float* __restrict__ cplx, const FieldParams P) {
+    const int f = blockIdx.y;
+    const int cpr = (P.nz + ZPL - 1) / ZPL;  // chunks per row
+    const long long lane_id = (long long)blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const long long rows = (long long)P.nx * P.ny;
+    const long long row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int i = (int)(row / P.ny), j = (int)(row - (long long)i * P.ny);
+    const int k0 = chunk * ZPL;
+    const float x = (float)(i + P.x_begin) * P.hx;
+    const float y = (float)j * P.hy;
+    float z[ZPL], re[ZPL], im[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        z[q] = (float)(k0 + q) * P.hz;
+        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+        re[q] = 0.f; im[q] = 0.f;
+    }
+    const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
+#pragma unroll 2
+    for (int e = 0; e < P.n_el; ++e) {
+        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
+        const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
+        const float phi = t[e * TAB_STRIDE + 4];
+        const float dx = x - ex, dy = y - ey;
+        const float r2 = fmaf(dy, dy, dx * dx);
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            float d2;
+            if (FLAT) {
+                d2 = r2 + z[q];
+            } else {
+                const float dz = z[q] - ez;
+                d2 = fmaf(dz, dz, r2);
+            }
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float d = d2 * ri;
+            const float ph = fmaf(d, P.rev_per_m, phi);
+            const float s = __builtin_amdgcn_sinf(ph);
+            const float c = __builtin_amdgcn_cosf(ph);
+            const float a = w * ri;
+            re[q] = fmaf(a, c, re[q]);
+            im[q] = fmaf(a, s, im[q]);
+        }
+    }
+    // epilogue: fused |p|, intensity, optional complex
+    const long long base = (long long)f * P.vox + row * P.nz + k0;
+    float pm[ZPL], it[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
+        pm[q] = __builtin_sqrtf(m2);
+        it[q] = m2 * P.inten_scale;
+    }
+    const bool full = (k0 + ZPL <= P.nz);
+    if (ZPL == 4 && full && (P.nz & 3) == 0) {
+        if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+        if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+        if (P.flags & 4u) {
+            float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
+            c4[0] = make_float4(re[0], im[0], re[1], im[1]);
+            c4[1] = make_float4(re[2], im[2], re[3], im[3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            if (k0 + q < P.nz) {
+                if (P.flags & 1u) pmag[base + q] = pm[q];
+                if (P.flags & 2u) inten[base + q] = it[q];
+                if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// aggregation over foci (plan/protocol.py:384-387) and per-focus scaling
+// (plan/solution.py:331-337).  HBM-bound streaming: float4 per lane, grid-stride.
+// ------------------------------------------------------------------------------------
+__global__ void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+                                  int n_foci, long long vox, float* __restrict__ pmax,
+                                  float* __restrict__ imean) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float inv = 1.0f / (float)n_foci;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        float m = 0.f, s = 0.f;
+        for (int f = 0; f < n_foci; ++f) {
+            if (pmag) m = fmaxf(m, pmag[(long long)f * vox + v]);
+            if (inten) s += inten[(long long)f * vox + v];
+        }
+        if (pmax) pmax[v] = m;
+        if (imean) imean[v] = s * inv;
+    }
+}
+
+__global__ void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
+                              float* __restrict__ cplx, const float* __restrict__ scale,
+                              long long vox) {
+    const int f = blockIdx.y;
+    const float s = scale[f];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        const long long o = (long long)f * vox + v;
+        if (pmag) pmag[o] *= s;
+        if (inten) inten[o] *= s * s;
+        if (cplx) { cplx[2 * o] *= s; cplx[2 * o + 1] *= s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// masked peak per focus (get_mask + max; plan/solution_analysis.py:384-442).  HBM-bound
+// scan of one float per voxel; the focal-frame affine is evaluated in fp64 so that the
+// mask edge matches the fp64 oracle.  Non-negative floats order like their bit patterns,
+// so the cross-block reduction is an integer atomicMax.
+// ------------------------------------------------------------------------------------
+struct PeakParams {
+    int nx, ny, nz;
+    double ox, oy, oz, hx, hy, hz;  // slab voxel (0,0,0) position and spacing [m]
+    double ia0, ia1, ia2;           // 1 / aspect
+    double radius; int op; int use_zmin; double zmin;
+    long long vox;
+};
+
+__global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restrict__ vol,
+                                                            const double* __restrict__ A,
+                                                            const PeakParams P,
+                                                            unsigned* __restrict__ out) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ float s_red[4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float* v = vol + (long long)f * P.vox;
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nyz = (long long)P.ny * P.nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / P.nz, iz = rem - iy * P.nz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        bool sel = true;
+        if (P.op != 4) {
+            const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+            const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+            const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+            const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+            sel = (P.op == 0) ? (dist < P.radius) : (P.op == 1) ? (dist <= P.radius)
+                : (P.op == 2) ? (dist > P.radius) : (dist >= P.radius);
+        }
+        if (P.use_zmin) sel = sel && (z > P.zmin);
+        if (sel) m = fmaxf(m, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        atomicMax(out + f, __float_as_uint(m));
+    }
+}
+
+}  // namespace olx

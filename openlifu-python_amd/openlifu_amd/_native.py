@@ -1,0 +1,307 @@
+"""ctypes binding of the C-ABI in include/olx.h (the only native entry point).
+
+No PyTorch, no Triton, no CPU fallback: if ``libolx.so`` is missing or no MI355X
+is visible, the calls raise -- the product path never silently computes on the
+host.  ``load(require_gpu=False)`` is used by CPU-only checks that only inspect
+the exported symbols.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_uint, c_void_p
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libolx.so")
+
+OLX_OK, OLX_EINVAL, OLX_ESTATE, OLX_EHIP, OLX_ENOMEM, OLX_ECOMM = 0, -1, -2, -3, -4, -5
+APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2
+OUT_PMAG, OUT_INTENSITY, OUT_COMPLEX = 1, 2, 4
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/olx.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
+    "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_field_plan",
+    "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
+    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_comm_unique_id", "olx_comm_init",
+    "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch",
+]
+
+
+class NativeError(RuntimeError):
+    """A C-ABI call returned a negative OLX_E* code."""
+
+
+class OlxGrid(ctypes.Structure):
+    _fields_ = [("origin", c_double * 3), ("spacing", c_double * 3), ("n", c_int32 * 3)]
+
+
+class OlxSlab(ctypes.Structure):
+    _fields_ = [("x_begin", c_int32), ("x_count", c_int32)]
+
+
+_lib = None
+
+
+def load(require_gpu: bool = True):
+    """dlopen libolx.so and declare prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        dp, fp, vp = POINTER(c_double), POINTER(c_float), c_void_p
+        lib.olx_abi_version.restype = c_int
+        lib.olx_device_count.argtypes = [POINTER(c_int)]
+        lib.olx_ctx_create.argtypes = [c_int, POINTER(vp)]
+        lib.olx_ctx_destroy.argtypes = [vp]
+        lib.olx_last_error.argtypes = [vp]; lib.olx_last_error.restype = c_char_p
+        lib.olx_sync.argtypes = [vp]
+        lib.olx_set_elements.argtypes = [vp, dp, dp, dp, c_int]
+        lib.olx_bf_solve.argtypes = [vp, dp, c_int, dp, c_double, c_int, c_double, c_double, dp, dp]
+        lib.olx_set_steering.argtypes = [vp, dp, dp, c_int]
+        lib.olx_field_plan.argtypes = [vp, POINTER(OlxGrid), POINTER(OlxSlab), c_int, c_double, c_double,
+                                       c_double, c_double, c_uint]
+        lib.olx_field_launch.argtypes = [vp]
+        lib.olx_field_fetch.argtypes = [vp, c_int, fp, fp, fp]
+        lib.olx_field.argtypes = [vp, POINTER(OlxGrid), c_int, c_double, c_double, c_double, c_double, fp, fp]
+        lib.olx_field_upload.argtypes = [vp, POINTER(OlxGrid), POINTER(OlxSlab), c_int, fp, fp]
+        lib.olx_field_time.argtypes = [vp, c_int, fp]
+        lib.olx_profile_begin.argtypes = [vp, c_int]
+        lib.olx_profile_end.argtypes = [vp, fp, c_int, POINTER(c_int)]
+        lib.olx_field_variant.argtypes = [vp]; lib.olx_field_variant.restype = c_char_p
+        lib.olx_field_aggregate.argtypes = [vp, fp, fp]
+        lib.olx_field_scale.argtypes = [vp, dp, c_int]
+        lib.olx_field_masked_peak.argtypes = [vp, c_int, dp, dp, c_double, c_int, c_int, c_double, fp]
+        lib.olx_comm_unique_id.argtypes = [vp, vp]
+        lib.olx_comm_init.argtypes = [vp, vp, c_int, c_int]
+        lib.olx_comm_destroy.argtypes = [vp]
+        lib.olx_field_allgather.argtypes = [vp]
+        lib.olx_allgather_fetch.argtypes = [vp, c_int, fp]
+        _lib = lib
+    if require_gpu and device_count() < 1:
+        raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
+                          "(there is no CPU fallback)")
+    return _lib
+
+
+def device_count() -> int:
+    n = c_int(0)
+    rc = load(require_gpu=False).olx_device_count(ctypes.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
+def _dptr(a):
+    return a.ctypes.data_as(POINTER(c_double)) if a is not None else None
+
+
+def _fptr(a):
+    return a.ctypes.data_as(POINTER(c_float)) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected array of shape {shape}, got {a.shape}")
+    return a
+
+
+class Context:
+    """One device context (stream + resident element / steering / field buffers)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load(require_gpu=True)
+        self._h = c_void_p()
+        rc = self._lib.olx_ctx_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            raise NativeError(f"olx_ctx_create(device={device}) failed with code {rc}")
+        self.device = int(device)
+        self.n_el = 0
+        self.n_foci = 0
+        self._vox = 0
+        self._flags = 0
+        self._shape = None
+        self.nranks = 1
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._lib.olx_last_error(self._h)
+            msg = msg.decode() if msg else ""
+            if rc == OLX_EINVAL:
+                raise ValueError(msg)
+            raise NativeError(f"[olx {rc}] {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.olx_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._chk(self._lib.olx_sync(self._h))
+
+    # -- element table
+    def set_elements(self, pos_m, normal, area_m2):
+        pos_m = _f64(pos_m); n = pos_m.shape[0]
+        if pos_m.ndim != 2 or pos_m.shape[1] != 3 or n < 1:
+            raise ValueError("pos_m must be [N,3] with N >= 1")
+        normal = _f64(normal, (n, 3)); area_m2 = _f64(area_m2, (n,))
+        self._chk(self._lib.olx_set_elements(self._h, _dptr(pos_m), _dptr(normal), _dptr(area_m2), n))
+        self.n_el = n
+        self.n_foci = 0
+
+    # -- kernel 1
+    def bf_solve(self, foci_m, c, matrix=None, apod_kind=APOD_UNIFORM, p0=1.0, p1=0.0, want_outputs=True):
+        foci_m = _f64(np.atleast_2d(foci_m))
+        if foci_m.shape[1] != 3:
+            raise ValueError("foci_m must be [F,3]")
+        F = foci_m.shape[0]
+        M = None if matrix is None else _f64(matrix, (4, 4))
+        delays = np.empty((F, self.n_el)) if want_outputs else None
+        apod = np.empty((F, self.n_el)) if want_outputs else None
+        self._chk(self._lib.olx_bf_solve(self._h, _dptr(foci_m), F, _dptr(M), float(c), int(apod_kind),
+                                         float(p0), float(p1), _dptr(delays), _dptr(apod)))
+        self.n_foci = F
+        return delays, apod
+
+    def set_steering(self, delays_s, apod):
+        delays_s = _f64(np.atleast_2d(delays_s)); apod = _f64(np.atleast_2d(apod))
+        if delays_s.shape != apod.shape or delays_s.shape[1] != self.n_el:
+            raise ValueError(f"delays/apod must both be [F,{self.n_el}], got {delays_s.shape} and {apod.shape}")
+        F = delays_s.shape[0]
+        self._chk(self._lib.olx_set_steering(self._h, _dptr(delays_s), _dptr(apod), F))
+        self.n_foci = F
+
+    # -- kernel 2
+    def field_plan(self, origin_m, spacing_m, n, freq, c, rho, p0_pa=1.0, flags=OUT_PMAG | OUT_INTENSITY,
+                   slab=None, n_foci=None):
+        g = OlxGrid()
+        for a in range(3):
+            g.origin[a] = float(origin_m[a]); g.spacing[a] = float(spacing_m[a]); g.n[a] = int(n[a])
+        s = None
+        nx = int(n[0])
+        if slab is not None:
+            s = OlxSlab(int(slab[0]), int(slab[1])); nx = int(slab[1])
+        F = self.n_foci if n_foci is None else int(n_foci)
+        self._chk(self._lib.olx_field_plan(self._h, ctypes.byref(g), ctypes.byref(s) if s else None, F,
+                                           float(freq), float(c), float(rho), float(p0_pa), int(flags)))
+        self._shape = (nx, int(n[1]), int(n[2]))
+        self._vox = nx * int(n[1]) * int(n[2])
+        self._flags = int(flags) | OUT_PMAG
+        self._plan_foci = F
+
+    def field_launch(self):
+        self._chk(self._lib.olx_field_launch(self._h))
+
+    def field_fetch(self, focus=0, want=("pmag", "intensity")):
+        out = {}
+        pm = np.empty(self._shape, dtype=np.float32) if "pmag" in want else None
+        it = np.empty(self._shape, dtype=np.float32) if "intensity" in want else None
+        cx = np.empty(self._shape + (2,), dtype=np.float32) if "complex" in want else None
+        self._chk(self._lib.olx_field_fetch(self._h, int(focus), _fptr(pm), _fptr(it), _fptr(cx)))
+        if pm is not None: out["pmag"] = pm
+        if it is not None: out["intensity"] = it
+        if cx is not None: out["complex"] = cx[..., 0] + 1j * cx[..., 1]
+        return out
+
+    def field_upload(self, origin_m, spacing_m, n, pmag, intensity=None):
+        """Bind host volumes [F, nx, ny, nz] as the resident result (for analysis of loaded Solutions)."""
+        pmag = np.ascontiguousarray(pmag, dtype=np.float32)
+        if pmag.ndim != 4 or pmag.shape[1:] != tuple(int(v) for v in n):
+            raise ValueError(f"pmag must be [F,{n[0]},{n[1]},{n[2]}], got {pmag.shape}")
+        it = None if intensity is None else np.ascontiguousarray(intensity, dtype=np.float32)
+        if it is not None and it.shape != pmag.shape:
+            raise ValueError("intensity must have the shape of pmag")
+        g = OlxGrid()
+        for a in range(3):
+            g.origin[a] = float(origin_m[a]); g.spacing[a] = float(spacing_m[a]); g.n[a] = int(n[a])
+        self._chk(self._lib.olx_field_upload(self._h, ctypes.byref(g), None, int(pmag.shape[0]), _fptr(pmag), _fptr(it)))
+        self._shape = tuple(int(v) for v in n)
+        self._vox = int(np.prod(self._shape))
+        self._plan_foci = int(pmag.shape[0])
+        self._flags = OUT_PMAG | (OUT_INTENSITY if it is not None else 0)
+
+    def field_time(self, iters: int) -> np.ndarray:
+        ms = np.empty(int(iters), dtype=np.float32)
+        self._chk(self._lib.olx_field_time(self._h, int(iters), _fptr(ms)))
+        return ms
+
+    def profile_begin(self, max_launches: int):
+        self._prof_cap = int(max_launches)
+        self._chk(self._lib.olx_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self) -> np.ndarray:
+        ms = np.empty(self._prof_cap, dtype=np.float32)
+        n = c_int(0)
+        self._chk(self._lib.olx_profile_end(self._h, _fptr(ms), self._prof_cap, ctypes.byref(n)))
+        return ms[: n.value].copy()
+
+    def field_variant(self) -> str:
+        v = self._lib.olx_field_variant(self._h)
+        return v.decode() if v else ""
+
+    def field_aggregate(self, want_intensity=True):
+        pm = np.empty(self._shape, dtype=np.float32)
+        it = np.empty(self._shape, dtype=np.float32) if want_intensity else None
+        self._chk(self._lib.olx_field_aggregate(self._h, _fptr(pm), _fptr(it)))
+        return pm, it
+
+    def field_scale(self, scale_per_focus):
+        s = _f64(scale_per_focus)
+        self._chk(self._lib.olx_field_scale(self._h, _dptr(s), int(s.shape[0])))
+
+    def field_masked_peak(self, A, aspect, radius_m, op="<", which="pmag", zmin_m=None):
+        """Per-focus peak of |p| (or intensity) over the focal-ellipsoid mask -> float32[F]."""
+        ops = {"<": 0, "<=": 1, ">": 2, ">=": 3, None: 4}
+        if op not in ops:
+            raise ValueError("Operator must be '<', '>', '<=', or '>='.")
+        F = self._plan_foci
+        A = None if A is None else _f64(A, (F, 12))
+        aspect = _f64(aspect, (3,))
+        out = np.empty(F, dtype=np.float32)
+        self._chk(self._lib.olx_field_masked_peak(self._h, 0 if which == "pmag" else 1, _dptr(A), _dptr(aspect),
+                                                  float(radius_m), ops[op], int(zmin_m is not None),
+                                                  float(zmin_m or 0.0), _fptr(out)))
+        return out
+
+    # -- multi-GPU
+    def comm_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        self._chk(self._lib.olx_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        buf = ctypes.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._chk(self._lib.olx_comm_init(self._h, buf, int(nranks), int(rank)))
+        self.nranks = int(nranks)
+
+    def comm_destroy(self):
+        self._chk(self._lib.olx_comm_destroy(self._h))
+        self.nranks = 1
+
+    def field_allgather(self):
+        self._chk(self._lib.olx_field_allgather(self._h))
+
+    def allgather_fetch(self, rank: int) -> np.ndarray:
+        out = np.empty((self._plan_foci,) + self._shape, dtype=np.float32)
+        self._chk(self._lib.olx_allgather_fetch(self._h, int(rank), _fptr(out)))
+        return out

@@ -1,0 +1,36 @@
+"""Apodization plug-in base (mirror of bf/apod_methods/apodmethod.py:16-42)."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+
+from ...util.units import getunittype
+
+
+@dataclass
+class ApodizationMethod(ABC):
+    @abstractmethod
+    def calc_apodization(self, arr, target, params, transform=None):
+        ...
+
+    @abstractmethod
+    def kernel_args(self):
+        """(apod_kind, p0, p1) for olx_bf_solve (include/olx.h)."""
+
+    def to_dict(self):
+        d = self.__dict__.copy()
+        d["class"] = self.__class__.__name__
+        return d
+
+    @staticmethod
+    def from_dict(d):
+        from .. import apod_methods
+        d = d.copy()
+        return getattr(apod_methods, d.pop("class"))(**d)
+
+
+def angle_kind(base_kind: int, units: str) -> int:
+    """deg is the kernel's default; any radian spelling sets OLX_APOD_RADIANS."""
+    if getunittype(units) != "angle":
+        raise ValueError(f"Units must be an angle type, got {units}.")
+    return base_kind | (0x10 if units.lower().startswith("rad") else 0)

@@ -1,0 +1,127 @@
+"""Host-side driver of the device hot path: one ``Engine`` per GPU owns a native
+context (include/olx.h), keeps the transducer's element table resident and turns
+the reference's per-focus Python calls into batched launches.
+
+There is no CPU path here: every method ends in a HIP kernel launched through
+the C-ABI, and raises if the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _native as nat
+from .geo import Point
+from .util.units import getunitconversion
+
+_engines: dict[int, "Engine"] = {}
+
+
+def default_device() -> int:
+    for var in ("OPENLIFU_AMD_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+def get_engine(device: int | None = None) -> "Engine":
+    device = default_device() if device is None else int(device)
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]
+
+
+def gpu_available() -> bool:
+    """HIP probe standing in for openlifu.util.checkgpu.gpu_available (NVML-only in the
+    reference, util/checkgpu.py:6-14, hence always False on AMD)."""
+    try:
+        return nat.device_count() > 0
+    except Exception:  # noqa: BLE001 - same contract as the reference: any failure = no GPU
+        return False
+
+
+def focus_positions_m(targets) -> np.ndarray:
+    """[F,3] metres from a Point, a list of Points, or an array already in metres."""
+    if isinstance(targets, Point):
+        targets = [targets]
+    if isinstance(targets, (list, tuple)) and len(targets) and isinstance(targets[0], Point):
+        return np.array([t.get_position(units="m") for t in targets], dtype=np.float64)
+    return np.atleast_2d(np.asarray(targets, dtype=np.float64))
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.ctx = nat.Context(device)
+        self.device = device
+        self._table_key = None
+        self.result_token = 0  # bumped whenever the resident result volumes change
+
+    # ---- element table ----------------------------------------------------------------------
+    def bind(self, arr):
+        """Upload ``arr``'s SoA element table unless the resident one is identical."""
+        pos, nrm, area, _, _ = arr.element_table()
+        # per-element sensitivity factors (Transducer.merge, xdc/transducer.py:236-247) scale the
+        # element's drive exactly like its area does in the source weight
+        sens = np.array([1.0 if el.sensitivity is None else el.sensitivity for el in arr.elements])
+        area = area * sens
+        key = hash((pos.tobytes(), nrm.tobytes(), area.tobytes()))
+        if key != self._table_key:
+            self.ctx.set_elements(pos, nrm, area)
+            self._table_key = key
+        return self.ctx.n_el
+
+    # ---- kernel 1 -----------------------------------------------------------------------------
+    def beamform(self, arr, targets, c: float, transform=None, apod=(nat.APOD_UNIFORM, 1.0, 0.0)):
+        """delays[F,N] (s), apod[F,N] for F foci in ONE launch (replaces F x N Python calls,
+        plan/protocol.py:318-320 -> bf/delay_methods/direct.py:35, bf/apod_methods/maxangle.py:36)."""
+        self.bind(arr)
+        kind, p0, p1 = apod
+        return self.ctx.bf_solve(focus_positions_m(targets), c, matrix=transform, apod_kind=kind, p0=p0, p1=p1)
+
+    # ---- kernel 2 -----------------------------------------------------------------------------
+    def field(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa,
+              want=("pmag", "intensity"), slab=None, steering_resident=False):
+        """Pressure field for F foci -> dict of float32 arrays [F, nx, ny, nz] (fresh, writable,
+        caller-owned).  ``steering_resident`` reuses the table the last ``beamform`` left on the
+        device instead of uploading ``delays`` / ``apod``."""
+        self.bind(arr)
+        if not steering_resident:
+            self.ctx.set_steering(delays, apod)
+        flags = nat.OUT_PMAG
+        if "intensity" in want:
+            flags |= nat.OUT_INTENSITY
+        if "complex" in want:
+            flags |= nat.OUT_COMPLEX
+        self.ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=flags, slab=slab)
+        self.ctx.field_launch()
+        self.result_token += 1
+        F = self.ctx.n_foci
+        outs = [self.ctx.field_fetch(f, want=want) for f in range(F)]
+        return {k: np.stack([o[k] for o in outs], axis=0) for k in outs[0]}
+
+
+    def upload_result(self, origin_m, spacing_m, n, pmag, intensity=None):
+        """Bind host volumes [F,nx,ny,nz] as the resident result (analysis of a detached Solution)."""
+        self.ctx.field_upload(origin_m, spacing_m, n, pmag, intensity)
+        self.result_token += 1
+        self.__dict__.pop("_plan_sig", None)
+
+
+def grid_from_coords(coords):
+    """(origin_m[3], spacing_m[3], n[3]) from a params.coords mapping; raises ValueError for
+    mixed units like the reference (sim/kwave_if.py:104-106)."""
+    dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
+    units = [coords[d].attrs["units"] for d in dims]
+    if not all(u == units[0] for u in units):
+        raise ValueError("All dimensions must have the same units")
+    scl = getunitconversion(units[0], "m")
+    origin, spacing, n = [], [], []
+    for d in dims:
+        v = np.asarray(coords[d].data if hasattr(coords[d], "data") else coords[d], dtype=np.float64)
+        origin.append(v[0] * scl)
+        spacing.append((np.diff(v)[0] * scl) if len(v) > 1 else scl)  # dx = diff(coord)[0]*scl, kwave_if.py:20
+        n.append(len(v))
+        if len(v) > 2 and not np.allclose(np.diff(v), np.diff(v)[0], rtol=1e-6, atol=0):
+            raise ValueError(f"coordinate {d} is not uniformly spaced")
+    return origin, spacing, n

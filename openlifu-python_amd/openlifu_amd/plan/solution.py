@@ -1,0 +1,204 @@
+"""Sonication solution container (mirror of openlifu.plan.solution.Solution,
+plan/solution.py:38-533): delays[F,N], apodizations[F,N], foci, simulation_result, plus
+``scale`` / ``analyze``.  NetCDF persistence is out of scope.
+
+``analyze`` / ``scale`` keep the volumes on the GPU: the masked peaks come from one HBM-bound scan
+per query (``olx_field_masked_peak``) over the result that ``calc_solution`` left resident; a
+Solution whose volumes are host-only (e.g. rebuilt from a dict) is uploaded once first.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from datetime import datetime
+from typing import List, Tuple
+
+import numpy as np
+
+from ..bf import Pulse, Sequence
+from ..bf.focal_patterns import FocalPattern
+from ..engine import get_engine, grid_from_coords
+from ..geo import Point
+from ..util import dataset as ds
+from ..util.units import getunitconversion
+from ..xdc import Transducer
+from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, get_focus_matrix
+
+
+@dataclass
+class Solution:
+    id: str = "solution"
+    name: str = "Solution"
+    protocol_id: str | None = None
+    transducer: Transducer | None = None
+    date_created: datetime = field(default_factory=datetime.now)
+    description: str = ""
+    delays: np.ndarray | None = None
+    apodizations: np.ndarray | None = None
+    pulse: Pulse = field(default_factory=Pulse)
+    voltage: float = 1.0
+    sequence: Sequence = field(default_factory=Sequence)
+    foci: List[Point] = field(default_factory=list)
+    target: Point | None = None
+    simulation_result: object = field(default_factory=ds.make_dataset)
+    approved: bool = False
+
+    def __post_init__(self):
+        if self.delays is not None:
+            self.delays = np.array(self.delays, ndmin=2)
+        if self.apodizations is not None:
+            self.apodizations = np.array(self.apodizations, ndmin=2)
+        if self.pulse.frequency <= 0:
+            raise ValueError("Pulse frequency must be positive")
+        if self.voltage <= 0:
+            raise ValueError("Voltage must be positive")
+        s = self.sequence
+        if s.pulse_interval <= 0:
+            raise ValueError("Pulse interval must be positive")
+        if s.pulse_count <= 0:
+            raise ValueError("Pulse count must be positive")
+        if s.pulse_train_interval < 0:
+            raise ValueError("Pulse train interval must be non-negative")
+        if 0 < s.pulse_train_interval < s.pulse_interval * s.pulse_count:
+            raise ValueError("Pulse train interval must be greater than or equal to the total pulse interval")
+        if s.pulse_train_count <= 0:
+            raise ValueError("Pulse train count must be positive")
+        nf = len(self.foci)
+        if nf > 0 and self.delays is not None and self.delays.shape[0] != nf:
+            raise ValueError(f"Delays number of foci ({self.delays.shape[0]}) does not match number of foci ({nf})")
+        if nf > 0 and self.apodizations is not None and self.apodizations.shape[0] != nf:
+            raise ValueError(f"Apodizations number of foci ({self.apodizations.shape[0]}) does not match number of foci ({nf})")
+        if self.delays is not None and self.apodizations is not None:
+            if self.apodizations.shape[0] != self.delays.shape[0]:
+                raise ValueError(f"Apodizations number of foci ({self.apodizations.shape[0]}) does not match delays number of foci ({self.delays.shape[0]})")
+            if self.apodizations.shape[1] != self.delays.shape[1]:
+                raise ValueError(f"Apodizations number of elements {self.apodizations.shape[1]} does not match delays shape ({self.delays.shape[1]})")
+        self._resident = None  # (engine, token) while the device still holds simulation_result
+
+    def num_foci(self) -> int:
+        return len(self.foci)
+
+    # ---- duty cycles (plan/solution.py:340-363) ---------------------------------------------
+    def get_pulsetrain_dutycycle(self) -> float:
+        return min(1.0, self.pulse.duration / self.sequence.pulse_interval)
+
+    def get_sequence_dutycycle(self) -> float:
+        s = self.sequence
+        between = 1 if s.pulse_train_interval == 0 else (s.pulse_count * s.pulse_interval) / s.pulse_train_interval
+        return self.get_pulsetrain_dutycycle() * between
+
+    # ---- device-side analysis -----------------------------------------------------------------
+    def _bind_device(self):
+        """Make sure the GPU holds this solution's volumes; returns (engine, origin, spacing, n)."""
+        res = self.simulation_result
+        origin, spacing, n = grid_from_coords({d: res.coords[d] for d in res["p_min"].dims if d != "focal_point_index"})
+        eng = get_engine()
+        if self._resident is None or self._resident[0] is not eng or self._resident[1] != eng.result_token:
+            eng.upload_result(origin, spacing, n, res["p_min"].data, res["intensity"].data)
+            self._resident = (eng, eng.result_token)
+        return eng, origin, spacing, n
+
+    def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None) -> SolutionAnalysis:
+        """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
+        options = SolutionAnalysisOptions() if options is None else options
+        an = SolutionAnalysis()
+        eng, _, _, _ = self._bind_device()
+        to_m = getunitconversion(options.distance_units, "m")
+        A = np.zeros((self.num_foci(), 12))
+        for i, focus in enumerate(self.foci):
+            f_m = focus.get_position(units="m")
+            o_m = self.transducer.get_effective_origin(apodizations=self.apodizations[i], units="m")
+            A[i] = np.linalg.inv(get_focus_matrix(f_m, origin=o_m))[:3].ravel()
+            f_mm = focus.get_position(units="mm")
+            an.target_position_lat_mm.append(f_mm[0]); an.target_position_ele_mm.append(f_mm[1])
+            an.target_position_ax_mm.append(f_mm[2])
+        aspect = options.mainlobe_aspect_ratio
+        ctx = eng.ctx
+        main_p = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "pmag")
+        main_i = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "intensity")
+        zmin = options.sidelobe_zmin * to_m
+        side_p = ctx.field_masked_peak(A, aspect, options.sidelobe_radius * to_m, ">", "pmag", zmin_m=zmin)
+        side_i = ctx.field_masked_peak(A, aspect, options.sidelobe_radius * to_m, ">", "intensity", zmin_m=zmin)
+        glob_p = ctx.field_masked_peak(None, aspect, 0.0, None, "pmag", zmin_m=zmin)
+        glob_i = ctx.field_masked_peak(None, aspect, 0.0, None, "intensity", zmin_m=zmin)
+        for i in range(self.num_foci()):
+            mp, mi, sp, si = float(main_p[i]) * 1e-6, float(main_i[i]), float(side_p[i]) * 1e-6, float(side_i[i])
+            an.mainlobe_pnp_MPa.append(mp); an.mainlobe_isppa_Wcm2.append(mi)
+            an.sidelobe_pnp_MPa.append(sp); an.sidelobe_isppa_Wcm2.append(si)
+            an.sidelobe_to_mainlobe_pressure_ratio.append((np.inf if sp != 0 else np.nan) if mp == 0 else sp / mp)
+            an.sidelobe_to_mainlobe_intensity_ratio.append((np.inf if si != 0 else np.nan) if mi == 0 else si / mi)
+            an.global_pnp_MPa.append(float(glob_p[i]) * 1e-6); an.global_isppa_Wcm2.append(float(glob_i[i]))
+        an.MI = float(np.max(an.mainlobe_pnp_MPa) / np.sqrt(self.pulse.frequency * 1e-6))
+        an.voltage_V = self.voltage
+        an.duty_cycle_pulse_train_pct = self.get_pulsetrain_dutycycle() * 100
+        an.duty_cycle_sequence_pct = self.get_sequence_dutycycle() * 100
+        s = self.sequence
+        an.sequence_duration_s = float(s.pulse_interval * s.pulse_count * s.pulse_train_count
+                                       if s.pulse_train_interval == 0 else s.pulse_train_interval * s.pulse_train_count)
+        an.param_constraints = param_constraints or {}
+        return an
+
+    def compute_scaling_factors(self, focal_pattern: FocalPattern, analysis: SolutionAnalysis) -> Tuple[np.ndarray, float, float]:
+        """plan/solution.py:283-311."""
+        target_mpa = focal_pattern.target_pressure * getunitconversion(focal_pattern.units, "MPa")
+        scaling = np.array([target_mpa / analysis.mainlobe_pnp_MPa[i] for i in range(self.num_foci())])
+        v0 = self.voltage
+        v1 = v0 * np.max(scaling)
+        return scaling / np.max(scaling), v0, v1
+
+    def scale(self, focal_pattern: FocalPattern, analysis_options: SolutionAnalysisOptions | None = None) -> None:
+        """Scale in place to the target pressure (plan/solution.py:313-338): host arrays are mutated
+        (the API contract) and the resident device copy is scaled by ``field_scale_k``."""
+        analysis = self.analyze(options=analysis_options)
+        apod_factors, v0, v1 = self.compute_scaling_factors(focal_pattern, analysis)
+        factors = v1 / v0 * apod_factors
+        res = self.simulation_result
+        for i in range(self.num_foci()):
+            res["p_min"][i].data *= factors[i]
+            res["p_max"][i].data *= factors[i]
+            res["intensity"][i].data *= factors[i] ** 2
+            self.apodizations[i] = self.apodizations[i] * apod_factors[i]
+        if self._resident is not None and self._resident[1] == self._resident[0].result_token:
+            self._resident[0].ctx.field_scale(factors)
+        self.voltage = v1
+
+    # ---- (de)serialisation: JSON part only (plan/solution.py:390-489) ------------------------------
+    def to_dict(self, include_simulation_data: bool = False) -> dict:
+        if include_simulation_data:
+            raise NotImplementedError("NetCDF embedding is outside the hot path")
+        return {"id": self.id, "name": self.name, "protocol_id": self.protocol_id,
+                "transducer": None if self.transducer is None else self.transducer.to_dict(),
+                "date_created": self.date_created.isoformat(), "description": self.description,
+                "delays": None if self.delays is None else self.delays.tolist(),
+                "apodizations": None if self.apodizations is None else self.apodizations.tolist(),
+                "pulse": self.pulse.to_dict(), "voltage": self.voltage, "sequence": self.sequence.to_dict(),
+                "foci": [p.to_dict() for p in self.foci],
+                "target": None if self.target is None else self.target.to_dict(), "approved": self.approved}
+
+    def to_json(self, include_simulation_data: bool = False, compact: bool = False) -> str:
+        d = self.to_dict(include_simulation_data)
+        return json.dumps(d, separators=(",", ":")) if compact else json.dumps(d, indent=4)
+
+    @staticmethod
+    def from_dict(solution_dict: dict) -> "Solution":
+        d = dict(solution_dict)
+        d["date_created"] = datetime.fromisoformat(d["date_created"])
+        if d.get("delays") is not None:
+            d["delays"] = np.array(d["delays"])
+        if d.get("apodizations") is not None:
+            d["apodizations"] = np.array(d["apodizations"], ndmin=2)
+        if d.get("transducer") is not None:
+            d["transducer"] = Transducer.from_dict(d["transducer"])
+        d["pulse"] = Pulse.from_dict(d["pulse"])
+        d["sequence"] = Sequence.from_dict(d["sequence"])
+        d["foci"] = [Point.from_dict(p) for p in d["foci"]]
+        if d.get("target") is not None:
+            d["target"] = Point.from_dict(d["target"])
+        return Solution(**d)
+
+    @staticmethod
+    def from_json(json_string: str, simulation_result=None) -> "Solution":
+        d = json.loads(json_string)
+        if simulation_result is not None:
+            d["simulation_result"] = simulation_result
+        return Solution.from_dict(d)

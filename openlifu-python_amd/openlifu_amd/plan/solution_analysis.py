@@ -1,0 +1,92 @@
+"""Focal-frame helpers and the device-side part of ``Solution.analyze``
+(mirror of plan/solution_analysis.py:232-442 as far as ``Solution.scale`` needs it).
+
+Implemented on the device (one HBM-bound scan per query, ``field_masked_peak_k``): the focal
+ellipsoid masks (``get_mask``) and the masked / global peaks that give ``mainlobe_pnp_MPa`` --
+the only analysis output ``compute_scaling_factors`` consumes (plan/solution.py:301-303) -- plus
+sidelobe and global peaks.  Beam widths and centroids (xarray interpolation in the reference) are
+not built yet: their fields stay empty.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Tuple
+
+import numpy as np
+
+from ..util.dict_conversion import DictMixin
+from ..util.units import getunittype
+
+DEFAULT_ORIGIN = np.zeros(3)
+
+
+def get_focus_matrix(focus, origin=(0, 0, 0)) -> np.ndarray:
+    """Focal frame -> grid coordinates (plan/solution_analysis.py:319-342): z axis along
+    origin->focus, x axis in the x-z plane, translation = focus."""
+    focus = np.asarray(focus, dtype=float)
+    origin = np.asarray(origin, dtype=float)
+    zvec = (focus - origin) / np.linalg.norm(focus - origin)
+    az = -np.arctan2(zvec[0], zvec[2])
+    xvec = np.array([np.cos(az), 0.0, np.sin(az)])
+    M = np.eye(4)
+    M[:3, 0] = xvec
+    M[:3, 1] = np.cross(zvec, xvec)
+    M[:3, 2] = zvec
+    M[:3, 3] = focus
+    return M
+
+
+@dataclass
+class SolutionAnalysisOptions(DictMixin):
+    standoff_sound_speed: float = 1500.0
+    standoff_density: float = 1000.0
+    ref_sound_speed: float = 1500.0
+    ref_density: float = 1000.0
+    mainlobe_aspect_ratio: Tuple[float, float, float] = (1.0, 1.0, 5.0)
+    mainlobe_radius: float = 2.5e-3
+    beamwidth_radius: float = 5e-3
+    sidelobe_radius: float = 3e-3
+    sidelobe_zmin: float = 1e-3
+    distance_units: str = "m"
+    param_constraints: Dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        for label, v in (("Standoff sound speed", self.standoff_sound_speed), ("Standoff density", self.standoff_density),
+                         ("Reference sound speed", self.ref_sound_speed), ("Reference density", self.ref_density)):
+            if v <= 0:
+                raise ValueError(f"{label} must be greater than 0")
+        if not isinstance(self.mainlobe_aspect_ratio, (tuple, list)) or len(self.mainlobe_aspect_ratio) != 3:
+            raise TypeError("Mainlobe aspect ratio must be a tuple or list of three floats (lat, ele, ax)")
+        self.mainlobe_aspect_ratio = tuple(self.mainlobe_aspect_ratio)
+        if not all(isinstance(x, (int, float)) for x in self.mainlobe_aspect_ratio):
+            raise TypeError("Mainlobe aspect ratio must contain only numbers")
+        for label, v, strict in (("Mainlobe radius", self.mainlobe_radius, True), ("Beamwidth radius", self.beamwidth_radius, True),
+                                 ("Sidelobe radius", self.sidelobe_radius, True), ("Sidelobe minimum z", self.sidelobe_zmin, False)):
+            if not isinstance(v, (int, float)) or (v <= 0 if strict else v < 0):
+                raise ValueError(f"{label} must be a {'positive' if strict else 'non-negative'} number")
+        if not isinstance(self.distance_units, str):
+            raise TypeError("Distance units must be a string")
+        if getunittype(self.distance_units) != "distance":
+            raise ValueError(f"Distance units must be a length unit, got {self.distance_units}")
+
+
+@dataclass
+class SolutionAnalysis(DictMixin):
+    """Per-focus result lists, same field names as the reference (plan/solution_analysis.py:48-112)."""
+    mainlobe_pnp_MPa: list = field(default_factory=list)
+    mainlobe_isppa_Wcm2: list = field(default_factory=list)
+    target_position_lat_mm: list = field(default_factory=list)
+    target_position_ele_mm: list = field(default_factory=list)
+    target_position_ax_mm: list = field(default_factory=list)
+    sidelobe_pnp_MPa: list = field(default_factory=list)
+    sidelobe_isppa_Wcm2: list = field(default_factory=list)
+    sidelobe_to_mainlobe_pressure_ratio: list = field(default_factory=list)
+    sidelobe_to_mainlobe_intensity_ratio: list = field(default_factory=list)
+    global_pnp_MPa: list = field(default_factory=list)
+    global_isppa_Wcm2: list = field(default_factory=list)
+    MI: float | None = None
+    voltage_V: float | None = None
+    duty_cycle_pulse_train_pct: float | None = None
+    duty_cycle_sequence_pct: float | None = None
+    sequence_duration_s: float | None = None
+    param_constraints: Dict = field(default_factory=dict)

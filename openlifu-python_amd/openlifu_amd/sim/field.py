@@ -1,0 +1,73 @@
+"""``run_simulation`` -- the drop-in for the reference's k-Wave adapter at the seam
+``openlifu.plan.protocol.run_simulation`` (sim/kwave_if.py:80-146, called from
+plan/protocol.py:324-336).
+
+Same signature, same output schema (Dataset{p_max [Pa], p_min [Pa], intensity [W/cm^2]} on
+``params.coords``), but the field is the steady-state monochromatic point-source superposition
+accumulated by HIP kernel 2 (definition: DESIGN.md section 3, oracle/field_oracle.py), not a
+time-domain k-space solve.  ``cycles/dt/t_end/cfl/bli_tolerance/upsampling_rate`` are accepted
+and ignored; ``gpu`` is accepted and ignored -- there is no CPU path and a missing MI355X raises.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from ..engine import get_engine, grid_from_coords
+from ..util import dataset as ds
+
+_ATTRS = {"p_max": {"units": "Pa", "long_name": "PPP"}, "p_min": {"units": "Pa", "long_name": "PNP"},
+          "intensity": {"units": "W/cm^2", "long_name": "Intensity"}}
+
+
+def _medium(params):
+    c = float(params["sound_speed"].attrs["ref_value"])
+    rho = float(params["density"].attrs["ref_value"])
+    for key, ref in (("sound_speed", c), ("density", rho)):
+        vol = np.asarray(params[key].data)
+        if vol.size and (vol.min() != ref or vol.max() != ref):
+            logging.warning(f"run_simulation: {key} volume is not uniform; the MI355X field kernel uses the "
+                            f"reference value {ref} (heterogeneous propagation is not implemented yet)")
+    return c, rho
+
+
+def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
+                  steering_resident=False, slab=None):
+    """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz]."""
+    coords = params.coords
+    origin, spacing, n = grid_from_coords(coords)
+    c, rho = _medium(params)
+    p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
+    return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
+                              slab=slab, steering_resident=steering_resident)
+
+
+def dataset_from_fields(fields, coords, focus=None):
+    """Schema of kwave_if.py:131-145.  p_max and p_min are separate, writable arrays (callers scale
+    them independently, plan/solution.py:333-334)."""
+    dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
+    sel = (lambda a: a) if focus is None else (lambda a: a[focus])
+    pm = sel(fields["pmag"])
+    out = {"p_max": ds.make_dataarray(pm, coords=coords, dims=dims, name="p_max", attrs=_ATTRS["p_max"]),
+           "p_min": ds.make_dataarray(pm.copy(), coords=coords, dims=dims, name="p_min", attrs=_ATTRS["p_min"]),
+           "intensity": ds.make_dataarray(sel(fields["intensity"]), coords=coords, dims=dims, name="I",
+                                          attrs=_ATTRS["intensity"])}
+    return ds.make_dataset(out)
+
+
+def run_simulation(arr, params, delays=None, apod=None, freq: float = 1e6, cycles: float = 20,
+                   amplitude: float = 1, dt: float = 0, t_end: float = 0, cfl: float = 0.5,
+                   bli_tolerance: float = 0.05, upsampling_rate: int = 5, gpu: bool = True,
+                   ref_values_only: bool = False):
+    n = arr.numelements()
+    delays = np.zeros(n) if delays is None else np.asarray(delays, dtype=np.float64)
+    apod = np.ones(n) if apod is None else np.asarray(apod, dtype=np.float64)
+    if delays.shape != (n,) or apod.shape != (n,):
+        raise ValueError(f"delays and apod must have shape ({n},), got {delays.shape} and {apod.shape}")
+    logging.info("Running simulation")
+    fields = simulate_foci(arr, params, delays[None, :], apod[None, :], freq, amplitude)
+    logging.info("Simulation Complete")
+    dataset = dataset_from_fields(fields, params.coords, focus=0)
+    raw = {"p_max": fields["pmag"][0], "p_min": -fields["pmag"][0], "backend": "openlifu_amd/hip-gfx950"}
+    return dataset, raw

@@ -1,0 +1,295 @@
+"""Labelled-array containers for the hot path's inputs and outputs.
+
+The reference passes ``xarray`` objects across the seams this package plugs into
+(``params`` Dataset in, ``Dataset{p_max, p_min, intensity}`` out,
+sim/kwave_if.py:131-146; plan/protocol.py:341-347).  xarray is not part of this
+image, so a minimal stand-in with the attribute surface those call sites use is
+provided; when xarray is importable (and ``OPENLIFU_AMD_USE_XARRAY`` is not "0")
+the factory functions return real xarray objects instead.
+
+Only what the path touches is implemented: ``.data .dims .coords .attrs .sizes
+.shape``, name lookup, integer indexing that returns WRITABLE VIEWS (Solution.scale
+multiplies ``simulation_result['p_min'][i].data`` in place, plan/solution.py:332-337),
+``max/mean(dim=...)``, ``isel``, ``assign_coords``, ``drop_dims``, ``copy``.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+try:  # pragma: no cover - xarray is absent in the build image
+    if os.environ.get("OPENLIFU_AMD_USE_XARRAY", "1") == "0":
+        raise ImportError
+    import xarray as _xa
+    HAVE_XARRAY = True
+except ImportError:
+    _xa = None
+    HAVE_XARRAY = False
+
+
+class DataArray:
+    def __init__(self, data, coords=None, dims=None, name=None, attrs=None):
+        self.data = np.asarray(data)
+        if dims is None:
+            dims = tuple(coords.keys())[: self.data.ndim] if coords is not None else tuple(
+                f"dim_{i}" for i in range(self.data.ndim))
+        self.dims = tuple(dims)
+        if len(self.dims) != self.data.ndim:
+            raise ValueError(f"dims {self.dims} do not match data of rank {self.data.ndim}")
+        self.coords = OrderedDict()
+        if coords is not None:
+            for k, v in coords.items():
+                self.coords[k] = v if isinstance(v, DataArray) else DataArray(np.asarray(v), dims=(k,), name=k)
+        self.name = name
+        self.attrs = dict(attrs) if attrs else {}
+
+    # numpy-ish surface
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def values(self):
+        return self.data
+
+    @property
+    def sizes(self):
+        return OrderedDict(zip(self.dims, self.data.shape))
+
+    @property
+    def ndim(self):
+        return self.data.ndim
+
+    @property
+    def size(self):
+        return self.data.size
+
+    def __len__(self):
+        return len(self.data)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.data, dtype=dtype)
+
+    def __iter__(self):
+        return iter(self.data)
+
+    def __float__(self):
+        return float(self.data)
+
+    def item(self):
+        return self.data.item()
+
+    def to_numpy(self):
+        return self.data
+
+    def __getitem__(self, key):
+        """Positional indexing along the leading axes; returns a VIEW-backed DataArray."""
+        if isinstance(key, str):
+            return self.coords[key]
+        sub = self.data[key]
+        keys = key if isinstance(key, tuple) else (key,)
+        dims = []
+        for i, d in enumerate(self.dims):
+            if i < len(keys) and isinstance(keys[i], (int, np.integer)):
+                continue
+            dims.append(d)
+        coords = OrderedDict()
+        for i, d in enumerate(self.dims):
+            if d in self.coords and d in dims:
+                c = self.coords[d]
+                coords[d] = DataArray(c.data[keys[i]] if i < len(keys) else c.data, dims=(d,), name=d, attrs=c.attrs)
+        return DataArray(sub, coords=coords, dims=tuple(dims), name=self.name, attrs=self.attrs)
+
+    def isel(self, **indexers):
+        key = tuple(indexers.get(d, slice(None)) for d in self.dims)
+        return self[key]
+
+    def _reduce(self, fn, dim, keep_attrs):
+        if dim is None:
+            return DataArray(fn(self.data), dims=(), name=self.name, attrs=self.attrs if keep_attrs else None)
+        ax = self.dims.index(dim)
+        dims = tuple(d for d in self.dims if d != dim)
+        coords = OrderedDict((k, v) for k, v in self.coords.items() if k != dim)
+        return DataArray(fn(self.data, axis=ax), coords=coords, dims=dims, name=self.name,
+                         attrs=self.attrs if keep_attrs else None)
+
+    def max(self, dim=None, keep_attrs=False):
+        return self._reduce(np.max, dim, keep_attrs)
+
+    def min(self, dim=None, keep_attrs=False):
+        return self._reduce(np.min, dim, keep_attrs)
+
+    def mean(self, dim=None, keep_attrs=False):
+        return self._reduce(np.mean, dim, keep_attrs)
+
+    def copy(self, deep=True):
+        return DataArray(self.data.copy() if deep else self.data,
+                         coords=OrderedDict((k, v if k == self.name and v is self else
+                                             DataArray(v.data.copy() if deep else v.data, dims=v.dims, name=v.name, attrs=v.attrs))
+                                            for k, v in self.coords.items()),
+                         dims=self.dims, name=self.name, attrs=dict(self.attrs))
+
+    def assign_coords(self, **kw):
+        out = self.copy(deep=False)
+        for k, v in kw.items():
+            out.coords[k] = DataArray(np.asarray(v), dims=() if np.ndim(v) == 0 else (k,), name=k)
+        return out
+
+    def __repr__(self):
+        return f"<openlifu_amd.DataArray {self.name!r} dims={self.dims} shape={self.shape} attrs={list(self.attrs)}>"
+
+
+class Coordinates(OrderedDict):
+    """Mapping dim -> 1-D coordinate DataArray (stand-in for xarray.Coordinates)."""
+
+    def __init__(self, coords=None):
+        super().__init__()
+        for k, v in (coords or {}).items():
+            self[k] = v if isinstance(v, DataArray) else DataArray(np.asarray(v), dims=(k,), name=k)
+
+    @property
+    def dims(self):
+        return tuple(k for k, v in self.items() if v.ndim == 1)
+
+    @property
+    def sizes(self):
+        return OrderedDict((k, v.shape[0]) for k, v in self.items() if v.ndim == 1)
+
+
+class Dataset:
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        self.data_vars = OrderedDict()
+        self.coords = Coordinates(coords)
+        self.attrs = dict(attrs) if attrs else {}
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    def __setitem__(self, name, da):
+        if not isinstance(da, DataArray):
+            raise TypeError("Dataset values must be DataArray")
+        da.name = name
+        for k, c in da.coords.items():
+            if k not in self.coords:
+                self.coords[k] = c
+        self.data_vars[name] = da
+
+    def __getitem__(self, name):
+        if name in self.data_vars:
+            return self.data_vars[name]
+        return self.coords[name]
+
+    def __contains__(self, name):
+        return name in self.data_vars or name in self.coords
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def keys(self):
+        return self.data_vars.keys()
+
+    def values(self):
+        return self.data_vars.values()
+
+    def items(self):
+        return self.data_vars.items()
+
+    def __len__(self):
+        return len(self.data_vars)
+
+    @property
+    def dims(self):
+        seen = []
+        for da in self.data_vars.values():
+            for d in da.dims:
+                if d not in seen:
+                    seen.append(d)
+        if not seen:
+            seen = list(self.coords.dims)
+        return tuple(seen)
+
+    @property
+    def sizes(self):
+        out = OrderedDict()
+        for da in self.data_vars.values():
+            out.update(da.sizes)
+        if not out:
+            out.update(self.coords.sizes)
+        return out
+
+    def isel(self, **indexers):
+        return Dataset({k: v.isel(**{d: i for d, i in indexers.items() if d in v.dims}) for k, v in self.items()},
+                       attrs=self.attrs)
+
+    def assign_coords(self, **kw):
+        out = Dataset({k: v for k, v in self.items()}, coords=self.coords, attrs=self.attrs)
+        for k, v in kw.items():
+            out.coords[k] = DataArray(np.asarray(v), dims=() if np.ndim(v) == 0 else (k,), name=k)
+        return out
+
+    def drop_dims(self, dim):
+        keep = OrderedDict((k, v) for k, v in self.items() if dim not in v.dims)
+        coords = OrderedDict((k, v) for k, v in self.coords.items() if k != dim)
+        return Dataset(keep, coords=coords, attrs=self.attrs)
+
+    def copy(self, deep=True):
+        return Dataset({k: v.copy(deep=deep) for k, v in self.items()}, coords=self.coords, attrs=self.attrs)
+
+    def __repr__(self):
+        return f"<openlifu_amd.Dataset vars={list(self.data_vars)} dims={dict(self.sizes)}>"
+
+
+# ---- factories: real xarray when present, the stand-in otherwise -------------------------------
+def make_coords(vectors: dict, attrs: dict):
+    """vectors: dim -> 1-D values; attrs: dim -> attrs dict (units, long_name)."""
+    if HAVE_XARRAY:  # pragma: no cover
+        c = _xa.Coordinates({d: np.asarray(v) for d, v in vectors.items()})
+        for d in vectors:
+            c[d].attrs.update(attrs.get(d, {}))
+        return c
+    return Coordinates({d: DataArray(np.asarray(v), dims=(d,), name=d, attrs=attrs.get(d, {}))
+                        for d, v in vectors.items()})
+
+
+def make_dataarray(data, coords, dims=None, name=None, attrs=None):
+    if HAVE_XARRAY:  # pragma: no cover
+        return _xa.DataArray(data, coords=coords, dims=dims, name=name, attrs=attrs)
+    dims = tuple(dims) if dims is not None else tuple(coords.dims if hasattr(coords, "dims") else coords.keys())
+    return DataArray(data, coords=OrderedDict((d, coords[d]) for d in dims if d in coords), dims=dims,
+                     name=name, attrs=attrs)
+
+
+def make_dataset(data_vars=None, attrs=None):
+    if HAVE_XARRAY:  # pragma: no cover
+        return _xa.Dataset(data_vars or {}, attrs=attrs)
+    return Dataset(data_vars or {}, attrs=attrs)
+
+
+def stack_foci(datasets, dim="focal_point_index"):
+    """plan/protocol.py:341-347: concat per-focus Datasets along a new leading dim.
+
+    ``datasets`` may also be a dict name -> (stacked ndarray [F,...], coords, attrs) built
+    directly from one batched device result (no per-focus copies)."""
+    if HAVE_XARRAY and not isinstance(datasets, dict):  # pragma: no cover
+        return _xa.concat([d.assign_coords(**{dim: i}) for i, d in enumerate(datasets)], dim=dim)
+    if isinstance(datasets, dict):
+        out = {}
+        for name, (arr, coords, attrs) in datasets.items():
+            c = OrderedDict([(dim, np.arange(arr.shape[0]))])
+            c.update(coords)
+            da_dims = (dim,) + tuple(coords.dims if hasattr(coords, "dims") else coords.keys())
+            if HAVE_XARRAY:  # pragma: no cover
+                out[name] = _xa.DataArray(arr, coords=c, dims=da_dims, name=name, attrs=attrs)
+            else:
+                out[name] = DataArray(arr, coords=c, dims=da_dims, name=name, attrs=attrs)
+        return make_dataset(out)
+    first = datasets[0]
+    out = {}
+    for name in first.keys():
+        arr = np.stack([np.asarray(d[name].data) for d in datasets], axis=0)
+        c = OrderedDict([(dim, np.arange(len(datasets)))])
+        c.update(first[name].coords)
+        out[name] = DataArray(arr, coords=c, dims=(dim,) + tuple(first[name].dims), name=name,
+                              attrs=first[name].attrs)
+    return Dataset(out)

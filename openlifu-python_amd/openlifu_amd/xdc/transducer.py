@@ -1,0 +1,294 @@
+"""Transducer = ordered list of Elements + frequency / units / sensitivity
+(mirror of openlifu.xdc.transducer, xdc/transducer.py:20-496; vtk drawing is out of
+scope).  ``element_table`` is the bridge to the device: it flattens the AoS element
+list into the SoA arrays ``olx_set_elements`` uploads (include/olx.h).
+"""
+from __future__ import annotations
+
+import copy
+import json
+import logging
+from dataclasses import dataclass, field
+from typing import Any, Dict, List
+
+import numpy as np
+
+from ..util.units import getunitconversion
+from .element import Element, rotation_from_angles
+
+DIMS = ["x", "y", "z"]
+
+
+def _axis_rotation(dim: str, angle_rad: float) -> np.ndarray:
+    m = np.eye(4)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[dim]
+    c, s = np.cos(angle_rad), np.sin(angle_rad)
+    m[i, i] = c; m[i, j] = -s; m[j, i] = s; m[j, j] = c
+    return m
+
+
+@dataclass
+class Transducer:
+    id: str = "transducer"
+    name: str = ""
+    elements: List[Element] = field(default_factory=list)
+    frequency: float = 400.6e3
+    units: str = "m"
+    attrs: Dict[str, Any] = field(default_factory=dict)
+    registration_surface_filename: str | None = None
+    transducer_body_filename: str | None = None
+    standoff_transform: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=float))
+    sensitivity: float | None = None
+    impulse_response: np.ndarray | None = None
+    impulse_dt: float | None = None
+    module_invert: List[bool] = field(default_factory=lambda: [False])
+
+    def __post_init__(self):
+        logging.info("Initializing transducer array")
+        if self.name == "":
+            self.name = self.id
+        for el in self.elements:
+            el.rescale(self.units)
+        if self.impulse_response is not None:
+            self.impulse_response = np.array(self.impulse_response, dtype=np.float64)
+            if self.impulse_response.ndim != 1 or len(self.impulse_response) < 2:
+                raise ValueError("Impulse response must be a 1-dimensional array.")
+            if self.impulse_dt is None:
+                raise ValueError("Impulse response timestep must be set if impulse response is set.")
+
+    # ---- SoA bridge to the device --------------------------------------------------------
+    def element_table(self):
+        """(pos_m[N,3], normal[N,3], area_m2[N], index[N], pin[N]) in ``elements`` order.
+
+        pos_m   = Element.get_position(units="m")            (xdc/element.py:166-172)
+        normal  = column 2 of Element.get_matrix()           (xdc/element.py:200-214)
+        area_m2 = Element.get_area("m")                      (xdc/element.py:181-184)
+        """
+        n = len(self.elements)
+        pos = np.empty((n, 3)); ori = np.empty((n, 3)); area = np.empty(n)
+        for i, el in enumerate(self.elements):
+            s = getunitconversion(el.units, "m")
+            pos[i] = el.position * s
+            ori[i] = el.orientation
+            area[i] = (el.size[0] * s) * (el.size[1] * s)
+        normal = rotation_from_angles(ori[:, 0], ori[:, 1], ori[:, 2])[:, :, 2] if n else np.empty((0, 3))
+        index = np.array([el.index for el in self.elements], dtype=np.int32)
+        pin = np.array([el.pin for el in self.elements], dtype=np.int32)
+        return pos, np.ascontiguousarray(normal), area, index, pin
+
+    def table_key(self):
+        """Cheap fingerprint used by the engine to avoid re-uploading an unchanged table."""
+        pos, nrm, area, _, _ = self.element_table()
+        return hash((pos.tobytes(), nrm.tobytes(), area.tobytes()))
+
+    # ---- reference API --------------------------------------------------------------------
+    def numelements(self):
+        return len(self.elements)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def calc_output(self, input_signal, dt, delays: np.ndarray = None, apod: np.ndarray = None):
+        """Per-element drive signal [N, T] (xdc/transducer.py:95-112): ``a_e * sensitivity * signal``
+        preceded by ``int(delay/dt)`` zeros.  Like the reference, ``input_signal`` is scaled IN PLACE
+        by ``sensitivity`` when no impulse response is set (transducer.py:100-106)."""
+        n = self.numelements()
+        delays = np.zeros(n) if delays is None else delays
+        apod = np.ones(n) if apod is None else apod
+        if self.impulse_response is not None:
+            raise NotImplementedError("array impulse responses are outside the hot path")
+        sig = input_signal
+        if self.sensitivity is not None:
+            sig *= self.sensitivity
+        outs = [np.concatenate([np.zeros(int(d / dt)), a * el.calc_output(sig, dt)])
+                for el, d, a in zip(self.elements, delays, apod)]
+        out = np.zeros((n, max(len(o) for o in outs)))
+        for i, o in enumerate(outs):
+            out[i, :len(o)] = o
+        return out
+
+    def get_area(self, units=None):
+        units = self.units if units is None else units
+        return sum(el.get_area(units) for el in self.elements)
+
+    def get_corners(self, transform=None, units=None):
+        units = self.units if units is None else units
+        return [el.get_corners(units=units, matrix=transform) for el in self.elements]
+
+    def get_positions(self, transform: np.ndarray | None = None, units: str | None = None):
+        units = self.units if units is None else units
+        return np.array([el.get_position(units=units, matrix=transform) for el in self.elements])
+
+    def get_effective_origin(self, apodizations: np.ndarray, units: str | None = None):
+        """Apodization-weighted centroid of the active aperture (xdc/transducer.py:191-201)."""
+        units = self.units if units is None else units
+        apodizations = np.asarray(apodizations)
+        return (apodizations.reshape(-1, 1) * self.get_positions(units=units)).sum(axis=0) / apodizations.sum()
+
+    def convert_transform(self, matrix: np.ndarray, units: str) -> np.ndarray:
+        matrix = np.array(matrix, dtype=float)
+        matrix[0:3, 3] *= getunitconversion(units, self.units)
+        return matrix
+
+    def get_standoff_transform_in_units(self, units: str) -> np.ndarray:
+        matrix = self.standoff_transform.copy()
+        matrix[0:3, 3] *= getunitconversion(self.units, units)
+        return matrix
+
+    @staticmethod
+    def merge(list_of_transducers, offset_pins: bool = False, offset_indices: bool = False,
+              merge_mismatched_sensitivity=True, merged_attrs: dict | None = None) -> "Transducer":
+        """Concatenate element lists (xdc/transducer.py:229-260); pins / indices optionally offset by
+        the running element count; mismatched sensitivities folded into per-element factors."""
+        arrays = [a.copy() for a in list_of_transducers]
+        sens = np.array([a.sensitivity for a in arrays if a.sensitivity is not None])
+        if 0 < len(sens) < len(arrays):
+            raise ValueError("If one transducer has a sensitivity, all must have a sensitivity.")
+        if len(set(sens)) > 1:
+            if not merge_mismatched_sensitivity:
+                raise ValueError("Transducers have different sensitivities. Use merge_mismatched_sensitivity=True "
+                                 "to merge the relative sensitivities into the merged elements")
+            smax = sens.max()
+            for a, rel in zip(arrays, sens / smax):
+                for el in a.elements:
+                    el.sensitivity = rel if el.sensitivity is None else el.sensitivity * rel
+                a.sensitivity = smax
+        merged = arrays[0]
+        for a in arrays[1:]:
+            n0 = merged.numelements()
+            for el in a.elements:
+                if offset_pins:
+                    el.pin += n0
+                if offset_indices:
+                    el.index += n0
+            merged.elements += a.elements
+            merged.module_invert += a.module_invert
+        for k, v in (merged_attrs or {}).items():
+            setattr(merged, k, v)
+        return merged
+
+    def rescale(self, units):
+        if self.units != units:
+            for el in self.elements:
+                el.rescale(units)
+            self.units = units
+
+    def sort_by_index(self):
+        self.elements = [self.elements[i] for i in np.argsort([el.index for el in self.elements])]
+
+    def sort_by_pin(self):
+        self.elements = [self.elements[i] for i in np.argsort([el.pin for el in self.elements])]
+
+    def transform(self, matrix, units=None):
+        """pose_e <- inv(M) . pose_e (xdc/transducer.py:297-301)."""
+        if units is not None:
+            self.rescale(units)
+        inv = np.linalg.inv(matrix)
+        for el in self.elements:
+            el.set_matrix(inv @ el.get_matrix())
+
+    def translate(self, dim, amount: float, units=None):
+        if units is not None:
+            self.rescale(units)
+        m = np.eye(4)
+        m[DIMS.index(dim), 3] = amount
+        self.transform(m, units=units)
+
+    def rotate(self, dim, angle: float, units="deg"):
+        self.transform(_axis_rotation(dim, np.deg2rad(angle) if units == "deg" else angle))
+
+    # ---- (de)serialisation -------------------------------------------------------------------
+    def to_dict(self):
+        d = self.__dict__.copy()
+        d["elements"] = [el.to_dict() for el in d["elements"]]
+        if self.impulse_response is None:
+            del d["impulse_response"]
+        else:
+            d["impulse_response"] = d["impulse_response"].tolist()
+        if self.impulse_dt is None:
+            del d["impulse_dt"]
+        d["standoff_transform"] = d["standoff_transform"].tolist()
+        return d
+
+    @staticmethod
+    def from_dict(d, **kwargs):
+        d = d.copy()
+        d["elements"] = [Element.from_dict(e) for e in d["elements"]]
+        if d.get("impulse_response") is not None:
+            if len(d["impulse_response"]) == 1 and "sensitivity" not in d:
+                d["sensitivity"] = d["impulse_response"][0]
+                del d["impulse_response"]
+            else:
+                d["impulse_response"] = np.array(d["impulse_response"])
+        if d.get("standoff_transform") is not None:
+            d["standoff_transform"] = np.array(d["standoff_transform"])
+        return Transducer(**d, **kwargs)
+
+    @staticmethod
+    def from_file(filename):
+        with open(filename) as f:
+            return Transducer.from_dict(json.load(f))
+
+    @staticmethod
+    def from_json(json_string: str) -> "Transducer":
+        return Transducer.from_dict(json.loads(json_string))
+
+    def to_json(self, compact: bool = False) -> str:
+        return json.dumps(self.to_dict(), separators=(",", ":")) if compact else json.dumps(self.to_dict(), indent=4)
+
+    def to_file(self, filename):
+        with open(filename, "w") as f:
+            f.write(self.to_json())
+
+    @staticmethod
+    def gen_matrix_array(nx=2, ny=2, pitch=1, kerf=0, units="mm", **kwargs):
+        """Flat nx x ny matrix array (xdc/transducer.py:372-406).  Element i sits at
+        x = xpos[i // ny], y = ypos[i % ny] with y DESCENDING; index = pin = i + 1."""
+        xpos = (np.arange(nx) - (nx - 1) / 2) * pitch
+        ypos = -(np.arange(ny) - (ny - 1) / 2) * pitch
+        elements = [Element(index=i + 1, pin=i + 1, position=np.array([xpos[i // ny], ypos[i % ny], 0]),
+                            orientation=np.array([0, 0, 0]), size=np.array([pitch - kerf, pitch - kerf]),
+                            units=units) for i in range(nx * ny)]
+        return Transducer(elements=elements, units=units, **kwargs)
+
+
+@dataclass
+class TransformedTransducer(Transducer):
+    """A Transducer plus a module placement transform (xdc/transducer.py:408-496)."""
+    transform: np.ndarray = field(default_factory=lambda: np.eye(4))
+
+    def bake(self) -> Transducer:
+        d = self.to_dict()
+        d.pop("transform")
+        t = Transducer.from_dict(d)
+        t.transform(self.transform, units=self.units)
+        return t
+
+    def translate_global(self, dim, amount, units=None):
+        m = np.eye(4); m[DIMS.index(dim), 3] = amount
+        self.transform = self.transform @ np.linalg.inv(m)
+
+    def translate_local(self, dim, amount, units=None):
+        m = np.eye(4); m[DIMS.index(dim), 3] = amount
+        self.transform = np.linalg.inv(m) @ self.transform
+
+    def rotate_global(self, dim, angle: float, units="deg"):
+        self.transform = self.transform @ _axis_rotation(dim, np.deg2rad(angle) if units == "deg" else angle)
+
+    def rotate_local(self, dim, angle: float, units="deg"):
+        self.transform = _axis_rotation(dim, np.deg2rad(angle) if units == "deg" else angle) @ self.transform
+
+    def to_dict(self):
+        d = Transducer.to_dict(self)
+        d["transform"] = np.asarray(self.transform).tolist()
+        return d
+
+    @staticmethod
+    def from_dict(data, **kwargs):
+        d = data.copy()
+        transform = np.array(d.pop("transform"))
+        return TransformedTransducer.from_transducer(Transducer.from_dict(d, **kwargs), transform)
+
+    @staticmethod
+    def from_transducer(t: Transducer, transform: np.ndarray) -> "TransformedTransducer":
+        return TransformedTransducer(**t.__dict__, transform=np.array(transform))

@@ -1,0 +1,75 @@
+"""ctypes loader for oracle/field_oracle.c (TEST INFRASTRUCTURE ONLY, see
+oracle/__init__.py).  Same definition as field_oracle.py, all host cores."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libfield_oracle.so")
+_lib = None
+
+
+def build() -> str:
+    src = os.path.join(_HERE, "field_oracle.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.olo_field_grid.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int,
+                                        dp, dp, dp, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_points.argtypes = [dp, ctypes.c_long, dp, dp, dp, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa):
+    pos = np.ascontiguousarray(pos_m, dtype=np.float64)
+    w = np.ascontiguousarray(np.asarray(apod, dtype=np.float64) * p0_pa
+                             * np.asarray(area_m2, dtype=np.float64) / (c / freq))
+    phi = np.ascontiguousarray(2 * np.pi * freq * np.asarray(delays_s, dtype=np.float64))
+    return pos, w, phi, 2 * np.pi * freq / c
+
+
+def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0,
+                  dmin=None, nthreads=0):
+    xs = np.ascontiguousarray(xs_m, dtype=np.float64)
+    ys = np.ascontiguousarray(ys_m, dtype=np.float64)
+    zs = np.ascontiguousarray(zs_m, dtype=np.float64)
+    if dmin is None:
+        dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
+    pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+    re = np.empty((len(xs), len(ys), len(zs))); im = np.empty_like(re)
+    lib().olo_field_grid(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(pos), _p(w),
+                         _p(phi), len(w), k, dmin, nthreads, _p(re), _p(im))
+    return re + 1j * im
+
+
+def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0, dmin=0.0,
+                    nthreads=0):
+    pts = np.ascontiguousarray(np.atleast_2d(points_m), dtype=np.float64)
+    pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+    re = np.empty(pts.shape[0]); im = np.empty_like(re)
+    lib().olo_field_points(_p(pts), pts.shape[0], _p(pos), _p(w), _p(phi), len(w), k, dmin,
+                           nthreads, _p(re), _p(im))
+    return re + 1j * im
+
+
+def max_threads() -> int:
+    return int(lib().olo_max_threads())

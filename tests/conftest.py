@@ -1,0 +1,85 @@
+"""Shared test plumbing.  `-m "not gpu"` runs here on CPU (oracle vs goldens, host logic, ABI
+symbols, gloo world_size-2); `-m gpu` runs on an MI355X and calls the HIP path through the C-ABI."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "openlifu-python_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        from openlifu_amd import _native
+        return _native.device_count() > 0
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The HIP extension and the C oracle must exist before any test imports them."""
+    import __graft_entry__ as g
+    g.build()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    class G:
+        def npz(self, name):
+            return np.load(os.path.join(GOLDEN, name))
+
+        def json(self, name):
+            with open(os.path.join(GOLDEN, name)) as f:
+                return json.load(f)
+    return G()
+
+
+@pytest.fixture()
+def ctx():
+    from openlifu_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def synthetic_array(nx, ny, pitch, jitter=False, seed=147):
+    """positions[mm], orientation[rad], size[mm] of the SURVEY 8(d) synthetic arrays."""
+    from oracle import bf_oracle as bo
+    pos, size, _ = bo.gen_matrix_array(nx, ny, pitch, 0.1 * pitch)
+    ori = np.zeros_like(pos)
+    if jitter:
+        rng = np.random.default_rng(seed)
+        pos = pos + rng.uniform(-0.1, 0.1, pos.shape)
+        ori = np.deg2rad(rng.uniform(-5, 5, pos.shape))
+    return pos, ori, size
+
+
+def centred_grid(n, spacing_mm, z0_mm=5.0):
+    """cubic grid, x,y centred on 0, z from z0; returns coordinate vectors in metres."""
+    xs = (np.arange(n) - (n - 1) / 2) * spacing_mm * 1e-3
+    zs = (z0_mm + np.arange(n) * spacing_mm) * 1e-3
+    return xs, xs.copy(), zs

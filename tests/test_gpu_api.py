@@ -1,0 +1,117 @@
+"""The drop-in boundary on a GPU: run_simulation / Protocol.beamform / Protocol.calc_solution with the
+reference's call patterns (tests/test_sim.py:18-60, plan/protocol.py:242-398), checked vs the oracle."""
+import numpy as np
+import pytest
+
+import openlifu_amd as ol
+from oracle import bf_oracle as bo, c_oracle as co, field_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_simulation_like_the_reference_test():
+    """Mirror of the reference's tests/test_sim.py:18-60 (2x2 array, 21x21x13 grid) plus values."""
+    transducer = ol.Transducer.gen_matrix_array(nx=2, ny=2, pitch=2, kerf=.5, units="mm", sensitivity=1e5)
+    dt = 2e-7
+    sim_setup = ol.SimSetup(dt=dt, t_end=3 * dt, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(-2, 10))
+    pulse = ol.Pulse(frequency=400e3, duration=1 / 400e3)
+    protocol = ol.Protocol(pulse=pulse, sequence=ol.Sequence(), sim_setup=sim_setup)
+    coords = sim_setup.get_coords()
+    params = protocol.seg_method.ref_params(coords)
+    delays, apod = protocol.beamform(arr=transducer, target=ol.Point(position=(0, 0, 50)), params=params)
+    delays[:] = 0.0
+    apod[:] = 1.0
+    dataset, _ = ol.sim.run_simulation(arr=transducer, params=params, delays=delays, apod=apod, freq=pulse.frequency,
+                                       cycles=1, dt=protocol.sim_setup.dt, t_end=protocol.sim_setup.t_end,
+                                       amplitude=1, gpu=False)
+    assert "p_max" in dataset and "p_min" in dataset and "intensity" in dataset
+    assert dataset["p_min"].data.shape == (21, 21, 13) and dataset["p_max"].attrs == {"units": "Pa", "long_name": "PPP"}
+    assert dataset["intensity"].attrs["units"] == "W/cm^2" and list(dataset["p_min"].dims) == ["x", "y", "z"]
+    pos_m, _, area, _, _ = transducer.element_table()
+    xs, ys, zs = (np.asarray(coords[d].data) * 1e-3 for d in "xyz")
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, np.zeros(4), np.ones(4), 400e3, 1500.0, 1e5))
+    assert np.abs(dataset["p_min"].data - ref).max() / ref.max() <= 1e-5
+    assert np.abs(dataset["intensity"].data - fo.intensity_wcm2(ref, 1000.0, 1500.0)).max() <= 2e-5 * fo.intensity_wcm2(ref.max(), 1000.0, 1500.0)
+    dataset["p_min"].data *= 2.0  # caller-owned, writable, independent of p_max
+    assert np.abs(dataset["p_max"].data - ref).max() / ref.max() <= 1e-5
+    d2, _ = ol.sim.run_simulation(arr=transducer, params=params, freq=400e3)  # delays/apod None -> zeros/ones
+    assert np.array_equal(d2["p_max"].data, dataset["p_max"].data)
+
+
+def test_run_simulation_mixed_units_raises():
+    from openlifu_amd.util import dataset as ds
+    t = ol.Transducer.gen_matrix_array(2, 2, 2.0, 0.5)
+    coords = ds.make_coords({"x": np.arange(3.), "y": np.arange(3.), "z": np.arange(3.)},
+                            {"x": {"units": "mm"}, "y": {"units": "mm"}, "z": {"units": "m"}})
+    params = ol.seg_methods.UniformWater().ref_params(coords)
+    with pytest.raises(ValueError, match="same units"):
+        ol.sim.run_simulation(t, params)
+    with pytest.raises(ValueError, match="shape"):
+        ol.sim.run_simulation(t, ol.SimSetup(spacing=5.0).setup_sim_scene(ol.seg_methods.UniformWater()), delays=np.zeros(3))
+
+
+def _oracle_solution(arr, foci, xs, ys, zs, f0, apod, p0):
+    pos_m, _, area, _, _ = arr.element_table()
+    out = []
+    for f in foci:
+        d, a = bo.beamform(pos_m, np.zeros_like(pos_m), f.get_position(units="m"), 1500.0, apod=apod)
+        out.append((d, a, np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d, a, f0, 1500.0, p0))))
+    return out
+
+
+def test_calc_solution_wheel_scale_and_aggregate():
+    arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-20, 20), y_extent=(-20, 20), z_extent=(5, 60))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, amplitude=0.8, duration=2e-5),
+                        sequence=ol.Sequence(pulse_count=10, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=4, spoke_radius=4.0,
+                                                              target_pressure=1.2, units="MPa"),
+                        sim_setup=setup, apod_method=ol.apod_methods.MaxAngle(max_angle=30.0))
+    target = ol.Point(position=(0, 0, 40), units="mm", id="t")
+    sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=False, voltage=2.0)
+    xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
+    ref = _oracle_solution(arr, sol.foci, xs, ys, zs, 400e3, ("maxangle", 30.0, 0.0), 0.8 * 2.0 * 1e5)
+    assert sol.delays.shape == (5, 256) and sol.num_foci() == 5 and sol.foci[0].id == "t (Center)"
+    res = sol.simulation_result
+    assert res["p_min"].dims == ("focal_point_index", "x", "y", "z") and res["p_min"].data.shape == (5, 41, 41, 56)
+    for i, (d, a, p) in enumerate(ref):
+        assert np.abs(sol.delays[i] - d).max() <= 1e-12 * d.max() and np.array_equal(sol.apodizations[i], a)
+        assert np.abs(res["p_min"].data[i] - p).max() / p.max() <= 1e-5
+        assert np.abs(res["intensity"].data[i] - fo.intensity_wcm2(p, 1000, 1500)).max() / fo.intensity_wcm2(p.max(), 1000, 1500) <= 2e-5
+    stack = np.stack([r[2] for r in ref])
+    assert np.abs(agg["p_min"].data - stack.max(axis=0)).max() / stack.max() <= 1e-5
+    assert np.abs(agg["intensity"].data - fo.intensity_wcm2(stack, 1000, 1500).mean(axis=0)).max() <= 2e-5 * fo.intensity_wcm2(stack.max(), 1000, 1500)
+    # mainlobe peaks vs an fp64 mask built with the oracle's offset grid (plan/solution_analysis.py:384-442)
+    for i, f in enumerate(sol.foci):
+        o = bo.effective_origin(arr.get_positions(units="m"), sol.apodizations[i])
+        og = fo.offset_grid(xs, ys, zs, f.get_position(units="m"), origin=o)
+        mask = np.sqrt(((og / np.array([1, 1, 5.0])) ** 2).sum(-1)) < 2.5e-3
+        assert np.isclose(an.mainlobe_pnp_MPa[i], stack[i][mask].max() * 1e-6, rtol=1e-5)
+    # scaling (plan/solution.py:283-338)
+    sol2, agg2, an2 = proto.calc_solution(target, arr, simulate=True, scale=True, voltage=2.0)
+    ps, its, aps, v1 = fo.scale_solution(stack, fo.intensity_wcm2(stack, 1000, 1500), np.stack([r[1] for r in ref]),
+                                         an.mainlobe_pnp_MPa, 1.2, 2.0)
+    assert np.isclose(sol2.voltage, v1, rtol=1e-5) and np.allclose(sol2.apodizations, aps, rtol=1e-5)
+    assert np.abs(sol2.simulation_result["p_max"].data - ps).max() / ps.max() <= 2e-5
+    assert np.abs(sol2.simulation_result["intensity"].data - its).max() / its.max() <= 4e-5
+    assert np.allclose(an2.mainlobe_pnp_MPa, 1.2, rtol=1e-4)                     # every focus hits the target pressure
+    assert np.abs(agg2["p_max"].data - ps.max(axis=0)).max() / ps.max() <= 2e-5   # aggregation sees the scaled volumes
+
+
+def test_calc_solution_without_simulation_and_scale_guard():
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
+    proto = ol.Protocol()
+    sol, agg, an = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, simulate=False, scale=False)
+    assert agg is None and an is None and sol.delays.shape == (1, 64) and len(sol.simulation_result) == 0
+    with pytest.raises(ValueError, match="Cannot scale"):
+        proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, simulate=False, scale=True)
+
+
+def test_detached_solution_is_uploaded_for_analysis():
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 40))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup)
+    sol, _, an = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=False)
+    proto.calc_solution(ol.Point(position=(2, 0, 25)), arr, scale=False)  # overwrites the resident volumes
+    an2 = sol.analyze()
+    assert an2.mainlobe_pnp_MPa == an.mainlobe_pnp_MPa and an2.global_isppa_Wcm2 == an.global_isppa_Wcm2

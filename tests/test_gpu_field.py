@@ -1,0 +1,189 @@
+"""Kernel 2 (field_accum_k) through the C-ABI vs the fp64 oracle.
+Gate (north_star / SURVEY 8(d)): max_v | |p_gpu| - |p_oracle| | / max_v |p_oracle| <= 1e-5 on fp32
+pressure magnitude; intensity 2e-5.  Full-size (256^3) checks use size-independent properties."""
+import numpy as np
+import pytest
+
+from openlifu_amd import _native as nat
+from oracle import bf_oracle as bo, c_oracle as co, field_oracle as fo
+from conftest import centred_grid, synthetic_array
+
+pytestmark = pytest.mark.gpu
+F0, C, RHO, P0 = 400e3, 1500.0, 1000.0, 1e5
+TOL_P, TOL_I = 1e-5, 2e-5
+
+
+def setup_ctx(ctx, pos, ori, size, foci_m, apod=("uniform", 1.0, 0.0)):
+    pos_m = pos * 1e-3
+    area = size[:, 0] * size[:, 1] * 1e-6
+    ctx.set_elements(pos_m, bo.element_rotations(ori)[:, :, 2], area)
+    steer = [bo.beamform(pos_m, ori, f, C, apod=apod) for f in np.atleast_2d(foci_m)]
+    delays = np.array([s[0] for s in steer]); ap = np.array([s[1] for s in steer])
+    ctx.set_steering(delays, ap)
+    return pos_m, area, delays, ap
+
+
+def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P):
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (len(xs), len(ys), len(zs)), F0, C, RHO, P0,
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX)
+    if want_variant:
+        assert want_variant in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    for f in range(delays.shape[0]):
+        out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
+        ref = co.field_on_grid(xs, ys, zs, pos_m, area, delays[f], ap[f], F0, C, P0, dmin=0.5 * min(h))
+        mx = np.abs(ref).max()
+        assert out["pmag"].dtype == np.float32 and out["pmag"].shape == ref.shape and out["pmag"].flags.writeable
+        assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= tol
+        assert np.abs(out["complex"] - ref).max() / mx <= 3 * tol
+        iref = fo.intensity_wcm2(np.abs(ref), RHO, C)
+        assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
+
+
+def test_c1_linear_array_32cubed(ctx):
+    """BASELINE config 1: 64-element linear array, single focus, 32^3."""
+    pos, ori, size = synthetic_array(64, 1, 0.5)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 40e-3]])
+    check(ctx, *centred_grid(32, 1.0), pos_m, area, d, a, want_variant="flat")
+
+
+def test_c2_matrix_array_128cubed(ctx):
+    """BASELINE config 2: 256-element matrix array, single focus, 128^3, full-volume parity."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 40e-3]])
+    check(ctx, *centred_grid(128, 0.5), pos_m, area, d, a, want_variant="flat,noclamp")
+
+
+def test_jittered_tilted_elements_general_variant(ctx):
+    pos, ori, size = synthetic_array(16, 16, 3.0, jitter=True)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[3e-3, -2e-3, 35e-3]], apod=("piecewise", 60.0, 20.0))
+    check(ctx, *centred_grid(48, 1.0), pos_m, area, d, a, want_variant="general")
+
+
+def test_ragged_grid_and_multiple_foci(ctx):
+    """nz not a multiple of the per-lane chunk, anisotropic extents, 3 foci in one launch."""
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    foci = np.array([[0, 0, 30e-3], [4e-3, 0, 32e-3], [-2e-3, 3e-3, 28e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 35.0, 0.0))
+    xs = np.linspace(-10e-3, 10e-3, 21); ys = np.linspace(-6e-3, 6e-3, 13); zs = 5e-3 + np.arange(13) * 1e-3
+    check(ctx, xs, ys, zs, pos_m, area, d, a)
+    xs1 = np.array([0.0, 1e-3]); zs1 = 5e-3 + np.arange(7) * 1e-3  # tiny: 2 x 2 x 7
+    check(ctx, xs1, xs1, zs1, pos_m, area, d, a)
+
+
+def test_grid_through_the_element_plane_needs_clamp(ctx):
+    """Default SimSetup z_extent starts behind the array: voxels coincide with element centres
+    (d = 0); the clamp variant must be selected and match the oracle's d >= spacing/2."""
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 30e-3]])
+    xs = np.linspace(-20e-3, 20e-3, 41); zs = np.linspace(-4e-3, 20e-3, 25)
+    assert np.isclose(xs, pos_m[0, 0]).any() and np.isclose(zs, 0).any()
+    check(ctx, xs, xs, zs, pos_m, area, d, a, want_variant=",clamp")
+
+
+def test_slab_sharding_matches_whole_volume(ctx):
+    """x-slabs (the multi-GPU shard unit) tile the volume exactly: bit-identical to the full launch."""
+    pos, ori, size = synthetic_array(16, 16, 3.0, jitter=True)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 40e-3]])
+    xs, ys, zs = centred_grid(40, 1.0)
+    h = (xs[1] - xs[0],) * 3
+    args = ((xs[0], ys[0], zs[0]), h, (40, 40, 40), F0, C, RHO, P0)
+    ctx.field_plan(*args); ctx.field_launch()
+    whole = ctx.field_fetch(0)["pmag"]
+    parts = []
+    for b, cnt in ((0, 13), (13, 13), (26, 14)):
+        ctx.field_plan(*args, slab=(b, cnt)); ctx.field_launch()
+        parts.append(ctx.field_fetch(0)["pmag"])
+        assert parts[-1].shape == (cnt, 40, 40)
+    assert np.array_equal(np.concatenate(parts, axis=0), whole)
+
+
+def test_headline_256cubed_properties(ctx):
+    """BASELINE headline size (256 el x 256^3): size-independent properties instead of a full oracle
+    pass -- sampled-voxel parity, the coherent-sum KAT at the focus voxel, linearity in apodization,
+    mirror symmetry of the centred flat array, idempotence of relaunching."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 40e-3]])
+    xs, ys, zs = centred_grid(256, 0.25)
+    zs = zs - (zs[140] - 40e-3)  # put a voxel plane exactly through the focus depth
+    h = (xs[1] - xs[0],) * 3
+    plan = lambda: ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0)  # noqa: E731
+    plan(); ctx.field_launch()
+    p = ctx.field_fetch(0)["pmag"]
+    rng = np.random.default_rng(147)
+    idx = rng.integers(0, 256, (20000, 3))
+    pts = np.stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2]]], axis=1)
+    ref = np.abs(co.field_at_points(pts, pos_m, area, d[0], a[0], F0, C, P0))
+    peak = np.abs(co.field_at_points([[0, 0, 40e-3]], pos_m, area, d[0], a[0], F0, C, P0))[0]
+    assert np.abs(p[idx[:, 0], idx[:, 1], idx[:, 2]] - ref).max() / peak <= TOL_P
+    # mirror symmetry x -> -x, y -> -y (centred grid, symmetric array, on-axis focus)
+    assert np.abs(p - p[::-1]).max() / peak <= TOL_P and np.abs(p - p[:, ::-1]).max() / peak <= TOL_P
+    ctx.field_launch()
+    assert np.array_equal(ctx.field_fetch(0)["pmag"], p)  # idempotent
+    # linearity: complex field of (a1 + a2) == field(a1) + field(a2), on a 256 x 256 x 8 slab
+    a1 = rng.uniform(0, 1, 256); a2 = rng.uniform(0, 1, 256)
+    outs = []
+    for ap in (a1, a2, a1 + a2):
+        ctx.set_steering(d, ap[None, :])
+        ctx.field_plan((xs[0], ys[0], zs[136]), h, (256, 256, 8), F0, C, RHO, P0, flags=nat.OUT_COMPLEX)
+        ctx.field_launch()
+        outs.append(ctx.field_fetch(0, want=("complex",))["complex"])
+    assert np.abs(outs[0] + outs[1] - outs[2]).max() / np.abs(outs[2]).max() <= TOL_P
+
+
+def test_aggregate_scale_masked_peak_and_upload(ctx):
+    from openlifu_amd.plan.solution_analysis import get_focus_matrix
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    foci = np.array([[0, 0, 30e-3], [3e-3, 0, 30e-3], [0, -3e-3, 33e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    xs, ys, zs = centred_grid(40, 1.0)
+    g = ((xs[0], ys[0], zs[0]), (1e-3,) * 3, (40,) * 3)
+    ctx.field_plan(*g, F0, C, RHO, P0); ctx.field_launch()
+    vols = np.stack([ctx.field_fetch(f)["pmag"] for f in range(3)])
+    ints = np.stack([ctx.field_fetch(f)["intensity"] for f in range(3)])
+    pm, im = ctx.field_aggregate()
+    assert np.array_equal(pm, vols.max(axis=0)) and np.allclose(im, ints.mean(axis=0), rtol=1e-6)
+    A = np.array([np.linalg.inv(get_focus_matrix(f, origin=[0, 0, 0]))[:3].ravel() for f in foci])
+    aspect = (1.0, 1.0, 5.0)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    for op, cmp in (("<", np.less), (">=", np.greater_equal)):
+        got = ctx.field_masked_peak(A, aspect, 2.5e-3, op)
+        for f in range(3):
+            og = fo.offset_grid(xs, ys, zs, foci[f])
+            mask = cmp(np.sqrt(((og / aspect) ** 2).sum(axis=-1)), 2.5e-3)
+            assert got[f] == vols[f][mask].max()
+    got = ctx.field_masked_peak(None, aspect, 0.0, None, zmin_m=10e-3)
+    assert np.array_equal(got, [v[Z > 10e-3].max() for v in vols])
+    ctx.field_scale([2.0, 0.5, 1.0])
+    assert np.allclose(ctx.field_fetch(0)["pmag"], vols[0] * 2) and np.allclose(ctx.field_fetch(1)["intensity"], ints[1] * 0.25)
+    fresh = nat.Context(0)
+    fresh.field_upload(*g, vols, ints)
+    assert np.array_equal(fresh.field_aggregate()[0], vols.max(axis=0))
+    with pytest.raises(nat.NativeError, match="uploaded"):
+        fresh.field_launch()
+    fresh.close()
+
+
+def test_call_order_and_argument_errors(ctx):
+    with pytest.raises(nat.NativeError, match="olx_set_elements first"):
+        ctx.field_plan((0, 0, 0), (1e-3,) * 3, (4, 4, 4), F0, C, RHO, P0, n_foci=1)
+    pos, ori, size = synthetic_array(4, 4, 3.0)
+    ctx.set_elements(pos * 1e-3, bo.element_rotations(ori)[:, :, 2], np.full(16, 1e-6))
+    with pytest.raises(nat.NativeError, match="no steering table"):
+        ctx.field_plan((0, 0, 0), (1e-3,) * 3, (4, 4, 4), F0, C, RHO, P0, n_foci=1)
+    with pytest.raises(nat.NativeError, match="olx_field_plan first"):
+        ctx.field_launch()
+    with pytest.raises(ValueError):
+        ctx.set_steering(np.zeros((1, 15)), np.ones((1, 15)))
+    ctx.set_steering(np.zeros((2, 16)), np.ones((2, 16)))
+    with pytest.raises(ValueError, match="bad grid"):
+        ctx.field_plan((0, 0, 0), (1e-3, 0.0, 1e-3), (4, 4, 4), F0, C, RHO, P0)
+    with pytest.raises(ValueError, match="slab outside grid"):
+        ctx.field_plan((0, 0, 0), (1e-3,) * 3, (4, 4, 4), F0, C, RHO, P0, slab=(2, 3))
+    ctx.field_plan((0, 0, 5e-3), (1e-3,) * 3, (4, 4, 4), F0, C, RHO, P0, flags=nat.OUT_PMAG)
+    ctx.field_launch()
+    with pytest.raises(nat.NativeError, match="intensity not planned"):
+        ctx.field_fetch(0, want=("intensity",))
+    with pytest.raises(ValueError, match="out of range"):
+        ctx.field_fetch(2)

@@ -1,0 +1,92 @@
+"""Analytic known-answer tests pinning the field oracle (the reference holds no field values:
+parity vs k-Wave is UNPINNED, see oracle/__init__.py), plus NumPy-vs-C oracle agreement."""
+import numpy as np
+
+from oracle import bf_oracle as bo, c_oracle as co, field_oracle as fo
+
+F0, C = 400e3, 1500.0
+LAM = C / F0
+
+
+def test_single_element_on_axis():
+    """|p| = P0 S / (lambda z) exactly for one element."""
+    z = np.array([0.01, 0.02, 0.05])
+    pts = np.stack([np.zeros(3), np.zeros(3), z], axis=1)
+    p = fo.field_at_points(pts, [[0, 0, 0]], [4e-6], [0.0], [1.0], F0, C, p0_pa=2e5)
+    assert np.allclose(np.abs(p), 2e5 * 4e-6 / (LAM * z), rtol=1e-14)
+    assert np.allclose(np.angle(p * np.exp(-1j * 2 * np.pi * z / LAM)), 0, atol=1e-9)
+
+
+def test_two_elements_in_and_out_of_phase():
+    pos = [[-1e-3, 0, 0], [1e-3, 0, 0]]
+    pt = [[0, 0, 0.03]]
+    d = np.hypot(1e-3, 0.03)
+    a = 1e-6 / (LAM * d)
+    p_in = fo.field_at_points(pt, pos, [1e-6, 1e-6], [0, 0], [1, 1], F0, C)
+    p_out = fo.field_at_points(pt, pos, [1e-6, 1e-6], [0, 0.5 / F0], [1, 1], F0, C)
+    assert np.isclose(abs(p_in[0]), 2 * a, rtol=1e-13) and abs(p_out[0]) < 1e-12 * a
+
+
+def test_focus_voxel_is_coherent_sum():
+    """With Direct delays every phase k d + w tau is equal at the focus: |p| = sum_e w_e / d_e."""
+    pos, size, _ = bo.gen_matrix_array(8, 8, 4.0, 0.4)
+    pos_m, area = pos * 1e-3, size[:, 0] * size[:, 1] * 1e-6
+    focus = np.array([2e-3, -1e-3, 0.04])
+    d = bo.distances_to_point(pos_m, focus)
+    delays = bo.direct_delays(d, C)
+    apod = np.linspace(0.2, 1.0, 64)
+    p = fo.field_at_points(focus[None], pos_m, area, delays, apod, F0, C, p0_pa=1e5)
+    assert np.isclose(abs(p[0]), (apod * 1e5 * area / (LAM * d)).sum(), rtol=1e-12)
+
+
+def test_linearity_and_dmin_clamp():
+    rng = np.random.default_rng(147)
+    pos = rng.uniform(-5e-3, 5e-3, (6, 3)); pos[:, 2] = 0
+    pts = rng.uniform(-5e-3, 5e-3, (20, 3)); pts[:, 2] += 0.02
+    a1, a2 = rng.uniform(0, 1, 6), rng.uniform(0, 1, 6)
+    tau = rng.uniform(0, 2e-6, 6)
+    f = lambda a: fo.field_at_points(pts, pos, np.full(6, 1e-6), tau, a, F0, C)  # noqa: E731
+    assert np.allclose(f(a1) + f(a2), f(a1 + a2), rtol=1e-12)
+    p = fo.field_at_points(pos[:1], pos, np.full(6, 1e-6), tau, a1, F0, C, dmin=1e-4)
+    assert np.isfinite(p).all()
+
+
+def test_intensity_and_scale_and_aggregate():
+    p = np.array([[1e5, 2e5], [3e5, 1e5]])
+    it = fo.intensity_wcm2(p, 1000.0, 1500.0)
+    assert np.allclose(it, 1e-4 * p ** 2 / 3e6)
+    ps, its, ap, v1 = fo.scale_solution(p, it, np.ones((2, 3)), [0.2, 0.3], 0.6, 2.0)
+    assert np.isclose(v1, 6.0) and np.allclose(ps[0], p[0] * 3.0) and np.allclose(ps[1], p[1] * 2.0)
+    assert np.allclose(its[1], it[1] * 4.0) and np.allclose(ap[1], 2 / 3)
+    pm, im = fo.aggregate(p, it)
+    assert np.allclose(pm, [3e5, 2e5]) and np.allclose(im, it.mean(axis=0))
+
+
+def test_c_oracle_matches_numpy_oracle():
+    pos, size, _ = bo.gen_matrix_array(16, 16, 3.0, 0.3)
+    rng = np.random.default_rng(147)
+    pos_m = (pos + rng.uniform(-0.1, 0.1, pos.shape)) * 1e-3
+    area = size[:, 0] * size[:, 1] * 1e-6
+    delays = rng.uniform(0, 3e-6, 256); apod = rng.uniform(0, 1, 256)
+    xs = np.linspace(-8e-3, 8e-3, 12); zs = np.linspace(-1e-3, 30e-3, 17)
+    a = fo.field_on_grid(xs, xs, zs, pos_m, area, delays, apod, F0, C, 1e5)
+    b = co.field_on_grid(xs, xs, zs, pos_m, area, delays, apod, F0, C, 1e5)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    pts = rng.uniform(-0.02, 0.02, (100, 3))
+    assert np.allclose(fo.field_at_points(pts, pos_m, area, delays, apod, F0, C, dmin=1e-4),
+                       co.field_at_points(pts, pos_m, area, delays, apod, F0, C, dmin=1e-4), rtol=1e-11)
+
+
+def test_plausible_beamwidth_vs_reference_fixture():
+    """Loose (+-12 %) sanity vs the k-Wave-derived example_solution_analysis.json values
+    (lateral -3 dB 4.57 mm, -6 dB 6.65 mm): 8x8, 4 mm pitch, 500 kHz."""
+    i = np.arange(64)
+    pos_m = np.stack([-14 + 4 * (i // 8), -14 + 4 * (i % 8), np.zeros(64)], axis=1) * 1e-3
+    focus = np.array([0.0, -0.0022437460888595447, 0.05518120697745499])
+    delays = bo.direct_delays(bo.distances_to_point(pos_m, focus), 1500.0)
+    x = np.linspace(-8e-3, 8e-3, 641)
+    pts = np.stack([x, np.full_like(x, focus[1]), np.full_like(x, focus[2])], axis=1)
+    p = np.abs(fo.field_at_points(pts, pos_m, np.full(64, 16e-6), delays, np.ones(64), 500e3, 1500.0))
+    for db, ref in ((3, 4.57e-3), (6, 6.65e-3)):
+        above = x[p >= p.max() * 10 ** (-db / 20)]
+        assert abs((above.max() - above.min()) - ref) < 0.12 * ref
