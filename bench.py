@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--elements", type=str, default="16x16")
     ap.add_argument("--pitch-mm", type=float, default=3.0)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with 1 rank")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -136,13 +137,13 @@ def main():
     ctx = eng.ctx
     eng.bind(arr)
     ctx.bf_solve(np.array([f.get_position(units="m") for f in foci]), 1500.0)  # kernel 1: steering stays resident
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 or args.force_gather) and not args.no_gather
     gather_note = None
     if gather:
         try:
-            import torch
             uid = [ctx.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0], world, rank)
         except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
             gather, gather_note = False, f"RCCL init failed: {e}"

@@ -187,3 +187,36 @@ def test_call_order_and_argument_errors(ctx):
         ctx.field_fetch(0, want=("intensity",))
     with pytest.raises(ValueError, match="out of range"):
         ctx.field_fetch(2)
+
+
+def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
+    """RCCL path with the one GPU a test box has: a 1-rank communicator must reproduce the local
+    volumes through olx_field_allgather (side stream, double-buffered outputs), repeatedly."""
+    import openlifu_amd as ol
+    from openlifu_amd.dist import ShardedField
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    foci = np.array([[0, 0, 30e-3], [3e-3, 0, 30e-3], [0, -3e-3, 33e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 1, 0)
+    with pytest.raises(nat.NativeError, match="already initialised"):
+        ctx.comm_init(uid, 1, 0)
+    xs, ys, zs = centred_grid(24, 1.0)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (1e-3,) * 3, (24,) * 3, F0, C, RHO, P0)
+    for _ in range(3):  # alternates the two output buffers; each gather must see the launch before it
+        ctx.field_launch()
+        ctx.field_allgather()
+    ctx.sync()
+    local = np.stack([ctx.field_fetch(f)["pmag"] for f in range(3)])
+    assert np.array_equal(ctx.allgather_fetch(0), local)
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[1], a[1], F0, C, P0))
+    assert np.abs(local[1] - ref).max() / ref.max() <= TOL_P
+    ctx.comm_destroy()
+    # the driver class on world = 1 (no communicator): foci mode and slab mode agree with each other
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
+    sf = ShardedField(ol.get_engine(0), 1, 0, exchange_id=lambda b: b)
+    args = ((xs[0], ys[0], zs[0]), (1e-3,) * 3, (24,) * 3)
+    pf = sf.sweep_foci(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), *args, F0, RHO, P0)
+    ps = sf.sweep_slabs(arr, d, a, *args, F0, C, RHO, P0)
+    assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
