@@ -141,7 +141,7 @@ def main():
     gather_note = None
     if gather:
         try:
-            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            uid = [ctx.comm_unique_id() if rank == 0 else None]  # (libolx keeps RCCL's banner off stdout)
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0], world, rank)

@@ -3,6 +3,7 @@
 #include "../../include/olx.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -55,6 +56,8 @@ struct olx_ctx {
     unsigned flags = 0;
     FieldParams fp{};
     bool flat = false, clamp = false;
+    // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
+    int mx = 1, my = 1, nf = 1; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
@@ -134,7 +137,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     olx_comm_destroy(c);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
-                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak};
+                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -247,10 +250,21 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
 static int pack_if_needed(olx_ctx* c) {
     if (c->packed_version == c->steer_version) return OLX_OK;
     const double lambda = c->c / c->freq;
-    dim3 g((c->n_el + 127) / 128, c->plan_foci);
-    hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
-                       c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
-                       c->p0_pa / lambda, c->d_tab);
+    if (c->mx * c->my * c->nf == 1) {
+        dim3 g((c->n_el + 127) / 128, c->plan_foci);
+        hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
+                           c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
+                           c->p0_pa / lambda, c->freq / c->c, c->d_tab);
+    } else {
+        // mirrored axes: table coordinates relative to the grid centre plane
+        const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
+        const double oy = c->my == 2 ? c->grid.origin[1] + 0.5 * (c->grid.n[1] - 1) * c->grid.spacing[1] : c->grid.origin[1];
+        const int tiles = (c->plan_foci + c->nf - 1) / c->nf;
+        dim3 g((c->n_el + 127) / 128, tiles);
+        hipLaunchKernelGGL(steer_pack_shared_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
+                           c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->p0_pa / lambda, c->freq / c->c,
+                           c->plan_foci, c->nf, c->mx * c->my, c->d_tab);
+    }
     HIPCHK(c, hipGetLastError());
     c->packed_version = c->steer_version;
     return OLX_OK;
@@ -300,10 +314,10 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     FieldParams& P = c->fp;
     P.nx = s.x_count; P.ny = g->n[1]; P.nz = g->n[2]; P.n_el = c->n_el;
     P.x_begin = s.x_begin;
-    P.hx = (float)g->spacing[0]; P.hy = (float)g->spacing[1]; P.hz = (float)g->spacing[2];
-    P.rev_per_m = (float)(freq / cs);
+    const double rev = freq / cs;  // kernel lengths are in wavelengths
+    P.hx = (float)(g->spacing[0] * rev); P.hy = (float)(g->spacing[1] * rev); P.hz = (float)(g->spacing[2] * rev);
     const double dmin = 0.5 * std::min({g->spacing[0], g->spacing[1], g->spacing[2]});
-    P.dmin2 = (float)(dmin * dmin);
+    P.dmin2 = (float)(dmin * dmin * rev * rev);
     P.inten_scale = (float)(1e-4 / (2.0 * rho * cs));
     P.vox = vox; P.flags = flags | OLX_OUT_PMAG;
     // variant decisions from host copies (exact, fp64)
@@ -311,7 +325,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     const double* hz = c->h_pos.data() + 2 * (size_t)n;
     c->flat = true;
     for (int e = 1; e < n; ++e) if (hz[e] != hz[0]) { c->flat = false; break; }
-    P.flat_ez = (float)(hz[0] - g->origin[2]);
+    P.flat_ez = (float)((hz[0] - g->origin[2]) * rev);
     // clamp needed iff some element lies within dmin (+ fp32 slack) of the slab's bounding box
     double lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
@@ -331,8 +345,72 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         }
         if (d2 < guard * guard) c->clamp = true;
     }
-    char nm[64];
-    snprintf(nm, sizeof nm, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
+    auto mirror_perm = [&](int axis, std::vector<int>& perm) -> bool {
+        const double ctr = g->origin[axis] + 0.5 * (g->n[axis] - 1) * g->spacing[axis];
+        const double tol = 1e-12;
+        perm.assign(n, -1);
+        std::vector<char> used(n, 0);
+        for (int e = 0; e < n; ++e) {
+            const double want = 2.0 * ctr - c->h_pos[(size_t)axis * n + e];
+            int hit = -1;
+            for (int o = 0; o < n && hit < 0; ++o) {
+                if (used[o] || std::fabs(c->h_pos[(size_t)axis * n + o] - want) > tol) continue;
+                bool same = true;
+                for (int a = 0; a < 3; ++a)
+                    if (a != axis && std::fabs(c->h_pos[(size_t)a * n + o] - c->h_pos[(size_t)a * n + e]) > tol) same = false;
+                if (same) hit = o;
+            }
+            if (hit < 0) return false;
+            used[hit] = 1; perm[e] = hit;
+        }
+        return true;
+    };
+    std::vector<int> px, py;
+    const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
+    const char* force = getenv("OLX_FIELD_VARIANT");  // "general" disables kernel 2b (A/B measurements)
+    const bool allow_shared = !(force && !strcmp(force, "general"));
+    c->mx = (allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, px)) ? 2 : 1;
+    c->my = (allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, py)) ? 2 : 1;
+    const int nm_ = c->mx * c->my;
+    c->nf = 1;
+    if (allow_shared) while (c->nf * 2 <= n_foci && c->nf * 2 * nm_ <= 8) c->nf *= 2;
+    if (nm_ * c->nf > 1) {
+        std::vector<int> perm((size_t)nm_ * n);
+        for (int m = 0; m < nm_; ++m)
+            for (int e = 0; e < n; ++e) {
+                int o = e;
+                const bool fx = c->mx == 2 && (m & 1), fy = c->my == 2 && (c->mx == 2 ? (m >> 1) : (m & 1));
+                if (fx) o = px[o];
+                if (fy) o = py[o];
+                perm[(size_t)m * n + e] = o;
+            }
+        if (c->perm_cap < perm.size()) {
+            if (c->d_perm) hipFree(c->d_perm);
+            c->d_perm = nullptr; c->perm_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_perm, sizeof(int) * perm.size()));
+            c->perm_cap = perm.size();
+        }
+        HIPCHK(c, hipMemcpy(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+        const size_t tiles = (size_t)(n_foci + c->nf - 1) / c->nf;
+        const size_t need = tiles * n * (4 + 2 * nm_ * c->nf);
+        if (c->tab_cap < need) {
+            if (c->d_tab) hipFree(c->d_tab);
+            c->d_tab = nullptr; c->tab_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_tab, sizeof(float) * need));
+            c->tab_cap = need;
+        }
+        SharedParams& S = c->sp;
+        S.nx = P.nx; S.ny = P.ny; S.nz = P.nz; S.n_el = n; S.x_begin = s.x_begin; S.n_foci = n_foci;
+        S.hx = P.hx; S.hy = P.hy; S.hz = P.hz; S.dmin2 = P.dmin2;
+        S.inten_scale = P.inten_scale; S.flat_ez = P.flat_ez; S.vox = P.vox; S.flags = P.flags;
+    }
+    char nm[96];
+    if (nm_ * c->nf == 1)
+        snprintf(nm, sizeof nm, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    else
+        snprintf(nm, sizeof nm, "field_shared_k<4,mx%d,my%d,nf%d,%s,%s>", c->mx, c->my, c->nf, c->flat ? "flat" : "general",
+                 c->clamp ? "clamp" : "noclamp");
     c->variant = nm;
     c->packed_version = ~0ull;
     c->planned = true; c->uploaded = false;
@@ -341,6 +419,35 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
 }
 
 }  // extern "C"
+
+template <int MX, int MY, int NF>
+static void launch_shared(olx_ctx* c, float* pm) {
+    const SharedParams& S = c->sp;
+    constexpr int ZPL = 4;
+    const long long cpr = (S.nz + ZPL - 1) / ZPL;
+    const long long lanes = (long long)(S.nx - (MX == 2 ? S.nx / 2 : 0)) * (S.ny - (MY == 2 ? S.ny / 2 : 0)) * cpr;
+    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), (c->plan_foci + NF - 1) / NF);
+    dim3 blk(FIELD_THREADS);
+    if (c->flat) {
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+    } else {
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+    }
+}
+
+static bool dispatch_shared(olx_ctx* c, float* pm) {
+    const int key = c->mx * 100 + c->my * 10 + 0;
+    (void)key;
+#define OLX_CASE(MX_, MY_, NF_) if (c->mx == MX_ && c->my == MY_ && c->nf == NF_) { launch_shared<MX_, MY_, NF_>(c, pm); return true; }
+    OLX_CASE(1, 1, 2) OLX_CASE(1, 1, 4) OLX_CASE(1, 1, 8)
+    OLX_CASE(2, 1, 1) OLX_CASE(2, 1, 2) OLX_CASE(2, 1, 4)
+    OLX_CASE(1, 2, 1) OLX_CASE(1, 2, 2) OLX_CASE(1, 2, 4)
+    OLX_CASE(2, 2, 1) OLX_CASE(2, 2, 2)
+#undef OLX_CASE
+    return false;
+}
 
 template <bool FLAT, bool CLAMP>
 static void launch_field(olx_ctx* c, float* pm) {
@@ -371,8 +478,10 @@ int olx_field_launch(olx_ctx* c) {
     float* pm = c->d_pmag[b];
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
-    else         { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }
+    if (c->mx * c->my * c->nf > 1) {
+        if (!dispatch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
+    } else if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
+    else                { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
     c->cur = b;
@@ -560,6 +669,14 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     return OLX_OK;
 }
 
+// RCCL prints a version banner through C stdio on stdout; callers (bench.py) own stdout for their
+// one-line JSON, so stdout is pointed at stderr while RCCL initialises and flushed before restoring.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+    ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
+
 // ---- RCCL reassembly ------------------------------------------------------------------------
 static int load_rccl(olx_ctx* c) {
     RcclApi& r = c->rccl;
@@ -587,6 +704,7 @@ int olx_comm_unique_id(olx_ctx* c, void* id_bytes) {
     int rc = load_rccl(c);
     if (rc) return rc;
     olx_nccl_id id;
+    StdoutToStderr quiet;
     NCCLCHK(c, c->rccl.GetUniqueId(&id));
     memcpy(id_bytes, &id, sizeof id);
     return OLX_OK;
@@ -601,7 +719,10 @@ int olx_comm_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
     HIPCHK(c, hipSetDevice(c->device));
     olx_nccl_id id;
     memcpy(&id, id_bytes, sizeof id);
-    NCCLCHK(c, c->rccl.CommInitRank(&c->comm, nranks, id, rank));
+    {
+        StdoutToStderr quiet;
+        NCCLCHK(c, c->rccl.CommInitRank(&c->comm, nranks, id, rank));
+    }
     c->nranks = nranks; c->rank = rank;
     HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int b = 0; b < olx_ctx::NBUF; ++b) {

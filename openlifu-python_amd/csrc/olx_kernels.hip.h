@@ -94,8 +94,10 @@ __global__ __launch_bounds__(BF_THREADS) void bf_solve_k(
 // ------------------------------------------------------------------------------------
 // steering pack: fp64 (pos, area, delays, apod) -> the fp32 table kernel 2 streams through
 // the scalar cache.  Entry (f, e) = 8 floats (32 B, one s_load_dwordx8):
-//   { x_e - ox, y_e - oy, z_e - oz, w_ef, phi_ef, 0, 0, 0 }
-// w_ef = a_ef P0 S_e / lambda [Pa m];  phi_ef = frac(f0 tau_ef) [revolutions].
+//   { (x_e - ox)/lambda, (y_e - oy)/lambda, (z_e - oz)/lambda, w_ef, phi_ef, 0, 0, 0 }
+// Lengths are in WAVELENGTHS (x f0/c) so that the phase in revolutions is the distance itself:
+// t = d2 * rsq(d2) + phi is ONE fma.  w_ef = a_ef P0 S_e / lambda^2 [Pa] (amplitude w/d with d in
+// wavelengths);  phi_ef = frac(f0 tau_ef) [revolutions].
 // Differences and products are formed in fp64 and rounded once.
 // ------------------------------------------------------------------------------------
 constexpr int TAB_STRIDE = 8;
@@ -103,17 +105,17 @@ constexpr int TAB_STRIDE = 8;
 __global__ void steer_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
                              const double* __restrict__ delays, const double* __restrict__ apod,
                              double ox, double oy, double oz, double freq, double p0_over_lambda,
-                             float* __restrict__ tab) {
+                             double rev, float* __restrict__ tab) {
     const int f = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const size_t o = ((size_t)f * n + e);
     const double cyc = freq * delays[o];
     float* t = tab + o * TAB_STRIDE;
-    t[0] = (float)(pos[e] - ox);
-    t[1] = (float)(pos[n + e] - oy);
-    t[2] = (float)(pos[2 * n + e] - oz);
-    t[3] = (float)(apod[o] * area[e] * p0_over_lambda);
+    t[0] = (float)((pos[e] - ox) * rev);
+    t[1] = (float)((pos[n + e] - oy) * rev);
+    t[2] = (float)((pos[2 * n + e] - oz) * rev);
+    t[3] = (float)(apod[o] * area[e] * p0_over_lambda * rev);
     t[4] = (float)(cyc - floor(cyc));
     t[5] = 0.f; t[6] = 0.f; t[7] = 0.f;
 }
@@ -129,7 +131,7 @@ __global__ void steer_pack_k(const double* __restrict__ pos, const double* __res
 // Element data is wave-uniform: read with scalar loads (s_load_dwordx8) from the packed
 // table, served by the scalar cache -- no VGPR, LDS or vector-memory traffic in the loop.
 // Per pair: v_rsq_f32 (1/d), v_sin_f32 + v_cos_f32 on the phase in REVOLUTIONS
-// (t = d f/c + frac(f tau)), ~7 plain VALU.  Transcendental issue is the bound
+// (t = d + frac(f tau), d in wavelengths), ~5 plain VALU.  Transcendental issue is the bound
 // (DESIGN.md section 5); HBM sees only the output stream.
 //   FLAT : every element has the same z -> (z_v - z_e)^2 hoisted out of the element loop.
 //   CLAMP: apply d >= dmin (needed only if a voxel can come within dmin of an element;
@@ -140,11 +142,10 @@ struct FieldParams {
     int n_el;
     int x_begin;           // slab start (global x index): coordinates are formed from GLOBAL indices so
                            // that a slab launch is bit-identical to the same voxels of a whole-grid launch
-    float hx, hy, hz;      // spacing [m]
-    float rev_per_m;       // f0 / c
-    float dmin2;           // dmin^2 [m^2]
+    float hx, hy, hz;      // spacing [wavelengths]
+    float dmin2;           // dmin^2 [wavelengths^2]
     float inten_scale;     // 1e-4 / (2 rho c)
-    float flat_ez;         // common element z (FLAT only), relative to table origin
+    float flat_ez;         // common element z (FLAT only), relative to table origin [wavelengths]
     long long vox;         // voxels per focus volume (nx*ny*nz)
     unsigned flags;        // OLX_OUT_*
 };
@@ -192,8 +193,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
             }
             if (CLAMP) d2 = fmaxf(d2, P.dmin2);
             const float ri = __builtin_amdgcn_rsqf(d2);
-            const float d = d2 * ri;
-            const float ph = fmaf(d, P.rev_per_m, phi);
+            const float ph = fmaf(d2, ri, phi);  // d [wavelengths] + phi = phase [revolutions]
             const float s = __builtin_amdgcn_sinf(ph);
             const float c = __builtin_amdgcn_cosf(ph);
             const float a = w * ri;
@@ -228,6 +228,163 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
                 if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 2b: shared-geometry accumulate.  The geometry term G(v,e) = exp(j k d)/d does not
+// depend on the focus, and for an element set that is mirror-symmetric about the grid's
+// centre plane(s) G(v,e) = G(sigma v, sigma e).  One lane therefore evaluates G once
+// (the 3 transcendentals) and feeds NOUT = MX*MY*NF complex accumulators
+//     P_f(sigma_m v) += W[sigma_m e, f] * G(v, e)
+// with 4 plain fma each (weights wave-uniform in SGPRs).  MX/MY = 2 folds the x / y mirror
+// (lanes cover only the upper half of that axis and also write the mirrored voxel),
+// NF = foci per tile (blockIdx.y = tile).  Exact: no approximation is involved, only
+// re-association of which (voxel, element) pair is evaluated where.
+// Table entry (tile, e) = { x_e, y_e, z_e, 0, (wr_k, wi_k) k < NOUT },  k = f_local*NM + m.
+// Coordinates on a mirrored axis are taken relative to the grid centre and formed as
+// (2 i - (n-1)) * h/2 so that x(n-1-i) == -x(i) bit for bit.
+// ------------------------------------------------------------------------------------
+struct SharedParams {
+    int nx, ny, nz, n_el;
+    int x_begin, n_foci;
+    float hx, hy, hz;                     // [wavelengths]
+    float dmin2, inten_scale, flat_ez;
+    long long vox;
+    unsigned flags;
+};
+
+template <int ZPL, int MX, int MY, int NF, bool FLAT, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
+    const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
+    float* __restrict__ cplx, const SharedParams P) {
+    constexpr int NM = MX * MY, NOUT = NM * NF, STRIDE = 4 + 2 * NOUT;
+    const int tile = blockIdx.y;
+    const unsigned cpr = (unsigned)(P.nz + ZPL - 1) / ZPL;
+    const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const int x_lo = (MX == 2) ? P.nx / 2 : 0, y_lo = (MY == 2) ? P.ny / 2 : 0;
+    const unsigned hyn = (unsigned)(P.ny - y_lo);
+    const unsigned rows = (unsigned)(P.nx - x_lo) * hyn;
+    const unsigned row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int ii = (int)(row / hyn);
+    const int i = ii + x_lo, j = (int)(row - (unsigned)ii * hyn) + y_lo;
+    const int k0 = chunk * ZPL;
+    const float x = (MX == 2) ? (float)(2 * i - (P.nx - 1)) * (0.5f * P.hx) : (float)(i + P.x_begin) * P.hx;
+    const float y = (MY == 2) ? (float)(2 * j - (P.ny - 1)) * (0.5f * P.hy) : (float)j * P.hy;
+    float z[ZPL], re[ZPL][NOUT], im[ZPL][NOUT];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        z[q] = (float)(k0 + q) * P.hz;
+        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) { re[q][k] = 0.f; im[q][k] = 0.f; }
+    }
+    const float* t = tab + (size_t)tile * P.n_el * STRIDE;
+#ifdef OLX_EXP_UNROLL
+#pragma unroll OLX_EXP_UNROLL
+#endif
+    for (int e = 0; e < P.n_el; ++e) {
+        const float* te = t + (size_t)e * STRIDE;
+        const float dx = x - te[0], dy = y - te[1];
+        const float ez = te[2];
+        const float r2 = fmaf(dy, dy, dx * dx);
+        float gr[ZPL], gi[ZPL];
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            float d2;
+            if (FLAT) {
+                d2 = r2 + z[q];
+            } else {
+                const float dz = z[q] - ez;
+                d2 = fmaf(dz, dz, r2);
+            }
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float ph = d2 * ri;  // distance in wavelengths = phase in revolutions
+            gr[q] = ri * __builtin_amdgcn_cosf(ph);
+            gi[q] = ri * __builtin_amdgcn_sinf(ph);
+        }
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const float wr = te[4 + 2 * k], wi = te[5 + 2 * k];
+#pragma unroll
+            for (int q = 0; q < ZPL; ++q) {
+                re[q][k] = fmaf(gr[q], wr, re[q][k]);
+                re[q][k] = fmaf(-gi[q], wi, re[q][k]);
+                im[q][k] = fmaf(gr[q], wi, im[q][k]);
+                im[q][k] = fmaf(gi[q], wr, im[q][k]);
+            }
+        }
+    }
+    const bool full = (k0 + ZPL <= P.nz) && (P.nz % ZPL == 0);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int f = tile * NF + k / NM;
+        if (f >= P.n_foci) continue;
+        const int m = k % NM;
+        const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+        const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+        const long long base = (long long)f * P.vox + ((long long)io * P.ny + jo) * P.nz + k0;
+        float pm[ZPL], it[ZPL];
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            const float m2 = fmaf(re[q][k], re[q][k], im[q][k] * im[q][k]);
+            pm[q] = __builtin_sqrtf(m2);
+            it[q] = m2 * P.inten_scale;
+        }
+        if (ZPL == 4 && full) {
+            if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+            if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+            if (P.flags & 4u) {
+                float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
+                c4[0] = make_float4(re[0][k], im[0][k], re[1][k], im[1][k]);
+                c4[1] = make_float4(re[2][k], im[2][k], re[3][k], im[3][k]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ZPL; ++q) {
+                if (k0 + q < P.nz) {
+                    if (P.flags & 1u) pmag[base + q] = pm[q];
+                    if (P.flags & 2u) inten[base + q] = it[q];
+                    if (P.flags & 4u) { cplx[2 * (base + q)] = re[q][k]; cplx[2 * (base + q) + 1] = im[q][k]; }
+                }
+            }
+        }
+    }
+}
+
+// pack for kernel 2b: complex weights W[sigma_m(e), f] = a P0 S / lambda * exp(j 2 pi frac(f0 tau)),
+// evaluated in fp64 and rounded once.  perm[m][e] = index of the mirror image of element e.
+__global__ void steer_pack_shared_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
+                                    const double* __restrict__ delays, const double* __restrict__ apod,
+                                    const int* __restrict__ perm, double ox, double oy, double oz, double freq,
+                                    double p0_over_lambda, double rev, int n_foci, int nf, int nm,
+                                    float* __restrict__ tab) {
+    const int tile = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int nout = nf * nm, stride = 4 + 2 * nout;
+    float* t = tab + ((size_t)tile * n + e) * stride;
+    t[0] = (float)((pos[e] - ox) * rev);
+    t[1] = (float)((pos[n + e] - oy) * rev);
+    t[2] = (float)((pos[2 * n + e] - oz) * rev);
+    t[3] = 0.f;
+    for (int k = 0; k < nout; ++k) {
+        const int f = tile * nf + k / nm, m = k % nm;
+        float wr = 0.f, wi = 0.f;
+        if (f < n_foci) {
+            const int es = perm[m * n + e];
+            const size_t o = (size_t)f * n + es;
+            const double cyc = freq * delays[o];
+            const double ph = 6.283185307179586476925286766559 * (cyc - floor(cyc));
+            const double w = apod[o] * area[es] * p0_over_lambda * rev;
+            wr = (float)(w * cos(ph));
+            wi = (float)(w * sin(ph));
+        }
+        t[4 + 2 * k] = wr;
+        t[5 + 2 * k] = wi;
     }
 }
 
