@@ -39,6 +39,8 @@ struct olx_ctx {
     int n_el = 0;
     double *d_pos = nullptr, *d_nrm = nullptr, *d_area = nullptr;
     std::vector<double> h_pos;  // [3][N]
+    std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
+    bool allow_shared = true;
     // steering
     int n_foci = 0;
     double *d_delays = nullptr, *d_apod = nullptr;
@@ -57,7 +59,7 @@ struct olx_ctx {
     FieldParams fp{};
     bool flat = false, clamp = false;
     // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
-    int mx = 1, my = 1, nf = 1; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
+    int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
@@ -177,6 +179,7 @@ int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, cons
     HIPCHK(c, hipMemcpy(c->d_nrm, nso.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_area, area_m2, sizeof(double) * n, hipMemcpyHostToDevice));
     c->h_pos.swap(soa);
+    c->h_area.assign(area_m2, area_m2 + n);
     c->n_el = n;
     c->n_foci = 0;      // steering shape depends on N
     c->planned = false;
@@ -217,9 +220,12 @@ int olx_bf_solve(olx_ctx* c, const double* foci_m, int n_foci, const double* M, 
     hipLaunchKernelGGL(bf_solve_k, dim3(n_foci), dim3(BF_THREADS), 0, c->stream, c->d_pos, c->d_nrm, c->n_el,
                        c->d_foci, c->d_M, cs, apod_kind, angle_scale, p0, p1, c->d_delays, c->d_apod);
     HIPCHK(c, hipGetLastError());
-    if (delays_out) HIPCHK(c, hipMemcpyAsync(delays_out, c->d_delays, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
-    if (apod_out) HIPCHK(c, hipMemcpyAsync(apod_out, c->d_apod, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
+    c->h_delays.resize(fn); c->h_apod.resize(fn);
+    HIPCHK(c, hipMemcpyAsync(c->h_delays.data(), c->d_delays, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_apod.data(), c->d_apod, sizeof(double) * fn, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (delays_out) memcpy(delays_out, c->h_delays.data(), sizeof(double) * fn);
+    if (apod_out) memcpy(apod_out, c->h_apod.data(), sizeof(double) * fn);
     c->n_foci = n_foci;
     c->steer_version++;
     return OLX_OK;
@@ -241,14 +247,59 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
     HIPCHK(c, hipMemcpyAsync(c->d_delays, delays_s, sizeof(double) * fn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_apod, apod, sizeof(double) * fn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_delays.assign(delays_s, delays_s + fn); c->h_apod.assign(apod, apod + fn);
     c->n_foci = n_foci;
     c->steer_version++;
     return OLX_OK;
 }
 
 // ---- kernel 2 -----------------------------------------------------------------------------
+// Steering-dependent part of the kernel-2 variant choice (runs whenever the steering table changed):
+// dx/dy = distinct weight columns along folded axes (1 when every focus' delays and apodization are
+// mirror-symmetric), nf = foci per tile so that dx*dy*nf <= 8 accumulator columns.
+static int configure_variant(olx_ctx* c) {
+    const int n = c->n_el, F = c->plan_foci;
+    auto steering_symmetric = [&](const std::vector<int>& perm) {
+        if (c->h_delays.size() != (size_t)F * n || c->h_apod.size() != (size_t)F * n) return false;
+        for (int f = 0; f < F; ++f)
+            for (int e = 0; e < n; ++e) {
+                const size_t a = (size_t)f * n + e, b = (size_t)f * n + perm[e];
+                if (std::fabs(c->h_delays[a] - c->h_delays[b]) * c->freq > 1e-9) return false;
+                if (std::fabs(c->h_apod[a] * c->h_area[e] - c->h_apod[b] * c->h_area[perm[e]]) >
+                    1e-12 * std::fabs(c->h_apod[a] * c->h_area[e])) return false;
+            }
+        return true;
+    };
+    c->dx = (c->mx == 2 && !steering_symmetric(c->h_px)) ? 2 : 1;
+    c->dy = (c->my == 2 && !steering_symmetric(c->h_py)) ? 2 : 1;
+    const int nm = c->dx * c->dy;
+    c->nf = 1;
+    if (c->allow_shared) while (c->nf * 2 <= F && c->nf * 2 * nm <= 8) c->nf *= 2;
+    char nmbuf[112];
+    if (c->mx * c->my * c->nf == 1) {
+        snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    } else {
+        std::vector<int> perm((size_t)nm * n);
+        for (int m = 0; m < nm; ++m)
+            for (int e = 0; e < n; ++e) {
+                int o = e;
+                const bool fx = c->dx == 2 && (m & 1), fy = c->dy == 2 && (c->dx == 2 ? (m >> 1) : (m & 1));
+                if (fx) o = c->h_px[o];
+                if (fy) o = c->h_py[o];
+                perm[(size_t)m * n + e] = o;
+            }
+        HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // perm is a stack vector
+        snprintf(nmbuf, sizeof nmbuf, "field_shared_k<4,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", c->mx, c->my, c->dx, c->dy, c->nf,
+                 c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    }
+    c->variant = nmbuf;
+    return OLX_OK;
+}
+
 static int pack_if_needed(olx_ctx* c) {
     if (c->packed_version == c->steer_version) return OLX_OK;
+    { int rc = configure_variant(c); if (rc) return rc; }
     const double lambda = c->c / c->freq;
     if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
@@ -263,7 +314,7 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g((c->n_el + 127) / 128, tiles);
         hipLaunchKernelGGL(steer_pack_shared_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->p0_pa / lambda, c->freq / c->c,
-                           c->plan_foci, c->nf, c->mx * c->my, c->d_tab);
+                           c->plan_foci, c->nf, c->dx * c->dy, c->d_tab);
     }
     HIPCHK(c, hipGetLastError());
     c->packed_version = c->steer_version;
@@ -366,61 +417,42 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         }
         return true;
     };
-    std::vector<int> px, py;
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // "general" disables kernel 2b (A/B measurements)
-    const bool allow_shared = !(force && !strcmp(force, "general"));
-    c->mx = (allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, px)) ? 2 : 1;
-    c->my = (allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, py)) ? 2 : 1;
-    const int nm_ = c->mx * c->my;
-    c->nf = 1;
-    if (allow_shared) while (c->nf * 2 <= n_foci && c->nf * 2 * nm_ <= 8) c->nf *= 2;
-    if (nm_ * c->nf > 1) {
-        std::vector<int> perm((size_t)nm_ * n);
-        for (int m = 0; m < nm_; ++m)
-            for (int e = 0; e < n; ++e) {
-                int o = e;
-                const bool fx = c->mx == 2 && (m & 1), fy = c->my == 2 && (c->mx == 2 ? (m >> 1) : (m & 1));
-                if (fx) o = px[o];
-                if (fy) o = py[o];
-                perm[(size_t)m * n + e] = o;
-            }
-        if (c->perm_cap < perm.size()) {
-            if (c->d_perm) hipFree(c->d_perm);
-            c->d_perm = nullptr; c->perm_cap = 0;
-            HIPCHK(c, hipMalloc((void**)&c->d_perm, sizeof(int) * perm.size()));
-            c->perm_cap = perm.size();
-        }
-        HIPCHK(c, hipMemcpy(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
-        const size_t tiles = (size_t)(n_foci + c->nf - 1) / c->nf;
-        const size_t need = tiles * n * (4 + 2 * nm_ * c->nf);
+    c->allow_shared = !(force && !strcmp(force, "general"));
+    c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
+    c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
+    {   // worst-case table: 12 floats per (focus, element) (nf = 1, four distinct mirror columns)
+        const size_t need = (size_t)n_foci * n * 12;
         if (c->tab_cap < need) {
             if (c->d_tab) hipFree(c->d_tab);
             c->d_tab = nullptr; c->tab_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_tab, sizeof(float) * need));
             c->tab_cap = need;
         }
-        SharedParams& S = c->sp;
-        S.nx = P.nx; S.ny = P.ny; S.nz = P.nz; S.n_el = n; S.x_begin = s.x_begin; S.n_foci = n_foci;
-        S.hx = P.hx; S.hy = P.hy; S.hz = P.hz; S.dmin2 = P.dmin2;
-        S.inten_scale = P.inten_scale; S.flat_ez = P.flat_ez; S.vox = P.vox; S.flags = P.flags;
+        if (c->perm_cap < (size_t)4 * n) {
+            if (c->d_perm) hipFree(c->d_perm);
+            c->d_perm = nullptr; c->perm_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_perm, sizeof(int) * 4 * n));
+            c->perm_cap = (size_t)4 * n;
+        }
     }
-    char nm[96];
-    if (nm_ * c->nf == 1)
-        snprintf(nm, sizeof nm, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
-    else
-        snprintf(nm, sizeof nm, "field_shared_k<4,mx%d,my%d,nf%d,%s,%s>", c->mx, c->my, c->nf, c->flat ? "flat" : "general",
-                 c->clamp ? "clamp" : "noclamp");
+    SharedParams& S = c->sp;
+    S.nx = P.nx; S.ny = P.ny; S.nz = P.nz; S.n_el = n; S.x_begin = s.x_begin; S.n_foci = n_foci;
+    S.hx = P.hx; S.hy = P.hy; S.hz = P.hz; S.dmin2 = P.dmin2;
+    S.inten_scale = P.inten_scale; S.flat_ez = P.flat_ez; S.vox = P.vox; S.flags = P.flags;
+    c->dx = c->mx; c->dy = c->my; c->nf = 1;
+    char nm[96] = "(steering-dependent)";
     c->variant = nm;
     c->packed_version = ~0ull;
     c->planned = true; c->uploaded = false;
     c->cur = 0;
-    return OLX_OK;
+    return configure_variant(c);  // provisional (re-evaluated when the steering table changes)
 }
 
 }  // extern "C"
 
-template <int MX, int MY, int NF>
+template <int MX, int MY, int DX, int DY, int NF>
 static void launch_shared(olx_ctx* c, float* pm) {
     const SharedParams& S = c->sp;
     constexpr int ZPL = 4;
@@ -429,22 +461,29 @@ static void launch_shared(olx_ctx* c, float* pm) {
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), (c->plan_foci + NF - 1) / NF);
     dim3 blk(FIELD_THREADS);
     if (c->flat) {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
     } else {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
     }
 }
 
 static bool dispatch_shared(olx_ctx* c, float* pm) {
-    const int key = c->mx * 100 + c->my * 10 + 0;
-    (void)key;
-#define OLX_CASE(MX_, MY_, NF_) if (c->mx == MX_ && c->my == MY_ && c->nf == NF_) { launch_shared<MX_, MY_, NF_>(c, pm); return true; }
-    OLX_CASE(1, 1, 2) OLX_CASE(1, 1, 4) OLX_CASE(1, 1, 8)
-    OLX_CASE(2, 1, 1) OLX_CASE(2, 1, 2) OLX_CASE(2, 1, 4)
-    OLX_CASE(1, 2, 1) OLX_CASE(1, 2, 2) OLX_CASE(1, 2, 4)
-    OLX_CASE(2, 2, 1) OLX_CASE(2, 2, 2)
+#define OLX_CASE(MX_, MY_, DX_, DY_, NF_) \
+    if (c->mx == MX_ && c->my == MY_ && c->dx == DX_ && c->dy == DY_ && c->nf == NF_) { launch_shared<MX_, MY_, DX_, DY_, NF_>(c, pm); return true; }
+    // no fold: foci tiles only
+    OLX_CASE(1, 1, 1, 1, 2) OLX_CASE(1, 1, 1, 1, 4) OLX_CASE(1, 1, 1, 1, 8)
+    // one fold
+    OLX_CASE(2, 1, 1, 1, 1) OLX_CASE(2, 1, 1, 1, 2) OLX_CASE(2, 1, 1, 1, 4) OLX_CASE(2, 1, 1, 1, 8)
+    OLX_CASE(2, 1, 2, 1, 1) OLX_CASE(2, 1, 2, 1, 2) OLX_CASE(2, 1, 2, 1, 4)
+    OLX_CASE(1, 2, 1, 1, 1) OLX_CASE(1, 2, 1, 1, 2) OLX_CASE(1, 2, 1, 1, 4) OLX_CASE(1, 2, 1, 1, 8)
+    OLX_CASE(1, 2, 1, 2, 1) OLX_CASE(1, 2, 1, 2, 2) OLX_CASE(1, 2, 1, 2, 4)
+    // two folds
+    OLX_CASE(2, 2, 1, 1, 1) OLX_CASE(2, 2, 1, 1, 2) OLX_CASE(2, 2, 1, 1, 4) OLX_CASE(2, 2, 1, 1, 8)
+    OLX_CASE(2, 2, 2, 1, 1) OLX_CASE(2, 2, 2, 1, 2) OLX_CASE(2, 2, 2, 1, 4)
+    OLX_CASE(2, 2, 1, 2, 1) OLX_CASE(2, 2, 1, 2, 2) OLX_CASE(2, 2, 1, 2, 4)
+    OLX_CASE(2, 2, 2, 2, 1) OLX_CASE(2, 2, 2, 2, 2)
 #undef OLX_CASE
     return false;
 }

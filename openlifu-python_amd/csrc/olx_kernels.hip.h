@@ -241,7 +241,8 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
 // (lanes cover only the upper half of that axis and also write the mirrored voxel),
 // NF = foci per tile (blockIdx.y = tile).  Exact: no approximation is involved, only
 // re-association of which (voxel, element) pair is evaluated where.
-// Table entry (tile, e) = { x_e, y_e, z_e, 0, (wr_k, wi_k) k < NOUT },  k = f_local*NM + m.
+// Table entry (tile, e) = { x_e, y_e, z_e, 0, (wr_k, wi_k) k < NOUT },  k = f_local*NM + cx + DX*cy,
+// NM = DX*DY distinct mirror columns (perm[m] passed to the pack kernel lists exactly those).
 // Coordinates on a mirrored axis are taken relative to the grid centre and formed as
 // (2 i - (n-1)) * h/2 so that x(n-1-i) == -x(i) bit for bit.
 // ------------------------------------------------------------------------------------
@@ -254,11 +255,15 @@ struct SharedParams {
     unsigned flags;
 };
 
-template <int ZPL, int MX, int MY, int NF, bool FLAT, bool CLAMP>
+// DX / DY (1 or 2) = distinct weight columns along a folded axis: when the steering itself is
+// mirror-symmetric (W[sigma e] == W[e] bit for bit, e.g. an on-axis focus) the mirrored voxel's
+// value is the same sum, so it is accumulated once (D = 1) and stored twice.
+template <int ZPL, int MX, int MY, int DX, int DY, int NF, bool FLAT, bool CLAMP>
 __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
     const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
     float* __restrict__ cplx, const SharedParams P) {
-    constexpr int NM = MX * MY, NOUT = NM * NF, STRIDE = 4 + 2 * NOUT;
+    static_assert(DX <= MX && DY <= MY, "distinct columns cannot exceed the fold");
+    constexpr int NM = DX * DY, NOUT = NM * NF, STRIDE = 4 + 2 * NOUT;
     const int tile = blockIdx.y;
     const unsigned cpr = (unsigned)(P.nz + ZPL - 1) / ZPL;
     const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
@@ -320,11 +325,14 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
     }
     const bool full = (k0 + ZPL <= P.nz) && (P.nz % ZPL == 0);
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        const int f = tile * NF + k / NM;
+    for (int kk = 0; kk < MX * MY * NF; ++kk) {      // every stored volume slice: (focus, mirror image)
+        const int f = tile * NF + kk / (MX * MY);
         if (f >= P.n_foci) continue;
-        const int m = k % NM;
-        const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+        const int ms = kk % (MX * MY);                // store mirror: bit 0 = x (if MX == 2), next = y
+        const bool fx = (MX == 2) && (ms & 1), fy = (MY == 2) && ((MX == 2) ? (ms >> 1) : (ms & 1));
+        // weight column that holds this image's sum (collapsed along axes with symmetric steering)
+        const int cx = (DX == 2 && fx) ? 1 : 0, cy = (DY == 2 && fy) ? 1 : 0;
+        const int k = (kk / (MX * MY)) * NM + cx + DX * cy;
         const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
         const long long base = (long long)f * P.vox + ((long long)io * P.ny + jo) * P.nz + k0;
         float pm[ZPL], it[ZPL];

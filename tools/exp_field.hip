@@ -20,6 +20,12 @@ using namespace olx;
 #ifndef EXP_MY
 #define EXP_MY 2
 #endif
+#ifndef EXP_DX
+#define EXP_DX EXP_MX
+#endif
+#ifndef EXP_DY
+#define EXP_DY EXP_MY
+#endif
 #ifndef EXP_NF
 #define EXP_NF 1
 #endif
@@ -47,12 +53,12 @@ int main(int argc, char** argv) {
         for (int i = 0; i < N; ++i) delays[f * N + i] = mx - tof[i];
     }
     // mirror permutations for the centred array
-    constexpr int NM = EXP_MX * EXP_MY;
+    constexpr int NM = EXP_DX * EXP_DY;
     std::vector<int> perm(NM * N);
     for (int m = 0; m < NM; ++m)
         for (int e = 0; e < N; ++e) {
             int ix = e / NE, iy = e % NE;
-            const bool fx = EXP_MX == 2 && (m & 1), fy = EXP_MY == 2 && (EXP_MX == 2 ? (m >> 1) : (m & 1));
+            const bool fx = EXP_DX == 2 && (m & 1), fy = EXP_DY == 2 && (EXP_DX == 2 ? (m >> 1) : (m & 1));
             if (fx) ix = NE - 1 - ix;
             if (fy) iy = NE - 1 - iy;
             perm[m * N + e] = ix * NE + iy;
@@ -81,7 +87,7 @@ int main(int argc, char** argv) {
     const long long lanes = (long long)(G - (EXP_MX == 2 ? G / 2 : 0)) * (G - (EXP_MY == 2 ? G / 2 : 0)) * cpr;
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), 1);
     auto launch = [&]() {
-        hipLaunchKernelGGL((field_shared_k<EXP_ZPL, EXP_MX, EXP_MY, EXP_NF, true, false>), grid, dim3(FIELD_THREADS), 0, 0,
+        hipLaunchKernelGGL((field_shared_k<EXP_ZPL, EXP_MX, EXP_MY, EXP_DX, EXP_DY, EXP_NF, true, false>), grid, dim3(FIELD_THREADS), 0, 0,
                            d_tab, d_pm, d_it, (float*)nullptr, S);
     };
     for (int i = 0; i < 3; ++i) launch();
