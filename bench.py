@@ -193,9 +193,20 @@ def main():
             tj = json.load(open(tpath))
             key = f"{args.elements}_{args.grid}_{F}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        # VALU-issue ceiling of the exact per-pair formulation: 6 plain + 3
-        # transcendental wave-instructions per 64 pairs per SIMD
-        ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 / (6 * CYC_PLAIN + 3 * CYC_TRANS)
+        # VALU-issue ceiling of the kernel variant in use: one geometry term G
+        # (4 plain + 3 transcendental wave-instructions per 64 lanes) serves mx*my*nf logical pairs and
+        # feeds dx*dy*nf complex accumulators at 4 fma each (issued as 2 v_pk_fma_f32 @4.2 cycles);
+        # the unfolded kernel 2a fuses phase and weight instead: 6 plain + 3 transcendental per pair.
+        import re
+        m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", ctx.field_variant())
+        if m:
+            mx, my, dx, dy, nf = (int(v) for v in m.groups())
+            cyc_per_g = 4 * CYC_PLAIN + 3 * CYC_TRANS + dx * dy * nf * 2 * 4.2
+            pairs_per_g, model = mx * my * nf, (f"per G: 4 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + "
+                                               f"{dx * dy * nf} x 2 v_pk_fma @4.2 cycles, serving {mx * my * nf} pairs")
+        else:
+            cyc_per_g, pairs_per_g, model = 6 * CYC_PLAIN + 3 * CYC_TRANS, 1, f"per pair: 6 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} cycles"
+        ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 * pairs_per_g / cyc_per_g
         out = {
             "metric": "Mvoxel-elements/s pressure-field accumulate", "value": value, "unit": "Mvoxel-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -209,12 +220,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "exact per-pair formulation is VALU/transcendental-issue bound, not HBM bound "
-                                 "(SURVEY 8(d)); see valu_ceiling"},
+                         "note": "the accumulate is VALU/transcendental-issue bound, not HBM bound "
+                                 "(SURVEY 8(d), DESIGN.md 5); see valu_ceiling"},
             "valu_ceiling": {"achieved_Mpairs_s": float(V) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
                              "frac": float(V) * N * F / (k_ms * 1e-3) / ceil_pairs,
-                             "model": "6 plain VALU @2.45 cyc + 3 transcendental @8.17 cyc per 64 pairs per SIMD, "
-                                      "1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"},
+                             "model": model + "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"},
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, setup, foci, args.cpu_seconds)

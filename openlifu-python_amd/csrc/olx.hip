@@ -59,6 +59,8 @@ struct olx_ctx {
     FieldParams fp{};
     bool flat = false, clamp = false;
     // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
+    bool use_mfma = false; int nt = 1; MfmaParams mp{}; float4* d_coords = nullptr; uint4* d_bfrag = nullptr; int* d_colinfo = nullptr;
+    size_t coords_cap = 0, bfrag_cap = 0; double min_dist = 0, mfma_wscale = 0; int force_kind = 0;  // 0 auto, 1 general, 2 shared, 3 mfma
     int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
     static constexpr int NBUF = 2;
@@ -139,7 +141,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     olx_comm_destroy(c);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
-                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm};
+                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -275,8 +277,75 @@ static int configure_variant(olx_ctx* c) {
     const int nm = c->dx * c->dy;
     c->nf = 1;
     if (c->allow_shared) while (c->nf * 2 <= F && c->nf * 2 * nm <= 8) c->nf *= 2;
-    char nmbuf[112];
-    if (c->mx * c->my * c->nf == 1) {
+    char nmbuf[128];
+    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2);
+    c->nt = 1;
+    if (c->use_mfma) {  // kernel 2c reuses each geometry fragment for up to 4 column tiles (32 outputs)
+        while (c->nf * 2 <= F && c->nf * 2 * nm <= MFMA_COLS * MFMA_MAX_NT) c->nf *= 2;
+        while (c->nt * MFMA_COLS < nm * c->nf) c->nt *= 2;
+    }
+    const int cols = nm * c->nf;
+    if (c->use_mfma) {
+        const double rev = c->freq / c->c, lambda = c->c / c->freq;
+        const int n_pad = (n + 15) / 16 * 16, tiles = (F + c->nf - 1) / c->nf;
+        // mirror permutation rows for the distinct columns
+        std::vector<int> perm((size_t)nm * n);
+        for (int m = 0; m < nm; ++m)
+            for (int e = 0; e < n; ++e) {
+                int o = e;
+                const bool fx = c->dx == 2 && (m & 1), fy = c->dy == 2 && (c->dx == 2 ? (m >> 1) : (m & 1));
+                if (fx) o = c->h_px[o];
+                if (fy) o = c->h_py[o];
+                perm[(size_t)m * n + e] = o;
+            }
+        HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+        // column map: o = f_local * nm + column(image); images = mask of mirror images stored from it
+        int colinfo[MFMA_COLS * MFMA_MAX_NT * 3];
+        MfmaParams& M = c->mp;
+        for (int o = 0; o < MFMA_COLS * MFMA_MAX_NT; ++o) {
+            const int fl = o / nm, cm = o % nm;
+            int images = 0;
+            if (o < cols)
+                for (int m = 0; m < c->mx * c->my; ++m) {
+                    const bool fx = c->mx == 2 && (m & 1), fy = c->my == 2 && (c->mx == 2 ? (m >> 1) : (m & 1));
+                    const int col_of_image = ((c->dx == 2 && fx) ? 1 : 0) + c->dx * ((c->dy == 2 && fy) ? 1 : 0);
+                    if (col_of_image == cm) images |= 1 << m;
+                }
+            M.cols[o].focus = fl; M.cols[o].images = images;
+            colinfo[3 * o] = fl; colinfo[3 * o + 1] = images; colinfo[3 * o + 2] = cm;
+        }
+        if (!c->d_colinfo) HIPCHK(c, hipMalloc((void**)&c->d_colinfo, sizeof colinfo));
+        HIPCHK(c, hipMemcpyAsync(c->d_colinfo, colinfo, sizeof colinfo, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // perm / colinfo live on this stack frame
+        if (c->coords_cap < (size_t)n_pad) {
+            if (c->d_coords) hipFree(c->d_coords);
+            c->d_coords = nullptr; c->coords_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
+            c->coords_cap = n_pad;
+        }
+        const size_t need = (size_t)tiles * (n_pad / 16) * 128 * c->nt;
+        if (c->bfrag_cap < need) {
+            if (c->d_bfrag) hipFree(c->d_bfrag);
+            c->d_bfrag = nullptr; c->bfrag_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_bfrag, sizeof(uint4) * need));
+            c->bfrag_cap = need;
+        }
+        // power-of-two operand scales: |G| <= 1/d'_min, |W| <= wmax  ->  hi parts <= 2^14, lo parts normal
+        const double dmin_w = std::max(c->min_dist * rev, 1e-6);
+        const double sg = std::exp2(std::floor(std::log2(16384.0 * dmin_w)));
+        double wmax = 0;
+        for (size_t q = 0; q < (size_t)F * n; ++q) wmax = std::max(wmax, std::fabs(c->h_apod[q] * c->h_area[q % n]));
+        wmax *= c->p0_pa / lambda * rev;
+        const double sw = wmax > 0 ? std::exp2(std::floor(std::log2(16384.0 / wmax))) : 1.0;
+        const FieldParams& P = c->fp;
+        M.nx = P.nx; M.ny = P.ny; M.nz = P.nz; M.n_el_pad = n_pad; M.x_begin = P.x_begin; M.n_tiles = tiles;
+        M.hx = P.hx; M.hy = P.hy; M.hz = P.hz; M.dmin2 = P.dmin2; M.flat_ez = P.flat_ez;
+        M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = P.inten_scale;
+        M.vox = P.vox; M.flags = P.flags; M.nf = c->nf; M.n_foci = F;
+        c->mfma_wscale = c->p0_pa / lambda * rev * sw;
+        snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", P.nz >= 48 ? 4 : 1, c->nt, c->mx,
+                 c->my, c->dx, c->dy, c->nf, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+    } else if (c->mx * c->my * c->nf == 1) {
         snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
         std::vector<int> perm((size_t)nm * n);
@@ -301,7 +370,14 @@ static int pack_if_needed(olx_ctx* c) {
     if (c->packed_version == c->steer_version) return OLX_OK;
     { int rc = configure_variant(c); if (rc) return rc; }
     const double lambda = c->c / c->freq;
-    if (c->mx * c->my * c->nf == 1) {
+    if (c->use_mfma) {
+        const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
+        const double oy = c->my == 2 ? c->grid.origin[1] + 0.5 * (c->grid.n[1] - 1) * c->grid.spacing[1] : c->grid.origin[1];
+        dim3 g(c->mp.n_el_pad / 16, c->mp.n_tiles, c->nt);
+        hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
+                           c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
+                           c->plan_foci, c->nf, c->d_colinfo, c->d_coords, c->d_bfrag);
+    } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
@@ -387,15 +463,18 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     }
     c->clamp = false;
     const double guard = 2.0 * dmin;
-    for (int e = 0; e < n && !c->clamp; ++e) {
+    double min_d2 = 1e300;
+    for (int e = 0; e < n; ++e) {
         double d2 = 0;
         for (int a = 0; a < 3; ++a) {
             const double p = c->h_pos[(size_t)a * n + e];
             const double d = p < lo[a] ? lo[a] - p : (p > hi[a] ? p - hi[a] : 0.0);
             d2 += d * d;
         }
+        min_d2 = std::min(min_d2, d2);
         if (d2 < guard * guard) c->clamp = true;
     }
+    c->min_dist = c->clamp ? dmin : std::sqrt(min_d2);  // lower bound of any voxel-element distance [m]
     // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
     auto mirror_perm = [&](int axis, std::vector<int>& perm) -> bool {
         const double ctr = g->origin[axis] + 0.5 * (g->n[axis] - 1) * g->spacing[axis];
@@ -418,8 +497,9 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         return true;
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
-    const char* force = getenv("OLX_FIELD_VARIANT");  // "general" disables kernel 2b (A/B measurements)
-    c->allow_shared = !(force && !strcmp(force, "general"));
+    const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma: pin a kernel family (A/B measurements)
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : 0;
+    c->allow_shared = c->force_kind != 1;
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
     {   // worst-case table: 12 floats per (focus, element) (nf = 1, four distinct mirror columns)
@@ -467,6 +547,32 @@ static void launch_shared(olx_ctx* c, float* pm) {
         if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
         else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
     }
+}
+
+template <int MT, int NT, int MX, int MY>
+static void launch_mfma(olx_ctx* c, float* pm) {
+    const MfmaParams& M = c->mp;
+    const long long rpr = (M.nz + MT * 16 - 1) / (MT * 16);
+    const long long runs = (long long)(M.nx - (MX == 2 ? M.nx / 2 : 0)) * (M.ny - (MY == 2 ? M.ny / 2 : 0)) * rpr;
+    dim3 grid((unsigned)((runs + 3) / 4), M.n_tiles), blk(FIELD_THREADS);
+#define OLX_MF(FL, CL) hipLaunchKernelGGL((field_mfma_k<MT, NT, MX, MY, FL, CL>), grid, blk, 0, c->stream, c->d_coords, c->d_bfrag, pm, c->d_inten, c->d_cplx, M)
+    if (c->flat) { if (c->clamp) OLX_MF(true, true); else OLX_MF(true, false); }
+    else         { if (c->clamp) OLX_MF(false, true); else OLX_MF(false, false); }
+#undef OLX_MF
+}
+
+template <int MX, int MY>
+static void dispatch_mfma_nt(olx_ctx* c, float* pm) {
+    const bool big = c->mp.nz >= 48;
+    if (big) { if (c->nt == 1) launch_mfma<4, 1, MX, MY>(c, pm); else if (c->nt == 2) launch_mfma<4, 2, MX, MY>(c, pm); else launch_mfma<4, 4, MX, MY>(c, pm); }
+    else     { if (c->nt == 1) launch_mfma<1, 1, MX, MY>(c, pm); else if (c->nt == 2) launch_mfma<1, 2, MX, MY>(c, pm); else launch_mfma<1, 4, MX, MY>(c, pm); }
+}
+
+static void dispatch_mfma(olx_ctx* c, float* pm) {
+    if (c->mx == 2 && c->my == 2) dispatch_mfma_nt<2, 2>(c, pm);
+    else if (c->mx == 2) dispatch_mfma_nt<2, 1>(c, pm);
+    else if (c->my == 2) dispatch_mfma_nt<1, 2>(c, pm);
+    else dispatch_mfma_nt<1, 1>(c, pm);
 }
 
 static bool dispatch_shared(olx_ctx* c, float* pm) {
@@ -517,7 +623,9 @@ int olx_field_launch(olx_ctx* c) {
     float* pm = c->d_pmag[b];
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    if (c->mx * c->my * c->nf > 1) {
+    if (c->use_mfma) {
+        dispatch_mfma(c, pm);
+    } else if (c->mx * c->my * c->nf > 1) {
         if (!dispatch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
     else                { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }

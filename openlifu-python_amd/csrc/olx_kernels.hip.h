@@ -397,6 +397,245 @@ __global__ void steer_pack_shared_k(const double* __restrict__ pos, const double
 }
 
 // ------------------------------------------------------------------------------------
+// kernel 2c: shared-geometry accumulate with the contraction on the matrix cores.
+//
+//   out[v, c] = sum_k A[v, k] B[k, c]      k = (element e, part in {re, im}),  c = (output o, part)
+//   A[v,(e,re)] = Re G(v,e), A[v,(e,im)] = Im G(v,e),   G = exp(j k d)/d  (focus independent)
+//   B[(e,re)][(o,re)] = wr, B[(e,im)][(o,re)] = -wi, B[(e,re)][(o,im)] = wi, B[(e,im)][(o,im)] = wr
+// "output o" = one (focus, mirror-column) pair of kernel 2b; up to 8 of them fill the 16 columns of
+// v_mfma_f32_16x16x32_f16.  The VALU produces G (the transcendentals) directly in the MFMA A-operand
+// layout -- lane l owns voxel row l&15 and the four elements 4*(l>>4)..+3 of the 16-element K-step,
+// i.e. exactly its eight k values -- so no LDS transpose is needed; the matrix pipe runs concurrently
+// with the VALU.  fp32 accuracy from fp16 matrix math: both operands are split hi + lo
+// (x*S = hi + lo, |lo| <= 2^-11 |hi|) and three products are accumulated in fp32,
+//   A B ~= Ah Bh + Al Bh + Ah Bl        (dropped term Al Bl ~ 2^-22 relative);
+// power-of-two scales S_G, S_W keep hi and lo in fp16's normal range and are undone in the epilogue.
+// A wave owns MT tiles of 16 consecutive z voxels of one grid row; B fragments (pre-packed in
+// lane order by mfma_pack_k) and element coordinates are staged per 256-element chunk in LDS.
+// ------------------------------------------------------------------------------------
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+constexpr int MFMA_COLS = 8;        // complex output columns per 16-column MFMA tile
+constexpr int MFMA_MAX_NT = 4;      // column tiles per launch tile (A fragments are reused across them)
+constexpr int MFMA_ELEMS_LDS = 256; // elements * NT staged in LDS at a time (32 KiB of B fragments)
+
+struct MfmaCol { int focus; int images; };  // images: bit m set -> store this column to mirror image m
+struct MfmaParams {
+    int nx, ny, nz, n_el_pad;      // n_el_pad: elements padded to a multiple of 16 (zero weights)
+    int x_begin, n_tiles;
+    float hx, hy, hz;              // [wavelengths]
+    float dmin2, flat_ez, g_scale; // g_scale = S_G
+    float out_scale;               // 1 / (S_G S_W)
+    float inten_scale;
+    long long vox;
+    unsigned flags;
+    int nf;                        // foci per launch tile
+    int n_foci;
+    MfmaCol cols[MFMA_COLS * MFMA_MAX_NT];  // same layout in every tile: focus = tile*nf + cols[o].focus
+};
+
+union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
+
+template <int MT, int NT, int MX, int MY, bool FLAT, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
+    const float4* __restrict__ coords /*[n_el_pad]*/, const uint4* __restrict__ bfrag /*[tiles][ks][NT][2][64]*/,
+    float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx, const MfmaParams P) {
+    constexpr int CH = MFMA_ELEMS_LDS / NT;              // elements per LDS chunk
+    __shared__ float4 s_xyz[CH];
+    __shared__ uint4 s_B[CH / 16][NT][2][64];
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    constexpr int RUN = MT * 16;                         // z voxels per wave
+    const unsigned rpr = (unsigned)(P.nz + RUN - 1) / RUN;  // runs per row
+    const int x_lo = (MX == 2) ? P.nx / 2 : 0, y_lo = (MY == 2) ? P.ny / 2 : 0;
+    const unsigned hyn = (unsigned)(P.ny - y_lo);
+    const unsigned rows = (unsigned)(P.nx - x_lo) * hyn;
+    const unsigned run = blockIdx.x * (FIELD_THREADS / 64) + wave;
+    const unsigned row = run / rpr;
+    const bool active = row < rows;                      // inactive waves still help staging LDS
+    const unsigned rowc = active ? row : 0;
+    const int zb = (int)(run - row * rpr) * RUN;
+    const int ii = (int)(rowc / hyn);
+    const int i = ii + x_lo, j = (int)(rowc - (unsigned)ii * hyn) + y_lo;
+    const float x = (MX == 2) ? (float)(2 * i - (P.nx - 1)) * (0.5f * P.hx) : (float)(i + P.x_begin) * P.hx;
+    const float y = (MY == 2) ? (float)(2 * j - (P.ny - 1)) * (0.5f * P.hy) : (float)j * P.hy;
+    float zz[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        zz[t] = (float)(zb + 16 * t + r16) * P.hz;
+        if (FLAT) { const float dz = zz[t] - P.flat_ez; zz[t] = dz * dz; }
+    }
+    floatx4_t acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int ks_total = P.n_el_pad / 16;
+    for (int chunk = 0; chunk < P.n_el_pad; chunk += CH) {
+        const int n_here = min(CH, P.n_el_pad - chunk), nks = n_here / 16;
+        __syncthreads();
+        if (tid < n_here) s_xyz[tid] = coords[chunk + tid];
+        const uint4* src = bfrag + ((size_t)tile * ks_total + chunk / 16) * (NT * 128);
+        for (int q = tid; q < nks * NT * 128; q += FIELD_THREADS) (&s_B[0][0][0][0])[q] = src[q];
+        __syncthreads();
+        if (!active) continue;
+        for (int ks = 0; ks < nks; ++ks) {
+            float r2[4], ez[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 e = s_xyz[16 * ks + 4 * g + q];
+                const float dx = x - e.x, dy = y - e.y;
+                r2[q] = fmaf(dy, dy, dx * dx);
+                ez[q] = e.z;
+            }
+            // B fragments of this K-step stay in registers and are reused by all MT voxel tiles.
+            Half8Bits bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bh[nt].u = s_B[ks][nt][0][lane];
+                bl[nt].u = s_B[ks][nt][1][lane];
+            }
+            // Per voxel tile: the VALU builds the A fragment (hi, lo), then its 3*NT MFMAs are issued.
+            // (Interleaving the MFMAs of tile t-1 into tile t's VALU stream with sched_group_barrier was
+            // measured: no gain -- on gfx950 the 16x16x32 MFMAs and this VALU mix add up)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                Half8Bits ah, al;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float d2;
+                    if (FLAT) {
+                        d2 = r2[q] + zz[t];
+                    } else {
+                        const float dz = zz[t] - ez[q];
+                        d2 = fmaf(dz, dz, r2[q]);
+                    }
+                    if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                    const float ri = __builtin_amdgcn_rsqf(d2);
+                    const float ph = d2 * ri;            // distance in wavelengths = phase in revolutions
+                    const float rs = ri * P.g_scale;
+                    const float gr = rs * __builtin_amdgcn_cosf(ph);
+                    const float gi = rs * __builtin_amdgcn_sinf(ph);
+                    const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
+                    const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
+                    ah.w[q] = __builtin_bit_cast(unsigned, hi);
+                    al.w[q] = __builtin_bit_cast(unsigned, lo);
+                }
+#ifdef OLX_EXP_NOMFMA
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt][0] += (float)bh[nt].h[0] + (float)bl[nt].h[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(ah.w[q]), "v"(al.w[q]));
+#else
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
+#endif
+            }
+        }
+    }
+    if (!active) return;
+    // epilogue.  D layout: lane holds rows 4*(lane>>4)+r (r = 0..3) of column lane&15 = (o, part):
+    // even lanes own Re, odd lanes Im of output o; after one cross-lane add both know |p|^2, the even
+    // lane stores |p| and the odd lane the intensity (16-B pieces, 64 B contiguous per column and tile).
+    const int part = r16 & 1;
+    float* const dst_arr = part == 0 ? pmag : inten;
+    const bool want = part == 0 ? (P.flags & 1u) != 0 : (P.flags & 2u) != 0;
+    const bool fast = (P.nz % RUN) == 0;  // wave-uniform: every z of the run exists, 16-B aligned
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const MfmaCol col = P.cols[nt * MFMA_COLS + (r16 >> 1)];
+        const int f = tile * P.nf + col.focus;
+        const bool col_live = col.images != 0 && f < P.n_foci;
+        float w[MT][4], v[MT][4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[t][r] = acc[t][nt][r] * P.out_scale;
+                const float sq = v[t][r] * v[t][r];
+                const float m2 = sq + __shfl_xor(sq, 1, 64);  // re^2 + im^2 (partner lane holds the other part)
+                w[t][r] = part == 0 ? __builtin_sqrtf(m2) : m2 * P.inten_scale;
+            }
+        if (!col_live) continue;
+#pragma unroll
+        for (int m = 0; m < MX * MY; ++m) {
+            if (!((col.images >> m) & 1)) continue;
+            const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+            const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+            const long long base = (long long)f * P.vox + ((long long)io * P.ny + jo) * P.nz + zb + 4 * g;
+            if (fast) {
+                if (want)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        *reinterpret_cast<float4*>(dst_arr + base + 16 * t) = make_float4(w[t][0], w[t][1], w[t][2], w[t][3]);
+            } else if (want) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (zb + 16 * t + 4 * g + r < P.nz) dst_arr[base + 16 * t + r] = w[t][r];
+            }
+            if (P.flags & 4u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (zb + 16 * t + 4 * g + r < P.nz) cplx[2 * (base + 16 * t + r) + part] = v[t][r];
+        }
+    }
+}
+
+// pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.
+// grid (n_el_pad/16, tiles, NT), block 64: thread = lane.  Column o (< 8*NT) of tile T carries weight
+// W[perm[colmirror[o]][e], focus T*nf + colfocus[o]] (zero beyond n_foci / unused columns).
+__global__ void mfma_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n, int n_pad,
+                            const double* __restrict__ delays, const double* __restrict__ apod,
+                            const int* __restrict__ perm, double ox, double oy, double oz, double freq,
+                            double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci, int nf,
+                            const int* __restrict__ colinfo /*[8*NT][3]: focus, images, mirror row of perm*/,
+                            float4* __restrict__ coords, uint4* __restrict__ bfrag) {
+    const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
+    if (tile == 0 && nt == 0 && lane < 16) {
+        const int e = 16 * ks + lane;
+        coords[e] = (e < n) ? make_float4((float)((pos[e] - ox) * rev), (float)((pos[n + e] - oy) * rev),
+                                          (float)((pos[2 * n + e] - oz) * rev), 0.f)
+                            : make_float4(1.0e4f, 1.0e4f, 1.0e4f, 0.f);  // padding: far away, zero weight
+    }
+    const int g = lane >> 4, c = lane & 15, o = nt * 8 + (c >> 1), part_c = c & 1;
+    const int col_focus = colinfo[3 * o], col_images = colinfo[3 * o + 1], col_mirror = colinfo[3 * o + 2];
+    Half8Bits hi, lo;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 8 * g + jj, e = 16 * ks + (k >> 1), part_k = k & 1;
+        double val = 0.0;
+        const int f = tile * nf + col_focus;
+        if (e < n && col_images != 0 && f < n_foci) {
+            const int es = perm[col_mirror * n + e];
+            const size_t off = (size_t)f * n + es;
+            const double cyc = freq * delays[off];
+            const double ph = 6.283185307179586476925286766559 * (cyc - floor(cyc));
+            const double w = apod[off] * area[es] * w_scale;
+            const double wr = w * cos(ph), wi = w * sin(ph);
+            val = part_k == 0 ? (part_c == 0 ? wr : wi) : (part_c == 0 ? -wi : wr);
+        }
+        const _Float16 h = (_Float16)(float)val;
+        const _Float16 l = (_Float16)(float)(val - (double)(float)h);
+        hi.h[jj] = h;
+        lo.h[jj] = l;
+    }
+    uint4* dst = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 128;
+    dst[lane] = hi.u;
+    dst[64 + lane] = lo.u;
+}
+
+// ------------------------------------------------------------------------------------
 // aggregation over foci (plan/protocol.py:384-387) and per-focus scaling
 // (plan/solution.py:331-337).  HBM-bound streaming: float4 per lane, grid-stride.
 // ------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 
 #include "../openlifu-python_amd/csrc/olx_kernels.hip.h"
@@ -28,6 +29,15 @@ using namespace olx;
 #endif
 #ifndef EXP_NF
 #define EXP_NF 1
+#endif
+#ifndef EXP_FLAGS
+#define EXP_FLAGS 3u
+#endif
+#ifndef EXP_NT
+#define EXP_NT 1
+#endif
+#ifndef EXP_MT
+#define EXP_MT 4
 #endif
 #ifndef EXP_ZPL
 #define EXP_ZPL 4
@@ -86,10 +96,42 @@ int main(int argc, char** argv) {
     const long long cpr = (G + EXP_ZPL - 1) / EXP_ZPL;
     const long long lanes = (long long)(G - (EXP_MX == 2 ? G / 2 : 0)) * (G - (EXP_MY == 2 ? G / 2 : 0)) * cpr;
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), 1);
-    auto launch = [&]() {
+    std::function<void()> launch = [&]() {
         hipLaunchKernelGGL((field_shared_k<EXP_ZPL, EXP_MX, EXP_MY, EXP_DX, EXP_DY, EXP_NF, true, false>), grid, dim3(FIELD_THREADS), 0, 0,
                            d_tab, d_pm, d_it, (float*)nullptr, S);
     };
+#ifdef EXP_MFMA
+    // kernel 2c on the same workload: 8 columns = EXP_NF2 foci x distinct mirror columns
+    constexpr int MT = EXP_MT;
+    const int n_pad = (N + 15) / 16 * 16;
+    float4* d_coords; uint4* d_bfrag; int* d_colinfo;
+    CHK(hipMalloc(&d_coords, sizeof(float4) * n_pad)); CHK(hipMalloc(&d_bfrag, sizeof(uint4) * (n_pad / 16) * 128 * EXP_NT));
+    int colinfo[96]; MfmaParams M{};
+    for (int o = 0; o < 8 * EXP_NT; ++o) {
+        const int fl = o / NM, cm = o % NM; int images = 0;
+        if (o < NM * EXP_NF)
+            for (int m = 0; m < EXP_MX * EXP_MY; ++m) {
+                const bool fx = EXP_MX == 2 && (m & 1), fy = EXP_MY == 2 && (EXP_MX == 2 ? (m >> 1) : (m & 1));
+                const int col = ((EXP_DX == 2 && fx) ? 1 : 0) + EXP_DX * ((EXP_DY == 2 && fy) ? 1 : 0);
+                if (col == cm) images |= 1 << m;
+            }
+        M.cols[o].focus = fl; M.cols[o].images = images; colinfo[3 * o] = fl; colinfo[3 * o + 1] = images; colinfo[3 * o + 2] = cm;
+    }
+    CHK(hipMalloc(&d_colinfo, sizeof colinfo)); CHK(hipMemcpy(d_colinfo, colinfo, sizeof colinfo, hipMemcpyHostToDevice));
+    const double sg = 16384.0, sw = 1024.0 * 16;
+    hipLaunchKernelGGL(mfma_pack_k, dim3(n_pad / 16, 1, EXP_NT), dim3(64), 0, 0, d_pos, d_area, N, n_pad, d_delays, d_apod, d_perm, ox, oy,
+                       oz, f0, 1e5 / (c0 / f0) * (f0 / c0) * sw, f0 / c0, F, EXP_NF, d_colinfo, d_coords, d_bfrag);
+    M.nx = M.ny = M.nz = G; M.n_el_pad = n_pad; M.x_begin = 0; M.n_tiles = 1; M.hx = M.hy = M.hz = S.hx; M.dmin2 = 0.f;
+    M.flat_ez = S.flat_ez; M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = S.inten_scale;
+    M.vox = vox; M.flags = EXP_FLAGS; M.nf = EXP_NF; M.n_foci = F;
+    const long long rpr = (G + MT * 16 - 1) / (MT * 16);
+    const long long runs = (long long)(G - (EXP_MX == 2 ? G / 2 : 0)) * (G - (EXP_MY == 2 ? G / 2 : 0)) * rpr;
+    dim3 mgrid((unsigned)((runs + 3) / 4), 1);
+    launch = [&]() {
+        hipLaunchKernelGGL((field_mfma_k<MT, EXP_NT, EXP_MX, EXP_MY, true, false>), mgrid, dim3(FIELD_THREADS), 0, 0, d_coords, d_bfrag,
+                           d_pm, d_it, (float*)nullptr, M);
+    };
+#endif
     for (int i = 0; i < 3; ++i) launch();
     CHK(hipDeviceSynchronize());
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
