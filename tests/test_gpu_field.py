@@ -220,3 +220,50 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     pf = sf.sweep_foci(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), *args, F0, RHO, P0)
     ps = sf.sweep_slabs(arr, d, a, *args, F0, C, RHO, P0)
     assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
+
+
+@pytest.mark.parametrize("family", ["general", "shared", "mfma"])
+def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
+    """Kernel 2a (per pair), 2b (shared geometry, VALU) and 2c (shared geometry, MFMA fp16 hi/lo split)
+    are pinned one at a time (OLX_FIELD_VARIANT) on the same off-axis symmetric-array case."""
+    monkeypatch.setenv("OLX_FIELD_VARIANT", family)
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = np.array([[2e-3, -1e-3, 38e-3], [0, 0, 40e-3], [-3e-3, 4e-3, 45e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("piecewise", 50.0, 15.0))
+    xs, ys, zs = centred_grid(64, 0.5)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (64,) * 3, F0, C, RHO, P0)
+    name = ctx.field_variant()
+    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k"}[family] in name, name
+    check(ctx, xs, ys, zs, pos_m, area, d, a)
+
+
+@pytest.mark.parametrize("n_foci", [5, 16, 33])
+def test_many_foci_without_symmetry_uses_wide_mfma_tiles(ctx, n_foci):
+    """Jittered (non-symmetric) array: foci tiles of 8 / 16 / 32 outputs per geometry term, ragged last
+    tile (n_foci not a multiple of the tile), grid sizes that are not multiples of the 64-voxel run."""
+    pos, ori, size = synthetic_array(8, 8, 4.0, jitter=True)
+    foci = bo.wheel_targets([0, 0, 30.0], True, n_foci - 1, 4.0) * 1e-3
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 40.0, 0.0))
+    xs = np.linspace(-6e-3, 6e-3, 13); ys = np.linspace(-5e-3, 5e-3, 11); zs = 5e-3 + np.arange(52) * 0.5e-3
+    ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0]), (13, 11, 52), F0, C, RHO, P0)
+    assert "field_mfma_k" in ctx.field_variant() and "mx1,my1" in ctx.field_variant(), ctx.field_variant()
+    check(ctx, xs, ys, zs, pos_m, area, d, a)
+
+
+def test_steering_change_reselects_variant(ctx):
+    """The kernel family depends on the steering table (symmetric steering collapses mirror columns):
+    replacing it after the plan must re-pack and re-select, not reuse a stale table."""
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 30e-3]])
+    xs, ys, zs = centred_grid(32, 1.0)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (1e-3,) * 3, (32,) * 3, F0, C, RHO, P0)
+    ctx.field_launch()
+    assert "dx1,dy1" in ctx.field_variant()
+    on_axis = ctx.field_fetch(0)["pmag"]
+    d2, a2 = bo.beamform(pos_m, ori, np.array([4e-3, 0, 30e-3]), C)
+    ctx.set_steering(d2[None], a2[None])
+    ctx.field_launch()
+    assert "dx2,dy1" in ctx.field_variant(), ctx.field_variant()
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d2, a2, F0, C, P0))
+    got = ctx.field_fetch(0)["pmag"]
+    assert np.abs(got - ref).max() / ref.max() <= TOL_P and not np.array_equal(got, on_axis)
