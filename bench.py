@@ -3,14 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of kernel 2
-(field_accum_k) that accumulates the complex pressure of `--foci-per-gpu` foci of a 256-element
-matrix array over a 256^3 grid -- BASELINE.json's metric configuration -- with the element table
-and the steering table already resident in HBM.  For N > 1 (launched by torch.distributed.run, one
-rank per GPU) each rank processes its own foci (weak scaling, no data-path collective in the
-compute) and the per-focus volumes are reassembled with an RCCL all-gather over xGMI on a side
-stream, overlapped with the next step's compute (north_star).  torch is used only for the
-rendezvous / barrier (gloo); the product path is ctypes -> HIP.
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of kernel 2 that
+accumulates the complex pressure of this GPU's `--foci-per-gpu` foci (default 8 = one GPU's share of
+BASELINE.json's 64-focus Wheel sweep, configs[2]) of a 256-element matrix array over a 256^3 grid,
+with the element table and the steering table already resident in HBM.  `--foci-per-gpu 1` is the
+single-focus accumulate.  For N > 1 (launched by torch.distributed.run, one rank per GPU) rank r takes
+foci [8r, 8r+8) of the sweep (weak scaling; the compute needs no collective).  `--reassemble` selects
+what crosses xGMI per step, on a side stream overlapped with the next step's compute:
+  aggregate (default)  local max/mean over the rank's foci + RCCL all-reduce of ONE volume pair -- the
+                       aggregated result of Protocol.calc_solution (plan/protocol.py:382-387), the only
+                       cross-rank dependency the sharded path has;
+  allgather            every per-focus |p| volume to every rank (north_star's reassembly; 67 MB per
+                       focus per peer: xGMI-bound, see DESIGN.md section 6);
+  none                 volumes stay sharded in each rank's HBM.
+torch is used only for the rendezvous / barrier (gloo); the product path is ctypes -> HIP.
 
 Prints ONE JSON line (rank 0).  `value` = V * N_el * F_total / time [Mvoxel-elements/s].
 """
@@ -46,13 +52,9 @@ def synthetic_workload(grid_n: int, spacing_mm: float, el=(16, 16), pitch_mm=3.0
     setup = ol.SimSetup(spacing=spacing_mm, x_extent=(-half, half), y_extent=(-half, half),
                         z_extent=(5.0, 5.0 + (grid_n - 1) * spacing_mm))
     target = ol.Point(position=(0, 0, 40), units="mm")
-    if n_foci == 1:
-        foci = [target]
-    else:
-        foci = ol.focal_patterns.Wheel(center=True, num_spokes=n_foci - 1, spoke_radius=5.0).get_targets(target)
-    if seed:  # distinct foci per rank
-        rng = np.random.default_rng(seed)
-        foci = [ol.Point(position=f.get_position(units="mm") + rng.uniform(-1, 1, 3), units="mm") for f in foci]
+    # BASELINE configs[2]: Wheel(center, 63 spokes, 5 mm) = 64 foci; rank r owns foci [r*F, r*F + F) (mod 64)
+    sweep = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0).get_targets(target)
+    foci = [sweep[(seed * n_foci + k) % len(sweep)] for k in range(n_foci)]
     return arr, setup, foci
 
 
@@ -103,13 +105,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--foci-per-gpu", type=int, default=1)
+    ap.add_argument("--foci-per-gpu", type=int, default=8)
+    ap.add_argument("--reassemble", choices=["aggregate", "allgather", "none"], default="aggregate")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--spacing-mm", type=float, default=0.25)
     ap.add_argument("--elements", type=str, default="16x16")
     ap.add_argument("--pitch-mm", type=float, default=3.0)
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
-    ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with 1 rank")
+    ap.add_argument("--force-comm", action="store_true", help="exercise the RCCL path even with 1 rank")
+    ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (debug: oversubscribe one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -133,11 +136,11 @@ def main():
     el = tuple(int(v) for v in args.elements.split("x"))
     arr, setup, foci = synthetic_workload(args.grid, args.spacing_mm, el, args.pitch_mm, args.foci_per_gpu, seed=rank)
     F, N = len(foci), arr.numelements()
-    eng = ol.get_engine(local_rank)
+    eng = ol.get_engine(local_rank if args.device is None else args.device)
     ctx = eng.ctx
     eng.bind(arr)
     ctx.bf_solve(np.array([f.get_position(units="m") for f in foci]), 1500.0)  # kernel 1: steering stays resident
-    gather = (world > 1 or args.force_gather) and not args.no_gather
+    gather = (world > 1 or args.force_comm) and args.reassemble != "none"
     gather_note = None
     if gather:
         try:
@@ -153,7 +156,9 @@ def main():
 
     def step():
         ctx.field_launch()
-        if gather:
+        if gather and args.reassemble == "aggregate":
+            ctx.field_allreduce_aggregate()
+        elif gather:
             ctx.field_allgather()
 
     def barrier():
@@ -212,10 +217,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N}-element {args.elements} matrix array x {args.grid}^3 grid "
-                                   f"({args.spacing_mm} mm), {F} focus/foci per GPU, |p|+intensity out",
+                                   f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
+                                   f"(BASELINE configs[2] shard), |p|+intensity out",
                        "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": 400e3,
                        "kernel": ctx.field_variant(),
-                       "reassembly": ("rccl-allgather-overlapped" if gather else ("none" if world == 1 else "skipped")),
+                       "reassembly": (f"rccl-{args.reassemble}-overlapped" if gather else
+                                      ("none" if (world == 1 or args.reassemble == "none") else "skipped")),
                        **({"reassembly_note": gather_note} if gather_note else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -174,6 +174,12 @@ int olx_comm_init(olx_ctx *ctx, const void *id_bytes, int nranks, int rank);
 int olx_comm_destroy(olx_ctx *ctx);
 int olx_field_allgather(olx_ctx *ctx);
 int olx_allgather_fetch(olx_ctx *ctx, int rank, float *pmag_out);
+/* Aggregated result with the foci sharded over ranks (plan/protocol.py:382-387): local max / sum over
+ * this rank's foci, then RCCL all-reduce (max for |p|, sum for the intensity mean) of one volume each,
+ * asynchronously on the side stream; the mean divides by n_foci * nranks (equal foci per rank).
+ * olx_aggregate_fetch waits for it and copies the reduced volumes to the host (either may be NULL). */
+int olx_field_allreduce_aggregate(olx_ctx *ctx);
+int olx_aggregate_fetch(olx_ctx *ctx, float *pmag_max_out, float *intensity_mean_out);
 
 #ifdef __cplusplus
 }

@@ -27,9 +27,11 @@ struct RcclApi {
     int (*CommInitRank)(olx_nccl_comm*, int, olx_nccl_id, int) = nullptr;
     int (*CommDestroy)(olx_nccl_comm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int /*dtype*/, olx_nccl_comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
+static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
 
 struct olx_ctx {
     int device = 0;
@@ -76,6 +78,7 @@ struct olx_ctx {
     hipStream_t comm_stream = nullptr; hipEvent_t ev_field[NBUF] = {nullptr, nullptr};
     hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
     float* d_gather = nullptr; size_t gather_cap = 0;
+    hipEvent_t ev_agg = nullptr, ev_red = nullptr; bool reduce_pending = false;
 };
 
 static int fail(olx_ctx* c, int code, const char* fmt, ...) {
@@ -754,7 +757,8 @@ int olx_field_aggregate(olx_ctx* c, float* pmax_out, float* imean_out) {
     if (pmax_out && !c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
     if (imean_out && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
     hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, pmax_out ? c->d_pmag[c->cur] : nullptr,
-                       imean_out ? c->d_inten : nullptr, c->plan_foci, (long long)vox, pmax_out ? c->d_agg_p : nullptr,
+                       imean_out ? c->d_inten : nullptr, c->plan_foci, (long long)vox, 1.0f / (float)c->plan_foci,
+                       pmax_out ? c->d_agg_p : nullptr,
                        imean_out ? c->d_agg_i : nullptr);
     HIPCHK(c, hipGetLastError());
     if (pmax_out) HIPCHK(c, hipMemcpyAsync(pmax_out, c->d_agg_p, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
@@ -836,7 +840,8 @@ static int load_rccl(olx_ctx* c) {
     r.CommDestroy = (int (*)(olx_nccl_comm))dlsym(r.handle, "ncclCommDestroy");
     r.AllGather = (int (*)(const void*, void*, size_t, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllGather");
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllReduce");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail(c, OLX_ECOMM, "RCCL symbols missing");
     return OLX_OK;
 }
@@ -889,6 +894,8 @@ int olx_comm_destroy(olx_ctx* c) {
         if (c->ev_gather[b]) { hipEventDestroy(c->ev_gather[b]); c->ev_gather[b] = nullptr; }
         c->gather_pending[b] = false;
     }
+    if (c->ev_agg) { hipEventDestroy(c->ev_agg); hipEventDestroy(c->ev_red); c->ev_agg = c->ev_red = nullptr; }
+    c->reduce_pending = false;
     if (c->comm_stream) { hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
     c->nranks = 1; c->rank = 0;
     return OLX_OK;
@@ -914,6 +921,49 @@ int olx_field_allgather(olx_ctx* c) {
     NCCLCHK(c, c->rccl.AllGather(c->d_pmag[b], c->d_gather, count, kNcclFloat32, c->comm, c->comm_stream));
     HIPCHK(c, hipEventRecord(c->ev_gather[b], c->comm_stream));
     c->gather_pending[b] = true;
+    return OLX_OK;
+}
+
+// Aggregated result across ranks (plan/protocol.py:382-387 with the foci sharded over GPUs): local
+// max / sum over this rank's foci on the compute stream, then RCCL all-reduce (max for |p|, sum for the
+// intensity mean) of ONE volume each on the side stream -- the exchange step the sharded path really has.
+int olx_field_allreduce_aggregate(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: call olx_comm_init first");
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: nothing planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t vox = (size_t)c->fp.vox;
+    const bool with_i = (c->flags & OLX_OUT_INTENSITY) != 0;
+    if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+    if (with_i && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+    if (!c->ev_agg) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_agg, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming)); }
+    if (c->reduce_pending) {  // the previous all-reduce still owns the aggregate buffers
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red, 0));
+        c->reduce_pending = false;
+    }
+    hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], with_i ? c->d_inten : nullptr,
+                       c->plan_foci, (long long)vox, 1.0f / ((float)c->plan_foci * (float)c->nranks), c->d_agg_p,
+                       with_i ? c->d_agg_i : nullptr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));
+    NCCLCHK(c, c->rccl.AllReduce(c->d_agg_p, c->d_agg_p, vox, kNcclFloat32, kNcclMax, c->comm, c->comm_stream));
+    if (with_i) NCCLCHK(c, c->rccl.AllReduce(c->d_agg_i, c->d_agg_i, vox, kNcclFloat32, kNcclSum, c->comm, c->comm_stream));
+    HIPCHK(c, hipEventRecord(c->ev_red, c->comm_stream));
+    c->reduce_pending = true;
+    return OLX_OK;
+}
+
+int olx_aggregate_fetch(olx_ctx* c, float* pmax_out, float* imean_out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->d_agg_p) return fail(c, OLX_ESTATE, "olx_aggregate_fetch: no aggregate computed");
+    if (imean_out && !c->d_agg_i) return fail(c, OLX_ESTATE, "olx_aggregate_fetch: intensity not aggregated");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    const size_t vox = (size_t)c->fp.vox;
+    if (pmax_out) HIPCHK(c, hipMemcpy(pmax_out, c->d_agg_p, sizeof(float) * vox, hipMemcpyDeviceToHost));
+    if (imean_out) HIPCHK(c, hipMemcpy(imean_out, c->d_agg_i, sizeof(float) * vox, hipMemcpyDeviceToHost));
     return OLX_OK;
 }
 

@@ -640,10 +640,9 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
 // (plan/solution.py:331-337).  HBM-bound streaming: float4 per lane, grid-stride.
 // ------------------------------------------------------------------------------------
 __global__ void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
-                                  int n_foci, long long vox, float* __restrict__ pmax,
-                                  float* __restrict__ imean) {
+                                  int n_foci, long long vox, float inv /* 1 / total foci (all ranks) */,
+                                  float* __restrict__ pmax, float* __restrict__ imean) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const float inv = 1.0f / (float)n_foci;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
         float m = 0.f, s = 0.f;
         for (int f = 0; f < n_foci; ++f) {

@@ -27,7 +27,8 @@ SYMBOLS = [
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_comm_unique_id", "olx_comm_init",
-    "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch",
+    "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
+    "olx_aggregate_fetch",
 ]
 
 
@@ -83,6 +84,8 @@ def load(require_gpu: bool = True):
         lib.olx_comm_destroy.argtypes = [vp]
         lib.olx_field_allgather.argtypes = [vp]
         lib.olx_allgather_fetch.argtypes = [vp, c_int, fp]
+        lib.olx_field_allreduce_aggregate.argtypes = [vp]
+        lib.olx_aggregate_fetch.argtypes = [vp, fp, fp]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -300,6 +303,15 @@ class Context:
 
     def field_allgather(self):
         self._chk(self._lib.olx_field_allgather(self._h))
+
+    def field_allreduce_aggregate(self):
+        self._chk(self._lib.olx_field_allreduce_aggregate(self._h))
+
+    def aggregate_fetch(self, want_intensity=True):
+        pm = np.empty(self._shape, dtype=np.float32)
+        it = np.empty(self._shape, dtype=np.float32) if want_intensity else None
+        self._chk(self._lib.olx_aggregate_fetch(self._h, _fptr(pm), _fptr(it)))
+        return pm, it
 
     def allgather_fetch(self, rank: int) -> np.ndarray:
         out = np.empty((self._plan_foci,) + self._shape, dtype=np.float32)

@@ -102,6 +102,15 @@ class ShardedField:
         gathered = np.stack([ctx.allgather_fetch(r) for r in range(self.world)])
         return assemble_foci(gathered, F)
 
+    def aggregate(self):
+        """Cross-rank aggregate of the volumes the last sweep left resident: (max_f |p|, mean_f I) over ALL
+        ranks' foci (plan/protocol.py:382-387) -- one RCCL all-reduce per volume instead of a gather."""
+        ctx = self.engine.ctx
+        if self.world == 1:
+            return ctx.field_aggregate(want_intensity=bool(ctx._flags & 2))
+        ctx.field_allreduce_aggregate()
+        return ctx.aggregate_fetch(want_intensity=bool(ctx._flags & 2))
+
     def sweep_slabs(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa):
         """mode "slabs": every rank accumulates ALL foci over its x-slab (better balance when
         F < world); returns |p| [F, nx, ny, nz] on every rank."""

@@ -49,6 +49,15 @@ def main():
     got = od.assemble_slabs(all_gather_np(local), len(xs))
     assert got.shape == full.shape and np.array_equal(got, full), "slab reassembly mismatch"
 
+    # --- aggregated result with sharded foci: all-reduce(max) / all-reduce(sum) of one volume
+    mine = full[np.unique(idx)] if rank * od.plan_foci(F, world)[0] < F else full[:0]
+    owned = od.plan_foci(F, world)[1][rank]
+    mine = full[owned[0]:owned[0] + owned[1]]
+    tmax = torch.from_numpy(mine.max(axis=0).copy()) if len(mine) else torch.zeros(full.shape[1:])
+    tsum = torch.from_numpy(mine.sum(axis=0).copy()) if len(mine) else torch.zeros(full.shape[1:])
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    assert np.array_equal(tmax.numpy(), full.max(axis=0)) and np.allclose(tsum.numpy() / F, full.mean(axis=0), rtol=1e-6)
+
     # --- max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
