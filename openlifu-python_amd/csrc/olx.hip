@@ -95,16 +95,6 @@ static int fail(olx_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                          \
     } while (0)
 
-template <typename T>
-static int ensure(olx_ctx* c, T** p, size_t* cap, size_t need) {
-    if (*cap >= need && *p) return OLX_OK;
-    if (*p) HIPCHK(c, hipFree(*p));
-    *p = nullptr; *cap = 0;
-    HIPCHK(c, hipMalloc((void**)p, need * sizeof(T)));
-    *cap = need;
-    return OLX_OK;
-}
-
 extern "C" {
 
 int olx_abi_version(void) { return OLX_ABI_VERSION; }
