@@ -143,13 +143,23 @@ def main():
     gather = (world > 1 or args.force_comm) and args.reassemble != "none"
     gather_note = None
     if gather:
+        ok = 1
         try:
             uid = [ctx.comm_unique_id() if rank == 0 else None]  # (libolx keeps RCCL's banner off stdout)
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0], world, rank)
         except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
-            gather, gather_note = False, f"RCCL init failed: {e}"
+            ok, gather_note = 0, f"RCCL init failed: {e}"
+        if dist is not None:  # every rank must take the same branch, or the collectives below would hang
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0 and ok:
+                gather_note = "RCCL init failed on another rank"
+                ctx.comm_destroy()
+            ok = int(flag[0])
+        gather = bool(ok)
     origin, spacing, n = grid_from_coords(setup.get_coords())
     ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
     V = int(np.prod(n))

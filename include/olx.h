@@ -157,9 +157,26 @@ int olx_field_scale(olx_ctx *ctx, const double *scale_per_focus, int n_foci);
  *   dist = sqrt(sum_a (q_a / aspect[a])^2)
  * the voxel is selected when `dist OP radius_m` (op 0 '<', 1 '<=', 2 '>', 3 '>=', 4 = no
  * distance test) and, if use_zmin, its z coordinate > zmin_m.  peak_out[F] receives the max
- * over selected voxels of |p_f| (which = 0) or intensity (which = 1); 0 when none selected. */
+ * over selected voxels of |p_f| (which = 0), intensity_f (which = 1) or the single weighted-intensity
+ * volume of olx_field_weighted_intensity (which = 2); 0 when none selected. */
 int olx_field_masked_peak(olx_ctx *ctx, int which, const double *A, const double *aspect,
                           double radius_m, int op, int use_zmin, double zmin_m, float *peak_out);
+
+/* Masked first moments per focus (find_centroid, plan/solution_analysis.py:306-317): over voxels with
+ * dist < radius_m (same focal-ellipsoid metric as above) and |p_f| > cutoff[f]:
+ * moments_out[F*4] = { sum p, sum p x, sum p y, sum p z } (x, y, z = voxel position in metres, fp64). */
+int olx_field_masked_moments(olx_ctx *ctx, const double *A, const double *aspect, double radius_m,
+                             const float *cutoff, double *moments_out);
+
+/* Trilinear samples of focus volume `focus` (|p| for which = 0, intensity for which = 1) at npts points
+ * pts_m[npts*3] (metres); NaN outside the grid, like the xarray interpolation behind get_beamwidth
+ * (plan/solution_analysis.py:444-574). */
+int olx_field_sample(olx_ctx *ctx, int which, int focus, const double *pts_m, int npts, float *out);
+
+/* out[v] = sum_f weights[f] * intensity_f[v] kept on the device as the "time-average" volume
+ * (Solution.get_ita, plan/solution.py:365-388); olx_field_masked_peak(which = 2) then scans THAT single
+ * volume with every focus' mask. */
+int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci);
 
 /* ---- multi-GPU reassembly (RCCL over xGMI) -------------------------------------------
  * One context per rank.  id_bytes = the 128-byte ncclUniqueId made by rank 0

@@ -70,6 +70,7 @@ struct olx_ctx {
     float* d_inten = nullptr; float* d_cplx = nullptr;
     float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
     double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
+    float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
     std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
@@ -134,7 +135,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     olx_comm_destroy(c);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
-                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo};
+                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -781,7 +782,8 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_masked_peak: nothing planned");
     if (!peak_out || !aspect || op < 0 || op > 4 || (op != 4 && !A)) return fail(c, OLX_EINVAL, "olx_field_masked_peak: bad arguments");
     if (which == 1 && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_masked_peak: intensity not planned");
-    if (which != 0 && which != 1) return fail(c, OLX_EINVAL, "olx_field_masked_peak: which must be 0 or 1");
+    if (which < 0 || which > 2) return fail(c, OLX_EINVAL, "olx_field_masked_peak: which must be 0, 1 or 2");
+    if (which == 2 && !c->d_wint) return fail(c, OLX_ESTATE, "olx_field_masked_peak: call olx_field_weighted_intensity first");
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->plan_foci;
     if (!c->d_peakA || c->peak_cap < (size_t)F) {
@@ -800,12 +802,89 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     P.hx = c->grid.spacing[0]; P.hy = c->grid.spacing[1]; P.hz = c->grid.spacing[2];
     P.ia0 = 1.0 / aspect[0]; P.ia1 = 1.0 / aspect[1]; P.ia2 = 1.0 / aspect[2];
     P.radius = radius_m; P.op = op; P.use_zmin = use_zmin; P.zmin = zmin_m; P.vox = c->fp.vox;
+    P.vol_stride = which == 2 ? 0 : c->fp.vox;
     const long long want = (P.vox + 255) / 256;
     dim3 grid((unsigned)std::min<long long>(want, 2048), F);
-    hipLaunchKernelGGL(field_masked_peak_k, grid, dim3(256), 0, c->stream, which == 0 ? c->d_pmag[c->cur] : c->d_inten,
-                       c->d_peakA, P, c->d_peak);
+    hipLaunchKernelGGL(field_masked_peak_k, grid, dim3(256), 0, c->stream,
+                       which == 0 ? c->d_pmag[c->cur] : (which == 1 ? c->d_inten : c->d_wint), c->d_peakA, P, c->d_peak);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(peak_out, c->d_peak, sizeof(float) * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+static void fill_scan_params(const olx_ctx* c, PeakParams& P, const double* aspect) {
+    P.nx = c->fp.nx; P.ny = c->fp.ny; P.nz = c->fp.nz;
+    P.ox = c->grid.origin[0] + c->slab.x_begin * c->grid.spacing[0]; P.oy = c->grid.origin[1]; P.oz = c->grid.origin[2];
+    P.hx = c->grid.spacing[0]; P.hy = c->grid.spacing[1]; P.hz = c->grid.spacing[2];
+    P.ia0 = aspect ? 1.0 / aspect[0] : 1.0; P.ia1 = aspect ? 1.0 / aspect[1] : 1.0; P.ia2 = aspect ? 1.0 / aspect[2] : 1.0;
+    P.radius = 0; P.op = 0; P.use_zmin = 0; P.zmin = 0; P.vox = c->fp.vox; P.vol_stride = c->fp.vox;
+}
+
+int olx_field_masked_moments(olx_ctx* c, const double* A, const double* aspect, double radius_m, const float* cutoff,
+                             double* moments_out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_masked_moments: nothing planned");
+    if (!A || !aspect || !cutoff || !moments_out) return fail(c, OLX_EINVAL, "olx_field_masked_moments: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->plan_foci;
+    double* d_A = nullptr; float* d_cut = nullptr; double* d_out = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_A, sizeof(double) * 12 * F));
+    HIPCHK(c, hipMalloc((void**)&d_cut, sizeof(float) * F));
+    HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * 4 * F));
+    HIPCHK(c, hipMemcpyAsync(d_A, A, sizeof(double) * 12 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cut, cutoff, sizeof(float) * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 4 * F, c->stream));
+    PeakParams P; fill_scan_params(c, P, aspect); P.radius = radius_m;
+    dim3 grid((unsigned)std::min<long long>((P.vox + 255) / 256, 1024), F);
+    hipLaunchKernelGGL(field_masked_moments_k, grid, dim3(256), 0, c->stream, c->d_pmag[c->cur], d_A, d_cut, P, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(moments_out, d_out, sizeof(double) * 4 * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_A); hipFree(d_cut); hipFree(d_out);
+    return OLX_OK;
+}
+
+int olx_field_sample(olx_ctx* c, int which, int focus, const double* pts_m, int npts, float* out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_sample: nothing planned");
+    if (!pts_m || !out || npts < 1) return fail(c, OLX_EINVAL, "olx_field_sample: null argument or npts < 1");
+    if (focus < 0 || focus >= c->plan_foci) return fail(c, OLX_EINVAL, "olx_field_sample: focus out of range");
+    if (which != 0 && which != 1) return fail(c, OLX_EINVAL, "olx_field_sample: which must be 0 or 1");
+    if (which == 1 && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_sample: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d_pts = nullptr; float* d_o = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_pts, sizeof(double) * 3 * npts));
+    HIPCHK(c, hipMalloc((void**)&d_o, sizeof(float) * npts));
+    HIPCHK(c, hipMemcpyAsync(d_pts, pts_m, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, c->stream));
+    PeakParams P; fill_scan_params(c, P, nullptr);
+    const float* vol = (which == 0 ? c->d_pmag[c->cur] : c->d_inten) + (size_t)focus * c->fp.vox;
+    hipLaunchKernelGGL(field_sample_k, dim3((npts + 127) / 128), dim3(128), 0, c->stream, vol, d_pts, npts, P, d_o);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_o, sizeof(float) * npts, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_pts); hipFree(d_o);
+    return OLX_OK;
+}
+
+int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_weighted_intensity: nothing planned");
+    if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_weighted_intensity: intensity not planned");
+    if (!weights || n_foci != c->plan_foci || n_foci > 4096) return fail(c, OLX_EINVAL, "olx_field_weighted_intensity: need %d weights", c->plan_foci);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+    if (!c->d_wint || c->wint_cap < (size_t)c->fp.vox) {
+        if (c->d_wint) hipFree(c->d_wint);
+        c->d_wint = nullptr; c->wint_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_wint, sizeof(float) * c->fp.vox));
+        c->wint_cap = (size_t)c->fp.vox;
+    }
+    std::vector<float> w(n_foci);
+    for (int i = 0; i < n_foci; ++i) w[i] = (float)weights[i];
+    HIPCHK(c, hipMemcpyAsync(c->d_scale, w.data(), sizeof(float) * n_foci, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, c->d_scale, n_foci, c->fp.vox, c->d_wint);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return OLX_OK;
 }

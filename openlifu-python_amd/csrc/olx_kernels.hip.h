@@ -680,6 +680,7 @@ struct PeakParams {
     double ia0, ia1, ia2;           // 1 / aspect
     double radius; int op; int use_zmin; double zmin;
     long long vox;
+    long long vol_stride;           // vox for per-focus volumes, 0 when every focus mask scans ONE volume
 };
 
 __global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restrict__ vol,
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restri
     __shared__ float s_red[4];
     if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
     __syncthreads();
-    const float* v = vol + (long long)f * P.vox;
+    const float* v = vol + (long long)f * P.vol_stride;
     float m = 0.f;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long nyz = (long long)P.ny * P.nz;
@@ -719,6 +720,96 @@ __global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restri
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         atomicMax(out + f, __float_as_uint(m));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// masked first moments per focus (find_centroid, plan/solution_analysis.py:306-317): over voxels inside
+// the focal ellipsoid (dist < radius) whose |p| exceeds cutoff_f:  S0 = sum p, S1 = sum p * (x, y, z).
+// fp64 sums, block-reduced, one atomicAdd(double) per block and component.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void field_masked_moments_k(const float* __restrict__ vol,
+                                                               const double* __restrict__ A,
+                                                               const float* __restrict__ cutoff,
+                                                               const PeakParams P, double* __restrict__ out /*[F][4]*/) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ double s_red[4][4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float* v = vol + (long long)f * P.vol_stride;
+    const float cut = cutoff[f];
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nyz = (long long)P.ny * P.nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / P.nz, iz = rem - iy * P.nz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+        const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+        const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+        const float p = v[i];
+        if (sqrt(q0 * q0 + q1 * q1 + q2 * q2) < P.radius && p > cut) {
+            s0 += p; sx += p * x; sy += p * y; sz += p * z;
+        }
+    }
+    double comp[4] = {s0, sx, sy, sz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) comp[k] += __shfl_xor(comp[k], off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = comp[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(out + 4 * f + threadIdx.x, s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
+                                                                s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------
+// trilinear samples of one resident volume at arbitrary points (interp_transformed_axis,
+// plan/solution_analysis.py:444-486: xarray linear interpolation, NaN outside the grid).
+// ------------------------------------------------------------------------------------
+__global__ void field_sample_k(const float* __restrict__ vol, const double* __restrict__ pts, int npts,
+                               const PeakParams P, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const double c[3] = {(pts[3 * i] - P.ox) / P.hx, (pts[3 * i + 1] - P.oy) / P.hy, (pts[3 * i + 2] - P.oz) / P.hz};
+    const int n[3] = {P.nx, P.ny, P.nz};
+    int i0[3]; double w[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double tol = 1e-9 * (n[a] > 1 ? n[a] - 1 : 1);
+        if (!(c[a] >= -tol && c[a] <= n[a] - 1 + tol)) inside = false;
+        double cc = fmin(fmax(c[a], 0.0), (double)(n[a] - 1));
+        i0[a] = (int)fmin(floor(cc), (double)max(n[a] - 2, 0));
+        w[a] = cc - i0[a];
+    }
+    if (!inside) { out[i] = __builtin_nanf(""); return; }
+    double acc = 0;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const int ix = min(i0[0] + dx, P.nx - 1), iy = min(i0[1] + dy, P.ny - 1), iz = min(i0[2] + dz, P.nz - 1);
+                const double ww = (dx ? w[0] : 1 - w[0]) * (dy ? w[1] : 1 - w[1]) * (dz ? w[2] : 1 - w[2]);
+                acc += ww * vol[((long long)ix * P.ny + iy) * P.nz + iz];
+            }
+    out[i] = (float)acc;
+}
+
+// weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
+__global__ void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
+                                     long long vox, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        float s = 0.f;
+        for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * vox + v];
+        out[v] = s;
     }
 }
 

@@ -26,7 +26,8 @@ SYMBOLS = [
     "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
-    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_comm_unique_id", "olx_comm_init",
+    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample",
+    "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
     "olx_aggregate_fetch",
 ]
@@ -79,6 +80,9 @@ def load(require_gpu: bool = True):
         lib.olx_field_aggregate.argtypes = [vp, fp, fp]
         lib.olx_field_scale.argtypes = [vp, dp, c_int]
         lib.olx_field_masked_peak.argtypes = [vp, c_int, dp, dp, c_double, c_int, c_int, c_double, fp]
+        lib.olx_field_masked_moments.argtypes = [vp, dp, dp, c_double, fp, dp]
+        lib.olx_field_sample.argtypes = [vp, c_int, c_int, dp, c_int, fp]
+        lib.olx_field_weighted_intensity.argtypes = [vp, dp, c_int]
         lib.olx_comm_unique_id.argtypes = [vp, vp]
         lib.olx_comm_init.argtypes = [vp, vp, c_int, c_int]
         lib.olx_comm_destroy.argtypes = [vp]
@@ -279,10 +283,30 @@ class Context:
         A = None if A is None else _f64(A, (F, 12))
         aspect = _f64(aspect, (3,))
         out = np.empty(F, dtype=np.float32)
-        self._chk(self._lib.olx_field_masked_peak(self._h, 0 if which == "pmag" else 1, _dptr(A), _dptr(aspect),
+        self._chk(self._lib.olx_field_masked_peak(self._h, {"pmag": 0, "intensity": 1, "weighted_intensity": 2}[which], _dptr(A), _dptr(aspect),
                                                   float(radius_m), ops[op], int(zmin_m is not None),
                                                   float(zmin_m or 0.0), _fptr(out)))
         return out
+
+    def field_masked_moments(self, A, aspect, radius_m, cutoff):
+        """[F,4] = (sum p, sum p x, sum p y, sum p z) over the mainlobe mask where |p| > cutoff[f]."""
+        F = self._plan_foci
+        A = _f64(A, (F, 12)); aspect = _f64(aspect, (3,))
+        cut = np.ascontiguousarray(cutoff, dtype=np.float32)
+        out = np.empty((F, 4))
+        self._chk(self._lib.olx_field_masked_moments(self._h, _dptr(A), _dptr(aspect), float(radius_m), _fptr(cut), _dptr(out)))
+        return out
+
+    def field_sample(self, focus, pts_m, which="pmag"):
+        """Trilinear samples of one focus volume at pts_m [P,3] (NaN outside the grid) -> float32[P]."""
+        pts = _f64(np.atleast_2d(pts_m))
+        out = np.empty(pts.shape[0], dtype=np.float32)
+        self._chk(self._lib.olx_field_sample(self._h, 0 if which == "pmag" else 1, int(focus), _dptr(pts), pts.shape[0], _fptr(out)))
+        return out
+
+    def field_weighted_intensity(self, weights):
+        w = _f64(weights)
+        self._chk(self._lib.olx_field_weighted_intensity(self._h, _dptr(w), int(w.shape[0])))
 
     # -- multi-GPU
     def comm_unique_id(self) -> bytes:

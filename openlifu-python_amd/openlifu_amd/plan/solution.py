@@ -22,7 +22,7 @@ from ..geo import Point
 from ..util import dataset as ds
 from ..util.units import getunitconversion
 from ..xdc import Transducer
-from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, get_focus_matrix
+from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, beam_bounds_from_samples, get_focus_matrix
 
 
 @dataclass
@@ -121,6 +121,15 @@ class Solution:
         side_i = ctx.field_masked_peak(A, aspect, options.sidelobe_radius * to_m, ">", "intensity", zmin_m=zmin)
         glob_p = ctx.field_masked_peak(None, aspect, 0.0, None, "pmag", zmin_m=zmin)
         glob_i = ctx.field_masked_peak(None, aspect, 0.0, None, "intensity", zmin_m=zmin)
+        # -3 dB centroid of the mainlobe (find_centroid) and time-average intensity volume (get_ita)
+        mom = ctx.field_masked_moments(A, aspect, options.mainlobe_radius * to_m, main_p * 10 ** (-3 / 20))
+        pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % self.num_foci() + 1
+        counts = np.array([np.sum(pulse_seq == (i + 1)) for i in range(self.num_foci())], dtype=float)
+        ita_w = 1e3 * counts / counts.sum() * self.get_pulsetrain_dutycycle() * self.get_sequence_dutycycle()  # W -> mW
+        ctx.field_weighted_intensity(ita_w)
+        ita_main = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "weighted_intensity")
+        ita_glob = ctx.field_masked_peak(None, aspect, 0.0, None, "weighted_intensity", zmin_m=zmin)
+        sizes = ctx._shape
         for i in range(self.num_foci()):
             mp, mi, sp, si = float(main_p[i]) * 1e-6, float(main_i[i]), float(side_p[i]) * 1e-6, float(side_i[i])
             an.mainlobe_pnp_MPa.append(mp); an.mainlobe_isppa_Wcm2.append(mi)
@@ -128,6 +137,22 @@ class Solution:
             an.sidelobe_to_mainlobe_pressure_ratio.append((np.inf if sp != 0 else np.nan) if mp == 0 else sp / mp)
             an.sidelobe_to_mainlobe_intensity_ratio.append((np.inf if si != 0 else np.nan) if mi == 0 else si / mi)
             an.global_pnp_MPa.append(float(glob_p[i]) * 1e-6); an.global_isppa_Wcm2.append(float(glob_i[i]))
+            an.mainlobe_ispta_mWcm2.append(float(ita_main[i]))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cen = mom[i, 1:] / mom[i, 0] * 1e3
+            an.focal_centroid_lat_mm.append(float(cen[0])); an.focal_centroid_ele_mm.append(float(cen[1]))
+            an.focal_centroid_ax_mm.append(float(cen[2]))
+            # beam widths: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
+            M = np.linalg.inv(np.vstack([A[i].reshape(3, 4), [0, 0, 0, 1]]))
+            for a, (named, scale) in enumerate(zip(("lat", "ele", "ax"), aspect)):
+                n = int(sizes[a]) * 2
+                off = np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, n)
+                local = np.zeros((n, 4)); local[:, a] = off; local[:, 3] = 1.0
+                vals = ctx.field_sample(i, (local @ M.T)[:, :3], "pmag")
+                for db in (3, 6):
+                    neg, pos = beam_bounds_from_samples(off, vals, float(main_p[i]) * 10 ** (-db / 20))
+                    getattr(an, f"beamwidth_{named}_{db}dB_mm").append((pos - neg) * 1e3)
+        an.global_ispta_mWcm2 = float(ita_glob[-1])
         an.MI = float(np.max(an.mainlobe_pnp_MPa) / np.sqrt(self.pulse.frequency * 1e-6))
         an.voltage_V = self.voltage
         an.duty_cycle_pulse_train_pct = self.get_pulsetrain_dutycycle() * 100

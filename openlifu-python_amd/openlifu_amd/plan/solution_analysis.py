@@ -1,11 +1,13 @@
 """Focal-frame helpers and the device-side part of ``Solution.analyze``
 (mirror of plan/solution_analysis.py:232-442 as far as ``Solution.scale`` needs it).
 
-Implemented on the device (one HBM-bound scan per query, ``field_masked_peak_k``): the focal
-ellipsoid masks (``get_mask``) and the masked / global peaks that give ``mainlobe_pnp_MPa`` --
-the only analysis output ``compute_scaling_factors`` consumes (plan/solution.py:301-303) -- plus
-sidelobe and global peaks.  Beam widths and centroids (xarray interpolation in the reference) are
-not built yet: their fields stay empty.
+Implemented on the device, volumes never leave HBM: the focal ellipsoid masks (``get_mask``) and
+masked / global peaks (``field_masked_peak_k``) that give ``mainlobe_pnp_MPa`` -- the only analysis
+output ``compute_scaling_factors`` consumes (plan/solution.py:301-303) -- sidelobe and global peaks,
+the -3 dB centroid (``field_masked_moments_k``, find_centroid :306-317), beam widths from trilinear
+line samples along the focal axes (``field_sample_k``; interp_transformed_axis / get_beam_bounds /
+get_beamwidth :444-574) and the time-average intensity peaks (``field_weighted_sum_k``, get_ita).
+Not built: p0 / power / TIC (drive-signal bookkeeping, outside the path).
 """
 from __future__ import annotations
 
@@ -75,6 +77,16 @@ class SolutionAnalysis(DictMixin):
     """Per-focus result lists, same field names as the reference (plan/solution_analysis.py:48-112)."""
     mainlobe_pnp_MPa: list = field(default_factory=list)
     mainlobe_isppa_Wcm2: list = field(default_factory=list)
+    mainlobe_ispta_mWcm2: list = field(default_factory=list)
+    focal_centroid_lat_mm: list = field(default_factory=list)
+    focal_centroid_ele_mm: list = field(default_factory=list)
+    focal_centroid_ax_mm: list = field(default_factory=list)
+    beamwidth_lat_3dB_mm: list = field(default_factory=list)
+    beamwidth_ele_3dB_mm: list = field(default_factory=list)
+    beamwidth_ax_3dB_mm: list = field(default_factory=list)
+    beamwidth_lat_6dB_mm: list = field(default_factory=list)
+    beamwidth_ele_6dB_mm: list = field(default_factory=list)
+    beamwidth_ax_6dB_mm: list = field(default_factory=list)
     target_position_lat_mm: list = field(default_factory=list)
     target_position_ele_mm: list = field(default_factory=list)
     target_position_ax_mm: list = field(default_factory=list)
@@ -84,9 +96,20 @@ class SolutionAnalysis(DictMixin):
     sidelobe_to_mainlobe_intensity_ratio: list = field(default_factory=list)
     global_pnp_MPa: list = field(default_factory=list)
     global_isppa_Wcm2: list = field(default_factory=list)
+    global_ispta_mWcm2: float | None = None
     MI: float | None = None
     voltage_V: float | None = None
     duty_cycle_pulse_train_pct: float | None = None
     duty_cycle_sequence_pct: float | None = None
     sequence_duration_s: float | None = None
     param_constraints: Dict = field(default_factory=dict)
+
+
+def beam_bounds_from_samples(offsets: np.ndarray, values: np.ndarray, cutoff: float):
+    """get_beam_bounds (plan/solution_analysis.py:488-535) on a sampled line: last offset <= 0 and first
+    offset >= 0 whose value is below ``cutoff`` (NaN samples -- outside the grid -- never qualify)."""
+    with np.errstate(invalid="ignore"):
+        below = values < cutoff
+    neg = offsets[(offsets <= 0) & below]
+    pos = offsets[(offsets >= 0) & below]
+    return (float(neg[-1]) if neg.size else np.nan), (float(pos[0]) if pos.size else np.nan)

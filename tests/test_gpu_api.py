@@ -115,3 +115,52 @@ def test_detached_solution_is_uploaded_for_analysis():
     proto.calc_solution(ol.Point(position=(2, 0, 25)), arr, scale=False)  # overwrites the resident volumes
     an2 = sol.analyze()
     assert an2.mainlobe_pnp_MPa == an.mainlobe_pnp_MPa and an2.global_isppa_Wcm2 == an.global_isppa_Wcm2
+
+
+def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
+    """Solution.analyze's device-side reductions vs a NumPy / SciPy recomputation on the fetched volumes,
+    following plan/solution.py:135-281 and plan/solution_analysis.py:306-574 step by step."""
+    from scipy.interpolate import RegularGridInterpolator
+    arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=0.5, x_extent=(-12, 12), y_extent=(-12, 12), z_extent=(20, 60))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5),
+                        sequence=ol.Sequence(pulse_interval=1e-3, pulse_count=6, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=2, spoke_radius=3.0),
+                        sim_setup=setup)
+    sol, _, an = proto.calc_solution(ol.Point(position=(0, 0, 40), units="mm"), arr, scale=False)
+    xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
+    P = sol.simulation_result["p_min"].data
+    I = sol.simulation_result["intensity"].data
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    opt = ol.plan.SolutionAnalysisOptions()
+    counts = np.array([2.0, 2.0, 2.0])
+    ita = (I * (1e3 * counts / counts.sum() * sol.get_pulsetrain_dutycycle() * sol.get_sequence_dutycycle())[:, None, None, None]).sum(axis=0)
+    assert np.isclose(an.global_ispta_mWcm2, ita[Z > opt.sidelobe_zmin].max(), rtol=1e-5)
+    for i, f in enumerate(sol.foci):
+        fm = f.get_position(units="m")
+        o = bo.effective_origin(arr.get_positions(units="m"), sol.apodizations[i])
+        og = fo.offset_grid(xs, ys, zs, fm, origin=o)
+        dist = np.sqrt(((og / np.array(opt.mainlobe_aspect_ratio)) ** 2).sum(-1))
+        mask = dist < opt.mainlobe_radius
+        pk = P[i][mask].max()
+        assert np.isclose(an.mainlobe_pnp_MPa[i], pk * 1e-6, rtol=1e-6)
+        sel = mask & (P[i] > pk * 10 ** (-3 / 20))
+        cen = np.array([(P[i][sel] * C_[sel]).sum() / P[i][sel].sum() for C_ in (X, Y, Z)]) * 1e3
+        got = np.array([an.focal_centroid_lat_mm[i], an.focal_centroid_ele_mm[i], an.focal_centroid_ax_mm[i]])
+        assert np.abs(got - cen).max() < 1e-3  # mm
+        assert np.isclose(an.mainlobe_ispta_mWcm2[i], ita[mask].max(), rtol=1e-5)
+        interp = RegularGridInterpolator((xs, ys, zs), P[i].astype(np.float64), bounds_error=False, fill_value=np.nan)
+        M = fo.focus_matrix(fm, o)
+        for a, (named, scale) in enumerate(zip(("lat", "ele", "ax"), opt.mainlobe_aspect_ratio)):
+            n = P[i].shape[a] * 2
+            off = np.linspace(-scale * opt.beamwidth_radius, scale * opt.beamwidth_radius, n)
+            local = np.zeros((n, 4)); local[:, a] = off; local[:, 3] = 1
+            vals = interp((local @ M.T)[:, :3])
+            for db in (3, 6):
+                below = np.nan_to_num(vals, nan=np.inf) < pk * 10 ** (-db / 20)
+                neg = off[(off <= 0) & below]; pos = off[(off >= 0) & below]
+                ref = (pos[0] - neg[-1]) * 1e3 if neg.size and pos.size else np.nan
+                got_bw = getattr(an, f"beamwidth_{named}_{db}dB_mm")[i]
+                assert (np.isnan(ref) and np.isnan(got_bw)) or abs(got_bw - ref) <= 1e-6 + 2 * (off[1] - off[0]) * 1e3 * 0, (named, db, got_bw, ref)
+    # physical plausibility: lateral -6 dB width of a 48 mm aperture at 40 mm, lambda 3.75 mm ~ 1.0-1.4 lambda F#
+    assert 2.0 < an.beamwidth_lat_6dB_mm[0] < 6.0
