@@ -1,32 +1,27 @@
-"""Apodization plug-in base (mirror of bf/apod_methods/apodmethod.py:16-42)."""
+"""Base of the apodization family (mirror of bf/apod_methods/apodmethod.py:16-42)."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
 
+from ...util.plugin import ClassTagged, lookup
 from ...util.units import getunittype
 
 
 @dataclass
-class ApodizationMethod(ABC):
+class ApodizationMethod(ClassTagged, ABC):
     @abstractmethod
     def calc_apodization(self, arr, target, params, transform=None):
-        ...
+        """weights[N] in [0, 1] for one focus."""
 
     @abstractmethod
     def kernel_args(self):
         """(apod_kind, p0, p1) for olx_bf_solve (include/olx.h)."""
 
-    def to_dict(self):
-        d = self.__dict__.copy()
-        d["class"] = self.__class__.__name__
-        return d
-
     @staticmethod
     def from_dict(d):
-        from .. import apod_methods
-        d = d.copy()
-        return getattr(apod_methods, d.pop("class"))(**d)
+        cls, kwargs = lookup(__package__, d)
+        return cls(**kwargs)
 
 
 def angle_kind(base_kind: int, units: str) -> int:

@@ -6,7 +6,7 @@ from dataclasses import dataclass
 
 from ... import _native as nat
 from ...engine import get_engine
-from ...util.units import getunittype
+from ...util import validate as v
 from .apodmethod import ApodizationMethod, angle_kind
 
 
@@ -16,12 +16,9 @@ class MaxAngle(ApodizationMethod):
     units: str = "deg"
 
     def __post_init__(self):
-        if not isinstance(self.max_angle, (int, float)):
-            raise TypeError(f"Max angle must be a number, got {type(self.max_angle).__name__}.")
-        if self.max_angle < 0:
-            raise ValueError(f"Max angle must be non-negative, got {self.max_angle}.")
-        if getunittype(self.units) != "angle":
-            raise ValueError(f"Units must be an angle type, got {self.units}.")
+        v.number("Max angle", self.max_angle)
+        v.non_negative("Max angle", self.max_angle)
+        v.unit_kind(self.units, "angle", f"Units must be an angle type, got {self.units}.")
 
     def kernel_args(self):
         return angle_kind(nat.APOD_MAXANGLE, self.units), float(self.max_angle), 0.0

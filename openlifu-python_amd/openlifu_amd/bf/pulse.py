@@ -1,4 +1,5 @@
-"""Sinusoidal pulse (mirror of openlifu.bf.pulse.Pulse, bf/pulse.py:13-63)."""
+"""Sinusoidal pulse (mirror of openlifu.bf.pulse.Pulse, bf/pulse.py:13-63): frequency and amplitude feed
+the field kernel (amplitude * voltage * sensitivity = surface pressure), duration the duty cycles."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -6,6 +7,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ..util.dict_conversion import DictMixin
+from ..util.validate import positive
 
 
 @dataclass
@@ -15,12 +17,10 @@ class Pulse(DictMixin):
     duration: float = 1.0   # s
 
     def __post_init__(self):
-        if self.frequency <= 0:
-            raise ValueError("Frequency must be greater than 0")
-        if self.amplitude < 0 or self.amplitude > 1:
+        positive("Frequency must be greater than 0", self.frequency)
+        if not 0 <= self.amplitude <= 1:
             raise ValueError("Amplitude must be between 0 and 1")
-        if self.duration <= 0:
-            raise ValueError("Duration must be greater than 0")
+        positive("Duration must be greater than 0", self.duration)
 
     def calc_pulse(self, t):
         return self.amplitude * np.sin(2 * np.pi * self.frequency * t)

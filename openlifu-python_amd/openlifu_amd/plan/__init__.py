@@ -1,9 +1,18 @@
+"""Planning API boundary: ``Protocol`` (beamform / calc_solution) and ``Solution`` (scale / analyze)."""
 from __future__ import annotations
 
-from .protocol import OnPulseMismatchAction, Protocol
-from .solution import Solution
-from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, get_focus_matrix
-from .target_constraints import TargetConstraints
+from . import protocol as _protocol
+from . import solution as _solution
+from . import solution_analysis as _analysis
+from . import target_constraints as _constraints
 
-__all__ = ["Protocol", "Solution", "SolutionAnalysis", "SolutionAnalysisOptions", "TargetConstraints",
-           "OnPulseMismatchAction", "get_focus_matrix"]
+Protocol = _protocol.Protocol
+OnPulseMismatchAction = _protocol.OnPulseMismatchAction
+Solution = _solution.Solution
+SolutionAnalysis = _analysis.SolutionAnalysis
+SolutionAnalysisOptions = _analysis.SolutionAnalysisOptions
+get_focus_matrix = _analysis.get_focus_matrix
+TargetConstraints = _constraints.TargetConstraints
+
+__all__ = ("Protocol", "Solution", "SolutionAnalysis", "SolutionAnalysisOptions", "TargetConstraints",
+           "OnPulseMismatchAction", "get_focus_matrix")

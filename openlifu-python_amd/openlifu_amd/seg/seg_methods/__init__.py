@@ -1,5 +1,11 @@
+"""Segmentation plug-ins (class-name lookup namespace for ``SegmentationMethod.from_dict``).
+Only uniform media exist upstream; the field kernels use the reference material of whichever is chosen."""
 from __future__ import annotations
 
-from .uniform import UniformSegmentation, UniformTissue, UniformWater
+from . import uniform as _uniform
 
-__all__ = ["UniformSegmentation", "UniformWater", "UniformTissue"]
+UniformSegmentation = _uniform.UniformSegmentation
+UniformWater = _uniform.UniformWater
+UniformTissue = _uniform.UniformTissue
+
+__all__ = ("UniformSegmentation", "UniformWater", "UniformTissue")

@@ -1,6 +1,9 @@
+"""Unit parsing, the labelled-array stand-in for xarray, dataclass <-> dict helper, validators."""
 from __future__ import annotations
 
-from . import dataset, units
-from .dict_conversion import DictMixin
+from . import dataset, units, validate
+from . import dict_conversion as _dc
 
-__all__ = ["units", "dataset", "DictMixin"]
+DictMixin = _dc.DictMixin
+
+__all__ = ("units", "dataset", "validate", "DictMixin")
