@@ -272,3 +272,38 @@ def test_steering_change_reselects_variant(ctx):
     ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d2, a2, F0, C, P0))
     got = ctx.field_fetch(0)["pmag"]
     assert np.abs(got - ref).max() / ref.max() <= TOL_P and not np.array_equal(got, on_axis)
+
+
+@pytest.mark.parametrize("n_side,n_foci", [(20, 1), (20, 6), (32, 3)])
+def test_large_element_counts_cross_lds_chunks(ctx, n_side, n_foci):
+    """N = 400 (not a multiple of 16: zero-weight padding) and N = 1024 (BASELINE config 4's array):
+    kernel 2c stages elements through LDS in chunks, kernels 2a/2b stream the table through the scalar cache."""
+    pos, ori, size = synthetic_array(n_side, n_side, 48.0 / n_side, jitter=(n_side == 20))
+    foci = bo.wheel_targets([1.0, -0.5, 35.0], True, n_foci - 1, 3.0) * 1e-3 if n_foci > 1 else np.array([[0, 0, 40e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("piecewise", 60.0, 20.0))
+    xs, ys, zs = centred_grid(32, 1.0)
+    zs = zs[:28]
+    check(ctx, xs, ys, zs, pos_m, area, d, a)
+
+
+def test_c4_1024_elements_512cubed_sampled(ctx):
+    """BASELINE config 4 (1024-element array, 512^3 grid, apodization + delay) at full size: sampled-voxel
+    parity against the oracle plus the coherent-sum KAT at the focus."""
+    pos, ori, size = synthetic_array(32, 32, 1.5)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[0, 0, 40e-3]], apod=("piecewise", 60.0, 20.0))
+    xs, ys, zs = centred_grid(512, 0.125)
+    zs = zs - (zs[280] - 40e-3)
+    h = (xs[1] - xs[0],) * 3
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (512,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG)
+    ctx.field_launch()
+    p = ctx.field_fetch(0, want=("pmag",))["pmag"]
+    rng = np.random.default_rng(147)
+    idx = rng.integers(0, 512, (8000, 3))
+    pts = np.stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2]]], axis=1)
+    ref = np.abs(co.field_at_points(pts, pos_m, area, d[0], a[0], F0, C, P0))
+    peak = (a[0] * P0 * area / ((C / F0) * bo.distances_to_point(pos_m, np.array([0, 0, 40e-3])))).sum()  # coherent sum
+    assert np.abs(p[idx[:, 0], idx[:, 1], idx[:, 2]] - ref).max() / peak <= TOL_P
+    kf = int(np.argmin(np.abs(zs - 40e-3)))
+    centre = p[255:257, 255:257, kf]  # the four voxels around the axis (even grid: none exactly on it)
+    off_axis = np.abs(co.field_at_points([[xs[255], ys[255], zs[kf]]], pos_m, area, d[0], a[0], F0, C, P0))[0]
+    assert np.abs(centre - off_axis).max() / peak <= TOL_P and off_axis > 0.95 * peak
