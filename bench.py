@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--elements", type=str, default="16x16")
     ap.add_argument("--pitch-mm", type=float, default=3.0)
     ap.add_argument("--force-comm", action="store_true", help="exercise the RCCL path even with 1 rank")
+    ap.add_argument("--medium", choices=["water", "skull"], default="water",
+                    help="skull: BASELINE configs[4] synthetic skull-slab mask, heterogeneous layered-ray kernel")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (debug: oversubscribe one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     args = ap.parse_args()
@@ -163,6 +165,13 @@ def main():
     origin, spacing, n = grid_from_coords(setup.get_coords())
     ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
     V = int(np.prod(n))
+    if args.medium == "skull":  # 8 mm <= z < 14 mm + 2 mm sin(2 pi x / 40 mm) cos(2 pi y / 40 mm)
+        xs, ys, zs = (np.asarray(c.data, dtype=np.float32) * 1e-3 for c in setup.get_coords().values())
+        zsurf = 14e-3 + 2e-3 * np.sin(2 * np.pi * xs / 40e-3)[:, None] * np.cos(2 * np.pi * ys / 40e-3)[None, :]
+        skull = (zs[None, None, :] >= 8e-3) & (zs[None, None, :] < zsurf[:, :, None])
+        ctx.field_set_medium(np.where(skull, 2800.0, 1500.0).astype(np.float32), np.where(skull, 6.0, 0.0).astype(np.float32),
+                             np.where(skull, 1900.0, 1000.0).astype(np.float32))
+        del skull
 
     def step():
         ctx.field_launch()
@@ -230,6 +239,7 @@ def main():
                                    f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
                                    f"(BASELINE configs[2] shard), |p|+intensity out",
                        "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": 400e3,
+                       "medium": args.medium,
                        "kernel": ctx.field_variant(),
                        "reassembly": (f"rccl-{args.reassemble}-overlapped" if gather else
                                       ("none" if (world == 1 or args.reassemble == "none") else "skipped")),

@@ -123,6 +123,15 @@ int olx_field_fetch(olx_ctx *ctx, int focus, float *pmag, float *intensity, floa
 int olx_field(olx_ctx *ctx, const olx_grid *grid, int n_foci, double freq, double c, double rho,
               double p0_pa, float *pmag_out, float *intensity_out);
 
+/* Heterogeneous medium for the planned grid (BASELINE config 5; the reference only forwards these
+ * volumes to k-Wave, sim/kwave_if.py:58-62): per-voxel sound speed [m/s], attenuation [dB/cm/MHz^y] and
+ * density [kg/m^3] of the WHOLE grid, C-order [nx,ny,nz]; any pointer may be NULL (= reference value given
+ * to olx_field_plan).  Switches the accumulate to the straight-ray layered model:
+ * phase 2 pi f0 (d/c0 + integral (1/c - 1/c0) ds), amplitude x exp(-integral alpha f^y ds), intensity with
+ * the voxel's own rho c.  Valid until the next olx_field_plan. */
+int olx_field_set_medium(olx_ctx *ctx, const float *sound_speed, const float *attenuation,
+                         const float *density, double alpha_power);
+
 /* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
  * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]
  * floats each; intensity may be NULL.  Needs no element or steering table; olx_field_launch is

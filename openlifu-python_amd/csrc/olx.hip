@@ -71,6 +71,9 @@ struct olx_ctx {
     float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
     double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
     float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
+    // heterogeneous medium (kernel 2h)
+    bool hetero = false; HeteroParams hp{}; float2* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
+    float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
     std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
@@ -135,7 +138,8 @@ int olx_ctx_destroy(olx_ctx* c) {
     olx_comm_destroy(c);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
-                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint};
+                    c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
+                    c->d_inv2z, c->d_kfirst, c->d_klast};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -266,6 +270,13 @@ static int configure_variant(olx_ctx* c) {
             }
         return true;
     };
+    if (c->hetero) {  // kernel 2h: no folds, no shared geometry
+        c->mx = c->my = c->dx = c->dy = c->nf = c->nt = 1; c->use_mfma = false;
+        char hb[96];
+        snprintf(hb, sizeof hb, "field_hetero_k<4,%s> (%d non-trivial planes)", c->clamp ? "clamp" : "noclamp", c->hp.n_planes);
+        c->variant = hb;
+        return OLX_OK;
+    }
     c->dx = (c->mx == 2 && !steering_symmetric(c->h_px)) ? 2 : 1;
     c->dy = (c->my == 2 && !steering_symmetric(c->h_py)) ? 2 : 1;
     const int nm = c->dx * c->dy;
@@ -375,7 +386,8 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
-                           c->p0_pa / lambda, c->freq / c->c, c->d_tab);
+                           c->p0_pa / lambda, c->freq / c->c, c->hetero ? c->d_kfirst : nullptr,
+                           c->hetero ? c->d_klast : nullptr, c->d_tab);
     } else {
         // mirrored axes: table coordinates relative to the grid centre plane
         const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
@@ -407,7 +419,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_plan: slab outside grid");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->grid = *g; c->slab = s; c->plan_foci = n_foci;
+    c->grid = *g; c->slab = s; c->plan_foci = n_foci; c->hetero = false;
     c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags;
     const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
     const size_t total = (size_t)vox * n_foci;
@@ -617,7 +629,13 @@ int olx_field_launch(olx_ctx* c) {
     float* pm = c->d_pmag[b];
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    if (c->use_mfma) {
+    if (c->hetero) {
+        const FieldParams& P = c->fp;
+        const long long lanes = (long long)P.nx * P.ny * ((P.nz + 3) / 4);
+        dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci), blk(FIELD_THREADS);
+        if (c->clamp) hipLaunchKernelGGL((field_hetero_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
+        else          hipLaunchKernelGGL((field_hetero_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
+    } else if (c->use_mfma) {
         dispatch_mfma(c, pm);
     } else if (c->mx * c->my * c->nf > 1) {
         if (!dispatch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
@@ -683,6 +701,82 @@ int olx_field(olx_ctx* c, const olx_grid* g, int n_foci, double freq, double cs,
         if (rc) return rc;
     }
     return OLX_OK;
+}
+
+int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* attenuation, const float* density,
+                         double alpha_power) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned || c->uploaded) return fail(c, OLX_ESTATE, "olx_field_set_medium: call olx_field_plan first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const olx_grid& g = c->grid;
+    const int nx = g.n[0], ny = g.n[1], nz = g.n[2], n = c->n_el;
+    const size_t nvox = (size_t)nx * ny * nz;
+    const double c0 = c->c, lambda = c->c / c->freq, rev = c->freq / c->c;
+    const double np_per_db = 1.0 / 8.685889638065035;
+    const double afac = std::pow(c->freq * 1e-6, alpha_power) * 100.0 * np_per_db * lambda;  // dB/cm/MHz^y -> Np per wavelength
+    // non-trivial planes
+    std::vector<int> plane_of_k(nz, -1), plane_k;
+    for (int k = 0; k < nz; ++k) {
+        bool any = false;
+        for (size_t ij = 0; ij < (size_t)nx * ny && !any; ++ij) {
+            const size_t o = ij * nz + k;
+            if (sound_speed && (double)sound_speed[o] != c0) any = true;
+            if (attenuation && attenuation[o] != 0.f) any = true;
+        }
+        if (any) { plane_of_k[k] = (int)plane_k.size(); plane_k.push_back(k); }
+    }
+    const int np = (int)plane_k.size();
+    std::vector<float2> med((size_t)std::max(np, 1) * nx * ny);
+    for (int p = 0; p < np; ++p)
+        for (size_t ij = 0; ij < (size_t)nx * ny; ++ij) {
+            const size_t o = ij * nz + plane_k[p];
+            float2 m;
+            if (sound_speed && !(sound_speed[o] > 0.f)) return fail(c, OLX_EINVAL, "olx_field_set_medium: sound speed must be > 0");
+            m.x = sound_speed ? (float)(c0 / (double)sound_speed[o] - 1.0) : 0.f;
+            m.y = attenuation ? (float)((double)attenuation[o] * afac) : 0.f;
+            med[(size_t)p * nx * ny + ij] = m;
+        }
+    // per element: first plane strictly above, last plane strictly below (fp64, same predicate as the oracle)
+    std::vector<int> kfirst(n), klast(n);
+    for (int e = 0; e < n; ++e) {
+        const double ez = c->h_pos[2 * (size_t)n + e];
+        int kf = 0;
+        while (kf < nz && !(g.origin[2] + kf * g.spacing[2] > ez)) ++kf;
+        int kl = nz - 1;
+        while (kl >= 0 && !(g.origin[2] + kl * g.spacing[2] < ez)) --kl;
+        kfirst[e] = kf; klast[e] = kl;
+    }
+    for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast})
+        if (*q) { hipFree(*q); *q = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->d_med, sizeof(float2) * med.size()));
+    HIPCHK(c, hipMalloc((void**)&c->d_plane_k, sizeof(int) * std::max(np, 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_plane_of_k, sizeof(int) * nz));
+    HIPCHK(c, hipMalloc((void**)&c->d_kfirst, sizeof(int) * n));
+    HIPCHK(c, hipMalloc((void**)&c->d_klast, sizeof(int) * n));
+    HIPCHK(c, hipMemcpy(c->d_med, med.data(), sizeof(float2) * med.size(), hipMemcpyHostToDevice));
+    if (np) HIPCHK(c, hipMemcpy(c->d_plane_k, plane_k.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_plane_of_k, plane_of_k.data(), sizeof(int) * nz, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_kfirst, kfirst.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_klast, klast.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    if (density || sound_speed) {  // per-voxel 1e-4 / (2 rho c) for the intensity (sim/kwave_if.py:140-141), slab part
+        const size_t sv = (size_t)c->fp.vox, off = (size_t)c->slab.x_begin * ny * nz;
+        std::vector<float> iz(sv);
+        for (size_t o = 0; o < sv; ++o) {
+            const double rho = density ? (double)density[off + o] : c->rho, cs = sound_speed ? (double)sound_speed[off + o] : c0;
+            iz[o] = (float)(1e-4 / (2.0 * rho * cs));
+        }
+        HIPCHK(c, hipMalloc((void**)&c->d_inv2z, sizeof(float) * sv));
+        HIPCHK(c, hipMemcpy(c->d_inv2z, iz.data(), sizeof(float) * sv, hipMemcpyHostToDevice));
+    }
+    (void)nvox;
+    HeteroParams& H = c->hp;
+    H.n_planes = np; H.nxg = nx; H.nyg = ny; H.xg_begin = c->slab.x_begin;
+    H.inv_hx = (float)(1.0 / (g.spacing[0] * rev)); H.inv_hy = (float)(1.0 / (g.spacing[1] * rev));
+    H.u0 = 0.f; H.v0 = 0.f;  // table origin == grid origin for kernel 2h
+    c->hetero = true;
+    c->packed_version = ~0ull;
+    return configure_variant(c);
 }
 
 int olx_field_upload(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_foci, const float* pmag,

@@ -105,7 +105,8 @@ constexpr int TAB_STRIDE = 8;
 __global__ void steer_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
                              const double* __restrict__ delays, const double* __restrict__ apod,
                              double ox, double oy, double oz, double freq, double p0_over_lambda,
-                             double rev, float* __restrict__ tab) {
+                             double rev, const int* __restrict__ kfirst, const int* __restrict__ klast,
+                             float* __restrict__ tab) {
     const int f = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -117,7 +118,9 @@ __global__ void steer_pack_k(const double* __restrict__ pos, const double* __res
     t[2] = (float)((pos[2 * n + e] - oz) * rev);
     t[3] = (float)(apod[o] * area[e] * p0_over_lambda * rev);
     t[4] = (float)(cyc - floor(cyc));
-    t[5] = 0.f; t[6] = 0.f; t[7] = 0.f;
+    t[5] = kfirst ? __int_as_float(kfirst[e]) : 0.f;  // kernel 2h: planes strictly above / below the element
+    t[6] = klast ? __int_as_float(klast[e]) : 0.f;
+    t[7] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------
@@ -633,6 +636,112 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
     uint4* dst = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 128;
     dst[lane] = hi.u;
     dst[64 + lane] = lo.u;
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 2h: heterogeneous medium, straight-ray layered model (definition: oracle/field_oracle.c,
+// DESIGN.md section 9).  Per (voxel, element) the ray is sampled where it crosses each NON-TRIVIAL grid plane
+// (planes whose excess slowness and absorption are identically zero are skipped; the host lists the others)
+// lying between the element and the voxel: bilinear gather (clamped to the border) of {sig, a'} (float2, plane-major [np][nx][ny],
+// L2 / Infinity-Cache resident) -> E' = l' sum sig (extra path, wavelengths), A = l' sum a' (nepers),
+// l' = hz d / |dz|.  Then the usual term with phase d + E' + phi and amplitude w exp(-A) / d.
+// Table entry: kernel-2a layout with slots 5 / 6 = first / last plane index strictly above / below the
+// element (bit-cast ints, decided on the host in fp64).  Work map as kernel 2a (ZPL z voxels per lane).
+// ------------------------------------------------------------------------------------
+struct HeteroParams {
+    int n_planes;          // non-trivial planes
+    float u0, v0;          // (table origin - grid x0) / hx, same for y: index-space offset of the table frame
+    float inv_hx, inv_hy;  // 1 / spacing [1/wavelengths]
+    int nxg, nyg;          // whole-grid lateral size of the medium planes
+    int xg_begin;          // slab start (voxel i of the slab is grid column i + xg_begin)
+};
+
+template <int ZPL, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
+    const float* __restrict__ tab, const float2* __restrict__ med, const int* __restrict__ plane_k,
+    const int* __restrict__ plane_of_k, const float* __restrict__ inv2z, float* __restrict__ pmag,
+    float* __restrict__ inten, float* __restrict__ cplx, const FieldParams P, const HeteroParams H) {
+    const int f = blockIdx.y;
+    const int cpr = (P.nz + ZPL - 1) / ZPL;
+    const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const unsigned rows = (unsigned)P.nx * P.ny;
+    const unsigned row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int i = (int)(row / P.ny), j = (int)(row - (unsigned)i * P.ny);
+    const int k0 = chunk * ZPL;
+    const float x = (float)(i + P.x_begin) * P.hx, y = (float)j * P.hy;
+    float z[ZPL], re[ZPL], im[ZPL], sv[ZPL], av[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        const int kq = min(k0 + q, P.nz - 1);
+        z[q] = (float)kq * P.hz;
+        re[q] = 0.f; im[q] = 0.f;
+        const int pq = plane_of_k[kq];                   // the voxel's own half layer
+        float2 m = make_float2(0.f, 0.f);
+        if (pq >= 0) m = med[((size_t)pq * H.nxg + (i + H.xg_begin)) * H.nyg + j];
+        sv[q] = 0.5f * m.x; av[q] = 0.5f * m.y;
+    }
+    const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
+    for (int e = 0; e < P.n_el; ++e) {
+        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1], ez = t[e * TAB_STRIDE + 2];
+        const float w = t[e * TAB_STRIDE + 3], phi = t[e * TAB_STRIDE + 4];
+        const int kfirst = __float_as_int(t[e * TAB_STRIDE + 5]), klast = __float_as_int(t[e * TAB_STRIDE + 6]);
+        const float dx = x - ex, dy = y - ey;
+        const float r2 = fmaf(dy, dy, dx * dx);
+        const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
+        const float dxu = dx * H.inv_hx, dyv = dy * H.inv_hy;
+        float dz[ZPL], idz[ZPL], ss[ZPL], as[ZPL];
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            dz[q] = z[q] - ez;
+            idz[q] = dz[q] != 0.f ? __builtin_amdgcn_rcpf(dz[q]) : 0.f;
+            ss[q] = sv[q]; as[q] = av[q];
+        }
+        for (int p = 0; p < H.n_planes; ++p) {
+            const int k = plane_k[p];                    // wave-uniform
+            const float zk = (float)k * P.hz - ez;
+            const float2* plane = med + (size_t)p * H.nxg * H.nyg;
+#pragma unroll
+            for (int q = 0; q < ZPL; ++q) {
+                const int kv = k0 + q;
+                const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);
+                if (!between) continue;
+                const float tt = zk * idz[q];
+                const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), (float)(H.nxg - 1));  // border values extend outwards
+                const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), (float)(H.nyg - 1));
+                int i0 = min((int)u, max(H.nxg - 2, 0)), j0 = min((int)v, max(H.nyg - 2, 0));
+                const int i1 = min(i0 + 1, H.nxg - 1), j1 = min(j0 + 1, H.nyg - 1);
+                const float fu = u - (float)i0, fv = v - (float)j0;
+                const float2 m00 = plane[(size_t)i0 * H.nyg + j0], m01 = plane[(size_t)i0 * H.nyg + j1];
+                const float2 m10 = plane[(size_t)i1 * H.nyg + j0], m11 = plane[(size_t)i1 * H.nyg + j1];
+                const float w00 = (1.f - fu) * (1.f - fv), w01 = (1.f - fu) * fv, w10 = fu * (1.f - fv), w11 = fu * fv;
+                ss[q] += w00 * m00.x + w01 * m01.x + w10 * m10.x + w11 * m11.x;
+                as[q] += w00 * m00.y + w01 * m01.y + w10 * m10.y + w11 * m11.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            float d2 = fmaf(dz[q], dz[q], r2);
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float d = d2 * ri;
+            const float l = dz[q] != 0.f ? P.hz * d * fabsf(idz[q]) : 0.f;   // path per layer [wavelengths]
+            const float ph = fmaf(l, ss[q], d) + phi;
+            const float a = w * ri * __expf(-l * as[q]);
+            re[q] = fmaf(a, __builtin_amdgcn_cosf(ph), re[q]);
+            im[q] = fmaf(a, __builtin_amdgcn_sinf(ph), im[q]);
+        }
+    }
+    const long long base = (long long)f * P.vox + (long long)row * P.nz + k0;
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        if (k0 + q >= P.nz) continue;
+        const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
+        if (P.flags & 1u) pmag[base + q] = __builtin_sqrtf(m2);
+        if (P.flags & 2u) inten[base + q] = m2 * (inv2z ? inv2z[(long long)row * P.nz + k0 + q] : P.inten_scale);
+        if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ UNIQUE_ID_BYTES = 128
 SYMBOLS = [
     "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_field_plan",
-    "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
+    "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
@@ -72,6 +72,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_launch.argtypes = [vp]
         lib.olx_field_fetch.argtypes = [vp, c_int, fp, fp, fp]
         lib.olx_field.argtypes = [vp, POINTER(OlxGrid), c_int, c_double, c_double, c_double, c_double, fp, fp]
+        lib.olx_field_set_medium.argtypes = [vp, fp, fp, fp, c_double]
         lib.olx_field_upload.argtypes = [vp, POINTER(OlxGrid), POINTER(OlxSlab), c_int, fp, fp]
         lib.olx_field_time.argtypes = [vp, c_int, fp]
         lib.olx_profile_begin.argtypes = [vp, c_int]
@@ -210,9 +211,19 @@ class Context:
         self._chk(self._lib.olx_field_plan(self._h, ctypes.byref(g), ctypes.byref(s) if s else None, F,
                                            float(freq), float(c), float(rho), float(p0_pa), int(flags)))
         self._shape = (nx, int(n[1]), int(n[2]))
+        self._grid_shape = (int(n[0]), int(n[1]), int(n[2]))
         self._vox = nx * int(n[1]) * int(n[2])
         self._flags = int(flags) | OUT_PMAG
         self._plan_foci = F
+
+    def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9):
+        """Per-voxel medium volumes [nx,ny,nz] of the WHOLE planned grid (None = reference value)."""
+        arrs = []
+        for a in (sound_speed, attenuation, density):
+            arrs.append(None if a is None else np.ascontiguousarray(a, dtype=np.float32))
+            if arrs[-1] is not None and arrs[-1].shape != self._grid_shape:
+                raise ValueError(f"medium volumes must have the grid shape {self._grid_shape}, got {arrs[-1].shape}")
+        self._chk(self._lib.olx_field_set_medium(self._h, _fptr(arrs[0]), _fptr(arrs[1]), _fptr(arrs[2]), float(alpha_power)))
 
     def field_launch(self):
         self._chk(self._lib.olx_field_launch(self._h))

@@ -81,7 +81,7 @@ class Engine:
 
     # ---- kernel 2 -----------------------------------------------------------------------------
     def field(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa,
-              want=("pmag", "intensity"), slab=None, steering_resident=False):
+              want=("pmag", "intensity"), slab=None, steering_resident=False, medium=None):
         """Pressure field for F foci -> dict of float32 arrays [F, nx, ny, nz] (fresh, writable,
         caller-owned).  ``steering_resident`` reuses the table the last ``beamform`` left on the
         device instead of uploading ``delays`` / ``apod``."""
@@ -94,6 +94,8 @@ class Engine:
         if "complex" in want:
             flags |= nat.OUT_COMPLEX
         self.ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=flags, slab=slab)
+        if medium is not None:  # heterogeneous medium: layered straight-ray kernel
+            self.ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"))
         self.ctx.field_launch()
         self.result_token += 1
         F = self.ctx.n_foci

@@ -22,14 +22,21 @@ _ATTRS = {"p_max": {"units": "Pa", "long_name": "PPP"}, "p_min": {"units": "Pa",
 
 
 def _medium(params):
+    """(c_ref, rho_ref, volumes | None).  Uniform media (every voxel equals the reference value, as with the
+    reference's UniformWater / UniformTissue) use the homogeneous kernels; anything else hands the per-voxel
+    sound speed / attenuation / density volumes to the layered straight-ray kernel (olx_field_set_medium)."""
     c = float(params["sound_speed"].attrs["ref_value"])
     rho = float(params["density"].attrs["ref_value"])
-    for key, ref in (("sound_speed", c), ("density", rho)):
+    vols, uniform = {}, True
+    for key, ref in (("sound_speed", c), ("density", rho), ("attenuation", 0.0)):
+        if key not in params:
+            vols[key] = None
+            continue
         vol = np.asarray(params[key].data)
         if vol.size and (vol.min() != ref or vol.max() != ref):
-            logging.warning(f"run_simulation: {key} volume is not uniform; the MI355X field kernel uses the "
-                            f"reference value {ref} (heterogeneous propagation is not implemented yet)")
-    return c, rho
+            uniform = False
+        vols[key] = vol
+    return c, rho, (None if uniform else vols)
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
@@ -37,10 +44,10 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
     """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz]."""
     coords = params.coords
     origin, spacing, n = grid_from_coords(coords)
-    c, rho = _medium(params)
+    c, rho, medium = _medium(params)
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
-                              slab=slab, steering_resident=steering_resident)
+                              slab=slab, steering_resident=steering_resident, medium=medium)
 
 
 def dataset_from_fields(fields, coords, focus=None):

@@ -31,6 +31,8 @@ def lib():
                                         ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_points.argtypes = [dp, ctypes.c_long, dp, dp, dp, ctypes.c_int,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_grid_hetero.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp,
+                                               ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -68,6 +70,30 @@ def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0
     re = np.empty(pts.shape[0]); im = np.empty_like(re)
     lib().olo_field_points(_p(pts), pts.shape[0], _p(pos), _p(w), _p(phi), len(w), k, dmin,
                            nthreads, _p(re), _p(im))
+    return re + 1j * im
+
+
+def medium_terms(c_vol, alpha_db_cm_mhz, c0, freq, alpha_power=0.9):
+    """(sig, a): relative excess slowness c0/c - 1 and absorption [Np/m] = alpha f_MHz^y * 100 / 8.686
+    (alpha in dB/cm/MHz^y as in the reference's materials; y = 0.9 is what it passes to k-Wave, kwave_if.py:57)."""
+    sig = c0 / np.asarray(c_vol, dtype=np.float64) - 1.0
+    a = np.asarray(alpha_db_cm_mhz, dtype=np.float64) * (freq * 1e-6) ** alpha_power * 100.0 / 8.685889638065035
+    return np.ascontiguousarray(sig), np.ascontiguousarray(a)
+
+
+def field_on_grid_hetero(xs_m, ys_m, zs_m, sig, ab, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0, dmin=None,
+                         nthreads=0):
+    """Heterogeneous straight-ray layered model (definition: oracle/field_oracle.c)."""
+    xs = np.ascontiguousarray(xs_m, dtype=np.float64); ys = np.ascontiguousarray(ys_m, dtype=np.float64)
+    zs = np.ascontiguousarray(zs_m, dtype=np.float64)
+    if dmin is None:
+        dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
+    pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+    sig = np.ascontiguousarray(sig, dtype=np.float64); ab = np.ascontiguousarray(ab, dtype=np.float64)
+    assert sig.shape == (len(xs), len(ys), len(zs)) == ab.shape
+    re = np.empty(sig.shape); im = np.empty_like(re)
+    lib().olo_field_grid_hetero(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), _p(pos), _p(w), _p(phi),
+                                len(w), k, dmin, nthreads, _p(re), _p(im))
     return re + 1j * im
 
 

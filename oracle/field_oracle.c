@@ -79,3 +79,77 @@ int olo_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ---- heterogeneous medium: straight-ray layered model (the build's definition) ------
+ * PARITY UNPINNED: the reference only forwards c / rho / alpha volumes to k-Wave (sim/kwave_if.py:58-62).
+ *
+ * For the ray element e -> voxel v the medium is sampled where the ray crosses each grid plane z_k lying
+ * strictly between the element and the voxel (bilinear in x,y inside the plane, border values extended
+ * beyond the lateral extent); every such plane stands for a layer of thickness hz, i.e. path l = hz d / |z_v - z_e|,
+ * and the voxel's own half layer is sampled at the voxel.  With sig = c0/c - 1 (relative excess slowness)
+ * and a = absorption [Np/m]:
+ *     E = l (sum_k sig(crossing_k) + sig(v)/2)       extra acoustic path [m]
+ *     A = l (sum_k a(crossing_k)   + a(v)/2)         attenuation exponent
+ *     p(v) = sum_e w_e / d * exp(-A) * exp(j (k (d + E) + phi_e))
+ * Volumes are C-order [nx,ny,nz]. */
+static inline void bilinear2(const double *sig, const double *ab, int nx, int ny, int nz, int kz, double u, double v,
+                             double *s_out, double *a_out) {
+    /* clamp to the edge: the medium is extended laterally by its border values (continuous, so that fp32
+     * and fp64 evaluations cannot disagree about which side of the boundary a crossing point lies on) */
+    u = u < 0 ? 0 : (u > nx - 1 ? nx - 1 : u);
+    v = v < 0 ? 0 : (v > ny - 1 ? ny - 1 : v);
+    int i0 = (int)floor(u), j0 = (int)floor(v);
+    if (i0 > nx - 2) i0 = nx - 2 < 0 ? 0 : nx - 2;
+    if (j0 > ny - 2) j0 = ny - 2 < 0 ? 0 : ny - 2;
+    const int i1 = i0 + 1 < nx ? i0 + 1 : i0, j1 = j0 + 1 < ny ? j0 + 1 : j0;
+    const double fu = u - i0, fv = v - j0;
+#define AT(arr, i, j) arr[((size_t)(i) * ny + (j)) * nz + kz]
+    *s_out = (1 - fu) * ((1 - fv) * AT(sig, i0, j0) + fv * AT(sig, i0, j1)) + fu * ((1 - fv) * AT(sig, i1, j0) + fv * AT(sig, i1, j1));
+    *a_out = (1 - fu) * ((1 - fv) * AT(ab, i0, j0) + fv * AT(ab, i0, j1)) + fu * ((1 - fv) * AT(ab, i1, j0) + fv * AT(ab, i1, j1));
+#undef AT
+}
+
+int olo_field_grid_hetero(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                          const double *sig, const double *ab, const double *pos, const double *w,
+                          const double *phi, int n, double k, double dmin, int nthreads, double *re_out,
+                          double *im_out) {
+    const double hx = nx > 1 ? xs[1] - xs[0] : 1.0, hy = ny > 1 ? ys[1] - ys[0] : 1.0, hz = nz > 1 ? zs[1] - zs[0] : 1.0;
+    long nxy = (long)nx * ny;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long ij = 0; ij < nxy; ++ij) {
+        const int i = (int)(ij / ny), j = (int)(ij % ny);
+        for (int kv = 0; kv < nz; ++kv) {
+            const double x = xs[i], y = ys[j], z = zs[kv];
+            double sr = 0, si = 0;
+            for (int e = 0; e < n; ++e) {
+                const double ex = pos[3 * e], ey = pos[3 * e + 1], ez = pos[3 * e + 2];
+                const double dx = x - ex, dy = y - ey, dz = z - ez;
+                double d = sqrt(dx * dx + dy * dy + dz * dz);
+                if (d < dmin) d = dmin;
+                double E = 0, A = 0;
+                if (dz != 0) {
+                    const double l = hz * d / fabs(dz);
+                    double ssum = 0.5 * sig[((size_t)i * ny + j) * nz + kv], asum = 0.5 * ab[((size_t)i * ny + j) * nz + kv];
+                    for (int kk = 0; kk < nz; ++kk) {
+                        const double t = (zs[kk] - ez) / dz;
+                        if (!(t > 0 && t < 1) || kk == kv) continue;
+                        double s1, a1;
+                        bilinear2(sig, ab, nx, ny, nz, kk, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                        ssum += s1; asum += a1;
+                    }
+                    E = l * ssum; A = l * asum;
+                }
+                double s, c;
+                sincos(k * (d + E) + phi[e], &s, &c);
+                const double amp = w[e] / d * exp(-A);
+                sr += amp * c; si += amp * s;
+            }
+            re_out[(size_t)ij * nz + kv] = sr;
+            im_out[(size_t)ij * nz + kv] = si;
+        }
+    }
+    return 0;
+}

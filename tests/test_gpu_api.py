@@ -164,3 +164,33 @@ def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
                 assert (np.isnan(ref) and np.isnan(got_bw)) or abs(got_bw - ref) <= 1e-6 + 2 * (off[1] - off[0]) * 1e3 * 0, (named, db, got_bw, ref)
     # physical plausibility: lateral -6 dB width of a 48 mm aperture at 40 mm, lambda 3.75 mm ~ 1.0-1.4 lambda F#
     assert 2.0 < an.beamwidth_lat_6dB_mm[0] < 6.0
+
+
+def test_run_simulation_with_segmented_medium():
+    """A params Dataset with a non-uniform label volume (what a real SegmentationMethod would produce through
+    _map_params) switches run_simulation to the heterogeneous layered-ray kernel; a uniform one does not."""
+    from openlifu_amd.util import dataset as ds
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 36))
+    mats = {"water": ol.WATER, "skull": ol.Material("skull", 2800.0, 1900.0, 6.0, 1100.0, 0.3)}
+    segm = ol.seg_methods.UniformWater(materials=mats)
+    coords = setup.get_coords()
+    labels = np.zeros((21, 21, 32), dtype=int)
+    labels[:, :, 4:9] = 1  # 5 planes of skull
+    params = segm._map_params(ds.make_dataarray(labels, coords=coords, dims=["x", "y", "z"]))
+    assert params["sound_speed"].attrs["ref_value"] == 1500.0 and params["sound_speed"].data.max() == 2800.0
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup)
+    target = ol.Point(position=(0, 0, 30), units="mm")
+    delays, apod = proto.beamform(arr, target, params)
+    dset, _ = ol.sim.run_simulation(arr, params, delays, apod, freq=400e3, amplitude=1.0)
+    assert "field_hetero_k" in ol.get_engine().ctx.field_variant()
+    pos_m, _, area, _, _ = arr.element_table()
+    xs, ys, zs = (np.asarray(coords[d].data) * 1e-3 for d in "xyz")
+    sig, ab = co.medium_terms(params["sound_speed"].data, params["attenuation"].data, 1500.0, 400e3)
+    ref = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, delays, apod, 400e3, 1500.0, 1e5))
+    assert np.abs(dset["p_min"].data - ref).max() / ref.max() <= 2e-5
+    iref = 1e-4 * ref ** 2 / (2 * params["density"].data * params["sound_speed"].data)
+    assert np.abs(dset["intensity"].data - iref).max() / iref.max() <= 4e-5
+    uni = setup.setup_sim_scene(segm)
+    ol.sim.run_simulation(arr, uni, delays, apod, freq=400e3, amplitude=1.0)
+    assert "field_hetero_k" not in ol.get_engine().ctx.field_variant()

@@ -307,3 +307,53 @@ def test_c4_1024_elements_512cubed_sampled(ctx):
     centre = p[255:257, 255:257, kf]  # the four voxels around the axis (even grid: none exactly on it)
     off_axis = np.abs(co.field_at_points([[xs[255], ys[255], zs[kf]]], pos_m, area, d[0], a[0], F0, C, P0))[0]
     assert np.abs(centre - off_axis).max() / peak <= TOL_P and off_axis > 0.95 * peak
+
+
+def _skull_medium(xs, ys, zs, c_skull=2800.0, a_skull=6.0):
+    """SURVEY 8(d) synthetic skull slab: 8 mm <= z < 14 mm + 2 mm sin(2 pi x/40 mm) cos(2 pi y/40 mm)."""
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
+    skull = (Z >= 8e-3) & (Z < 14e-3 + 2e-3 * np.sin(2 * np.pi * X / 40e-3) * np.cos(2 * np.pi * Y / 40e-3))
+    cvol = np.where(skull, c_skull, 1500.0); avol = np.where(skull, a_skull, 0.0); rvol = np.where(skull, 1900.0, 1000.0)
+    return cvol, avol, rvol
+
+
+def test_heterogeneous_medium_layered_ray_model(ctx):
+    """BASELINE config 5 shape (skull-slab mask, attenuated propagation) at a size the fp64 oracle finishes:
+    kernel 2h vs oracle/field_oracle.c's definition, plus the analytic slab KAT through the C-ABI."""
+    pos, ori, size = synthetic_array(8, 8, 4.0, jitter=True)
+    foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 28e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 50.0, 0.0))
+    xs = np.linspace(-12e-3, 12e-3, 25); ys = np.linspace(-10e-3, 10e-3, 21); zs = 5e-3 + np.arange(36) * 1e-3
+    cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 36), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX)
+    ctx.field_set_medium(cvol, avol, rvol)
+    assert "field_hetero_k" in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    sig, ab = co.medium_terms(cvol, avol, C, F0)
+    homog = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], a[0], F0, C, P0))
+    for f in range(2):
+        out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
+        ref = co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0)
+        mx = np.abs(ref).max()
+        assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= 2e-5        # bilinear gathers add fp32 rounding
+        assert np.abs(out["complex"] - ref).max() / mx <= 6e-5
+        iref = 1e-4 * np.abs(ref) ** 2 / (2 * rvol * cvol)                    # voxel's own rho c (kwave_if.py:140)
+        assert np.abs(out["intensity"] - iref).max() / iref.max() <= 4e-5
+    assert np.abs(ctx.field_fetch(0)["pmag"] - homog).max() / homog.max() > 0.05  # the skull visibly changes the field
+    # voxels in front of the slab see the reference medium only
+    assert np.abs(ctx.field_fetch(0)["pmag"][:, :, :3] - homog[:, :, :3]).max() / homog.max() <= TOL_P
+    # analytic slab: one on-axis element, flat 4-plane slab -> amplitude exp(-A), extra phase k E
+    ctx.set_elements([[0, 0, 0.0]], [[0, 0, 1.0]], [1e-6]); ctx.set_steering([[0.0]], [[1.0]])
+    xs2 = np.linspace(-4e-3, 4e-3, 9); zs2 = 5e-3 + np.arange(21) * 1e-3
+    c2 = np.full((9, 9, 21), 1500.0); c2[:, :, 5:9] = 2800.0
+    a2 = np.zeros_like(c2); a2[:, :, 5:9] = 6.0
+    ctx.field_plan((xs2[0], xs2[0], zs2[0]), (1e-3,) * 3, (9, 9, 21), F0, C, RHO, 1.0, flags=nat.OUT_COMPLEX)
+    ctx.field_launch(); p0 = ctx.field_fetch(0, want=("complex",))["complex"]
+    ctx.field_set_medium(c2, a2, None); ctx.field_launch(); p1 = ctx.field_fetch(0, want=("complex",))["complex"]
+    E = 4e-3 * (1500 / 2800 - 1); A = 4e-3 * 6.0 * 0.4 ** 0.9 * 100 / 8.685889638
+    assert np.isclose(abs(p1[4, 4, 15]) / abs(p0[4, 4, 15]), np.exp(-A), rtol=1e-5)
+    assert np.isclose(np.angle(p1[4, 4, 15] / p0[4, 4, 15]), (2 * np.pi * F0 / C * E + np.pi) % (2 * np.pi) - np.pi, atol=1e-4)
+    ctx.field_plan((xs2[0], xs2[0], zs2[0]), (1e-3,) * 3, (9, 9, 21), F0, C, RHO, 1.0, flags=nat.OUT_COMPLEX)  # re-plan clears the medium
+    ctx.field_launch()
+    assert np.array_equal(ctx.field_fetch(0, want=("complex",))["complex"], p0)
