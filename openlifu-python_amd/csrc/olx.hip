@@ -72,7 +72,7 @@ struct olx_ctx {
     double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
     float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
     // heterogeneous medium (kernel 2h)
-    bool hetero = false; HeteroParams hp{}; float2* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
+    bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
     float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
@@ -364,6 +364,13 @@ static int configure_variant(olx_ctx* c) {
             }
         HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // perm is a stack vector
+        const size_t need = (size_t)((F + c->nf - 1) / c->nf) * n * (4 + 2 * nm * c->nf);  // never trust the plan-time bound
+        if (c->tab_cap < need) {
+            if (c->d_tab) hipFree(c->d_tab);
+            c->d_tab = nullptr; c->tab_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_tab, sizeof(float) * need));
+            c->tab_cap = need;
+        }
         snprintf(nmbuf, sizeof nmbuf, "field_shared_k<4,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", c->mx, c->my, c->dx, c->dy, c->nf,
                  c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     }
@@ -508,8 +515,9 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     c->allow_shared = c->force_kind != 1;
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
-    {   // worst-case table: 12 floats per (focus, element) (nf = 1, four distinct mirror columns)
-        const size_t need = (size_t)n_foci * n * 12;
+    {   // worst-case kernel-2a/2b table over every (dx, dy, nf) the steering may select later: tiles = ceil(F / nf)
+        // entries of 4 + 2 dx dy nf <= 20 floats, i.e. at most 12 F + 20 floats per element (the last tile is padded)
+        const size_t need = ((size_t)n_foci * 12 + 24) * n;
         if (c->tab_cap < need) {
             if (c->d_tab) hipFree(c->d_tab);
             c->d_tab = nullptr; c->tab_cap = 0;
@@ -631,8 +639,8 @@ int olx_field_launch(olx_ctx* c) {
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) {
         const FieldParams& P = c->fp;
-        const long long lanes = (long long)P.nx * P.ny * ((P.nz + 3) / 4);
-        dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci), blk(FIELD_THREADS);
+        const long long nblk = (long long)((P.nx + 7) / 8) * ((P.ny + 7) / 8) * ((P.nz + 15) / 16);  // 8x8 tile x 16 z
+        dim3 grid((unsigned)nblk, c->plan_foci), blk(FIELD_THREADS);
         if (c->clamp) hipLaunchKernelGGL((field_hetero_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
         else          hipLaunchKernelGGL((field_hetero_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
     } else if (c->use_mfma) {
@@ -727,16 +735,23 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         if (any) { plane_of_k[k] = (int)plane_k.size(); plane_k.push_back(k); }
     }
     const int np = (int)plane_k.size();
-    std::vector<float2> med((size_t)std::max(np, 1) * nx * ny);
+    // pre-gathered bilinear stencil: texel (p,i,j) = { sig, a' } of (i,j), (i,j+1), (i+1,j), (i+1,j+1), edge-clamped
+    std::vector<float> med((size_t)std::max(np, 1) * nx * ny * 8, 0.f);
+    auto term = [&](int i, int j, int k, float* out) {
+        const size_t o = ((size_t)i * ny + j) * nz + k;
+        out[0] = sound_speed ? (float)(c0 / (double)sound_speed[o] - 1.0) : 0.f;
+        out[1] = attenuation ? (float)((double)attenuation[o] * afac) : 0.f;
+    };
+    if (sound_speed)
+        for (size_t o = 0; o < nvox; ++o)
+            if (!(sound_speed[o] > 0.f)) return fail(c, OLX_EINVAL, "olx_field_set_medium: sound speed must be > 0");
     for (int p = 0; p < np; ++p)
-        for (size_t ij = 0; ij < (size_t)nx * ny; ++ij) {
-            const size_t o = ij * nz + plane_k[p];
-            float2 m;
-            if (sound_speed && !(sound_speed[o] > 0.f)) return fail(c, OLX_EINVAL, "olx_field_set_medium: sound speed must be > 0");
-            m.x = sound_speed ? (float)(c0 / (double)sound_speed[o] - 1.0) : 0.f;
-            m.y = attenuation ? (float)((double)attenuation[o] * afac) : 0.f;
-            med[(size_t)p * nx * ny + ij] = m;
-        }
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < ny; ++j) {
+                float* tx = &med[(((size_t)p * nx + i) * ny + j) * 8];
+                const int i1 = std::min(i + 1, nx - 1), j1 = std::min(j + 1, ny - 1), k = plane_k[p];
+                term(i, j, k, tx); term(i, j1, k, tx + 2); term(i1, j, k, tx + 4); term(i1, j1, k, tx + 6);
+            }
     // per element: first plane strictly above, last plane strictly below (fp64, same predicate as the oracle)
     std::vector<int> kfirst(n), klast(n);
     for (int e = 0; e < n; ++e) {
@@ -749,12 +764,12 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
     }
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast})
         if (*q) { hipFree(*q); *q = nullptr; }
-    HIPCHK(c, hipMalloc((void**)&c->d_med, sizeof(float2) * med.size()));
+    HIPCHK(c, hipMalloc((void**)&c->d_med, sizeof(float) * med.size()));
     HIPCHK(c, hipMalloc((void**)&c->d_plane_k, sizeof(int) * std::max(np, 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_plane_of_k, sizeof(int) * nz));
     HIPCHK(c, hipMalloc((void**)&c->d_kfirst, sizeof(int) * n));
     HIPCHK(c, hipMalloc((void**)&c->d_klast, sizeof(int) * n));
-    HIPCHK(c, hipMemcpy(c->d_med, med.data(), sizeof(float2) * med.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_med, med.data(), sizeof(float) * med.size(), hipMemcpyHostToDevice));
     if (np) HIPCHK(c, hipMemcpy(c->d_plane_k, plane_k.data(), sizeof(int) * np, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_plane_of_k, plane_of_k.data(), sizeof(int) * nz, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_kfirst, kfirst.data(), sizeof(int) * n, hipMemcpyHostToDevice));

@@ -656,21 +656,28 @@ struct HeteroParams {
     int xg_begin;          // slab start (voxel i of the slab is grid column i + xg_begin)
 };
 
+// Work map of kernel 2h: a wave = an 8 x 8 (x, y) tile of voxels x ZPL consecutive z per lane, the four
+// waves of a block = four consecutive z chunks of the same tile.  For a fixed plane and element the
+// crossing points of the wave's 64 rays then form a compact (shrunken) image of the tile, so the gathers
+// of one wave-instruction fall into a few cache lines.  The medium is stored as a PRE-GATHERED bilinear
+// stencil: texel (p, i, j) = 8 floats { sig, a' } x {(i,j), (i,j+1), (i+1,j), (i+1,j+1)} (edge-clamped),
+// 32 B aligned, so one sample = two 16-B loads from one cache line instead of four 8-B gathers from two rows.
 template <int ZPL, bool CLAMP>
 __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
-    const float* __restrict__ tab, const float2* __restrict__ med, const int* __restrict__ plane_k,
+    const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_k,
     const int* __restrict__ plane_of_k, const float* __restrict__ inv2z, float* __restrict__ pmag,
     float* __restrict__ inten, float* __restrict__ cplx, const FieldParams P, const HeteroParams H) {
     const int f = blockIdx.y;
-    const int cpr = (P.nz + ZPL - 1) / ZPL;
-    const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
-    const unsigned rows = (unsigned)P.nx * P.ny;
-    const unsigned row = lane_id / cpr;
-    if (row >= rows) return;
-    const int chunk = (int)(lane_id - row * cpr);
-    const int i = (int)(row / P.ny), j = (int)(row - (unsigned)i * P.ny);
-    const int k0 = chunk * ZPL;
-    const float x = (float)(i + P.x_begin) * P.hx, y = (float)j * P.hy;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_y = (P.ny + 7) >> 3, zblocks = (P.nz + 4 * ZPL - 1) / (4 * ZPL);
+    const int zb = blockIdx.x % zblocks;
+    const int tile = blockIdx.x / zblocks;
+    const int ti = tile / tiles_y, tj = tile - ti * tiles_y;
+    const int i = ti * 8 + (lane >> 3), j = tj * 8 + (lane & 7);
+    const int k0 = (zb * 4 + wave) * ZPL;
+    const bool live = i < P.nx && j < P.ny && k0 < P.nz;
+    const int ic = min(i, P.nx - 1), jc = min(j, P.ny - 1);
+    const float x = (float)(ic + P.x_begin) * P.hx, y = (float)jc * P.hy;
     float z[ZPL], re[ZPL], im[ZPL], sv[ZPL], av[ZPL];
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
@@ -678,8 +685,8 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
         z[q] = (float)kq * P.hz;
         re[q] = 0.f; im[q] = 0.f;
         const int pq = plane_of_k[kq];                   // the voxel's own half layer
-        float2 m = make_float2(0.f, 0.f);
-        if (pq >= 0) m = med[((size_t)pq * H.nxg + (i + H.xg_begin)) * H.nyg + j];
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pq >= 0) m = med[(((size_t)pq * H.nxg + (ic + H.xg_begin)) * H.nyg + jc) * 2];
         sv[q] = 0.5f * m.x; av[q] = 0.5f * m.y;
     }
     const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
         const float r2 = fmaf(dy, dy, dx * dx);
         const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
         const float dxu = dx * H.inv_hx, dyv = dy * H.inv_hy;
+        const float umax = (float)(H.nxg - 1), vmax = (float)(H.nyg - 1);
         float dz[ZPL], idz[ZPL], ss[ZPL], as[ZPL];
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
@@ -698,26 +706,30 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
             idz[q] = dz[q] != 0.f ? __builtin_amdgcn_rcpf(dz[q]) : 0.f;
             ss[q] = sv[q]; as[q] = av[q];
         }
+        // planes between element and voxel: k in [kfirst, kv) (voxel above) or (kv, klast] (voxel below).
+        // k0..k0+ZPL-1 are wave-uniform, so the trip bounds are too.
         for (int p = 0; p < H.n_planes; ++p) {
             const int k = plane_k[p];                    // wave-uniform
+            const bool any_above = k >= kfirst && k < k0 + ZPL - 1, any_below = k <= klast && k > k0;
+            if (!any_above && !any_below) continue;
             const float zk = (float)k * P.hz - ez;
-            const float2* plane = med + (size_t)p * H.nxg * H.nyg;
+            const float4* plane = med + (size_t)p * H.nxg * H.nyg * 2;
 #pragma unroll
             for (int q = 0; q < ZPL; ++q) {
                 const int kv = k0 + q;
-                const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);
+                const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);   // wave-uniform
                 if (!between) continue;
                 const float tt = zk * idz[q];
-                const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), (float)(H.nxg - 1));  // border values extend outwards
-                const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), (float)(H.nyg - 1));
-                int i0 = min((int)u, max(H.nxg - 2, 0)), j0 = min((int)v, max(H.nyg - 2, 0));
-                const int i1 = min(i0 + 1, H.nxg - 1), j1 = min(j0 + 1, H.nyg - 1);
+                const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), umax);   // border values extend outwards
+                const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), vmax);
+                const int i0 = (int)u, j0 = (int)v;
                 const float fu = u - (float)i0, fv = v - (float)j0;
-                const float2 m00 = plane[(size_t)i0 * H.nyg + j0], m01 = plane[(size_t)i0 * H.nyg + j1];
-                const float2 m10 = plane[(size_t)i1 * H.nyg + j0], m11 = plane[(size_t)i1 * H.nyg + j1];
-                const float w00 = (1.f - fu) * (1.f - fv), w01 = (1.f - fu) * fv, w10 = fu * (1.f - fv), w11 = fu * fv;
-                ss[q] += w00 * m00.x + w01 * m01.x + w10 * m10.x + w11 * m11.x;
-                as[q] += w00 * m00.y + w01 * m01.y + w10 * m10.y + w11 * m11.y;
+                const float4* tx = plane + ((size_t)i0 * H.nyg + j0) * 2;
+                const float4 lo = tx[0], hi = tx[1];     // {s00,a00,s01,a01}, {s10,a10,s11,a11}
+                const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
+                const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
+                ss[q] += fmaf(fu, s1 - s0, s0);
+                as[q] += fmaf(fu, a1 - a0, a0);
             }
         }
 #pragma unroll
@@ -733,13 +745,15 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
             im[q] = fmaf(a, __builtin_amdgcn_sinf(ph), im[q]);
         }
     }
-    const long long base = (long long)f * P.vox + (long long)row * P.nz + k0;
+    if (!live) return;
+    const long long vrow = ((long long)i * P.ny + j) * P.nz + k0;
+    const long long base = (long long)f * P.vox + vrow;
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
         if (k0 + q >= P.nz) continue;
         const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
         if (P.flags & 1u) pmag[base + q] = __builtin_sqrtf(m2);
-        if (P.flags & 2u) inten[base + q] = m2 * (inv2z ? inv2z[(long long)row * P.nz + k0 + q] : P.inten_scale);
+        if (P.flags & 2u) inten[base + q] = m2 * (inv2z ? inv2z[vrow + q] : P.inten_scale);
         if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
     }
 }
