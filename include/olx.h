@@ -126,7 +126,7 @@ int olx_field(olx_ctx *ctx, const olx_grid *grid, int n_foci, double freq, doubl
 /* Heterogeneous medium for the planned grid (BASELINE config 5; the reference only forwards these
  * volumes to k-Wave, sim/kwave_if.py:58-62): per-voxel sound speed [m/s], attenuation [dB/cm/MHz^y] and
  * density [kg/m^3] of the WHOLE grid, C-order [nx,ny,nz]; any pointer may be NULL (= reference value given
- * to olx_field_plan).  Switches the accumulate to the straight-ray layered model (DESIGN.md section 9):
+ * to olx_field_plan).  Switches the accumulate to the straight-ray layered model (DESIGN.md section 7):
  * phase 2 pi f0 (d/c0 + integral (1/c - 1/c0) ds), amplitude x exp(-integral alpha f^y ds), intensity with
  * the voxel's own rho c.  Valid until the next olx_field_plan. */
 int olx_field_set_medium(olx_ctx *ctx, const float *sound_speed, const float *attenuation,

@@ -640,7 +640,7 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
 
 // ------------------------------------------------------------------------------------
 // kernel 2h: heterogeneous medium, straight-ray layered model (definition: oracle/field_oracle.c,
-// DESIGN.md section 9).  Per (voxel, element) the ray is sampled where it crosses each NON-TRIVIAL grid plane
+// DESIGN.md section 7).  Per (voxel, element) the ray is sampled where it crosses each NON-TRIVIAL grid plane
 // (planes whose excess slowness and absorption are identically zero are skipped; the host lists the others)
 // lying between the element and the voxel: bilinear gather (clamped to the border) of {sig, a'} (float2, plane-major [np][nx][ny],
 // L2 / Infinity-Cache resident) -> E' = l' sum sig (extra path, wavelengths), A = l' sum a' (nepers),

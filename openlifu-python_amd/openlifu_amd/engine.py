@@ -94,7 +94,7 @@ class Engine:
         if "complex" in want:
             flags |= nat.OUT_COMPLEX
         self.ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=flags, slab=slab)
-        if medium is not None:  # heterogeneous medium: layered straight-ray kernel (DESIGN.md section 9)
+        if medium is not None:  # heterogeneous medium: layered straight-ray kernel (DESIGN.md section 7)
             self.ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"))
         self.ctx.field_launch()
         self.result_token += 1

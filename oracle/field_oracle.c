@@ -80,7 +80,7 @@ int olo_max_threads(void) {
 #endif
 }
 
-/* ---- heterogeneous medium: straight-ray layered model (the build's definition, DESIGN.md section 9) ------
+/* ---- heterogeneous medium: straight-ray layered model (the build's definition, DESIGN.md section 7) ------
  * PARITY UNPINNED: the reference only forwards c / rho / alpha volumes to k-Wave (sim/kwave_if.py:58-62).
  *
  * For the ray element e -> voxel v the medium is sampled where the ray crosses each grid plane z_k lying
