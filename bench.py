@@ -54,7 +54,10 @@ def synthetic_workload(grid_n: int, spacing_mm: float, el=(16, 16), pitch_mm=3.0
     target = ol.Point(position=(0, 0, 40), units="mm")
     # BASELINE configs[2]: Wheel(center, 63 spokes, 5 mm) = 64 foci; rank r owns foci [r*F, r*F + F) (mod 64)
     sweep = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0).get_targets(target)
-    foci = [sweep[(seed * n_foci + k) % len(sweep)] for k in range(n_foci)]
+    # shard order: centre, spoke 0, then mirror partners (i, 63 - i) side by side, so that a shard holds whole
+    # mirror orbits -- their steering vectors coincide up to the array's symmetry and kernel 2c accumulates each once
+    order = [0, 1] + [k for i in range(1, 32) for k in (1 + i, 1 + 63 - i)]
+    foci = [sweep[order[(seed * n_foci + k) % len(order)]] for k in range(n_foci)]
     return arr, setup, foci
 
 

@@ -61,7 +61,7 @@ struct olx_ctx {
     FieldParams fp{};
     bool flat = false, clamp = false;
     // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
-    bool use_mfma = false; int nt = 1; MfmaParams mp{}; float4* d_coords = nullptr; uint4* d_bfrag = nullptr; int* d_colinfo = nullptr;
+    bool use_mfma = false; int nt = 1; MfmaParams mp{}; float4* d_coords = nullptr; uint4* d_bfrag = nullptr; int* d_colinfo = nullptr; int* d_targets = nullptr; size_t colinfo_cap = 0;
     size_t coords_cap = 0, bfrag_cap = 0; double min_dist = 0, mfma_wscale = 0; int force_kind = 0;  // 0 auto, 1 general, 2 shared, 3 mfma
     int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
@@ -285,50 +285,79 @@ static int configure_variant(olx_ctx* c) {
     char nmbuf[128];
     c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2);
     c->nt = 1;
-    if (c->use_mfma) {  // kernel 2c reuses each geometry fragment for up to 4 column tiles (32 outputs)
-        while (c->nf * 2 <= F && c->nf * 2 * nm <= MFMA_COLS * MFMA_MAX_NT) c->nf *= 2;
-        while (c->nt * MFMA_COLS < nm * c->nf) c->nt *= 2;
-    }
-    const int cols = nm * c->nf;
     if (c->use_mfma) {
+        // ---- kernel 2c column plan.  A column = one distinct steering vector W[sigma_m(e), f]; every
+        // (focus, mirror image) whose vector equals it (on-axis foci: all their images; mirror-partner foci of a
+        // Wheel: each other's images) is a store TARGET of that column, so it is accumulated once.  Foci are packed
+        // greedily into launch tiles of at most 32 columns (NT = 4 MFMA column tiles share each geometry fragment).
         const double rev = c->freq / c->c, lambda = c->c / c->freq;
-        const int n_pad = (n + 15) / 16 * 16, tiles = (F + c->nf - 1) / c->nf;
-        // mirror permutation rows for the distinct columns
-        std::vector<int> perm((size_t)nm * n);
-        for (int m = 0; m < nm; ++m)
+        const int n_pad = (n + 15) / 16 * 16, n_img = c->mx * c->my;
+        constexpr int MAXC = MFMA_COLS * MFMA_MAX_NT;
+        std::vector<int> perm((size_t)4 * n);
+        for (int m = 0; m < 4; ++m)
             for (int e = 0; e < n; ++e) {
                 int o = e;
-                const bool fx = c->dx == 2 && (m & 1), fy = c->dy == 2 && (c->dx == 2 ? (m >> 1) : (m & 1));
-                if (fx) o = c->h_px[o];
-                if (fy) o = c->h_py[o];
+                const bool fx = c->mx == 2 && (m & 1), fy = c->my == 2 && (c->mx == 2 ? (m >> 1) : (m & 1));
+                if (m < n_img && fx) o = c->h_px[o];
+                if (m < n_img && fy) o = c->h_py[o];
                 perm[(size_t)m * n + e] = o;
             }
-        HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
-        // column map: o = f_local * nm + column(image); images = mask of mirror images stored from it
-        int colinfo[MFMA_COLS * MFMA_MAX_NT * 3];
-        MfmaParams& M = c->mp;
-        for (int o = 0; o < MFMA_COLS * MFMA_MAX_NT; ++o) {
-            const int fl = o / nm, cm = o % nm;
-            int images = 0;
-            if (o < cols)
-                for (int m = 0; m < c->mx * c->my; ++m) {
-                    const bool fx = c->mx == 2 && (m & 1), fy = c->my == 2 && (c->mx == 2 ? (m >> 1) : (m & 1));
-                    const int col_of_image = ((c->dx == 2 && fx) ? 1 : 0) + c->dx * ((c->dy == 2 && fy) ? 1 : 0);
-                    if (col_of_image == cm) images |= 1 << m;
+        auto same_vector = [&](int f1, int m1, int f2, int m2) {
+            for (int e = 0; e < n; ++e) {
+                const size_t a = (size_t)f1 * n + perm[(size_t)m1 * n + e], b = (size_t)f2 * n + perm[(size_t)m2 * n + e];
+                double dph = (c->h_delays[a] - c->h_delays[b]) * c->freq;
+                dph -= std::nearbyint(dph);
+                const double wa = c->h_apod[a] * c->h_area[a % n], wb = c->h_apod[b] * c->h_area[b % n];
+                if (std::fabs(wa - wb) > 1e-12 * std::max(std::fabs(wa), std::fabs(wb))) return false;
+                if (wa != 0.0 && std::fabs(dph) > 1e-9) return false;
+            }
+            return true;
+        };
+        struct Col { int f, m, ntgt; int tgt[4]; };
+        std::vector<std::vector<Col>> tiles(1);
+        int total_cols = 0;
+        for (int f = 0; f < F; ++f) {
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                std::vector<Col> cur = tiles.back();
+                for (int m = 0; m < n_img; ++m) {
+                    int hit = -1;
+                    for (size_t q = 0; q < cur.size() && hit < 0; ++q)
+                        if (cur[q].ntgt < 4 && same_vector(cur[q].f, cur[q].m, f, m)) hit = (int)q;
+                    if (hit < 0) { cur.push_back(Col{f, m, 0, {-1, -1, -1, -1}}); hit = (int)cur.size() - 1; }
+                    cur[hit].tgt[cur[hit].ntgt++] = f * 4 + m;
                 }
-            M.cols[o].focus = fl; M.cols[o].images = images;
-            colinfo[3 * o] = fl; colinfo[3 * o + 1] = images; colinfo[3 * o + 2] = cm;
+                if ((int)cur.size() <= MAXC || tiles.back().empty()) { tiles.back() = cur; break; }
+                tiles.emplace_back();  // focus does not fit: start the next launch tile with it
+            }
         }
-        if (!c->d_colinfo) HIPCHK(c, hipMalloc((void**)&c->d_colinfo, sizeof colinfo));
-        HIPCHK(c, hipMemcpyAsync(c->d_colinfo, colinfo, sizeof colinfo, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // perm / colinfo live on this stack frame
+        c->nt = 1;
+        for (auto& t : tiles) { total_cols += (int)t.size(); while (c->nt * MFMA_COLS < (int)t.size()) c->nt *= 2; }
+        const int ntiles = (int)tiles.size();
+        std::vector<int> colinfo((size_t)ntiles * MAXC * 2, -1), targets((size_t)ntiles * MAXC * 4, -1);
+        for (int t = 0; t < ntiles; ++t)
+            for (size_t o = 0; o < tiles[t].size(); ++o) {
+                colinfo[((size_t)t * MAXC + o) * 2] = tiles[t][o].f;
+                colinfo[((size_t)t * MAXC + o) * 2 + 1] = tiles[t][o].m;
+                for (int q = 0; q < 4; ++q) targets[((size_t)t * MAXC + o) * 4 + q] = tiles[t][o].tgt[q];
+            }
+        HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+        if (c->colinfo_cap < colinfo.size() + targets.size()) {
+            if (c->d_colinfo) hipFree(c->d_colinfo);
+            c->d_colinfo = nullptr; c->colinfo_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_colinfo, sizeof(int) * (colinfo.size() + targets.size())));
+            c->colinfo_cap = colinfo.size() + targets.size();
+        }
+        c->d_targets = c->d_colinfo + colinfo.size();
+        HIPCHK(c, hipMemcpyAsync(c->d_colinfo, colinfo.data(), sizeof(int) * colinfo.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_targets, targets.data(), sizeof(int) * targets.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // perm / colinfo / targets live on this stack frame
         if (c->coords_cap < (size_t)n_pad) {
             if (c->d_coords) hipFree(c->d_coords);
             c->d_coords = nullptr; c->coords_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
             c->coords_cap = n_pad;
         }
-        const size_t need = (size_t)tiles * (n_pad / 16) * 128 * c->nt;
+        const size_t need = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;
         if (c->bfrag_cap < need) {
             if (c->d_bfrag) hipFree(c->d_bfrag);
             c->d_bfrag = nullptr; c->bfrag_cap = 0;
@@ -343,13 +372,15 @@ static int configure_variant(olx_ctx* c) {
         wmax *= c->p0_pa / lambda * rev;
         const double sw = wmax > 0 ? std::exp2(std::floor(std::log2(16384.0 / wmax))) : 1.0;
         const FieldParams& P = c->fp;
-        M.nx = P.nx; M.ny = P.ny; M.nz = P.nz; M.n_el_pad = n_pad; M.x_begin = P.x_begin; M.n_tiles = tiles;
+        MfmaParams& M = c->mp;
+        M.nx = P.nx; M.ny = P.ny; M.nz = P.nz; M.n_el_pad = n_pad; M.x_begin = P.x_begin; M.n_tiles = ntiles;
         M.hx = P.hx; M.hy = P.hy; M.hz = P.hz; M.dmin2 = P.dmin2; M.flat_ez = P.flat_ez;
         M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = P.inten_scale;
-        M.vox = P.vox; M.flags = P.flags; M.nf = c->nf; M.n_foci = F;
+        M.vox = P.vox; M.flags = P.flags;
         c->mfma_wscale = c->p0_pa / lambda * rev * sw;
-        snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", P.nz >= 48 ? 4 : 1, c->nt, c->mx,
-                 c->my, c->dx, c->dy, c->nf, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+        snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
+                 P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
+                 n_img, ntiles);
     } else if (c->mx * c->my * c->nf == 1) {
         snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
@@ -388,7 +419,7 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g(c->mp.n_el_pad / 16, c->mp.n_tiles, c->nt);
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
-                           c->plan_foci, c->nf, c->d_colinfo, c->d_coords, c->d_bfrag);
+                           c->plan_foci, c->d_colinfo, c->d_coords, c->d_bfrag);
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -569,7 +600,7 @@ static void launch_mfma(olx_ctx* c, float* pm) {
     const long long rpr = (M.nz + MT * 16 - 1) / (MT * 16);
     const long long runs = (long long)(M.nx - (MX == 2 ? M.nx / 2 : 0)) * (M.ny - (MY == 2 ? M.ny / 2 : 0)) * rpr;
     dim3 grid((unsigned)((runs + 3) / 4), M.n_tiles), blk(FIELD_THREADS);
-#define OLX_MF(FL, CL) hipLaunchKernelGGL((field_mfma_k<MT, NT, MX, MY, FL, CL>), grid, blk, 0, c->stream, c->d_coords, c->d_bfrag, pm, c->d_inten, c->d_cplx, M)
+#define OLX_MF(FL, CL) hipLaunchKernelGGL((field_mfma_k<MT, NT, MX, MY, FL, CL>), grid, blk, 0, c->stream, c->d_coords, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, M)
     if (c->flat) { if (c->clamp) OLX_MF(true, true); else OLX_MF(true, false); }
     else         { if (c->clamp) OLX_MF(false, true); else OLX_MF(false, false); }
 #undef OLX_MF

@@ -405,7 +405,8 @@ __global__ void steer_pack_shared_k(const double* __restrict__ pos, const double
 //   out[v, c] = sum_k A[v, k] B[k, c]      k = (element e, part in {re, im}),  c = (output o, part)
 //   A[v,(e,re)] = Re G(v,e), A[v,(e,im)] = Im G(v,e),   G = exp(j k d)/d  (focus independent)
 //   B[(e,re)][(o,re)] = wr, B[(e,im)][(o,re)] = -wi, B[(e,re)][(o,im)] = wi, B[(e,im)][(o,im)] = wr
-// "output o" = one (focus, mirror-column) pair of kernel 2b; up to 8 of them fill the 16 columns of
+// "output o" = one distinct steering vector (a focus seen through one mirror image; images and foci whose
+// vectors coincide share it and become its store targets); up to 8 of them fill the 16 columns of
 // v_mfma_f32_16x16x32_f16.  The VALU produces G (the transcendentals) directly in the MFMA A-operand
 // layout -- lane l owns voxel row l&15 and the four elements 4*(l>>4)..+3 of the 16-element K-step,
 // i.e. exactly its eight k values -- so no LDS transpose is needed; the matrix pipe runs concurrently
@@ -423,7 +424,6 @@ constexpr int MFMA_COLS = 8;        // complex output columns per 16-column MFMA
 constexpr int MFMA_MAX_NT = 4;      // column tiles per launch tile (A fragments are reused across them)
 constexpr int MFMA_ELEMS_LDS = 256; // elements * NT staged in LDS at a time (32 KiB of B fragments)
 
-struct MfmaCol { int focus; int images; };  // images: bit m set -> store this column to mirror image m
 struct MfmaParams {
     int nx, ny, nz, n_el_pad;      // n_el_pad: elements padded to a multiple of 16 (zero weights)
     int x_begin, n_tiles;
@@ -433,9 +433,6 @@ struct MfmaParams {
     float inten_scale;
     long long vox;
     unsigned flags;
-    int nf;                        // foci per launch tile
-    int n_foci;
-    MfmaCol cols[MFMA_COLS * MFMA_MAX_NT];  // same layout in every tile: focus = tile*nf + cols[o].focus
 };
 
 union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
@@ -443,7 +440,9 @@ union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
 template <int MT, int NT, int MX, int MY, bool FLAT, bool CLAMP>
 __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
     const float4* __restrict__ coords /*[n_el_pad]*/, const uint4* __restrict__ bfrag /*[tiles][ks][NT][2][64]*/,
-    float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx, const MfmaParams P) {
+    float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
+    const int* __restrict__ targets /*[tiles][32][4]: focus*4 + image of every store target of a column, -1 = none*/,
+    const MfmaParams P) {
     constexpr int CH = MFMA_ELEMS_LDS / NT;              // elements per LDS chunk
     __shared__ float4 s_xyz[CH];
     __shared__ uint4 s_B[CH / 16][NT][2][64];
@@ -553,9 +552,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
     const bool fast = (P.nz % RUN) == 0;  // wave-uniform: every z of the run exists, 16-B aligned
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const MfmaCol col = P.cols[nt * MFMA_COLS + (r16 >> 1)];
-        const int f = tile * P.nf + col.focus;
-        const bool col_live = col.images != 0 && f < P.n_foci;
+        const int4 tg = reinterpret_cast<const int4*>(targets)[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (r16 >> 1)];
         float w[MT][4], v[MT][4];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -566,10 +563,12 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
                 const float m2 = sq + __shfl_xor(sq, 1, 64);  // re^2 + im^2 (partner lane holds the other part)
                 w[t][r] = part == 0 ? __builtin_sqrtf(m2) : m2 * P.inten_scale;
             }
-        if (!col_live) continue;
+        const int tgs[4] = {tg.x, tg.y, tg.z, tg.w};
 #pragma unroll
-        for (int m = 0; m < MX * MY; ++m) {
-            if (!((col.images >> m) & 1)) continue;
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int code = tgs[s4];
+            if (code < 0) continue;
+            const int f = code >> 2, m = code & 3;
             const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
             const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
             const long long base = (long long)f * P.vox + ((long long)io * P.ny + jo) * P.nz + zb + 4 * g;
@@ -596,13 +595,13 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
 }
 
 // pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.
-// grid (n_el_pad/16, tiles, NT), block 64: thread = lane.  Column o (< 8*NT) of tile T carries weight
-// W[perm[colmirror[o]][e], focus T*nf + colfocus[o]] (zero beyond n_foci / unused columns).
+// grid (n_el_pad/16, tiles, NT), block 64: thread = lane.  Column o (< 8*NT) of tile T carries the steering
+// vector of its representative (focus, mirror image): W[perm[image][e], focus]; unused columns are zero.
 __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n, int n_pad,
                             const double* __restrict__ delays, const double* __restrict__ apod,
                             const int* __restrict__ perm, double ox, double oy, double oz, double freq,
-                            double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci, int nf,
-                            const int* __restrict__ colinfo /*[8*NT][3]: focus, images, mirror row of perm*/,
+                            double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci,
+                            const int* __restrict__ colinfo /*[tiles][32][2]: representative focus, mirror image (-1 = unused)*/,
                             float4* __restrict__ coords, uint4* __restrict__ bfrag) {
     const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
     if (tile == 0 && nt == 0 && lane < 16) {
@@ -612,14 +611,15 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                             : make_float4(1.0e4f, 1.0e4f, 1.0e4f, 0.f);  // padding: far away, zero weight
     }
     const int g = lane >> 4, c = lane & 15, o = nt * 8 + (c >> 1), part_c = c & 1;
-    const int col_focus = colinfo[3 * o], col_images = colinfo[3 * o + 1], col_mirror = colinfo[3 * o + 2];
+    const int col_focus = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2];
+    const int col_mirror = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2 + 1];
     Half8Bits hi, lo;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const int k = 8 * g + jj, e = 16 * ks + (k >> 1), part_k = k & 1;
         double val = 0.0;
-        const int f = tile * nf + col_focus;
-        if (e < n && col_images != 0 && f < n_foci) {
+        const int f = col_focus;
+        if (e < n && f >= 0 && f < n_foci) {
             const int es = perm[col_mirror * n + e];
             const size_t off = (size_t)f * n + es;
             const double cyc = freq * delays[off];

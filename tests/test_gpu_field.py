@@ -268,7 +268,7 @@ def test_steering_change_reselects_variant(ctx):
     d2, a2 = bo.beamform(pos_m, ori, np.array([4e-3, 0, 30e-3]), C)
     ctx.set_steering(d2[None], a2[None])
     ctx.field_launch()
-    assert "dx2,dy1" in ctx.field_variant(), ctx.field_variant()
+    assert "2 columns for 1 foci x 4 images" in ctx.field_variant(), ctx.field_variant()  # focus on the x axis: y-mirror images coincide
     ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d2, a2, F0, C, P0))
     got = ctx.field_fetch(0)["pmag"]
     assert np.abs(got - ref).max() / ref.max() <= TOL_P and not np.array_equal(got, on_axis)
@@ -357,3 +357,18 @@ def test_heterogeneous_medium_layered_ray_model(ctx):
     ctx.field_plan((xs2[0], xs2[0], zs2[0]), (1e-3,) * 3, (9, 9, 21), F0, C, RHO, 1.0, flags=nat.OUT_COMPLEX)  # re-plan clears the medium
     ctx.field_launch()
     assert np.array_equal(ctx.field_fetch(0, want=("complex",))["complex"], p0)
+
+
+def test_mirror_partner_foci_share_columns(ctx):
+    """A Wheel's spokes come in mirror orbits: the steering vector of spoke -theta seen through the y-mirror
+    equals spoke +theta's, so kernel 2c accumulates one column for both and stores it to both volumes.  The
+    result must still match the oracle focus by focus (and the column count proves the sharing happened)."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    w = bo.wheel_targets([0, 0, 40.0], True, 8, 5.0) * 1e-3      # centre + 8 spokes: orbits under x- and y-mirror
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, w, apod=("maxangle", 40.0, 0.0))
+    xs, ys, zs = centred_grid(48, 1.0)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (48,) * 3, F0, C, RHO, P0)
+    name = ctx.field_variant()
+    # 9 foci x 4 images = 36 vectors; centre 1, axis spokes (0, 90, 180, 270 deg) collapse to 4, diagonals to 4
+    assert "field_mfma_k" in name and " 9 columns for 9 foci x 4 images" in name, name
+    check(ctx, xs, ys, zs, pos_m, area, d, a)

@@ -106,30 +106,33 @@ int main(int argc, char** argv) {
     const int n_pad = (N + 15) / 16 * 16;
     float4* d_coords; uint4* d_bfrag; int* d_colinfo;
     CHK(hipMalloc(&d_coords, sizeof(float4) * n_pad)); CHK(hipMalloc(&d_bfrag, sizeof(uint4) * (n_pad / 16) * 128 * EXP_NT));
-    int colinfo[96]; MfmaParams M{};
-    for (int o = 0; o < 8 * EXP_NT; ++o) {
-        const int fl = o / NM, cm = o % NM; int images = 0;
+    int colinfo[64], tgts[128]; MfmaParams M{};
+    for (int o = 0; o < 32; ++o) {   // one column per (focus, distinct mirror column); its targets = the images mapped to it
+        const int fl = o / NM, cm = o % NM;
+        colinfo[2 * o] = o < NM * EXP_NF ? fl : -1; colinfo[2 * o + 1] = cm;
+        int nt_ = 0; for (int q = 0; q < 4; ++q) tgts[4 * o + q] = -1;
         if (o < NM * EXP_NF)
             for (int m = 0; m < EXP_MX * EXP_MY; ++m) {
                 const bool fx = EXP_MX == 2 && (m & 1), fy = EXP_MY == 2 && (EXP_MX == 2 ? (m >> 1) : (m & 1));
                 const int col = ((EXP_DX == 2 && fx) ? 1 : 0) + EXP_DX * ((EXP_DY == 2 && fy) ? 1 : 0);
-                if (col == cm) images |= 1 << m;
+                if (col == cm) tgts[4 * o + nt_++] = fl * 4 + m;
             }
-        M.cols[o].focus = fl; M.cols[o].images = images; colinfo[3 * o] = fl; colinfo[3 * o + 1] = images; colinfo[3 * o + 2] = cm;
     }
+    int* d_tgts;
     CHK(hipMalloc(&d_colinfo, sizeof colinfo)); CHK(hipMemcpy(d_colinfo, colinfo, sizeof colinfo, hipMemcpyHostToDevice));
+    CHK(hipMalloc(&d_tgts, sizeof tgts)); CHK(hipMemcpy(d_tgts, tgts, sizeof tgts, hipMemcpyHostToDevice));
     const double sg = 16384.0, sw = 1024.0 * 16;
     hipLaunchKernelGGL(mfma_pack_k, dim3(n_pad / 16, 1, EXP_NT), dim3(64), 0, 0, d_pos, d_area, N, n_pad, d_delays, d_apod, d_perm, ox, oy,
-                       oz, f0, 1e5 / (c0 / f0) * (f0 / c0) * sw, f0 / c0, F, EXP_NF, d_colinfo, d_coords, d_bfrag);
+                       oz, f0, 1e5 / (c0 / f0) * (f0 / c0) * sw, f0 / c0, F, d_colinfo, d_coords, d_bfrag);
     M.nx = M.ny = M.nz = G; M.n_el_pad = n_pad; M.x_begin = 0; M.n_tiles = 1; M.hx = M.hy = M.hz = S.hx; M.dmin2 = 0.f;
     M.flat_ez = S.flat_ez; M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = S.inten_scale;
-    M.vox = vox; M.flags = EXP_FLAGS; M.nf = EXP_NF; M.n_foci = F;
+    M.vox = vox; M.flags = EXP_FLAGS;
     const long long rpr = (G + MT * 16 - 1) / (MT * 16);
     const long long runs = (long long)(G - (EXP_MX == 2 ? G / 2 : 0)) * (G - (EXP_MY == 2 ? G / 2 : 0)) * rpr;
     dim3 mgrid((unsigned)((runs + 3) / 4), 1);
     launch = [&]() {
         hipLaunchKernelGGL((field_mfma_k<MT, EXP_NT, EXP_MX, EXP_MY, true, false>), mgrid, dim3(FIELD_THREADS), 0, 0, d_coords, d_bfrag,
-                           d_pm, d_it, (float*)nullptr, M);
+                           d_pm, d_it, (float*)nullptr, d_tgts, M);
     };
 #endif
     for (int i = 0; i < 3; ++i) launch();
