@@ -220,13 +220,20 @@ def main():
             tj = json.load(open(tpath))
             key = f"{args.elements}_{args.grid}_{F}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        # VALU-issue ceiling of the kernel variant in use: one geometry term G
-        # (4 plain + 3 transcendental wave-instructions per 64 lanes) serves mx*my*nf logical pairs and
-        # feeds dx*dy*nf complex accumulators at 4 fma each (issued as 2 v_pk_fma_f32 @4.2 cycles);
-        # the unfolded kernel 2a fuses phase and weight instead: 6 plain + 3 transcendental per pair.
+        # VALU-issue ceiling of the kernel variant in use: how many logical (voxel, element,
+        # focus) pairs one evaluation of the geometry term G serves, and what that evaluation costs to issue.
         import re
-        m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", ctx.field_variant())
-        if m:
+        name = ctx.field_variant()
+        m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
+        mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
+        if mm:  # kernel 2c: per G 5 plain + 3 transcendental + 4 half-rate (hi/lo split) VALU instructions, plus the
+            # issue slots its share of the 3*NT MFMAs blocks (8 cycles each, 0.75*NT MFMAs per 64 terms)
+            ntc, _, nfoci, nimg, ntile = (int(v) for v in mm.groups())
+            cyc_per_g = 5 * CYC_PLAIN + 3 * CYC_TRANS + 4 * 4.2 + 6.0 * ntc
+            pairs_per_g = nfoci * nimg / ntile
+            model = (f"per G: 5 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + 4 half-rate @4.2 + {0.75 * ntc:.2f} MFMA "
+                     f"issue slots @8 cycles, serving {pairs_per_g:.0f} pairs")
+        elif m:
             mx, my, dx, dy, nf = (int(v) for v in m.groups())
             cyc_per_g = 4 * CYC_PLAIN + 3 * CYC_TRANS + dx * dy * nf * 2 * 4.2
             pairs_per_g, model = mx * my * nf, (f"per G: 4 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + "
