@@ -65,6 +65,15 @@ struct olx_ctx {
     size_t coords_cap = 0, bfrag_cap = 0; double min_dist = 0, mfma_wscale = 0; int force_kind = 0;  // 0 auto, 1 general, 2 shared, 3 mfma
     int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
+    // lattice variant (kernel 2d): matrix array whose pitch is a whole number of voxels
+    struct Lattice {
+        bool ok = false;
+        int ax = 0, ay = 0, nsa = 0, nsb = 0, mx = 1, my = 1, n_pad = 0;
+        double x0 = 0, y0 = 0, px = 0, py = 0;     // position of lattice index (0, 0) and pitch [m]
+        double min_d2 = 0; bool clamp = false;     // incl. the zero-weight virtual elements of the padding
+        std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
+    } lat;
+    bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
     float* d_inten = nullptr; float* d_cplx = nullptr;
@@ -139,7 +148,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -254,6 +263,73 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
 }
 
 // ---- kernel 2 -----------------------------------------------------------------------------
+// Kernel 2d precondition: the elements fill a regular ax x ay lattice in one z plane and the pitch is a whole number
+// of voxels along x and y.  Fills c->lat (slot map in 8 x 8 super-blocks of four 4 x 4 K-steps, padded with
+// virtual elements) and the clamp / minimum-distance bounds including the virtual lattice points.
+static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], double dmin) {
+    olx_ctx::Lattice& L = c->lat;
+    L = olx_ctx::Lattice();
+    const int n = c->n_el;
+    if (!c->flat || n < 16 || n > 16384) return;
+    const double* X = c->h_pos.data();
+    const double* Y = X + n;
+    const double tol = 1e-10;
+    auto axis = [&](const double* v, std::vector<double>& u) {
+        u.assign(v, v + n);
+        std::sort(u.begin(), u.end());
+        size_t m = 0;
+        for (size_t q = 0; q < u.size(); ++q)
+            if (m == 0 || u[q] - u[m - 1] > tol) u[m++] = u[q];
+        u.resize(m);
+    };
+    std::vector<double> xs, ys;
+    axis(X, xs); axis(Y, ys);
+    const int ax = (int)xs.size(), ay = (int)ys.size();
+    if (ax < 2 || ay < 2 || (long long)ax * ay != n) return;
+    const double px = (xs.back() - xs.front()) / (ax - 1), py = (ys.back() - ys.front()) / (ay - 1);
+    for (int a = 0; a < ax; ++a) if (std::fabs(xs[a] - (xs[0] + a * px)) > tol) return;
+    for (int b = 0; b < ay; ++b) if (std::fabs(ys[b] - (ys[0] + b * py)) > tol) return;
+    const double rx = px / c->grid.spacing[0], ry = py / c->grid.spacing[1];
+    const int mx = (int)std::llround(rx), my = (int)std::llround(ry);
+    if (mx < 1 || my < 1 || std::fabs(rx - mx) > 1e-9 * mx || std::fabs(ry - my) > 1e-9 * my) return;
+    const int nsa = (ax + 7) / 8, nsb = (ay + 7) / 8;
+    if ((long long)nsa * nsb * 64 > 2LL * n) return;          // padding would more than double the contraction
+    std::vector<int> cell((size_t)ax * ay, -1);
+    for (int e = 0; e < n; ++e) {
+        const int a = (int)std::llround((X[e] - xs[0]) / px), b = (int)std::llround((Y[e] - ys[0]) / py);
+        if (a < 0 || a >= ax || b < 0 || b >= ay || cell[(size_t)a * ay + b] >= 0) return;
+        cell[(size_t)a * ay + b] = e;
+    }
+    L.slot_elem.assign((size_t)nsa * nsb * 64, -1);
+    for (int sbb = 0; sbb < nsb; ++sbb)
+        for (int sa = 0; sa < nsa; ++sa)
+            for (int ks = 0; ks < 4; ++ks)
+                for (int bb = 0; bb < 4; ++bb)
+                    for (int aa = 0; aa < 4; ++aa) {
+                        const int a = 8 * sa + 4 * (ks & 1) + aa, b = 8 * sbb + 4 * (ks >> 1) + bb;
+                        if (a < ax && b < ay)
+                            L.slot_elem[((size_t)(sbb * nsa + sa) * 4 + ks) * 16 + 4 * bb + aa] = cell[(size_t)a * ay + b];
+                    }
+    // distance bounds over every lattice point of the padded array (virtual ones included: their G must stay finite)
+    const double ez = c->h_pos[2 * (size_t)n];
+    double min_d2 = 1e300; bool clamp = false;
+    const double guard = 2.0 * dmin;
+    for (int a = 0; a < 8 * nsa; ++a)
+        for (int b = 0; b < 8 * nsb; ++b) {
+            const double p[3] = {xs[0] + a * px, ys[0] + b * py, ez};
+            double d2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double d = p[k] < lo[k] ? lo[k] - p[k] : (p[k] > hi[k] ? p[k] - hi[k] : 0.0);
+                d2 += d * d;
+            }
+            min_d2 = std::min(min_d2, d2);
+            if (d2 < guard * guard) clamp = true;
+        }
+    L.ax = ax; L.ay = ay; L.nsa = nsa; L.nsb = nsb; L.mx = mx; L.my = my; L.n_pad = nsa * nsb * 64;
+    L.x0 = xs[0]; L.y0 = ys[0]; L.px = px; L.py = py; L.min_d2 = min_d2; L.clamp = clamp;
+    L.ok = true;
+}
+
 // Steering-dependent part of the kernel-2 variant choice (runs whenever the steering table changed):
 // dx/dy = distinct weight columns along folded axes (1 when every focus' delays and apodization are
 // mirror-symmetric), nf = foci per tile so that dx*dy*nf <= 8 accumulator columns.
@@ -271,7 +347,7 @@ static int configure_variant(olx_ctx* c) {
         return true;
     };
     if (c->hetero) {  // kernel 2h: no folds, no shared geometry
-        c->mx = c->my = c->dx = c->dy = c->nf = c->nt = 1; c->use_mfma = false;
+        c->mx = c->my = c->dx = c->dy = c->nf = c->nt = 1; c->use_mfma = false; c->use_lattice = false;
         char hb[96];
         snprintf(hb, sizeof hb, "field_hetero_k<4,%s> (%d non-trivial planes)", c->clamp ? "clamp" : "noclamp", c->hp.n_planes);
         c->variant = hb;
@@ -282,8 +358,15 @@ static int configure_variant(olx_ctx* c) {
     const int nm = c->dx * c->dy;
     c->nf = 1;
     if (c->allow_shared) while (c->nf * 2 <= F && c->nf * 2 * nm <= 8) c->nf *= 2;
-    char nmbuf[128];
-    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2);
+    char nmbuf[192];
+    // kernel 2d applies when the array is a lattice commensurate with the grid and the pitch-strided row tiles
+    // (4 rows x pitch) do not overhang the computed region by more than 2x per axis
+    auto tile_fill = [](int width, int m) { const int blk = 4 * m; return (double)width / (double)(((width + blk - 1) / blk) * blk); };
+    const bool lat_ok = c->allow_shared && c->lat.ok && (c->force_kind == 0 || c->force_kind == 4) &&
+                        tile_fill(c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), c->lat.mx) >= 0.5 &&
+                        tile_fill(c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), c->lat.my) >= 0.5;
+    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok);
+    c->use_lattice = c->use_mfma && lat_ok;
     c->nt = 1;
     if (c->use_mfma) {
         // ---- kernel 2c column plan.  A column = one distinct steering vector W[sigma_m(e), f]; every
@@ -291,7 +374,7 @@ static int configure_variant(olx_ctx* c) {
         // Wheel: each other's images) is a store TARGET of that column, so it is accumulated once.  Foci are packed
         // greedily into launch tiles of at most 32 columns (NT = 4 MFMA column tiles share each geometry fragment).
         const double rev = c->freq / c->c, lambda = c->c / c->freq;
-        const int n_pad = (n + 15) / 16 * 16, n_img = c->mx * c->my;
+        const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16, n_img = c->mx * c->my;
         constexpr int MAXC = MFMA_COLS * MFMA_MAX_NT;
         std::vector<int> perm((size_t)4 * n);
         for (int m = 0; m < 4; ++m)
@@ -364,8 +447,20 @@ static int configure_variant(olx_ctx* c) {
             HIPCHK(c, hipMalloc((void**)&c->d_bfrag, sizeof(uint4) * need));
             c->bfrag_cap = need;
         }
+        const double dmin_m = 0.5 * std::min({c->grid.spacing[0], c->grid.spacing[1], c->grid.spacing[2]});
+        const bool lat_clamp = c->use_lattice && (c->clamp || c->lat.clamp);
+        const double min_dist = !c->use_lattice ? c->min_dist : (lat_clamp ? dmin_m : std::sqrt(c->lat.min_d2));
+        if (c->use_lattice) {
+            if (c->slot_cap < (size_t)n_pad) {
+                if (c->d_slot) hipFree(c->d_slot);
+                c->d_slot = nullptr; c->slot_cap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_slot, sizeof(int) * n_pad));
+                c->slot_cap = n_pad;
+            }
+            HIPCHK(c, hipMemcpy(c->d_slot, c->lat.slot_elem.data(), sizeof(int) * n_pad, hipMemcpyHostToDevice));
+        }
         // power-of-two operand scales: |G| <= 1/d'_min, |W| <= wmax  ->  hi parts <= 2^14, lo parts normal
-        const double dmin_w = std::max(c->min_dist * rev, 1e-6);
+        const double dmin_w = std::max(min_dist * rev, 1e-6);
         const double sg = std::exp2(std::floor(std::log2(16384.0 * dmin_w)));
         double wmax = 0;
         for (size_t q = 0; q < (size_t)F * n; ++q) wmax = std::max(wmax, std::fabs(c->h_apod[q] * c->h_area[q % n]));
@@ -378,6 +473,31 @@ static int configure_variant(olx_ctx* c) {
         M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = P.inten_scale;
         M.vox = P.vox; M.flags = P.flags;
         c->mfma_wscale = c->p0_pa / lambda * rev * sw;
+        if (c->use_lattice) {
+            const olx_ctx::Lattice& A = c->lat;
+            LatParams& L = c->lp;
+            c->lat_mt = 4;   // MFMA tiles per wave (2 planes each)
+            L.nx = P.nx; L.ny = P.ny; L.nz = P.nz;
+            L.x_lo = c->mx == 2 ? P.nx / 2 : 0; L.y_lo = c->my == 2 ? P.ny / 2 : 0; L.x_begin = P.x_begin;
+            L.mx = A.mx; L.my = A.my;
+            L.tiles_x = ((P.nx - L.x_lo + 4 * A.mx - 1) / (4 * A.mx)) * 2 * A.mx;   // 2 x rows two pitches apart per tile
+            L.tiles_y = ((P.ny - L.y_lo + 4 * A.my - 1) / (4 * A.my)) * A.my;       // 4 y rows one pitch apart
+            L.kgroups = (P.nz + 2 * c->lat_mt - 1) / (2 * c->lat_mt);
+            L.nsa = A.nsa; L.nsb = A.nsb;
+            // dx(i, a) = (origin - x0) + (i - mx a) h: whole voxels go into the integer part, the rest is |f| <= h/2
+            const double offx = c->grid.origin[0] - A.x0, offy = c->grid.origin[1] - A.y0;
+            L.ux0 = (int)std::llround(offx / c->grid.spacing[0]); L.uy0 = (int)std::llround(offy / c->grid.spacing[1]);
+            L.fx0 = (float)((offx - L.ux0 * c->grid.spacing[0]) * rev); L.fy0 = (float)((offy - L.uy0 * c->grid.spacing[1]) * rev);
+            const double hxw = c->grid.spacing[0] * rev, hyw = c->grid.spacing[1] * rev;
+            L.hx_hi = (float)hxw; L.hx_lo = (float)(hxw - (double)L.hx_hi);
+            L.hy_hi = (float)hyw; L.hy_lo = (float)(hyw - (double)L.hy_hi);
+            L.hz = P.hz; L.dmin2 = P.dmin2; L.flat_ez = P.flat_ez;
+            L.g_scale = M.g_scale; L.out_scale = M.out_scale; L.inten_scale = P.inten_scale;
+            L.vox = P.vox; L.flags = P.flags;
+            snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                     "%dx%d lattice, pitch %dx%d voxels", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp", total_cols, F,
+                     n_img, ntiles, A.ax, A.ay, A.mx, A.my);
+        } else
         snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
                  P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
                  n_img, ntiles);
@@ -419,7 +539,7 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g(c->mp.n_el_pad / 16, c->mp.n_tiles, c->nt);
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
-                           c->plan_foci, c->d_colinfo, c->d_coords, c->d_bfrag);
+                           c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr, c->d_coords, c->d_bfrag);
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -519,6 +639,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         if (d2 < guard * guard) c->clamp = true;
     }
     c->min_dist = c->clamp ? dmin : std::sqrt(min_d2);  // lower bound of any voxel-element distance [m]
+    detect_lattice(c, lo, hi, dmin);
     // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
     auto mirror_perm = [&](int axis, std::vector<int>& perm) -> bool {
         const double ctr = g->origin[axis] + 0.5 * (g->n[axis] - 1) * g->spacing[axis];
@@ -541,8 +662,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         return true;
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
-    const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma: pin a kernel family (A/B measurements)
-    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : 0;
+    const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : !strcmp(force, "lattice") ? 4 : 0;
     c->allow_shared = c->force_kind != 1;
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
@@ -613,7 +734,33 @@ static void dispatch_mfma_nt(olx_ctx* c, float* pm) {
     else     { if (c->nt == 1) launch_mfma<1, 1, MX, MY>(c, pm); else if (c->nt == 2) launch_mfma<1, 2, MX, MY>(c, pm); else launch_mfma<1, 4, MX, MY>(c, pm); }
 }
 
+template <int MT, int NT, int MX, int MY>
+static void launch_lattice(olx_ctx* c, float* pm, bool clamp) {
+    const LatParams& L = c->lp;
+    constexpr int NW = LAT_THREADS / 64;
+    const long long blocks = (long long)L.tiles_x * L.tiles_y * ((L.kgroups + NW - 1) / NW);
+    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(LAT_THREADS);
+    if (clamp) hipLaunchKernelGGL((field_lattice_k<MT, NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, L);
+    else       hipLaunchKernelGGL((field_lattice_k<MT, NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, L);
+}
+
+template <int MX, int MY>
+static void dispatch_lattice_nt(olx_ctx* c, float* pm) {
+    const bool clamp = c->clamp || c->lat.clamp;
+    if (c->nt == 1) launch_lattice<4, 1, MX, MY>(c, pm, clamp);
+    else if (c->nt == 2) launch_lattice<4, 2, MX, MY>(c, pm, clamp);
+    else launch_lattice<4, 4, MX, MY>(c, pm, clamp);
+}
+
+static void dispatch_lattice(olx_ctx* c, float* pm) {
+    if (c->mx == 2 && c->my == 2) dispatch_lattice_nt<2, 2>(c, pm);
+    else if (c->mx == 2) dispatch_lattice_nt<2, 1>(c, pm);
+    else if (c->my == 2) dispatch_lattice_nt<1, 2>(c, pm);
+    else dispatch_lattice_nt<1, 1>(c, pm);
+}
+
 static void dispatch_mfma(olx_ctx* c, float* pm) {
+    if (c->use_lattice) { dispatch_lattice(c, pm); return; }
     if (c->mx == 2 && c->my == 2) dispatch_mfma_nt<2, 2>(c, pm);
     else if (c->mx == 2) dispatch_mfma_nt<2, 1>(c, pm);
     else if (c->my == 2) dispatch_mfma_nt<1, 2>(c, pm);
@@ -1188,3 +1335,10 @@ int olx_allgather_fetch(olx_ctx* c, int rank, float* out) {
 }
 
 }  // extern "C"
+
+#ifdef OLX_EXP_STAMPS
+// developer build only (tools/stamps.py): per-wave phase time stamps of the lattice kernel
+extern "C" int olx_exp_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif

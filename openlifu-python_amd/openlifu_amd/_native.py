@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_uint,
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libolx.so")
+LIB_PATH = os.environ.get("OLX_LIB_PATH") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libolx.so")  # env: kernel A/B builds
 
 OLX_OK, OLX_EINVAL, OLX_ESTATE, OLX_EHIP, OLX_ENOMEM, OLX_ECOMM = 0, -1, -2, -3, -4, -5
 APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2

@@ -227,10 +227,11 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
 
 
-@pytest.mark.parametrize("family", ["general", "shared", "mfma"])
+@pytest.mark.parametrize("family", ["general", "shared", "mfma", "lattice"])
 def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
-    """Kernel 2a (per pair), 2b (shared geometry, VALU) and 2c (shared geometry, MFMA fp16 hi/lo split)
-    are pinned one at a time (OLX_FIELD_VARIANT) on the same off-axis symmetric-array case."""
+    """Kernel 2a (per pair), 2b (shared geometry, VALU), 2c (shared geometry, MFMA fp16 hi/lo split) and 2d
+    (lattice: block-Toeplitz geometry tables) are pinned one at a time (OLX_FIELD_VARIANT) on the same
+    off-axis symmetric-array case."""
     monkeypatch.setenv("OLX_FIELD_VARIANT", family)
     pos, ori, size = synthetic_array(16, 16, 3.0)
     foci = np.array([[2e-3, -1e-3, 38e-3], [0, 0, 40e-3], [-3e-3, 4e-3, 45e-3]])
@@ -238,7 +239,7 @@ def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     xs, ys, zs = centred_grid(64, 0.5)
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (64,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
-    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k"}[family] in name, name
+    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k", "lattice": "field_lattice_k"}[family] in name, name
     check(ctx, xs, ys, zs, pos_m, area, d, a)
 
 
@@ -263,7 +264,7 @@ def test_steering_change_reselects_variant(ctx):
     xs, ys, zs = centred_grid(32, 1.0)
     ctx.field_plan((xs[0], ys[0], zs[0]), (1e-3,) * 3, (32,) * 3, F0, C, RHO, P0)
     ctx.field_launch()
-    assert "dx1,dy1" in ctx.field_variant()
+    assert "dx1,dy1" in ctx.field_variant() or " 1 columns for 1 foci x 4 images" in ctx.field_variant()  # one shared column
     on_axis = ctx.field_fetch(0)["pmag"]
     d2, a2 = bo.beamform(pos_m, ori, np.array([4e-3, 0, 30e-3]), C)
     ctx.set_steering(d2[None], a2[None])
@@ -370,5 +371,5 @@ def test_mirror_partner_foci_share_columns(ctx):
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (48,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
     # 9 foci x 4 images = 36 vectors; centre 1, axis spokes (0, 90, 180, 270 deg) collapse to 4, diagonals to 4
-    assert "field_mfma_k" in name and " 9 columns for 9 foci x 4 images" in name, name
+    assert ("field_mfma_k" in name or "field_lattice_k" in name) and " 9 columns for 9 foci x 4 images" in name, name
     check(ctx, xs, ys, zs, pos_m, area, d, a)
