@@ -373,3 +373,59 @@ def test_mirror_partner_foci_share_columns(ctx):
     # 9 foci x 4 images = 36 vectors; centre 1, axis spokes (0, 90, 180, 270 deg) collapse to 4, diagonals to 4
     assert ("field_mfma_k" in name or "field_lattice_k" in name) and " 9 columns for 9 foci x 4 images" in name, name
     check(ctx, xs, ys, zs, pos_m, area, d, a)
+
+
+def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0.0), z0=5e-3, foci=None, apod=("uniform", 1.0, 0.0),
+                  slab=None, expect="field_lattice_k"):
+    """Flat nax x nay array with pitch (px, py) [mm]; grid of grid_n voxels with spacing [mm] centred on the array
+    (+ origin_shift voxels); full-volume parity against the oracle."""
+    px, py = pitch_xy
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * px, (b.ravel() - (nay - 1) / 2) * py, np.zeros(nax * nay)], axis=1)
+    ori = np.zeros_like(pos)
+    size = np.tile([0.9 * px, 0.9 * py], (nax * nay, 1))
+    foci = np.array([[0, 0, 30e-3]]) if foci is None else np.asarray(foci)
+    pos_m, area, d, ap = setup_ctx(ctx, pos, ori, size, foci, apod=apod)
+    coords = []
+    for n, h, sh in zip(grid_n[:2], spacing[:2], origin_shift):
+        coords.append(((np.arange(n) - (n - 1) / 2) + sh) * h * 1e-3)
+    zs = z0 + np.arange(grid_n[2]) * spacing[2] * 1e-3
+    xs, ys = coords
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    if slab is None:
+        check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect)
+        return
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab)
+    assert expect in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    for f in range(len(foci)):
+        got = ctx.field_fetch(f)["pmag"]
+        ref = np.abs(co.field_on_grid(xs[slab[0]:slab[0] + slab[1]], ys, zs, pos_m, area, d[f], ap[f], F0, C, P0, dmin=0.5 * min(h)))
+        assert got.shape == ref.shape and np.abs(got - ref).max() / ref.max() <= TOL_P
+
+
+def test_lattice_padded_array_with_virtual_elements(ctx):
+    """20 x 12 elements: padded to 24 x 16 with zero-weight virtual lattice points; pitch 4 x 3 voxels (mx != my);
+    grid sizes that are not multiples of the row tiles, nz not a multiple of the block's 64 planes."""
+    _lattice_case(ctx, 20, 12, (2.4, 1.8), (50, 46, 70), (0.6, 0.6, 0.5),
+                  foci=[[0, 0, 30e-3], [2e-3, -1e-3, 28e-3], [-3e-3, 2e-3, 34e-3]], apod=("piecewise", 50.0, 15.0))
+
+
+def test_lattice_grid_through_element_plane_clamps(ctx):
+    """Voxels coincide with real AND virtual lattice points (z = 0 plane inside the grid): the clamp variant must be
+    chosen (a virtual element has zero weight but its G must stay finite)."""
+    _lattice_case(ctx, 12, 12, (2.0, 2.0), (41, 41, 24), (1.0, 1.0, 1.0), z0=-4e-3, expect="flat,clamp")
+
+
+def test_lattice_without_mirror_folds_and_in_slabs(ctx):
+    """Grid not centred on the array (no mirror symmetry: mx1,my1) and x-slab launches (multi-GPU shard unit):
+    the lattice offsets come from global voxel indices."""
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), origin_shift=(3.0, -2.0), foci=[[1e-3, 2e-3, 25e-3]],
+                  expect="mx1,my1")
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[1e-3, 2e-3, 25e-3], [0, 0, 30e-3]],
+                  slab=(13, 14), expect="field_lattice_k")
+
+
+def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
+    """3.0 mm pitch on a 0.7 mm grid is not commensurate: kernel 2b / 2c take over, same results."""
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
