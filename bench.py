@@ -226,7 +226,16 @@ def main():
         name = ctx.field_variant()
         m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
         mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-        if mm:  # kernel 2c: per G 5 plain + 3 transcendental + 4 half-rate (hi/lo split) VALU instructions, plus the
+        ml = re.search(r"field_lattice_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+        if ml:  # kernel 2d: the table arithmetic is amortised over 8 voxel rows x 64 elements; the matrix pipe is the ceiling.
+            # On this chip MFMA and VALU issue add up (tools/ubench_clock.hip), so the MFMA-only time is a strict floor.
+            n_mfma = int(ml.group(5))
+            floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
+            ceil_pairs = float(V) * N * F / floor_s
+            cyc_per_g, pairs_per_g = None, None
+            model = (f"{n_mfma} v_mfma_f32_16x16x32_f16 per launch (3 fp16 hi/lo products, padded row tiles included) at "
+                     f"16 cycles each on {N_SIMD} SIMDs @{CLK_GHZ} GHz = {floor_s * 1e3:.3f} ms if nothing else issued")
+        elif mm:  # kernel 2c: per G 5 plain + 3 transcendental + 4 half-rate (hi/lo split) VALU instructions, plus the
             # issue slots its share of the 3*NT MFMAs blocks (8 cycles each, 0.75*NT MFMAs per 64 terms)
             ntc, _, nfoci, nimg, ntile = (int(v) for v in mm.groups())
             cyc_per_g = 5 * CYC_PLAIN + 3 * CYC_TRANS + 4 * 4.2 + 6.0 * ntc
@@ -240,7 +249,8 @@ def main():
                                                f"{dx * dy * nf} x 2 v_pk_fma @4.2 cycles, serving {mx * my * nf} pairs")
         else:
             cyc_per_g, pairs_per_g, model = 6 * CYC_PLAIN + 3 * CYC_TRANS, 1, f"per pair: 6 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} cycles"
-        ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 * pairs_per_g / cyc_per_g
+        if cyc_per_g is not None:
+            ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 * pairs_per_g / cyc_per_g
         out = {
             "metric": "Mvoxel-elements/s pressure-field accumulate", "value": value, "unit": "Mvoxel-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -257,11 +267,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the accumulate is VALU/transcendental-issue bound, not HBM bound "
-                                 "(SURVEY 8(d), DESIGN.md 5); see valu_ceiling"},
-            "valu_ceiling": {"achieved_Mpairs_s": float(V) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
+                         "note": "the accumulate is issue bound (matrix pipe + VALU), not HBM bound "
+                                 "(SURVEY 8(d), DESIGN.md 5); see issue_ceiling"},
+            "issue_ceiling": {"achieved_Mpairs_s": float(V) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
                              "frac": float(V) * N * F / (k_ms * 1e-3) / ceil_pairs,
-                             "model": model + "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"},
+                             "model": model + ("" if ml else "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)")},
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, setup, foci, args.cpu_seconds)

@@ -358,7 +358,7 @@ static int configure_variant(olx_ctx* c) {
     const int nm = c->dx * c->dy;
     c->nf = 1;
     if (c->allow_shared) while (c->nf * 2 <= F && c->nf * 2 * nm <= 8) c->nf *= 2;
-    char nmbuf[192];
+    char nmbuf[256];
     // kernel 2d applies when the array is a lattice commensurate with the grid and the pitch-strided row tiles
     // (4 rows x pitch) do not overhang the computed region by more than 2x per axis
     auto tile_fill = [](int width, int m) { const int blk = 4 * m; return (double)width / (double)(((width + blk - 1) / blk) * blk); };
@@ -494,9 +494,10 @@ static int configure_variant(olx_ctx* c) {
             L.hz = P.hz; L.dmin2 = P.dmin2; L.flat_ez = P.flat_ez;
             L.g_scale = M.g_scale; L.out_scale = M.out_scale; L.inten_scale = P.inten_scale;
             L.vox = P.vox; L.flags = P.flags;
+            const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
             snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
-                     "%dx%d lattice, pitch %dx%d voxels", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp", total_cols, F,
-                     n_img, ntiles, A.ax, A.ay, A.mx, A.my);
+                     "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                     total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
         } else
         snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
                  P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
