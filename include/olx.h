@@ -103,6 +103,15 @@ int olx_bf_solve(olx_ctx *ctx, const double *foci_m, int n_foci, const double *M
  * (run_simulation's `delays`, `apod` arguments, sim/kwave_if.py:81-83, 98-99). */
 int olx_set_steering(olx_ctx *ctx, const double *delays_s, const double *apod, int n_foci);
 
+/* Hardware hand-off of the resident steering table: what LIFUTXDevice.set_solution derives per
+ * focus before it packs registers (io/LIFUTXDevice.py:1357-1372): ticks[F*N] = int(delay * 1.0 * bf_clk) (the
+ * reference's fp64 expression, :1874, truncated toward zero -- bit-exact), apod_off[F*N] = int(1 - apod) (the
+ * apodization register bit, :1811), max_apod[F] (duty_cycle = 0.66 * max(apod) * amplitude, :1358) and
+ * n_overflow[F] = delays that do not fit width_bits (DELAY_WIDTH = 13; set_register_value raises, :1500).
+ * Any output pointer may be NULL.  Register addresses / bit positions are device tables and stay in openlifu. */
+int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ticks_out,
+                    uint8_t *apod_off_out, double *max_apod_out, int32_t *n_overflow_out);
+
 /* ---- kernel 2: pressure-field accumulate --------------------------------------------
  * Stands in for run_simulation (sim/kwave_if.py:80-146) at the seam
  * plan/protocol.py:324-336.  Steady-state monochromatic point-source superposition

@@ -262,6 +262,33 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
     return OLX_OK;
 }
 
+int olx_bf_quantize(olx_ctx* c, double bf_clk_hz, int width_bits, uint16_t* ticks_out, uint8_t* apod_off_out,
+                    double* max_apod_out, int32_t* n_overflow_out) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_foci <= 0) return fail(c, OLX_ESTATE, "olx_bf_quantize: no steering table (olx_bf_solve / olx_set_steering)");
+    if (!(bf_clk_hz > 0) || width_bits < 1 || width_bits > 16) return fail(c, OLX_EINVAL, "olx_bf_quantize: bad clock or width");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->n_foci, n = c->n_el;
+    const size_t fn = (size_t)F * n;
+    unsigned short* d_t = nullptr; unsigned char* d_a = nullptr; double* d_m = nullptr; int* d_o = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_t, sizeof(unsigned short) * fn));
+    HIPCHK(c, hipMalloc((void**)&d_a, fn));
+    HIPCHK(c, hipMalloc((void**)&d_m, sizeof(double) * F));
+    HIPCHK(c, hipMalloc((void**)&d_o, sizeof(int) * F));
+    hipLaunchKernelGGL(bf_quantize_k, dim3(F), dim3(BF_THREADS), 0, c->stream, c->d_delays, c->d_apod, n, bf_clk_hz,
+                       (1u << width_bits) - 1u, d_t, d_a, d_m, d_o);
+    int rc = OLX_OK;
+    if (hipGetLastError() != hipSuccess) rc = fail(c, OLX_EHIP, "olx_bf_quantize: launch failed");
+    if (!rc && ticks_out && hipMemcpyAsync(ticks_out, d_t, sizeof(unsigned short) * fn, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (!rc && apod_off_out && hipMemcpyAsync(apod_off_out, d_a, fn, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (!rc && max_apod_out && hipMemcpyAsync(max_apod_out, d_m, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (!rc && n_overflow_out && hipMemcpyAsync(n_overflow_out, d_o, sizeof(int) * F, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = OLX_EHIP;
+    hipFree(d_t); hipFree(d_a); hipFree(d_m); hipFree(d_o);
+    if (rc == OLX_EHIP) return fail(c, OLX_EHIP, "olx_bf_quantize: HIP error");
+    return rc;
+}
+
 // ---- kernel 2 -----------------------------------------------------------------------------
 // Kernel 2d precondition: the elements fill a regular ax x ay lattice in one z plane and the pitch is a whole number
 // of voxels along x and y.  Fills c->lat (slot map in 8 x 8 super-blocks of four 4 x 4 K-steps, padded with

@@ -92,6 +92,46 @@ __global__ __launch_bounds__(BF_THREADS) void bf_solve_k(
 }
 
 // ------------------------------------------------------------------------------------
+// hardware hand-off of the steering table (io/LIFUTXDevice.py:1357-1372, 1874): per focus and
+// element the beamformer-clock delay count int(delay * 1.0 * bf_clk) -- the reference's own fp64 expression,
+// truncated toward zero, so the ticks are bit-exact -- and the apodization-off bit int(1 - apod)
+// (LIFUTXDevice.py:1811); per focus max(apod) (the duty-cycle factor of :1358) and the number of delays that
+// do not fit `width` bits (set_register_value would raise, :1500-1501).  F blocks x 256 threads.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BF_THREADS) void bf_quantize_k(const double* __restrict__ delays, const double* __restrict__ apod,
+                                                             int n, double bf_clk, unsigned max_ticks,
+                                                             unsigned short* __restrict__ ticks, unsigned char* __restrict__ apod_off,
+                                                             double* __restrict__ max_apod, int* __restrict__ n_overflow) {
+    __shared__ double s_red[BF_THREADS / 64];
+    __shared__ int s_ovf[BF_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    double amax = -1.0e300;
+    int ovf = 0;
+    for (int e = tid; e < n; e += BF_THREADS) {
+        const size_t o = (size_t)f * n + e;
+        const double prod = delays[o] * 1.0 * bf_clk;
+        const long long t = (long long)prod;                 // int(): toward zero
+        if (t < 0 || t > (long long)max_ticks) ++ovf;
+        ticks[o] = (unsigned short)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
+        const double a = apod[o];
+        apod_off[o] = (unsigned char)(int)(1.0 - a);
+        amax = fmax(amax, a);
+    }
+    amax = wave_max(amax);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ovf += __shfl_xor(ovf, off, 64);
+    if ((tid & 63) == 0) { s_red[tid >> 6] = amax; s_ovf[tid >> 6] = ovf; }
+    __syncthreads();
+    if (tid == 0) {
+        double m = s_red[0]; int v = s_ovf[0];
+#pragma unroll
+        for (int w = 1; w < BF_THREADS / 64; ++w) { m = fmax(m, s_red[w]); v += s_ovf[w]; }
+        max_apod[f] = m;
+        n_overflow[f] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // steering pack: fp64 (pos, area, delays, apod) -> the fp32 table kernel 2 streams through
 // the scalar cache.  Entry (f, e) = 8 floats (32 B, one s_load_dwordx8):
 //   { (x_e - ox)/lambda, (y_e - oy)/lambda, (z_e - oz)/lambda, w_ef, phi_ef, 0, 0, 0 }

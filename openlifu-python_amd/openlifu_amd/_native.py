@@ -24,7 +24,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/olx.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
-    "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_field_plan",
+    "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_bf_quantize", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
@@ -67,6 +67,7 @@ def load(require_gpu: bool = True):
         lib.olx_set_elements.argtypes = [vp, dp, dp, dp, c_int]
         lib.olx_bf_solve.argtypes = [vp, dp, c_int, dp, c_double, c_int, c_double, c_double, dp, dp]
         lib.olx_set_steering.argtypes = [vp, dp, dp, c_int]
+        lib.olx_bf_quantize.argtypes = [vp, c_double, c_int, c_void_p, c_void_p, dp, c_void_p]
         lib.olx_field_plan.argtypes = [vp, POINTER(OlxGrid), POINTER(OlxSlab), c_int, c_double, c_double,
                                        c_double, c_double, c_uint]
         lib.olx_field_launch.argtypes = [vp]
@@ -196,6 +197,16 @@ class Context:
         F = delays_s.shape[0]
         self._chk(self._lib.olx_set_steering(self._h, _dptr(delays_s), _dptr(apod), F))
         self.n_foci = F
+
+    def bf_quantize(self, bf_clk_hz=10e6, width_bits=13):
+        """Hand-off numbers of the resident steering table (include/olx.h olx_bf_quantize): returns
+        (ticks uint16 [F,N], apod_off uint8 [F,N], max_apod float64 [F], n_overflow int32 [F])."""
+        F, N = self.n_foci, self.n_el
+        ticks = np.empty((F, N), dtype=np.uint16); aoff = np.empty((F, N), dtype=np.uint8)
+        amax = np.empty(F, dtype=np.float64); ovf = np.empty(F, dtype=np.int32)
+        self._chk(self._lib.olx_bf_quantize(self._h, float(bf_clk_hz), int(width_bits), ticks.ctypes.data, aoff.ctypes.data,
+                                            _dptr(amax), ovf.ctypes.data))
+        return ticks, aoff, amax, ovf
 
     # -- kernel 2
     def field_plan(self, origin_m, spacing_m, n, freq, c, rho, p0_pa=1.0, flags=OUT_PMAG | OUT_INTENSITY,

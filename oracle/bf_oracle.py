@@ -244,3 +244,13 @@ def sim_coords(extents, spacing):
 def delay_ticks(delays_s, clk_hz=10e6) -> np.ndarray:
     """``int(delay * bf_clk)`` truncation (io/LIFUTXDevice.py:1874)."""
     return np.array([int(d * clk_hz) for d in np.asarray(delays_s).ravel()]).reshape(np.shape(delays_s))
+
+
+def tx_quantize(delays_s, apod, bf_clk=10e6, width=13):
+    """Hardware hand-off numbers (io/LIFUTXDevice.py:1874 `int(delay * unitconv * bf_clk)`, :1811 `1 - apod`,
+    :1358 `max(apodizations)`): returns (ticks int64, apod_off int64, max_apod, n_overflow)."""
+    d = np.atleast_2d(np.asarray(delays_s, dtype=np.float64)); a = np.atleast_2d(np.asarray(apod, dtype=np.float64))
+    ticks = np.trunc(d * 1.0 * bf_clk).astype(np.int64)
+    aoff = np.trunc(1.0 - a).astype(np.int64)
+    ovf = ((ticks < 0) | (ticks > (1 << width) - 1)).sum(axis=1)
+    return ticks, aoff, a.max(axis=1), ovf

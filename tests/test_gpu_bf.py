@@ -112,3 +112,37 @@ def test_edge_cases(ctx):
     with pytest.raises(nat.NativeError, match="olx_set_elements first"):
         fresh.bf_solve(foci, 1500.0)
     fresh.close()
+
+
+def test_tx_handoff_quantisation_on_device(ctx, golden):
+    """olx_bf_quantize vs the registers packed by the reference (G10, bit-exact) and vs the oracle on a 64-focus
+    table; overflow of the 13-bit delay field is reported like set_register_value's ValueError."""
+    import openlifu_amd as ol
+    from openlifu_amd.io import tx_profiles
+    g = golden.json("g10_tx_handoff.json")
+    ctx.set_elements(np.zeros((32, 3)), np.tile([0, 0, 1.0], (32, 1)), np.ones(32))
+    for case in g["cases"]:
+        ctx.set_steering(np.array([case["delays"]]), np.array([case["apod"]]))
+        ticks, aoff, amax, ovf = ctx.bf_quantize(g["bf_clk"], 13)
+        assert ticks.dtype == np.uint16 and ticks[0].tolist() == case["ticks"], case["label"]
+        assert aoff[0].tolist() == case["apod_off"] and amax[0] == max(case["apod"]) and ovf[0] == 0
+    rng = np.random.default_rng(147)
+    d = rng.uniform(0, 819.1e-6, (64, 32)); a = rng.uniform(0, 1, (64, 32))
+    d[5, 7] = 8192 / 10e6
+    ctx.set_steering(d, a)
+    got = ctx.bf_quantize(10e6, 13)
+    ref = bo.tx_quantize(d, a)
+    ok = np.ones_like(d, dtype=bool); ok[5, 7] = False
+    assert np.array_equal(got[0][ok], ref[0][ok]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert got[3].tolist() == ref[3].tolist() and got[3][5] == 1
+    # host entry point on a Solution
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=4, pitch=4, kerf=0.4, units="mm")
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, amplitude=0.5, duration=2e-5), sequence=ol.Sequence(pulse_count=2, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=1, spoke_radius=3.0))
+    sol, _, _ = proto.calc_solution(ol.Point(position=(0, 0, 30), units="mm"), arr, simulate=False, scale=False)
+    prof = tx_profiles(sol)
+    assert len(prof) == 2 and prof[1].profile == 2 and prof[0].cycles == 8 and prof[0].duty_cycle == 0.66 * 1.0 * 0.5
+    assert np.array_equal(prof[0].delay_ticks, np.trunc(sol.delays[0] * 10e6).astype(np.uint16)) and not prof[0].apod_off.any()
+    sol.delays[1, 3] = 1e-3
+    with pytest.raises(ValueError, match="does not fit in 13 bits"):
+        tx_profiles(sol)

@@ -99,3 +99,15 @@ def test_g8_sim_grid(golden):
 
 def test_delay_ticks_truncate():
     assert list(bo.delay_ticks([0.0, 1.49e-7, 9.99e-8, 2.5e-6])) == [0, 1, 0, 25]
+
+
+def test_tx_handoff_quantisation_matches_reference_registers(golden):
+    """G10: delay counts and apodization bits read back from the registers the reference's Tx7332Registers packs."""
+    g = golden.json("g10_tx_handoff.json")
+    assert g["overflow_error"] == "ValueError"
+    for case in g["cases"]:
+        ticks, aoff, amax, ovf = bo.tx_quantize(case["delays"], case["apod"], g["bf_clk"])
+        assert ticks[0].tolist() == case["ticks"], case["label"]
+        assert aoff[0].tolist() == case["apod_off"], case["label"]
+        assert ovf[0] == 0 and amax[0] == max(case["apod"])
+    assert bo.tx_quantize(np.full(32, 8192 / 10e6), np.ones(32))[3][0] == 32

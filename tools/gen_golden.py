@@ -278,6 +278,41 @@ def main():
             g9["errors"].append([label, type(e).__name__])
     json.dump(g9, open(os.path.join(OUT, "g9_misc.json"), "w"))
 
+    # ---- G10: hardware hand-off numbers from the reference's TX7332 register code (io/LIFUTXDevice.py) --------
+    for m in ("serial", "serial.tools", "serial.tools.list_ports", "crcmod", "crcmod.predefined"):
+        sys.modules.setdefault(m, MagicMock())
+    iopkg = types.ModuleType("openlifu.io")
+    iopkg.__path__ = [os.path.join(REF, "src", "openlifu", "io")]
+    sys.modules["openlifu.io"] = iopkg
+    from openlifu.io.LIFUTXDevice import (APODIZATION_CHANNEL_ORDER_REVERSED, ADDRESS_APODIZATION, DELAY_WIDTH,
+                                          Tx7332DelayProfile, Tx7332Registers, get_delay_location, get_register_value)
+    g10 = {"bf_clk": 10e6, "cases": []}
+    exact = np.arange(32) * 1e-7                         # multiples of the clock period: int(0.3e-6 * 1e7) == 2
+    cases10 = [("clock_multiples", exact, np.ones(32)),
+               ("random", rng.uniform(0, 8191 / 10e6, 32), (rng.uniform(size=32) > 0.3).astype(float)),
+               ("example_solution", np.array(g1["delays"][:32]), np.ones(32)),
+               ("example_solution_hi", np.array(g1["delays"][32:]), np.ones(32)),
+               ("full_scale", np.linspace(0, 819.1e-6, 32), np.zeros(32))]
+    for label, dl, ap in cases10:
+        regs = Tx7332Registers(bf_clk=10e6)
+        regs.add_delay_profile(Tx7332DelayProfile(profile=1, delays=dl, apodizations=[int(a) for a in ap]))
+        data = regs.get_delay_data_registers(1)
+        ticks = []
+        for ch in range(1, 33):
+            addr, lsb = get_delay_location(ch, 1)
+            ticks.append(get_register_value(data[addr], lsb=lsb, width=DELAY_WIDTH))
+        apreg = regs.get_delay_control_registers(1)[ADDRESS_APODIZATION]
+        aoff = [get_register_value(apreg, lsb=APODIZATION_CHANNEL_ORDER_REVERSED.index(ch), width=1) for ch in range(1, 33)]
+        g10["cases"].append({"label": label, "delays": dl.tolist(), "apod": ap.tolist(), "ticks": ticks, "apod_off": aoff})
+    try:
+        regs = Tx7332Registers(bf_clk=10e6)
+        regs.add_delay_profile(Tx7332DelayProfile(profile=1, delays=np.full(32, 8192 / 10e6), apodizations=[1] * 32))
+        regs.get_delay_data_registers(1)
+        g10["overflow_error"] = "none"
+    except Exception as e:  # noqa: BLE001
+        g10["overflow_error"] = type(e).__name__
+    json.dump(g10, open(os.path.join(OUT, "g10_tx_handoff.json"), "w"))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
