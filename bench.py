@@ -106,8 +106,11 @@ def cpu_baseline_c(arr, setup, foci, budget_s: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
+                    help="before the W warm-up steps, keep the GPU busy this long so that DVFS has left the idle clock "
+                         "(the first ~20 launches after idle run 15-20 %% slower, tools/launch_series.py); 0 disables")
     ap.add_argument("--foci-per-gpu", type=int, default=8)
     ap.add_argument("--reassemble", choices=["aggregate", "allgather", "none"], default="aggregate")
     ap.add_argument("--grid", type=int, default=256)
@@ -188,6 +191,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.clock_ramp_ms > 0:  # not steps: the same launches, discarded, until the shader clock has ramped up
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
+            ctx.field_launch()
+            ctx.sync()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -259,7 +267,7 @@ def main():
                                    f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
                                    f"(BASELINE configs[2] shard), |p|+intensity out",
                        "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": 400e3,
-                       "medium": args.medium,
+                       "medium": args.medium, "clock_ramp_ms": args.clock_ramp_ms,
                        "kernel": ctx.field_variant(),
                        "reassembly": (f"rccl-{args.reassemble}-overlapped" if gather else
                                       ("none" if (world == 1 or args.reassemble == "none") else "skipped")),
