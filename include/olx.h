@@ -191,6 +191,15 @@ int olx_field_masked_moments(olx_ctx *ctx, const double *A, const double *aspect
  * (plan/solution_analysis.py:444-574). */
 int olx_field_sample(olx_ctx *ctx, int which, int focus, const double *pts_m, int npts, float *out);
 
+/* Offset grid of ANY coordinate grid (get_gridded_transformed_coords / get_offset_grid / calc_dist_from_focus,
+ * plan/solution_analysis.py:344-403): the grid is given by its three axis vectors xs[nx], ys[ny], zs[nz] (the
+ * DataArray coords, any units); A[12] = first three rows of inv(get_focus_matrix(focus, origin)), row-major.
+ * coords_out[nx*ny*nz*3] (C order, last axis = d_x, d_y, d_z) and / or dist_out[nx*ny*nz] =
+ * sqrt(sum_a (coords_a / aspect[a])^2) (aspect NULL = [1,1,1]); fp64, same operation order as the reference's
+ * np.dot rows.  Needs no element table or plan. */
+int olx_offset_grid(olx_ctx *ctx, const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                    const double *A, const double *aspect, double *coords_out, double *dist_out);
+
 /* out[v] = sum_f weights[f] * intensity_f[v] kept on the device as the "time-average" volume
  * (Solution.get_ita, plan/solution.py:365-388); olx_field_masked_peak(which = 2) then scans THAT single
  * volume with every focus' mask. */

@@ -1182,6 +1182,35 @@ int olx_field_sample(olx_ctx* c, int which, int focus, const double* pts_m, int 
     return OLX_OK;
 }
 
+int olx_offset_grid(olx_ctx* c, const double* xs, int nx, const double* ys, int ny, const double* zs, int nz, const double* A,
+                    const double* aspect, double* coords_out, double* dist_out) {
+    if (!c) return OLX_EINVAL;
+    if (!xs || !ys || !zs || !A || nx < 1 || ny < 1 || nz < 1) return fail(c, OLX_EINVAL, "olx_offset_grid: null axis / matrix or empty grid");
+    if (!coords_out && !dist_out) return fail(c, OLX_EINVAL, "olx_offset_grid: no output requested");
+    if (dist_out && aspect) for (int a = 0; a < 3; ++a) if (!(aspect[a] != 0.0)) return fail(c, OLX_EINVAL, "olx_offset_grid: zero aspect ratio");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t vox = (size_t)nx * ny * nz;
+    double *d_ax = nullptr, *d_c = nullptr, *d_d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_ax, sizeof(double) * ((size_t)nx + ny + nz + 12)));
+    if (coords_out && hipMalloc((void**)&d_c, sizeof(double) * 3 * vox) != hipSuccess) { hipFree(d_ax); return fail(c, OLX_ENOMEM, "olx_offset_grid: out of device memory"); }
+    if (dist_out && hipMalloc((void**)&d_d, sizeof(double) * vox) != hipSuccess) { hipFree(d_ax); if (d_c) hipFree(d_c); return fail(c, OLX_ENOMEM, "olx_offset_grid: out of device memory"); }
+    hipMemcpyAsync(d_ax, xs, sizeof(double) * nx, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_ax + nx, ys, sizeof(double) * ny, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_ax + nx + ny, zs, sizeof(double) * nz, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_ax + nx + ny + nz, A, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream);
+    const unsigned blocks = (unsigned)std::min<size_t>((vox + 255) / 256, 4096);
+    hipLaunchKernelGGL(offset_grid_k, dim3(blocks), dim3(256), 0, c->stream, d_ax, d_ax + nx, d_ax + nx + ny, nx, ny, nz,
+                       d_ax + nx + ny + nz, aspect ? 1.0 / aspect[0] : 1.0, aspect ? 1.0 / aspect[1] : 1.0, aspect ? 1.0 / aspect[2] : 1.0,
+                       d_c, d_d);
+    int rc = hipGetLastError() == hipSuccess ? OLX_OK : OLX_EHIP;
+    if (!rc && coords_out && hipMemcpyAsync(coords_out, d_c, sizeof(double) * 3 * vox, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (!rc && dist_out && hipMemcpyAsync(dist_out, d_d, sizeof(double) * vox, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = OLX_EHIP;
+    hipFree(d_ax); if (d_c) hipFree(d_c); if (d_d) hipFree(d_d);
+    if (rc) return fail(c, OLX_EHIP, "olx_offset_grid: HIP error");
+    return OLX_OK;
+}
+
 int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) {
     if (!c) return OLX_EINVAL;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_weighted_intensity: nothing planned");

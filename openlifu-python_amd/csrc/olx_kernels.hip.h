@@ -1316,6 +1316,38 @@ __global__ void field_sample_k(const float* __restrict__ vol, const double* __re
     out[i] = (float)acc;
 }
 
+// ------------------------------------------------------------------------------------
+// offset grid (get_gridded_transformed_coords / get_offset_grid / calc_dist_from_focus,
+// plan/solution_analysis.py:344-403): per voxel q = A . [x, y, z, 1] in fp64 (A = first three rows of
+// inv(get_focus_matrix)), optionally dist = sqrt(sum (q_a / aspect_a)^2).  Pure HBM write stream: 24 (+8) bytes
+// per voxel, coordinates come from the three axis vectors (a few KB, cache resident).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void offset_grid_k(const double* __restrict__ xs, const double* __restrict__ ys,
+                                                      const double* __restrict__ zs, int nx, int ny, int nz,
+                                                      const double* __restrict__ A, double ia0, double ia1, double ia2,
+                                                      double* __restrict__ coords, double* __restrict__ dist) {
+    __shared__ double sA[12];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[threadIdx.x];
+    __syncthreads();
+    const long long vox = (long long)nx * ny * nz, nyz = (long long)ny * nz;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / nz, iz = rem - iy * nz;
+        const double x = xs[ix], y = ys[iy], z = zs[iz];
+        // same association as the reference's np.dot row: ((a0 x + a1 y) + a2 z) + a3, no fused contraction
+        const double q0 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[0], x), __dmul_rn(sA[1], y)), __dmul_rn(sA[2], z)), sA[3]);
+        const double q1 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[4], x), __dmul_rn(sA[5], y)), __dmul_rn(sA[6], z)), sA[7]);
+        const double q2 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[8], x), __dmul_rn(sA[9], y)), __dmul_rn(sA[10], z)), sA[11]);
+        if (coords) { coords[3 * i] = q0; coords[3 * i + 1] = q1; coords[3 * i + 2] = q2; }
+        if (dist) {
+            const double d0 = q0 * ia0, d1 = q1 * ia1, d2 = q2 * ia2;
+            dist[i] = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        }
+    }
+}
+
 // weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
 __global__ void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
                                      long long vox, float* __restrict__ out) {

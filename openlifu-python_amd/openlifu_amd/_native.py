@@ -26,7 +26,7 @@ SYMBOLS = [
     "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_bf_quantize", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
-    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample",
+    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
     "olx_aggregate_fetch",
@@ -85,6 +85,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_masked_moments.argtypes = [vp, dp, dp, c_double, fp, dp]
         lib.olx_field_sample.argtypes = [vp, c_int, c_int, dp, c_int, fp]
         lib.olx_field_weighted_intensity.argtypes = [vp, dp, c_int]
+        lib.olx_offset_grid.argtypes = [vp, dp, c_int, dp, c_int, dp, c_int, dp, dp, dp, dp]
         lib.olx_comm_unique_id.argtypes = [vp, vp]
         lib.olx_comm_init.argtypes = [vp, vp, c_int, c_int]
         lib.olx_comm_destroy.argtypes = [vp]
@@ -207,6 +208,18 @@ class Context:
         self._chk(self._lib.olx_bf_quantize(self._h, float(bf_clk_hz), int(width_bits), ticks.ctypes.data, aoff.ctypes.data,
                                             _dptr(amax), ovf.ctypes.data))
         return ticks, aoff, amax, ovf
+
+    def offset_grid(self, xs, ys, zs, A, aspect=None, want=("coords",)):
+        """olx_offset_grid: focal-frame coordinates [nx,ny,nz,3] and / or the aspect-scaled distance [nx,ny,nz] (fp64)."""
+        xs, ys, zs = _f64(np.ravel(xs)), _f64(np.ravel(ys)), _f64(np.ravel(zs))
+        A = _f64(np.ravel(A), (12,))
+        asp = None if aspect is None else _f64(np.ravel(aspect), (3,))
+        shape = (len(xs), len(ys), len(zs))
+        coords = np.empty(shape + (3,), dtype=np.float64) if "coords" in want else None
+        dist = np.empty(shape, dtype=np.float64) if "dist" in want else None
+        self._chk(self._lib.olx_offset_grid(self._h, _dptr(xs), len(xs), _dptr(ys), len(ys), _dptr(zs), len(zs), _dptr(A),
+                                            _dptr(asp), _dptr(coords), _dptr(dist)))
+        return coords, dist
 
     # -- kernel 2
     def field_plan(self, origin_m, spacing_m, n, freq, c, rho, p0_pa=1.0, flags=OUT_PMAG | OUT_INTENSITY,

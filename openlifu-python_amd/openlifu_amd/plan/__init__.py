@@ -12,7 +12,12 @@ Solution = _solution.Solution
 SolutionAnalysis = _analysis.SolutionAnalysis
 SolutionAnalysisOptions = _analysis.SolutionAnalysisOptions
 get_focus_matrix = _analysis.get_focus_matrix
+get_offset_grid = _analysis.get_offset_grid
+get_gridded_transformed_coords = _analysis.get_gridded_transformed_coords
+calc_dist_from_focus = _analysis.calc_dist_from_focus
+get_mask = _analysis.get_mask
 TargetConstraints = _constraints.TargetConstraints
 
 __all__ = ("Protocol", "Solution", "SolutionAnalysis", "SolutionAnalysisOptions", "TargetConstraints",
-           "OnPulseMismatchAction", "get_focus_matrix")
+           "OnPulseMismatchAction", "get_focus_matrix", "get_offset_grid", "get_gridded_transformed_coords",
+           "calc_dist_from_focus", "get_mask")

@@ -113,3 +113,49 @@ def beam_bounds_from_samples(offsets: np.ndarray, values: np.ndarray, cutoff: fl
     neg = offsets[(offsets <= 0) & below]
     pos = offsets[(offsets >= 0) & below]
     return (float(neg[-1]) if neg.size else np.nan), (float(pos[0]) if pos.size else np.nan)
+
+
+# ---- standalone focal-frame grids (plan/solution_analysis.py:344-442), evaluated on the device ----------------
+def _grid_axes(da):
+    dims = tuple(da.dims)
+    return dims, [np.asarray(da.coords[d].data if hasattr(da.coords[d], "data") else da.coords[d], dtype=np.float64) for d in dims]
+
+
+def get_gridded_transformed_coords(da, matrix: np.ndarray, as_dataset: bool = True, engine=None):
+    """Coordinates of ``da``'s grid in the frame whose transform TO ``da``'s frame is ``matrix``
+    (plan/solution_analysis.py:344-363): array [..., 3] or a Dataset of ``d_<dim>`` arrays on ``da.coords``."""
+    from .. import get_engine
+    from ..util.dataset import make_dataarray, make_dataset
+    dims, axes = _grid_axes(da)
+    if len(dims) != 3:
+        raise ValueError("get_gridded_transformed_coords expects a 3-D DataArray")
+    A = np.linalg.inv(np.asarray(matrix, dtype=np.float64))[:3]
+    coords, _ = (engine or get_engine()).ctx.offset_grid(*axes, A, want=("coords",))
+    if not as_dataset:
+        return coords
+    return make_dataset({f"d_{d}": make_dataarray(coords[..., i], da.coords, dims=dims) for i, d in enumerate(dims)})
+
+
+def get_offset_grid(da, focus, origin=DEFAULT_ORIGIN, as_dataset: bool = True, engine=None):
+    """Grid of ``da`` in focus coordinates (plan/solution_analysis.py:365-382)."""
+    return get_gridded_transformed_coords(da, get_focus_matrix(focus, origin=origin), as_dataset=as_dataset, engine=engine)
+
+
+def calc_dist_from_focus(da, focus, origin=DEFAULT_ORIGIN, aspect_ratio=(1, 1, 1), as_dataarray: bool = True, engine=None):
+    """Distance from the focus under the aspect-scaled focal metric (plan/solution_analysis.py:384-403)."""
+    from .. import get_engine
+    from ..util.dataset import make_dataarray
+    dims, axes = _grid_axes(da)
+    A = np.linalg.inv(get_focus_matrix(focus, origin=origin))[:3]
+    _, dist = (engine or get_engine()).ctx.offset_grid(*axes, A, aspect=np.asarray(aspect_ratio, dtype=np.float64), want=("dist",))
+    return make_dataarray(dist, da.coords, dims=dims) if as_dataarray else dist
+
+
+def get_mask(da, focus, distance: float, origin=DEFAULT_ORIGIN, aspect_ratio=(1, 1, 1), operator: str = "<", engine=None):
+    """Boolean mask of the focal ellipsoid (plan/solution_analysis.py:405-442)."""
+    from ..util.dataset import make_dataarray
+    if operator not in ("<", "<=", ">", ">="):
+        raise ValueError("Operator must be '<', '>', '<=', or '>='.")
+    dist = calc_dist_from_focus(da, focus, origin=origin, aspect_ratio=aspect_ratio, as_dataarray=False, engine=engine)
+    mask = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}[operator](dist, distance)
+    return make_dataarray(mask, da.coords, dims=tuple(da.dims))
