@@ -130,6 +130,23 @@ class Solution:
         ita_main = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "weighted_intensity")
         ita_glob = ctx.field_masked_peak(None, aspect, 0.0, None, "weighted_intensity", zmin_m=zmin)
         sizes = ctx._shape
+        # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
+        # drive signal is created once and handed to calc_output for every focus (which scales it in place by the
+        # transducer sensitivity, xdc/transducer.py:100-106).
+        dt = 1 / (self.pulse.frequency * 20)
+        input_signal_V = self.pulse.calc_pulse(self.pulse.calc_time(dt)) * self.voltage
+        standoff_Z = options.standoff_density * 1500
+        c_tic = 40e-3  # W cm-1
+        d_eq_cm = np.sqrt(4 * self.transducer.get_area("cm") / np.pi)
+        ele_sizes_cm2 = np.array([el.get_area("cm") for el in self.transducer.elements])
+        power_W = np.zeros(self.num_foci()); tic = np.zeros(self.num_foci())
+        for i in range(self.num_foci()):
+            p0_Pa = np.max(self.transducer.calc_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :]), axis=1)
+            i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()
+            power_W[i] = np.mean(np.sum(i0ta_Wcm2 * ele_sizes_cm2 * self.apodizations[i, :]))
+            tic[i] = power_W[i] / (d_eq_cm * c_tic)
+            an.p0_MPa.append(float(1e-6 * np.max(p0_Pa)))
+        an.TIC = float(np.mean(tic)); an.power_W = float(np.mean(power_W))
         for i in range(self.num_foci()):
             mp, mi, sp, si = float(main_p[i]) * 1e-6, float(main_i[i]), float(side_p[i]) * 1e-6, float(side_i[i])
             an.mainlobe_pnp_MPa.append(mp); an.mainlobe_isppa_Wcm2.append(mi)

@@ -7,7 +7,8 @@ output ``compute_scaling_factors`` consumes (plan/solution.py:301-303) -- sidelo
 the -3 dB centroid (``field_masked_moments_k``, find_centroid :306-317), beam widths from trilinear
 line samples along the focal axes (``field_sample_k``; interp_transformed_axis / get_beam_bounds /
 get_beamwidth :444-574) and the time-average intensity peaks (``field_weighted_sum_k``, get_ita).
-Not built: p0 / power / TIC (drive-signal bookkeeping, outside the path).
+Emitted pressure / power / TIC (plan/solution.py:152-154, 191-193, 268-276) are a few scalars per focus from the
+drive signal; they are host arithmetic on `Transducer.calc_output`, like the reference.
 """
 from __future__ import annotations
 
@@ -98,7 +99,10 @@ class SolutionAnalysis(DictMixin):
     global_isppa_Wcm2: list = field(default_factory=list)
     global_ispta_mWcm2: float | None = None
     MI: float | None = None
+    TIC: float | None = None
     voltage_V: float | None = None
+    p0_MPa: list = field(default_factory=list)
+    power_W: float | None = None
     duty_cycle_pulse_train_pct: float | None = None
     duty_cycle_sequence_pct: float | None = None
     sequence_duration_s: float | None = None

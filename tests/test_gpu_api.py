@@ -164,6 +164,16 @@ def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
                 assert (np.isnan(ref) and np.isnan(got_bw)) or abs(got_bw - ref) <= 1e-6 + 2 * (off[1] - off[0]) * 1e3 * 0, (named, db, got_bw, ref)
     # physical plausibility: lateral -6 dB width of a 48 mm aperture at 40 mm, lambda 3.75 mm ~ 1.0-1.4 lambda F#
     assert 2.0 < an.beamwidth_lat_6dB_mm[0] < 6.0
+    # emitted pressure / power / TIC (plan/solution.py:152-154, 191-193, 268-276): the drive signal peaks at
+    # amplitude * voltage (a quarter period is sampled exactly at dt = 1/(20 f)) and calc_output scales the SHARED signal by the
+    # sensitivity once per focus (xdc/transducer.py:100-106), so focus i sees sensitivity^(i+1) -- reproduced, not "fixed"
+    area_cm2 = np.array([el.get_area("cm") for el in arr.elements])
+    seq_dc = sol.get_sequence_dutycycle()
+    p0 = [sol.voltage * 1.0 * 1e5 ** (i + 1) for i in range(3)]
+    assert np.allclose(an.p0_MPa, [1e-6 * v for v in p0], rtol=1e-12)
+    pw = [np.sum((v ** 2 / (2 * 1000.0 * 1500)) * 1e-4 * seq_dc * area_cm2 * sol.apodizations[i]) for i, v in enumerate(p0)]
+    assert np.isclose(an.power_W, np.mean(pw), rtol=1e-12)
+    assert np.isclose(an.TIC, np.mean(pw) / (np.sqrt(4 * area_cm2.sum() / np.pi) * 40e-3), rtol=1e-12)
 
 
 def test_run_simulation_with_segmented_medium():
