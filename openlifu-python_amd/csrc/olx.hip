@@ -401,7 +401,7 @@ static int configure_variant(olx_ctx* c) {
         // Wheel: each other's images) is a store TARGET of that column, so it is accumulated once.  Foci are packed
         // greedily into launch tiles of at most 32 columns (NT = 4 MFMA column tiles share each geometry fragment).
         const double rev = c->freq / c->c, lambda = c->c / c->freq;
-        const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16, n_img = c->mx * c->my;
+        const int n_img = c->mx * c->my;
         constexpr int MAXC = MFMA_COLS * MFMA_MAX_NT;
         std::vector<int> perm((size_t)4 * n);
         for (int m = 0; m < 4; ++m)
@@ -442,6 +442,11 @@ static int configure_variant(olx_ctx* c) {
         }
         c->nt = 1;
         for (auto& t : tiles) { total_cols += (int)t.size(); while (c->nt * MFMA_COLS < (int)t.size()) c->nt *= 2; }
+        // kernel 2d saves table arithmetic but pays ~27 % padded MFMA rows on BASELINE's grids; with 4 column tiles per
+        // geometry fragment the MFMAs dominate and kernel 2c's exact z-run tiling wins (measured, steady state, 64-focus
+        // sweep: 4.6 vs 4.9 ms; 8-focus shard: 0.74 vs 0.58 ms) -- unless the family is pinned for A/B runs
+        if (c->use_lattice && c->nt >= 4 && c->force_kind != 4) c->use_lattice = false;
+        const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();
         std::vector<int> colinfo((size_t)ntiles * MAXC * 2, -1), targets((size_t)ntiles * MAXC * 4, -1);
         for (int t = 0; t < ntiles; ++t)
