@@ -1359,9 +1359,13 @@ int olx_field_allreduce_aggregate(olx_ctx* c) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red, 0));
         c->reduce_pending = false;
     }
-    hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], with_i ? c->d_inten : nullptr,
-                       c->plan_foci, (long long)vox, 1.0f / ((float)c->plan_foci * (float)c->nranks), c->d_agg_p,
-                       with_i ? c->d_agg_i : nullptr);
+    const float inv_n = 1.0f / ((float)c->plan_foci * (float)c->nranks);
+    if (!c->uploaded && (vox & 3) == 0)   // launched result: intensity == scale(v) |p|^2, aggregate from |p| alone (half the reads)
+        hipLaunchKernelGGL(field_aggregate_p_k, dim3(4096), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->plan_foci, (long long)vox,
+                           inv_n, c->fp.inten_scale, c->hetero ? c->d_inv2z : nullptr, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
+    else
+        hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], with_i ? c->d_inten : nullptr,
+                           c->plan_foci, (long long)vox, inv_n, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));

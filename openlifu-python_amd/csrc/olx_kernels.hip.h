@@ -1168,6 +1168,35 @@ __global__ void field_aggregate_k(const float* __restrict__ pmag, const float* _
     }
 }
 
+// Same aggregate from the |p| volumes alone: the intensity of a launched (not uploaded) result is scale(v) |p|^2 by
+// construction (kwave_if.py:140-141), so the mean intensity is scale(v) mean_f |p_f|^2 and the intensity volumes
+// need not be read back -- half the HBM traffic of field_aggregate_k (4 B per voxel and focus, float4 per lane).
+__global__ __launch_bounds__(256) void field_aggregate_p_k(const float* __restrict__ pmag, int n_foci, long long vox, float inv,
+                                                            float inten_scale, const float* __restrict__ inv2z,
+                                                            float* __restrict__ pmax, float* __restrict__ imean) {
+    const long long stride = (long long)gridDim.x * blockDim.x, v4 = vox >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = m;
+        for (int f = 0; f < n_foci; ++f) {
+            const float4 p = reinterpret_cast<const float4*>(pmag + (long long)f * vox)[q];
+            m.x = fmaxf(m.x, p.x); m.y = fmaxf(m.y, p.y); m.z = fmaxf(m.z, p.z); m.w = fmaxf(m.w, p.w);
+            s.x = fmaf(p.x, p.x, s.x); s.y = fmaf(p.y, p.y, s.y); s.z = fmaf(p.z, p.z, s.z); s.w = fmaf(p.w, p.w, s.w);
+        }
+        reinterpret_cast<float4*>(pmax)[q] = m;
+        if (imean) {
+            float4 k = make_float4(inten_scale, inten_scale, inten_scale, inten_scale);
+            if (inv2z) k = reinterpret_cast<const float4*>(inv2z)[q];
+            reinterpret_cast<float4*>(imean)[q] = make_float4(s.x * k.x * inv, s.y * k.y * inv, s.z * k.z * inv, s.w * k.w * inv);
+        }
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {   // tail
+        float m = 0.f, s = 0.f;
+        for (int f = 0; f < n_foci; ++f) { const float p = pmag[(long long)f * vox + v]; m = fmaxf(m, p); s = fmaf(p, p, s); }
+        pmax[v] = m;
+        if (imean) imean[v] = s * (inv2z ? inv2z[v] : inten_scale) * inv;
+    }
+}
+
 __global__ void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
                               float* __restrict__ cplx, const float* __restrict__ scale,
                               long long vox) {

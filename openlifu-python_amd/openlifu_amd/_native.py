@@ -344,7 +344,17 @@ class Context:
         self._chk(self._lib.olx_field_weighted_intensity(self._h, _dptr(w), int(w.shape[0])))
 
     # -- multi-GPU
+    @staticmethod
+    def _single_node_rccl_env():
+        """The communicators of this package live inside one node (one process per GPU over xGMI): keep RCCL's
+        bootstrap on the loopback interface and away from InfiniBand probing, which can stall for minutes on hosts
+        without a routable network.  Respects values the user already set; OLX_RCCL_SINGLE_NODE=0 opts out."""
+        if os.environ.get("OLX_RCCL_SINGLE_NODE", "1") != "0":
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
     def comm_unique_id(self) -> bytes:
+        self._single_node_rccl_env()
         buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
         self._chk(self._lib.olx_comm_unique_id(self._h, buf))
         return buf.raw
@@ -352,6 +362,7 @@ class Context:
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         if len(unique_id) != UNIQUE_ID_BYTES:
             raise ValueError("unique_id must be 128 bytes")
+        self._single_node_rccl_env()
         buf = ctypes.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
         self._chk(self._lib.olx_comm_init(self._h, buf, int(nranks), int(rank)))
         self.nranks = int(nranks)
