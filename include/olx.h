@@ -200,6 +200,13 @@ int olx_field_sample(olx_ctx *ctx, int which, int focus, const double *pts_m, in
 int olx_offset_grid(olx_ctx *ctx, const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
                     const double *A, const double *aspect, double *coords_out, double *dist_out);
 
+/* Time-of-flight spread over a grid (SimSetup.get_max_cycle_offset, sim/sim_setup.py:132-143): for every grid
+ * point (axis vectors in metres) tof_e = dist(point, element e) / c0 + delays_s[e] (NULL = zeros) over the resident
+ * element table; *max_dtof_s = max over points of (max_e tof - min_e tof), fp64.  The caller multiplies by the
+ * frequency and applies the zmin cut by passing the z axis it wants. */
+int olx_tof_spread(olx_ctx *ctx, const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                   const double *delays_s, double c0, double *max_dtof_s);
+
 /* out[v] = sum_f weights[f] * intensity_f[v] kept on the device as the "time-average" volume
  * (Solution.get_ita, plan/solution.py:365-388); olx_field_masked_peak(which = 2) then scans THAT single
  * volume with every focus' mask. */

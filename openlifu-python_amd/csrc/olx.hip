@@ -1216,6 +1216,36 @@ int olx_offset_grid(olx_ctx* c, const double* xs, int nx, const double* ys, int 
     return OLX_OK;
 }
 
+int olx_tof_spread(olx_ctx* c, const double* xs, int nx, const double* ys, int ny, const double* zs, int nz,
+                   const double* delays_s, double c0, double* max_dtof_s) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_el <= 0) return fail(c, OLX_ESTATE, "olx_tof_spread: call olx_set_elements first");
+    if (!xs || !ys || !zs || !max_dtof_s || nx < 1 || ny < 1 || nz < 1 || !(c0 > 0)) return fail(c, OLX_EINVAL, "olx_tof_spread: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->n_el;
+    double* d_buf = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_buf, sizeof(double) * ((size_t)nx + ny + nz + n + 1)));
+    double* d_del = d_buf + nx + ny + nz;
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(d_del + n);
+    hipMemcpyAsync(d_buf, xs, sizeof(double) * nx, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_buf + nx, ys, sizeof(double) * ny, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_buf + nx + ny, zs, sizeof(double) * nz, hipMemcpyHostToDevice, c->stream);
+    if (delays_s) hipMemcpyAsync(d_del, delays_s, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
+    hipMemsetAsync(d_out, 0, sizeof(unsigned long long), c->stream);
+    const size_t vox = (size_t)nx * ny * nz;
+    const unsigned blocks = (unsigned)std::min<size_t>((vox + 255) / 256, 8192);
+    hipLaunchKernelGGL(tof_spread_k, dim3(blocks), dim3(256), 0, c->stream, d_buf, d_buf + nx, d_buf + nx + ny, nx, ny, nz, c->d_pos,
+                       delays_s ? d_del : nullptr, n, c0, d_out);
+    int rc = hipGetLastError() == hipSuccess ? OLX_OK : OLX_EHIP;
+    unsigned long long bits = 0;
+    if (!rc && hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = OLX_EHIP;
+    hipFree(d_buf);
+    if (rc) return fail(c, OLX_EHIP, "olx_tof_spread: HIP error");
+    memcpy(max_dtof_s, &bits, sizeof bits);
+    return OLX_OK;
+}
+
 int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) {
     if (!c) return OLX_EINVAL;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_weighted_intensity: nothing planned");

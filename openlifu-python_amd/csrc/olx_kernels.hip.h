@@ -1377,6 +1377,43 @@ __global__ __launch_bounds__(256) void offset_grid_k(const double* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// time-of-flight spread (SimSetup.get_max_cycle_offset, sim/sim_setup.py:132-143): per voxel
+// tof_e = ||r_v - r_e|| / c0 + delay_e, dtof = max_e tof - min_e tof; result = max over voxels (fp64, the reference's
+// arithmetic).  Element positions / delays are wave-uniform scalar loads; block max via __shfl_xor, then one
+// atomicMax on the bit pattern (non-negative doubles order like their uint64 images).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tof_spread_k(const double* __restrict__ xs, const double* __restrict__ ys,
+                                                     const double* __restrict__ zs, int nx, int ny, int nz,
+                                                     const double* __restrict__ pos /*[3][N]*/, const double* __restrict__ delays,
+                                                     int n, double c0, unsigned long long* __restrict__ out) {
+    __shared__ double s_red[4];
+    const long long vox = (long long)nx * ny * nz, nyz = (long long)ny * nz;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    double best = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / nz, iz = rem - iy * nz;
+        const double x = xs[ix], y = ys[iy], z = zs[iz];
+        double tmax = -1.0e300, tmin = 1.0e300;
+        for (int e = 0; e < n; ++e) {
+            const double dx = x - pos[e], dy = y - pos[n + e], dz = z - pos[2 * n + e];
+            const double t = __dadd_rn(__ddiv_rn(sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz))), c0),
+                                       delays ? delays[e] : 0.0);
+            tmax = fmax(tmax, t); tmin = fmin(tmin, t);
+        }
+        best = fmax(best, tmax - tmin);
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        atomicMax(out, (unsigned long long)__double_as_longlong(best));
+    }
+}
+
 // weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
 __global__ void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
                                      long long vox, float* __restrict__ out) {

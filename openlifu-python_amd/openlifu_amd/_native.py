@@ -26,7 +26,7 @@ SYMBOLS = [
     "olx_abi_version", "olx_device_count", "olx_ctx_create", "olx_ctx_destroy", "olx_last_error",
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_bf_quantize", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
-    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid",
+    "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
     "olx_aggregate_fetch",
@@ -86,6 +86,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_sample.argtypes = [vp, c_int, c_int, dp, c_int, fp]
         lib.olx_field_weighted_intensity.argtypes = [vp, dp, c_int]
         lib.olx_offset_grid.argtypes = [vp, dp, c_int, dp, c_int, dp, c_int, dp, dp, dp, dp]
+        lib.olx_tof_spread.argtypes = [vp, dp, c_int, dp, c_int, dp, c_int, dp, c_double, dp]
         lib.olx_comm_unique_id.argtypes = [vp, vp]
         lib.olx_comm_init.argtypes = [vp, vp, c_int, c_int]
         lib.olx_comm_destroy.argtypes = [vp]
@@ -220,6 +221,15 @@ class Context:
         self._chk(self._lib.olx_offset_grid(self._h, _dptr(xs), len(xs), _dptr(ys), len(ys), _dptr(zs), len(zs), _dptr(A),
                                             _dptr(asp), _dptr(coords), _dptr(dist)))
         return coords, dist
+
+    def tof_spread(self, xs_m, ys_m, zs_m, delays_s=None, c0=1500.0) -> float:
+        """olx_tof_spread: max over grid points of (max_e tof - min_e tof) [s] for the resident element table."""
+        xs, ys, zs = _f64(np.ravel(xs_m)), _f64(np.ravel(ys_m)), _f64(np.ravel(zs_m))
+        d = None if delays_s is None else _f64(np.ravel(delays_s), (self.n_el,))
+        out = c_double(0.0)
+        self._chk(self._lib.olx_tof_spread(self._h, _dptr(xs), len(xs), _dptr(ys), len(ys), _dptr(zs), len(zs), _dptr(d),
+                                           float(c0), ctypes.byref(out)))
+        return float(out.value)
 
     # -- kernel 2
     def field_plan(self, origin_m, spacing_m, n, freq, c, rho, p0_pa=1.0, flags=OUT_PMAG | OUT_INTENSITY,

@@ -98,6 +98,20 @@ class SimSetup(DictMixin):
         return ds.make_coords({d: np.linspace(ext[i][0], ext[i][1], int(sizes[i])) for i, d in enumerate(dims)},
                               {d: {"units": units, "long_name": COORD_NAMES[COORD_DIMS.index(d)]} for d in dims})
 
+    def get_max_cycle_offset(self, arr, frequency: float | None = None, delays=None, zmin: float = 10e-3):
+        """Largest spread of element times of flight over the grid points with z >= zmin [m], in cycles
+        (sim/sim_setup.py:132-143); the V x N pair loop runs on the device (`tof_spread_k`, fp64)."""
+        from .. import get_engine
+        frequency = arr.frequency if frequency is None else frequency
+        coords = self.get_coords(units="m")
+        xs, ys, zs = (np.asarray(c.data, dtype=np.float64) for c in coords.values())
+        zs = zs[zs >= zmin]
+        if zs.size == 0:
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")  # np.max of an empty grid
+        eng = get_engine()
+        eng.bind(arr)
+        return eng.ctx.tof_spread(xs, ys, zs, delays, self.c0) * frequency
+
     def get_max_distance(self, arr, units: str | None = None):
         """Largest element-to-grid-corner distance (sim_setup.py:145-150), vectorised."""
         units = self.units if units is None else units

@@ -238,3 +238,23 @@ def test_offset_grid_matches_reference_literal_and_oracle(golden):
         assert m.data.dtype == bool and (m.data != want).sum() <= 2      # voxels within 1e-12 of the surface may flip
     with pytest.raises(ValueError, match="Operator must be"):
         get_mask(da, focus, 6.0, operator="==")
+
+
+def test_max_cycle_offset_matches_numpy_restatement():
+    """SimSetup.get_max_cycle_offset (sim/sim_setup.py:132-143) on the device vs the reference's own NumPy steps."""
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=6, pitch=4.0, kerf=0.4, units="mm")
+    arr.frequency = 400e3
+    setup = ol.SimSetup(spacing=2.0, x_extent=(-20, 20), y_extent=(-14, 14), z_extent=(-4, 60), c0=1480.0)
+    rng = np.random.default_rng(147)
+    delays = rng.uniform(0, 5e-6, arr.numelements())
+    xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
+    for dl, zmin in ((None, 10e-3), (delays, 10e-3), (delays, 31e-3)):
+        z = zs[zs >= zmin]
+        ndg = np.meshgrid(xs, ys, z)
+        d0 = np.zeros(arr.numelements()) if dl is None else dl
+        tof = np.array([np.sqrt((ndg[0] - p[0]) ** 2 + (ndg[1] - p[1]) ** 2 + (ndg[2] - p[2]) ** 2) / 1480.0 + d0[i]
+                        for i, p in enumerate(arr.get_positions(units="m"))])
+        ref = (tof.max(axis=0) - tof.min(axis=0)).max() * 400e3
+        got = setup.get_max_cycle_offset(arr, delays=dl, zmin=zmin)
+        assert np.isclose(got, ref, rtol=1e-13), (got, ref)
+    assert np.isclose(setup.get_max_cycle_offset(arr, frequency=1e6, delays=delays), ref / 400e3 * 1e6 * 0 + setup.get_max_cycle_offset(arr, delays=delays) * 2.5)
