@@ -429,3 +429,41 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
 def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
     """3.0 mm pitch on a 0.7 mm grid is not commensurate: kernel 2b / 2c take over, same results."""
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
+
+
+@pytest.mark.parametrize("n_foci,expect", [(8, "field_lattice_k"), (64, "field_mfma_k")])
+def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
+    """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and one GPU's 8-focus
+    shard in bench.py's mirror-orbit order): sampled-voxel parity per focus, the per-focus focal peak, and the
+    aggregate over foci (max |p|, mean intensity, plan/protocol.py:382-387) against the fetched volumes."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    sweep = bo.wheel_targets([0, 0, 40.0], True, 63, 5.0) * 1e-3
+    order = [0, 1] + [k for i in range(1, 32) for k in (1 + i, 1 + 63 - i)]
+    foci = sweep[order[:n_foci]]
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    xs, ys, zs = centred_grid(256, 0.25)
+    h = (xs[1] - xs[0],) * 3
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0)
+    assert expect in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    rng = np.random.default_rng(147)
+    idx = rng.integers(0, 256, (4000, 3))
+    pts = np.stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2]]], axis=1)
+    check_foci = range(n_foci) if n_foci <= 8 else (0, 1, 2, 17, 40, 63)
+    pmax = np.zeros(4000, dtype=np.float32); isum = np.zeros(4000)
+    for f in range(n_foci):
+        out = ctx.field_fetch(f) if f in check_foci else None
+        if out is None:
+            continue
+        ref = np.abs(co.field_at_points(pts, pos_m, area, d[f], a[f], F0, C, P0))
+        peak = np.abs(co.field_at_points([foci[f]], pos_m, area, d[f], a[f], F0, C, P0))[0]
+        got = out["pmag"][idx[:, 0], idx[:, 1], idx[:, 2]]
+        assert np.abs(got - ref).max() / peak <= TOL_P, f
+        assert np.abs(out["intensity"][idx[:, 0], idx[:, 1], idx[:, 2]] - fo.intensity_wcm2(ref, RHO, C)).max() <= TOL_I * fo.intensity_wcm2(peak, RHO, C)
+    pm, im = ctx.field_aggregate()
+    for f in range(n_foci):
+        out = ctx.field_fetch(f)
+        pmax = np.maximum(pmax, out["pmag"][idx[:, 0], idx[:, 1], idx[:, 2]])
+        isum += out["intensity"][idx[:, 0], idx[:, 1], idx[:, 2]]
+    assert np.array_equal(pm[idx[:, 0], idx[:, 1], idx[:, 2]], pmax)
+    assert np.allclose(im[idx[:, 0], idx[:, 1], idx[:, 2]], isum / n_foci, rtol=1e-5)
