@@ -74,6 +74,7 @@ struct olx_ctx {
         std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
     } lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
+    bool use_coset = false; CosetParams cp{};   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
     float* d_inten = nullptr; float* d_cplx = nullptr;
@@ -526,10 +527,41 @@ static int configure_variant(olx_ctx* c) {
             L.hz = P.hz; L.dmin2 = P.dmin2; L.flat_ez = P.flat_ez;
             L.g_scale = M.g_scale; L.out_scale = M.out_scale; L.inten_scale = P.inten_scale;
             L.vox = P.vox; L.flags = P.flags;
+            // kernel 2e: whole cosets per wave (no row-tile padding, one 18 x 18 table per plane); 2d stays for A/B runs
+            const char* fv = getenv("OLX_FIELD_VARIANT");
+            c->use_coset = c->nt <= 2 && !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
+            if (c->use_coset) {
+                CosetParams& Q = c->cp;
+                Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
+                const int kx_max = (P.nx - L.x_lo + 2 * A.mx - 1) / (2 * A.mx), ky_max = (P.ny - L.y_lo + A.my - 1) / A.my;
+                Q.nsx = (kx_max + COS_KXW - 1) / COS_KXW; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
+                Q.kblocks = (P.nz + COS_ZB - 1) / COS_ZB;
+                Q.nsa = L.nsa; Q.nsb = L.nsb; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
+                Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
+                Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
+                Q.vox = L.vox; Q.flags = L.flags;
+                // MFMAs: per (coset, part, plane pair) ceil(2 KX KY / 16) tiles
+                long long tiles16 = 0;
+                for (int rx = 0; rx < 2 * A.mx; ++rx)
+                    for (int ry = 0; ry < A.my; ++ry) {
+                        const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
+                        const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                        for (int sx = 0; sx < Q.nsx; ++sx)
+                            for (int sy = 0; sy < Q.nsy; ++sy) {
+                                const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
+                                tiles16 += (COS_P * KX * KY + 15) / 16;
+                            }
+                    }
+                const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * 3 * ntiles;
+                snprintf(nmbuf, sizeof nmbuf, "field_coset_k<nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+            } else {
             const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
             snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
                      "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                      total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+            }
         } else
         snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
                  P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
@@ -696,7 +728,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
-    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : !strcmp(force, "lattice") ? 4 : 0;
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : 0;
     c->allow_shared = c->force_kind != 1;
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
@@ -785,7 +817,29 @@ static void dispatch_lattice_nt(olx_ctx* c, float* pm) {
     else launch_lattice<4, 4, MX, MY>(c, pm, clamp);
 }
 
+template <int NT, int MX, int MY>
+static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
+    const CosetParams& Q = c->cp;
+    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
+    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
+    if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, Q);
+    else       hipLaunchKernelGGL((field_coset_k<NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, Q);
+}
+
+template <int MX, int MY>
+static void dispatch_coset_nt(olx_ctx* c, float* pm) {
+    const bool clamp = c->clamp || c->lat.clamp;
+    if (c->nt == 1) launch_coset<1, MX, MY>(c, pm, clamp); else launch_coset<2, MX, MY>(c, pm, clamp);
+}
+
 static void dispatch_lattice(olx_ctx* c, float* pm) {
+    if (c->use_coset) {
+        if (c->mx == 2 && c->my == 2) dispatch_coset_nt<2, 2>(c, pm);
+        else if (c->mx == 2) dispatch_coset_nt<2, 1>(c, pm);
+        else if (c->my == 2) dispatch_coset_nt<1, 2>(c, pm);
+        else dispatch_coset_nt<1, 1>(c, pm);
+        return;
+    }
     if (c->mx == 2 && c->my == 2) dispatch_lattice_nt<2, 2>(c, pm);
     else if (c->mx == 2) dispatch_lattice_nt<2, 1>(c, pm);
     else if (c->my == 2) dispatch_lattice_nt<1, 2>(c, pm);

@@ -983,6 +983,293 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// kernel 2e: lattice accumulate, whole cosets per wave.  Same mathematics and operands as kernel 2d; the row map is
+// changed to remove 2d's two costs: its row tiles overhang the (half) axis (27 % of all MFMA rows on BASELINE's
+// grids) and each 8-position tile evaluates its own G table.
+//   * The voxels of one plane that share a lattice coset -- x = xbase + 2 mx kx, y = ybase + my ky -- form a
+//     KX x KY grid of positions (KX <= 6, KY <= 11: the whole half axis at 128 voxels / 12-voxel pitch; longer
+//     axes are cut into equal parts on the host).  ALL of them see the same offsets against an 8 x 8 element
+//     super-block: ud = 2 kx - a in [-7, 10], wd = ky - b in [-7, 10], i.e. ONE 18 x 18 table per plane serves up
+//     to 66 positions (4.9 - 6.5 entries per position against 13.75 in kernel 2d).
+//   * A wave owns such a position grid on 2 consecutive planes; its MFMA rows are simply n = 0 .. 2 KX KY - 1
+//     (plane-major, then kx, then ky), 16 per tile, so only the last tile of a wave can hold padding (2 - 6 %).
+//     MT = ceil(2 KX KY / 16) <= 9 tiles, all sharing the K-step's B fragments.
+//   * Fragment of row n, K-step (ka, kb), k-group g: table row ky - 4 kb - g + 7, entries p .. p+3,
+//     p = 10 - 2 kx + 4 ka (even: two aligned ds_read_b64 per part, as in 2d).  TW = 20, plane stride 378 words:
+//     conflict-free for the row sets that occur (brute-forced, 1.03 LDS cycles per access).
+//   * 8 waves = 16 consecutive planes per block; the epilogue transposes through LDS in two halves of the position
+//     grid and writes 64-byte z runs.
+// ------------------------------------------------------------------------------------
+struct CosetParams {
+    int nx, ny, nz;
+    int x_lo, y_lo, x_begin;
+    int mx, my;
+    int nsx, nsy;              // parts the coset's positions are cut into along x / y
+    int kblocks;               // plane blocks of COS_ZB planes
+    int nsa, nsb;
+    int ux0, uy0;
+    float fx0, fy0, hx_hi, hx_lo, hy_hi, hy_lo, hz;
+    float dmin2, flat_ez, g_scale, out_scale, inten_scale;
+    long long vox;
+    unsigned flags;
+};
+
+constexpr int COS_NW = 8;                  // waves per block
+constexpr int COS_P = 2;                   // planes per wave
+constexpr int COS_ZB = COS_NW * COS_P;     // planes per block
+constexpr int COS_KXW = 6, COS_KYW = 11;   // positions per wave along x / y (table 18 x 18)
+constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // 9 tiles
+constexpr int COS_TW = 20, COS_PSZ = 378;  // table row / plane stride [words]
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+template <int NT, int MX, int MY, bool CLAMP>
+__global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
+    const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
+    const int* __restrict__ targets, const CosetParams P) {
+    constexpr int THREADS = COS_NW * 64;
+    constexpr int SB_PER_CHUNK = (LAT_ELEMS_LDS / NT) / 64 > 0 ? (LAT_ELEMS_LDS / NT) / 64 : 1;
+    // staging strides [floats]: odd column stride and row stride = 4 (mod 8) spread the 64 lanes of a staging write
+    // (16 columns x 4 row groups) over all 32 banks (2-way, which is free for ds_write_b32)
+    constexpr int CS = COS_ZB + 1, RS = 16 * CS + 4;
+    constexpr int B_BYTES = SB_PER_CHUNK * 4 * NT * 2 * 64 * 16, T_BYTES = COS_NW * 2 * COS_P * COS_PSZ * 4;
+    constexpr int OUT_BYTES = COS_KXW * COS_KYW * RS * 4;      // the whole position grid in one pass
+    constexpr int ARENA = B_BYTES + T_BYTES > OUT_BYTES ? B_BYTES + T_BYTES : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ARENA];
+    typedef uint4 (*BArr)[NT][2][64];
+    BArr s_B = reinterpret_cast<BArr>(smem);
+    unsigned* const s_T = reinterpret_cast<unsigned*>(smem + B_BYTES);
+    float* const s_out = reinterpret_cast<float*>(smem);
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    // block -> (x coset, y coset, x part, y part, plane block)
+    unsigned b = blockIdx.x;
+    const int kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks;
+    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
+    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
+    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
+    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
+    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
+    // equal parts: part s of n covers [s K / n, (s+1) K / n)
+    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
+    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
+    const int npos = KX * KY, nrow = COS_P * npos;
+    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
+    const int k0 = (kblock * COS_NW + wave) * COS_P;
+    const bool active = npos > 0 && k0 < P.nz;
+    const int ntile = (nrow + 15) >> 4;              // block-uniform (<= COS_MT)
+    float dz2[COS_P];
+#pragma unroll
+    for (int z = 0; z < COS_P; ++z) {
+        const float dz = (float)(k0 + z) * P.hz - P.flat_ez;
+        dz2[z] = dz * dz;
+    }
+    // table generation role: lane -> (wl = lane / 18 < 3, ui = lane % 18); round r covers table rows 3 r + wl
+    const int wl = lane / 18, ui = lane - 18 * wl;
+    const bool gen_lane = wl < 3;
+    const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
+    const int Wlane = jbase + P.uy0 + P.my * (wl - 7);
+    const int tw_off = gen_lane ? wl * COS_TW + (17 - ui) : COS_PSZ - 1;   // + 3 r TW per round; spare lanes hit the pad
+    unsigned* const Thi = s_T + (wave * 2 + 0) * COS_P * COS_PSZ;
+    unsigned* const Tlo = s_T + (wave * 2 + 1) * COS_P * COS_PSZ;
+    // fragment read offset of every tile's row for K-step (0, 0)
+    int roffT[COS_MT];
+#pragma unroll
+    for (int t = 0; t < COS_MT; ++t) {
+        int n = 16 * t + (lane & 15);
+        n = n < nrow ? n : (nrow > 0 ? nrow - 1 : 0);
+        const int plane = npos > 0 ? n / npos : 0, pos = n - plane * npos;
+        const int kx = KY > 0 ? pos / KY : 0, ky = pos - kx * KY;
+        roffT[t] = plane * COS_PSZ + (ky - g + 7) * COS_TW + (10 - 2 * kx);
+    }
+    floatx4_t acc[COS_MT][NT];
+#pragma unroll
+    for (int t = 0; t < COS_MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int n_sb = P.nsa * P.nsb;
+    constexpr int CHUNK_U4 = SB_PER_CHUNK * 4 * NT * 128, PRE = CHUNK_U4 / THREADS;
+    static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
+    uint4 pre[PRE];
+    const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * 128);
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int idx = tid + q * THREADS;
+        pre[q] = idx < n_sb * 4 * NT * 128 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
+    }
+    for (int sb0 = 0; sb0 < n_sb; sb0 += SB_PER_CHUNK) {
+        const int sb_here = min(SB_PER_CHUNK, n_sb - sb0);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
+        __syncthreads();
+        {
+            const int nxt = (sb0 + SB_PER_CHUNK) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int idx = nxt + tid + q * THREADS;
+                if (idx < lim) pre[q] = bsrc[idx];
+            }
+        }
+        if (!active) continue;
+        for (int sbl = 0; sbl < sb_here; ++sbl) {
+            const int sb = sb0 + sbl;
+            const int sbb = sb / P.nsa, sa = sb - sbb * P.nsa;
+            // ---- G table of this super-block: 18 x 18 offsets x 2 planes, 6 rounds of 3 table rows
+            {
+                const float U = (float)(Ulane - 8 * P.mx * sa);
+                const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
+                const float dx2 = dx * dx;
+                const int Wsb = Wlane - 8 * P.my * sbb;
+#pragma unroll 2
+                for (int r = 0; r < 6; ++r) {
+                    const float W = (float)(Wsb + 3 * P.my * r);
+                    const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
+                    const float r2 = fmaf(dy, dy, dx2);
+#pragma unroll
+                    for (int z = 0; z < COS_P; ++z) {
+                        float d2 = r2 + dz2[z];
+                        if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                        const float ri = __builtin_amdgcn_rsqf(d2);
+                        const float ph = d2 * ri;
+                        const float rs = ri * P.g_scale;
+                        const float gr = rs * __builtin_amdgcn_cosf(ph);
+                        const float gi = rs * __builtin_amdgcn_sinf(ph);
+                        const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
+                        const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
+                        const int o = z * COS_PSZ + (gen_lane ? tw_off + 3 * r * COS_TW : tw_off);
+                        Thi[o] = __builtin_bit_cast(unsigned, hi);
+                        Tlo[o] = __builtin_bit_cast(unsigned, lo);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ka = ks & 1, kb = ks >> 1;
+                Half8Bits bh[NT], bl[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt].u = s_B[sbl * 4 + ks][nt][0][lane];
+                    bl[nt].u = s_B[sbl * 4 + ks][nt][1][lane];
+                }
+                const int kso = 4 * ka - 4 * kb * COS_TW;
+#pragma unroll
+                for (int t = 0; t < COS_MT; ++t) {
+                    if (t >= ntile) continue;            // block-uniform
+                    Half8Bits ah, al;
+                    const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + roffT[t] + kso);
+                    const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tlo + roffT[t] + kso);
+                    const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const unsigned long long l1 = __hip_atomic_load(pl2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    ah.w[0] = (unsigned)h0; ah.w[1] = (unsigned)(h0 >> 32); ah.w[2] = (unsigned)h1; ah.w[3] = (unsigned)(h1 >> 32);
+                    al.w[0] = (unsigned)l0; al.w[1] = (unsigned)(l0 >> 32); al.w[2] = (unsigned)l1; al.w[3] = (unsigned)(l1 >> 32);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    // ---- epilogue.  D layout: lane holds rows 4 (lane >> 4) + r of tile t = rows n = 16 t + 4 gy + r -> (plane, position),
+    // column lane & 15 = (o, part).  Staging [position][column][plane of the block], two halves of the position grid.
+    const int c16 = lane & 15, part = c16 & 1, gy = lane >> 4;
+    const int kb0 = kblock * COS_ZB;
+    const bool fast = (P.nz % COS_ZB) == 0;
+    // |p| / intensity in place, then one staged pass per column tile (complex output is served by kernel 2d: the host
+    // does not select this kernel when OLX_OUT_COMPLEX is planned)
+#pragma unroll
+    for (int t = 0; t < COS_MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[t][nt][r] * P.out_scale;
+                const float sq = v * v;
+                const float m2 = sq + quad_swap1(sq);
+                acc[t][nt][r] = part == 0 ? __builtin_amdgcn_sqrtf(m2) : m2 * P.inten_scale;
+            }
+    // (the column tile is a compile-time argument so that the accumulators keep static indices; the pass loop is rolled)
+    auto stage_and_store = [&](auto nt_c) {
+            constexpr int nt = decltype(nt_c)::value;
+            __syncthreads();                         // arena free (K loop / previous read-out done)
+            if (active) {
+                // (the row -> position arithmetic is loop-invariant; the opaque copy keeps the compiler from hoisting all
+                // 36 of them out of the pass loop, which costs > 100 registers)
+                int n0 = 4 * gy;
+                asm volatile("" : "+v"(n0));
+#pragma unroll
+                for (int t = 0; t < COS_MT; ++t) {
+                    if (t >= ntile) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float w = acc[t][nt][r];
+                        const int n = 16 * t + n0 + r;
+                        const int plane = n >= npos ? 1 : 0, pos = n - plane * npos;   // COS_P == 2
+                        if (n < nrow) s_out[pos * RS + c16 * CS + wave * COS_P + plane] = w;
+                    }
+                }
+            }
+            __syncthreads();
+            // read-out: thread -> (piece of 4 planes, column, positions q0, q0 + QSTEP, ...)
+            constexpr int PIECES = COS_ZB / 4, QSTEP = THREADS / (PIECES * 16);
+            const int piece = tid % PIECES, col = (tid / PIECES) & 15, q0 = tid / (PIECES * 16);
+            const int kz = kb0 + 4 * piece;
+            const bool is_p = (col & 1) == 0;
+            float* const arr = is_p ? pmag : inten;
+            const bool want = (is_p ? (P.flags & 1u) : (P.flags & 2u)) != 0 && kz < P.nz && npos > 0;
+            const int4 tg = reinterpret_cast<const int4*>(targets)[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (col >> 1)];
+            const int tgs[4] = {tg.x, tg.y, tg.z, tg.w};
+            if (want) {
+                float* tb[4]; bool tfx[4], tfy[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int code = tgs[s4], m = code & 3;
+                    tb[s4] = code < 0 ? nullptr : arr + (long long)(code >> 2) * P.vox + kz;
+                    tfx[s4] = (MX == 2) && (m & 1);
+                    tfy[s4] = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+                }
+                int kx = q0 / KY, ky = q0 - kx * KY;     // one division, then carried
+#pragma unroll 1
+                for (int q = q0; q < npos; q += QSTEP) {
+                    const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
+                    ky += QSTEP;
+                    while (ky >= KY) { ky -= KY; ++kx; }
+                    const float* sv = s_out + q * RS + col * CS + 4 * piece;
+                    const float4 val = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                    const int ai = i * P.ny, aX = (P.nx - 1 - i) * P.ny, bY = P.ny - 1 - j;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (!tb[s4]) continue;
+                        float* o = tb[s4] + (long long)((tfx[s4] ? aX : ai) + (tfy[s4] ? bY : j)) * P.nz;
+                        if (fast) {
+                            *reinterpret_cast<float4*>(o) = val;
+                        } else {
+                            const float vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (kz + e < P.nz) o[e] = vv[e];
+                        }
+                    }
+                }
+            }
+    };
+    stage_and_store(IntC<0>{});
+    if constexpr (NT > 1) stage_and_store(IntC<1>{});
+}
+
 // pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.
 // grid (n_el_pad/16, tiles, NT), block 64: thread = lane.  Column o (< 8*NT) of tile T carries the steering
 // vector of its representative (focus, mirror image): W[perm[image][e], focus]; unused columns are zero.

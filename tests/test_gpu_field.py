@@ -23,20 +23,22 @@ def setup_ctx(ctx, pos, ori, size, foci_m, apod=("uniform", 1.0, 0.0)):
     return pos_m, area, delays, ap
 
 
-def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P):
+def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P, complex_out=True):
+    """complex_out=False plans |p| + intensity only (kernel 2e serves that; complex output goes through 2d / 2c)."""
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (len(xs), len(ys), len(zs)), F0, C, RHO, P0,
-                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX)
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.OUT_COMPLEX if complex_out else 0))
     if want_variant:
         assert want_variant in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     for f in range(delays.shape[0]):
-        out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
+        out = ctx.field_fetch(f, want=("pmag", "intensity", "complex") if complex_out else ("pmag", "intensity"))
         ref = co.field_on_grid(xs, ys, zs, pos_m, area, delays[f], ap[f], F0, C, P0, dmin=0.5 * min(h))
         mx = np.abs(ref).max()
         assert out["pmag"].dtype == np.float32 and out["pmag"].shape == ref.shape and out["pmag"].flags.writeable
         assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= tol
-        assert np.abs(out["complex"] - ref).max() / mx <= 3 * tol
+        if complex_out:
+            assert np.abs(out["complex"] - ref).max() / mx <= 3 * tol
         iref = fo.intensity_wcm2(np.abs(ref), RHO, C)
         assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
 
@@ -227,7 +229,7 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
 
 
-@pytest.mark.parametrize("family", ["general", "shared", "mfma", "lattice"])
+@pytest.mark.parametrize("family", ["general", "shared", "mfma", "lattice", "lattice2d"])
 def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     """Kernel 2a (per pair), 2b (shared geometry, VALU), 2c (shared geometry, MFMA fp16 hi/lo split) and 2d
     (lattice: block-Toeplitz geometry tables) are pinned one at a time (OLX_FIELD_VARIANT) on the same
@@ -239,8 +241,9 @@ def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     xs, ys, zs = centred_grid(64, 0.5)
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (64,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
-    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k", "lattice": "field_lattice_k"}[family] in name, name
-    check(ctx, xs, ys, zs, pos_m, area, d, a)
+    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k", "lattice": "field_coset_k", "lattice2d": "field_lattice_k"}[family] in name, name
+    check(ctx, xs, ys, zs, pos_m, area, d, a, complex_out=(family != "lattice"),
+          want_variant={"lattice": "field_coset_k", "lattice2d": "field_lattice_k"}.get(family))
 
 
 @pytest.mark.parametrize("n_foci", [5, 16, 33])
@@ -371,12 +374,12 @@ def test_mirror_partner_foci_share_columns(ctx):
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (48,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
     # 9 foci x 4 images = 36 vectors; centre 1, axis spokes (0, 90, 180, 270 deg) collapse to 4, diagonals to 4
-    assert ("field_mfma_k" in name or "field_lattice_k" in name) and " 9 columns for 9 foci x 4 images" in name, name
-    check(ctx, xs, ys, zs, pos_m, area, d, a)
+    assert ("field_mfma_k" in name or "field_coset_k" in name) and " 9 columns for 9 foci x 4 images" in name, name
+    check(ctx, xs, ys, zs, pos_m, area, d, a, complex_out=False)
 
 
 def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0.0), z0=5e-3, foci=None, apod=("uniform", 1.0, 0.0),
-                  slab=None, expect="field_lattice_k"):
+                  slab=None, expect="field_coset_k"):
     """Flat nax x nay array with pitch (px, py) [mm]; grid of grid_n voxels with spacing [mm] centred on the array
     (+ origin_shift voxels); full-volume parity against the oracle."""
     px, py = pitch_xy
@@ -393,7 +396,9 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     xs, ys = coords
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     if slab is None:
-        check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect)
+        check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect, complex_out=False)
+        if expect == "field_coset_k":      # the same case with complex output: served by kernel 2d
+            check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant="field_lattice_k")
         return
     ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab)
     assert expect in ctx.field_variant(), ctx.field_variant()
@@ -423,7 +428,7 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), origin_shift=(3.0, -2.0), foci=[[1e-3, 2e-3, 25e-3]],
                   expect="mx1,my1")
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[1e-3, 2e-3, 25e-3], [0, 0, 30e-3]],
-                  slab=(13, 14), expect="field_lattice_k")
+                  slab=(13, 14), expect="field_coset_k")
 
 
 def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
@@ -431,7 +436,7 @@ def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
 
 
-@pytest.mark.parametrize("n_foci,expect", [(8, "field_lattice_k"), (64, "field_mfma_k")])
+@pytest.mark.parametrize("n_foci,expect", [(8, "field_coset_k"), (64, "field_mfma_k")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
     """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and one GPU's 8-focus
     shard in bench.py's mirror-orbit order): sampled-voxel parity per focus, the per-focus focal peak, and the
