@@ -234,7 +234,7 @@ def main():
         name = ctx.field_variant()
         m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
         mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-        ml = re.search(r"field_lattice_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+        ml = re.search(r"field_(?:lattice|coset)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
         if ml:  # kernel 2d: the table arithmetic is amortised over 8 voxel rows x 64 elements; the matrix pipe is the ceiling.
             # On this chip MFMA and VALU issue add up (tools/ubench_clock.hip), so the MFMA-only time is a strict floor.
             n_mfma = int(ml.group(5))

@@ -74,7 +74,7 @@ struct olx_ctx {
         std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
     } lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    bool use_coset = false; CosetParams cp{};   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
+    bool use_coset = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
     float* d_inten = nullptr; float* d_cplx = nullptr;
@@ -149,7 +149,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -534,12 +534,40 @@ static int configure_variant(olx_ctx* c) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 const int kx_max = (P.nx - L.x_lo + 2 * A.mx - 1) / (2 * A.mx), ky_max = (P.ny - L.y_lo + A.my - 1) / A.my;
-                Q.nsx = (kx_max + COS_KXW - 1) / COS_KXW; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
+                const int kxw = cos_kxw(c->nt);
+                Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
                 Q.kblocks = (P.nz + COS_ZB - 1) / COS_ZB;
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
                 Q.vox = L.vox; Q.flags = L.flags;
+                {   // dense store-job lists per (launch tile, column tile): job = c16 | image << 4 | focus << 6
+                    std::vector<int> jobs((size_t)ntiles * MFMA_MAX_NT * (COS_JOBS + 1), -1);
+                    for (int t = 0; t < ntiles; ++t)
+                        for (int nt = 0; nt < MFMA_MAX_NT; ++nt) {
+                            int* jb = &jobs[((size_t)t * MFMA_MAX_NT + nt) * (COS_JOBS + 1)];
+                            int cnt = 0;
+                            for (int c16 = 0; c16 < 16; ++c16) {
+                                const bool wantp = (c16 & 1) ? (P.flags & OLX_OUT_INTENSITY) != 0 : (P.flags & OLX_OUT_PMAG) != 0;
+                                const size_t o = (size_t)nt * MFMA_COLS + (c16 >> 1);
+                                if (!wantp || o >= tiles[t].size()) continue;
+                                for (int q = 0; q < 4; ++q) {
+                                    const int code = tiles[t][o].tgt[q];
+                                    if (code >= 0) jb[cnt++] = c16 | ((code & 3) << 4) | ((code >> 2) << 6);
+                                }
+                            }
+                            int lg = 0;
+                            while ((1 << lg) < cnt) ++lg;
+                            jb[COS_JOBS] = lg;
+                        }
+                    if (c->jobs_cap < jobs.size()) {
+                        if (c->d_jobs) hipFree(c->d_jobs);
+                        c->d_jobs = nullptr; c->jobs_cap = 0;
+                        HIPCHK(c, hipMalloc((void**)&c->d_jobs, sizeof(int) * jobs.size()));
+                        c->jobs_cap = jobs.size();
+                    }
+                    HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
+                }
                 // MFMAs: per (coset, part, plane pair) ceil(2 KX KY / 16) tiles
                 long long tiles16 = 0;
                 for (int rx = 0; rx < 2 * A.mx; ++rx)
@@ -822,8 +850,8 @@ static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
     const CosetParams& Q = c->cp;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
-    if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, Q);
-    else       hipLaunchKernelGGL((field_coset_k<NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, Q);
+    if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q);
+    else       hipLaunchKernelGGL((field_coset_k<NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q);
 }
 
 template <int MX, int MY>

@@ -1018,17 +1018,26 @@ struct CosetParams {
 constexpr int COS_NW = 8;                  // waves per block
 constexpr int COS_P = 2;                   // planes per wave
 constexpr int COS_ZB = COS_NW * COS_P;     // planes per block
-constexpr int COS_KXW = 6, COS_KYW = 11;   // positions per wave along x / y (table 18 x 18)
-constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // 9 tiles
-constexpr int COS_TW = 20, COS_PSZ = 378;  // table row / plane stride [words]
+constexpr int COS_KYW = 11;                // positions per wave along y (18 table rows)
+constexpr int COS_JOBS = 64;               // store jobs per column tile: 16 (column, part) x up to 4 targets
+// positions per wave along x: 6 (the whole half axis at 128 voxels / 12-voxel pitch; table 18 x 18, 9 MFMA tiles) when
+// one column tile leaves registers for 36 accumulators, 3 (table 18 x 12, 5 tiles) with two column tiles
+constexpr int cos_kxw(int nt) { return nt >= 2 ? 3 : 6; }
 
 template <int V> struct IntC { static constexpr int value = V; };
 
 template <int NT, int MX, int MY, bool CLAMP>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
-    const int* __restrict__ targets, const CosetParams P) {
+    const int* __restrict__ jobs /*[tiles][MFMA_MAX_NT][COS_JOBS + 1]: dense (column, focus, image) store jobs, [COS_JOBS] = log2 count*/,
+    const CosetParams P) {
     constexpr int THREADS = COS_NW * 64;
+    constexpr int COS_KXW = cos_kxw(NT);
+    constexpr int UW = 8 + 2 * (COS_KXW - 1);                       // table columns: ud = 2 kx - a in [-7, 2 (KXW - 1)]
+    constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // MFMA tiles per wave
+    // table row / plane stride [words], conflict-free for the row sets that occur (brute-forced per shape)
+    constexpr int COS_TW = COS_KXW == 6 ? 20 : 12, COS_PSZ = COS_KXW == 6 ? 378 : 216;
+    constexpr int RPR = 64 / UW, NROUND = (18 + RPR - 1) / RPR;     // table rows per generation round, rounds
     constexpr int SB_PER_CHUNK = (LAT_ELEMS_LDS / NT) / 64 > 0 ? (LAT_ELEMS_LDS / NT) / 64 : 1;
     // staging strides [floats]: odd column stride and row stride = 4 (mod 8) spread the 64 lanes of a staging write
     // (16 columns x 4 row groups) over all 32 banks (2-way, which is free for ds_write_b32)
@@ -1060,18 +1069,19 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const int k0 = (kblock * COS_NW + wave) * COS_P;
     const bool active = npos > 0 && k0 < P.nz;
     const int ntile = (nrow + 15) >> 4;              // block-uniform (<= COS_MT)
+    const float inv_ky = KY > 0 ? 1.0f / (float)KY : 0.f;
     float dz2[COS_P];
 #pragma unroll
     for (int z = 0; z < COS_P; ++z) {
         const float dz = (float)(k0 + z) * P.hz - P.flat_ez;
         dz2[z] = dz * dz;
     }
-    // table generation role: lane -> (wl = lane / 18 < 3, ui = lane % 18); round r covers table rows 3 r + wl
-    const int wl = lane / 18, ui = lane - 18 * wl;
-    const bool gen_lane = wl < 3;
+    // table generation role: lane -> (wl = lane / UW < RPR, ui = lane % UW); round r covers table rows RPR r + wl
+    const int wl = lane / UW, ui = lane - UW * wl;
+    const bool gen_lane = wl < RPR;
     const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
     const int Wlane = jbase + P.uy0 + P.my * (wl - 7);
-    const int tw_off = gen_lane ? wl * COS_TW + (17 - ui) : COS_PSZ - 1;   // + 3 r TW per round; spare lanes hit the pad
+    const int tw_off = wl * COS_TW + (UW - 1 - ui);   // + RPR r TW per round
     unsigned* const Thi = s_T + (wave * 2 + 0) * COS_P * COS_PSZ;
     unsigned* const Tlo = s_T + (wave * 2 + 1) * COS_P * COS_PSZ;
     // fragment read offset of every tile's row for K-step (0, 0)
@@ -1080,9 +1090,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     for (int t = 0; t < COS_MT; ++t) {
         int n = 16 * t + (lane & 15);
         n = n < nrow ? n : (nrow > 0 ? nrow - 1 : 0);
-        const int plane = npos > 0 ? n / npos : 0, pos = n - plane * npos;
-        const int kx = KY > 0 ? pos / KY : 0, ky = pos - kx * KY;
-        roffT[t] = plane * COS_PSZ + (ky - g + 7) * COS_TW + (10 - 2 * kx);
+        const int plane = n >= npos ? 1 : 0, pos = n - plane * npos;             // COS_P == 2
+        const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;   // exact for these small integers
+        roffT[t] = plane * COS_PSZ + (ky - g + 7) * COS_TW + (UW - 8 - 2 * kx);
     }
     floatx4_t acc[COS_MT][NT];
 #pragma unroll
@@ -1125,8 +1135,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 const float dx2 = dx * dx;
                 const int Wsb = Wlane - 8 * P.my * sbb;
 #pragma unroll 2
-                for (int r = 0; r < 6; ++r) {
-                    const float W = (float)(Wsb + 3 * P.my * r);
+                for (int r = 0; r < NROUND; ++r) {
+                    const bool row_ok = gen_lane && RPR * r + wl < 18;  // the last round may run past the 18 table rows
+                    const float W = (float)(Wsb + RPR * P.my * r);
                     const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
                     const float r2 = fmaf(dy, dy, dx2);
 #pragma unroll
@@ -1140,17 +1151,19 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         const float gi = rs * __builtin_amdgcn_sinf(ph);
                         const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
                         const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
-                        const int o = z * COS_PSZ + (gen_lane ? tw_off + 3 * r * COS_TW : tw_off);
-                        Thi[o] = __builtin_bit_cast(unsigned, hi);
-                        Tlo[o] = __builtin_bit_cast(unsigned, lo);
+                        if (row_ok) {                    // spare lanes / rows past the table do not store
+                            const int o = z * COS_PSZ + tw_off + RPR * r * COS_TW;
+                            Thi[o] = __builtin_bit_cast(unsigned, hi);
+                            Tlo[o] = __builtin_bit_cast(unsigned, lo);
+                        }
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {         // unrolled: the K-step's table offset becomes an immediate
                 const int ka = ks & 1, kb = ks >> 1;
                 Half8Bits bh[NT], bl[NT];
 #pragma unroll
@@ -1224,44 +1237,35 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 }
             }
             __syncthreads();
-            // read-out: thread -> (piece of 4 planes, column, positions q0, q0 + QSTEP, ...)
-            constexpr int PIECES = COS_ZB / 4, QSTEP = THREADS / (PIECES * 16);
-            const int piece = tid % PIECES, col = (tid / PIECES) & 15, q0 = tid / (PIECES * 16);
+            // read-out.  The host lists the (column, focus, mirror image) store jobs of this column tile densely
+            // (count padded to a power of two), so thread -> (piece of 4 planes, job, positions q0, q0 + step, ...) keeps
+            // every lane of a store instruction busy whatever the number of targets per column is.
+            constexpr int PIECES = COS_ZB / 4;
+            static_assert(PIECES == 4, "piece index is two bits");
+            const int* jb = jobs + ((size_t)tile * MFMA_MAX_NT + nt) * (COS_JOBS + 1);
+            const int lg = jb[COS_JOBS];
+            const int piece = tid & 3, jidx = (tid >> 2) & ((1 << lg) - 1), q0 = tid >> (2 + lg), qstep = THREADS >> (2 + lg);
+            const int job = jb[jidx];
             const int kz = kb0 + 4 * piece;
-            const bool is_p = (col & 1) == 0;
-            float* const arr = is_p ? pmag : inten;
-            const bool want = (is_p ? (P.flags & 1u) : (P.flags & 2u)) != 0 && kz < P.nz && npos > 0;
-            const int4 tg = reinterpret_cast<const int4*>(targets)[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (col >> 1)];
-            const int tgs[4] = {tg.x, tg.y, tg.z, tg.w};
-            if (want) {
-                float* tb[4]; bool tfx[4], tfy[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int code = tgs[s4], m = code & 3;
-                    tb[s4] = code < 0 ? nullptr : arr + (long long)(code >> 2) * P.vox + kz;
-                    tfx[s4] = (MX == 2) && (m & 1);
-                    tfy[s4] = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
-                }
-                int kx = q0 / KY, ky = q0 - kx * KY;     // one division, then carried
+            if (job >= 0 && kz < P.nz && npos > 0) {
+                const int col = job & 15, m = (job >> 4) & 3;
+                const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+                float* const base = ((col & 1) ? inten : pmag) + (long long)(job >> 6) * P.vox + kz;
+                const float* sv = s_out + col * CS + 4 * piece;
+                int kx = (int)(((float)q0 + 0.5f) * inv_ky), ky = q0 - kx * KY;     // then carried
 #pragma unroll 1
-                for (int q = q0; q < npos; q += QSTEP) {
+                for (int q = q0; q < npos; q += qstep) {
                     const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
-                    ky += QSTEP;
+                    ky += qstep;
                     while (ky >= KY) { ky -= KY; ++kx; }
-                    const float* sv = s_out + q * RS + col * CS + 4 * piece;
-                    const float4 val = make_float4(sv[0], sv[1], sv[2], sv[3]);
-                    const int ai = i * P.ny, aX = (P.nx - 1 - i) * P.ny, bY = P.ny - 1 - j;
+                    const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+                    float* o = base + (long long)(io * P.ny + jo) * P.nz;
+                    const float* v = sv + q * RS;
+                    if (fast) {
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        if (!tb[s4]) continue;
-                        float* o = tb[s4] + (long long)((tfx[s4] ? aX : ai) + (tfy[s4] ? bY : j)) * P.nz;
-                        if (fast) {
-                            *reinterpret_cast<float4*>(o) = val;
-                        } else {
-                            const float vv[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (kz + e < P.nz) o[e] = vv[e];
-                        }
+                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) o[e] = v[e];
                     }
                 }
             }
