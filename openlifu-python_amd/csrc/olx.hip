@@ -530,6 +530,23 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2e: whole cosets per wave (no row-tile padding, one 18 x 18 table per plane); 2d stays for A/B runs
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = c->nt <= 2 && !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
+            // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
+            // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
+            long long tiles16 = 0;
+            {
+                const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo, kxw = cos_kxw(c->nt);
+                const int nsx = ((wx + 2 * A.mx - 1) / (2 * A.mx) + kxw - 1) / kxw, nsy = ((wy + A.my - 1) / A.my + COS_KYW - 1) / COS_KYW;
+                for (int rx = 0; rx < 2 * A.mx; ++rx)
+                    for (int ry = 0; ry < A.my; ++ry) {
+                        const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                        for (int sx = 0; sx < nsx; ++sx)
+                            for (int sy = 0; sy < nsy; ++sy) {
+                                const int KX = (sx + 1) * kxa / nsx - sx * kxa / nsx, KY = (sy + 1) * kya / nsy - sy * kya / nsy;
+                                tiles16 += (COS_P * KX * KY + 15) / 16;
+                            }
+                    }
+                if (tiles16 > 0 && (double)COS_P * wx * wy / (16.0 * (double)tiles16) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
+            }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
@@ -568,18 +585,6 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
                 }
-                // MFMAs: per (coset, part, plane pair) ceil(2 KX KY / 16) tiles
-                long long tiles16 = 0;
-                for (int rx = 0; rx < 2 * A.mx; ++rx)
-                    for (int ry = 0; ry < A.my; ++ry) {
-                        const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
-                        const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
-                        for (int sx = 0; sx < Q.nsx; ++sx)
-                            for (int sy = 0; sy < Q.nsy; ++sy) {
-                                const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                tiles16 += (COS_P * KX * KY + 15) / 16;
-                            }
-                    }
                 const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * 3 * ntiles;
                 snprintf(nmbuf, sizeof nmbuf, "field_coset_k<nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
