@@ -446,7 +446,22 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2d saves table arithmetic but pays ~27 % padded MFMA rows on BASELINE's grids; with 4 column tiles per
         // geometry fragment the MFMAs dominate and kernel 2c's exact z-run tiling wins (measured, steady state, 64-focus
         // sweep: 4.6 vs 4.9 ms; 8-focus shard: 0.74 vs 0.58 ms) -- unless the family is pinned for A/B runs
-        if (c->use_lattice && c->nt >= 4 && c->force_kind != 4) c->use_lattice = false;
+        // Kernel 2e's NT = 4 shape (3 tiles per wave) takes the sweep when its tiles are reasonably full.
+        auto coset_fill = [&](int nt) {
+            const olx_ctx::Lattice& A = c->lat;
+            const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), kxw = cos_kxw(nt);
+            const int nsx = ((wx + 2 * A.mx - 1) / (2 * A.mx) + kxw - 1) / kxw, nsy = ((wy + A.my - 1) / A.my + COS_KYW - 1) / COS_KYW;
+            long long t16 = 0;
+            for (int rx = 0; rx < 2 * A.mx; ++rx)
+                for (int ry = 0; ry < A.my; ++ry) {
+                    const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                    for (int sx = 0; sx < nsx; ++sx)
+                        for (int sy = 0; sy < nsy; ++sy)
+                            t16 += (COS_P * ((sx + 1) * kxa / nsx - sx * kxa / nsx) * ((sy + 1) * kya / nsy - sy * kya / nsy) + 15) / 16;
+                }
+            return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
+        };
+        if (c->use_lattice && c->nt >= 4 && c->force_kind != 4 && ((c->flags & OLX_OUT_COMPLEX) || coset_fill(c->nt) < 0.6)) c->use_lattice = false;
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();
         std::vector<int> colinfo((size_t)ntiles * MAXC * 2, -1), targets((size_t)ntiles * MAXC * 4, -1);
@@ -529,7 +544,7 @@ static int configure_variant(olx_ctx* c) {
             L.vox = P.vox; L.flags = P.flags;
             // kernel 2e: whole cosets per wave (no row-tile padding, one 18 x 18 table per plane); 2d stays for A/B runs
             const char* fv = getenv("OLX_FIELD_VARIANT");
-            c->use_coset = c->nt <= 2 && !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
+            c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
             // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
             long long tiles16 = 0;
@@ -862,7 +877,8 @@ static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
 template <int MX, int MY>
 static void dispatch_coset_nt(olx_ctx* c, float* pm) {
     const bool clamp = c->clamp || c->lat.clamp;
-    if (c->nt == 1) launch_coset<1, MX, MY>(c, pm, clamp); else launch_coset<2, MX, MY>(c, pm, clamp);
+    if (c->nt == 1) launch_coset<1, MX, MY>(c, pm, clamp); else if (c->nt == 2) launch_coset<2, MX, MY>(c, pm, clamp);
+    else launch_coset<4, MX, MY>(c, pm, clamp);
 }
 
 static void dispatch_lattice(olx_ctx* c, float* pm) {

@@ -1021,8 +1021,9 @@ constexpr int COS_ZB = COS_NW * COS_P;     // planes per block
 constexpr int COS_KYW = 11;                // positions per wave along y (18 table rows)
 constexpr int COS_JOBS = 64;               // store jobs per column tile: 16 (column, part) x up to 4 targets
 // positions per wave along x: 6 (the whole half axis at 128 voxels / 12-voxel pitch; table 18 x 18, 9 MFMA tiles) when
-// one column tile leaves registers for 36 accumulators, 3 (table 18 x 12, 5 tiles) with two column tiles
-constexpr int cos_kxw(int nt) { return nt >= 2 ? 3 : 6; }
+// one column tile leaves registers for 36 accumulators, 3 (table 18 x 12, 5 tiles) with two column tiles, 2 (table
+// 18 x 10, 3 tiles) with four
+constexpr int cos_kxw(int nt) { return nt >= 4 ? 2 : (nt >= 2 ? 3 : 6); }
 
 template <int V> struct IntC { static constexpr int value = V; };
 
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     constexpr int UW = 8 + 2 * (COS_KXW - 1);                       // table columns: ud = 2 kx - a in [-7, 2 (KXW - 1)]
     constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // MFMA tiles per wave
     // table row / plane stride [words], conflict-free for the row sets that occur (brute-forced per shape)
-    constexpr int COS_TW = COS_KXW == 6 ? 20 : 12, COS_PSZ = COS_KXW == 6 ? 378 : 216;
+    constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 378 : (COS_KXW == 3 ? 216 : 184);
     constexpr int RPR = 64 / UW, NROUND = (18 + RPR - 1) / RPR;     // table rows per generation round, rounds
     constexpr int SB_PER_CHUNK = (LAT_ELEMS_LDS / NT) / 64 > 0 ? (LAT_ELEMS_LDS / NT) / 64 : 1;
     // staging strides [floats]: odd column stride and row stride = 4 (mod 8) spread the 64 lanes of a staging write
@@ -1272,6 +1273,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     };
     stage_and_store(IntC<0>{});
     if constexpr (NT > 1) stage_and_store(IntC<1>{});
+    if constexpr (NT > 2) { stage_and_store(IntC<2>{}); stage_and_store(IntC<3>{}); }
 }
 
 // pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.

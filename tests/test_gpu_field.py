@@ -436,7 +436,7 @@ def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
 
 
-@pytest.mark.parametrize("n_foci,expect", [(8, "field_coset_k"), (64, "field_mfma_k")])
+@pytest.mark.parametrize("n_foci,expect", [(8, "field_coset_k"), (64, "field_coset_k")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
     """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and one GPU's 8-focus
     shard in bench.py's mirror-orbit order): sampled-voxel parity per focus, the per-focus focal peak, and the
