@@ -1102,6 +1102,12 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
     const int n_sb = P.nsa * P.nsb;
+#ifdef OLX_EXP_STAGGER
+    if (blockIdx.y == 0 && blockIdx.x < 768) {   // first-round blocks start staggered (A/B: do store bursts of lock-stepped blocks add up?)
+        const long long t0 = __builtin_readcyclecounter(), wait = (long long)((blockIdx.x * 7) % 16) * (OLX_EXP_STAGGER);
+        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     constexpr int CHUNK_U4 = SB_PER_CHUNK * 4 * NT * 128, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
@@ -1254,23 +1260,48 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 float* const base = ((col & 1) ? inten : pmag) + (long long)(job >> 6) * P.vox + kz;
                 const float* sv = s_out + col * CS + 4 * piece;
                 int kx = (int)(((float)q0 + 0.5f) * inv_ky), ky = q0 - kx * KY;     // then carried
+                // RU positions per trip: their LDS reads and address arithmetic first, then RU stores back to back, so that
+                // RU stores are in flight per lane instead of one (a store holds its data registers until it is sent; the
+                // one-store loop spent ~12 k cycles per wave here waiting, which keeps the block's slot on the CU busy)
+                constexpr int RU = 4;
 #pragma unroll 1
-                for (int q = q0; q < npos; q += qstep) {
-                    const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
-                    ky += qstep;
-                    while (ky >= KY) { ky -= KY; ++kx; }
-                    const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
-                    float* o = base + (long long)(io * P.ny + jo) * P.nz;
-                    const float* v = sv + q * RS;
-                    if (fast) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
+                for (int q = q0; q < npos; q += RU * qstep) {
+                    float4 val[RU]; float* dst[RU];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) o[e] = v[e];
+                    for (int u = 0; u < RU; ++u) {
+                        const int qu = q + u * qstep;
+                        const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
+                        ky += qstep;
+                        while (ky >= KY) { ky -= KY; ++kx; }
+                        const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+                        dst[u] = qu < npos ? base + (long long)(io * P.ny + jo) * P.nz : nullptr;
+                        const float* v = sv + (qu < npos ? qu : q) * RS;
+                        val[u] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        if (!dst[u]) continue;
+                        if (fast) {
+                            *reinterpret_cast<float4*>(dst[u]) = val[u];
+                        } else {
+                            const float vv[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[u][e] = vv[e];
+                        }
                     }
                 }
             }
     };
+#ifdef OLX_EXP_NOEPILOGUE
+    {   // A/B build: keep every accumulator live, skip staging + stores
+        float live = 0.f;
+#pragma unroll
+        for (int t = 0; t < COS_MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) live += acc[t][nt][0] + acc[t][nt][1] + acc[t][nt][2] + acc[t][nt][3];
+        if (live != 123.456f) return;
+    }
+#endif
     stage_and_store(IntC<0>{});
     if constexpr (NT > 1) stage_and_store(IntC<1>{});
     if constexpr (NT > 2) { stage_and_store(IntC<2>{}); stage_and_store(IntC<3>{}); }
