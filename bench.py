@@ -10,8 +10,9 @@ with the element table and the steering table already resident in HBM.  `--foci-
 single-focus accumulate.  For N > 1 (launched by torch.distributed.run, one rank per GPU) rank r takes
 foci [8r, 8r+8) of the sweep (weak scaling; the compute needs no collective).  `--reassemble` selects
 what crosses xGMI per step, on a side stream overlapped with the next step's compute:
-  aggregate (default)  local max/mean over the rank's foci + RCCL all-reduce of ONE volume pair -- the
-                       aggregated result of Protocol.calc_solution (plan/protocol.py:382-387), the only
+  aggregate (default)  local max/mean over the rank's foci + RCCL reduce-scatter of ONE volume pair (rank r ends
+                       up owning its 1/N of the global aggregate; OLX_AGG_COLLECTIVE=allreduce replicates it) --
+                       the aggregated result of Protocol.calc_solution (plan/protocol.py:382-387), the only
                        cross-rank dependency the sharded path has;
   allgather            every per-focus |p| volume to every rank (north_star's reassembly; 67 MB per
                        focus per peer: xGMI-bound, see DESIGN.md section 6);

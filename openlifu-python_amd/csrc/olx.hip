@@ -28,6 +28,7 @@ struct RcclApi {
     int (*CommDestroy)(olx_nccl_comm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int /*dtype*/, olx_nccl_comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t /*recvcount*/, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
@@ -1392,6 +1393,7 @@ static int load_rccl(olx_ctx* c) {
     r.AllGather = (int (*)(const void*, void*, size_t, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllGather");
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllReduce");
+    r.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclReduceScatter");  // optional
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail(c, OLX_ECOMM, "RCCL symbols missing");
     return OLX_OK;
@@ -1502,8 +1504,20 @@ int olx_field_allreduce_aggregate(olx_ctx* c) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));
-    NCCLCHK(c, c->rccl.AllReduce(c->d_agg_p, c->d_agg_p, vox, kNcclFloat32, kNcclMax, c->comm, c->comm_stream));
-    if (with_i) NCCLCHK(c, c->rccl.AllReduce(c->d_agg_i, c->d_agg_i, vox, kNcclFloat32, kNcclSum, c->comm, c->comm_stream));
+    // Exchange.  Default: in-place reduce-scatter -- rank r ends up owning voxels [r vox/N, (r+1) vox/N) of the global
+    // aggregate (max |p|, mean intensity), i.e. the result stays sharded in HBM like the per-focus volumes; that moves
+    // (N-1)/N of one volume pair per rank, half of an all-reduce.  OLX_AGG_COLLECTIVE=allreduce (or a voxel count that
+    // does not divide by N) replicates the whole aggregate on every rank instead.
+    const char* coll = getenv("OLX_AGG_COLLECTIVE");
+    const bool scatter = c->rccl.ReduceScatter && vox % (size_t)c->nranks == 0 && !(coll && !strcmp(coll, "allreduce"));
+    if (scatter) {
+        const size_t chunk = vox / (size_t)c->nranks;
+        NCCLCHK(c, c->rccl.ReduceScatter(c->d_agg_p, c->d_agg_p + chunk * c->rank, chunk, kNcclFloat32, kNcclMax, c->comm, c->comm_stream));
+        if (with_i) NCCLCHK(c, c->rccl.ReduceScatter(c->d_agg_i, c->d_agg_i + chunk * c->rank, chunk, kNcclFloat32, kNcclSum, c->comm, c->comm_stream));
+    } else {
+        NCCLCHK(c, c->rccl.AllReduce(c->d_agg_p, c->d_agg_p, vox, kNcclFloat32, kNcclMax, c->comm, c->comm_stream));
+        if (with_i) NCCLCHK(c, c->rccl.AllReduce(c->d_agg_i, c->d_agg_i, vox, kNcclFloat32, kNcclSum, c->comm, c->comm_stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_red, c->comm_stream));
     c->reduce_pending = true;
     return OLX_OK;
