@@ -11,7 +11,7 @@ single-focus accumulate.  For N > 1 (launched by torch.distributed.run, one rank
 foci [8r, 8r+8) of the sweep (weak scaling; the compute needs no collective).  `--reassemble` selects
 what crosses xGMI per step, on a side stream overlapped with the next step's compute:
   aggregate (default)  local max/mean over the rank's foci + RCCL reduce-scatter of ONE volume pair (rank r ends
-                       up owning its 1/N of the global aggregate; OLX_AGG_COLLECTIVE=allreduce replicates it) --
+                       up owning its 1/N of the global aggregate; olx_field_allreduce_aggregate would replicate it) --
                        the aggregated result of Protocol.calc_solution (plan/protocol.py:382-387), the only
                        cross-rank dependency the sharded path has;
   allgather            every per-focus |p| volume to every rank (north_star's reassembly; 67 MB per
@@ -183,7 +183,7 @@ def main():
     def step():
         ctx.field_launch()
         if gather and args.reassemble == "aggregate":
-            ctx.field_allreduce_aggregate()
+            ctx.field_reduce_scatter_aggregate()
         elif gather:
             ctx.field_allgather()
 

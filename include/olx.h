@@ -228,11 +228,12 @@ int olx_allgather_fetch(olx_ctx *ctx, int rank, float *pmag_out);
 /* Aggregated result with the foci sharded over ranks (plan/protocol.py:382-387): local max / sum over
  * this rank's foci, then RCCL all-reduce (max for |p|, sum for the intensity mean) of one volume each,
  * asynchronously on the side stream; the mean divides by n_foci * nranks (equal foci per rank).
- * By default the exchange is an in-place reduce-scatter: rank r then owns voxels [r V/N, (r+1) V/N) of the global
- * aggregate (the rest of its buffer holds its local partial result); OLX_AGG_COLLECTIVE=allreduce, or a voxel count
- * not divisible by N, replicates the whole aggregate on every rank (all-reduce, twice the xGMI traffic).
- * olx_aggregate_fetch waits for it and copies the volumes to the host (either may be NULL). */
+ * olx_field_reduce_scatter_aggregate is the sharded form: an in-place reduce-scatter after which rank r owns voxels
+ * [r V/N, (r+1) V/N) of the global aggregate (the rest of its buffer holds its local partial result) -- half the
+ * xGMI traffic; it falls back to the all-reduce when V is not divisible by N.
+ * olx_aggregate_fetch waits for either and copies the volumes to the host (either may be NULL). */
 int olx_field_allreduce_aggregate(olx_ctx *ctx);
+int olx_field_reduce_scatter_aggregate(olx_ctx *ctx);
 int olx_aggregate_fetch(olx_ctx *ctx, float *pmag_max_out, float *intensity_mean_out);
 
 #ifdef __cplusplus

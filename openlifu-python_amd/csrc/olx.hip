@@ -1480,9 +1480,9 @@ int olx_field_allgather(olx_ctx* c) {
 // Aggregated result across ranks (plan/protocol.py:382-387 with the foci sharded over GPUs): local
 // max / sum over this rank's foci on the compute stream, then RCCL all-reduce (max for |p|, sum for the
 // intensity mean) of ONE volume each on the side stream -- the exchange step the sharded path really has.
-int olx_field_allreduce_aggregate(olx_ctx* c) {
+static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
     if (!c) return OLX_EINVAL;
-    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: call olx_comm_init first");
+    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate: call olx_comm_init first");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: nothing planned");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t vox = (size_t)c->fp.vox;
@@ -1504,12 +1504,11 @@ int olx_field_allreduce_aggregate(olx_ctx* c) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));
-    // Exchange.  Default: in-place reduce-scatter -- rank r ends up owning voxels [r vox/N, (r+1) vox/N) of the global
-    // aggregate (max |p|, mean intensity), i.e. the result stays sharded in HBM like the per-focus volumes; that moves
-    // (N-1)/N of one volume pair per rank, half of an all-reduce.  OLX_AGG_COLLECTIVE=allreduce (or a voxel count that
-    // does not divide by N) replicates the whole aggregate on every rank instead.
-    const char* coll = getenv("OLX_AGG_COLLECTIVE");
-    const bool scatter = c->rccl.ReduceScatter && vox % (size_t)c->nranks == 0 && !(coll && !strcmp(coll, "allreduce"));
+    // Exchange.  Reduce-scatter (in place): rank r ends up owning voxels [r vox/N, (r+1) vox/N) of the global aggregate
+    // (max |p|, mean intensity), i.e. the result stays sharded in HBM like the per-focus volumes; that moves (N-1)/N of
+    // one volume pair per rank, half of an all-reduce.  All-reduce replicates the whole aggregate on every rank; it is
+    // also the fallback when the voxel count does not divide by N.
+    const bool scatter = want_scatter && c->rccl.ReduceScatter && vox % (size_t)c->nranks == 0;
     if (scatter) {
         const size_t chunk = vox / (size_t)c->nranks;
         NCCLCHK(c, c->rccl.ReduceScatter(c->d_agg_p, c->d_agg_p + chunk * c->rank, chunk, kNcclFloat32, kNcclMax, c->comm, c->comm_stream));
@@ -1522,6 +1521,9 @@ int olx_field_allreduce_aggregate(olx_ctx* c) {
     c->reduce_pending = true;
     return OLX_OK;
 }
+
+int olx_field_allreduce_aggregate(olx_ctx* c) { return aggregate_exchange(c, false); }
+int olx_field_reduce_scatter_aggregate(olx_ctx* c) { return aggregate_exchange(c, true); }
 
 int olx_aggregate_fetch(olx_ctx* c, float* pmax_out, float* imean_out) {
     if (!c) return OLX_EINVAL;

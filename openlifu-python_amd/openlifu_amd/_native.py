@@ -28,7 +28,7 @@ SYMBOLS = [
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
-    "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate",
+    "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch",
 ]
 
@@ -93,6 +93,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_allgather.argtypes = [vp]
         lib.olx_allgather_fetch.argtypes = [vp, c_int, fp]
         lib.olx_field_allreduce_aggregate.argtypes = [vp]
+        lib.olx_field_reduce_scatter_aggregate.argtypes = [vp]
         lib.olx_aggregate_fetch.argtypes = [vp, fp, fp]
         _lib = lib
     if require_gpu and device_count() < 1:
@@ -386,6 +387,10 @@ class Context:
 
     def field_allreduce_aggregate(self):
         self._chk(self._lib.olx_field_allreduce_aggregate(self._h))
+
+    def field_reduce_scatter_aggregate(self):
+        """Sharded aggregate: rank r ends up owning voxels [r V/N, (r+1) V/N) of the global max |p| / mean intensity."""
+        self._chk(self._lib.olx_field_reduce_scatter_aggregate(self._h))
 
     def aggregate_fetch(self, want_intensity=True):
         pm = np.empty(self._shape, dtype=np.float32)

@@ -214,11 +214,14 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     assert np.array_equal(ctx.allgather_fetch(0), local)
     ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[1], a[1], F0, C, P0))
     assert np.abs(local[1] - ref).max() / ref.max() <= TOL_P
+    ctx.field_reduce_scatter_aggregate() # 1-rank reduce-scatter == local aggregate as well (rank 0 owns every voxel)
+    pm_rs, im_rs = ctx.aggregate_fetch()
     ctx.field_allreduce_aggregate()      # 1-rank all-reduce == local aggregate (max |p|, mean intensity)
     ctx.field_allreduce_aggregate()      # twice: the second must wait for the first to release the buffers
     pm, im = ctx.aggregate_fetch()
     ints = np.stack([ctx.field_fetch(f)["intensity"] for f in range(3)])
     assert np.array_equal(pm, local.max(axis=0)) and np.allclose(im, ints.mean(axis=0), rtol=1e-6)
+    assert np.array_equal(pm_rs, pm) and np.array_equal(im_rs, im)
     ctx.comm_destroy()
     # the driver class on world = 1 (no communicator): foci mode and slab mode agree with each other
     arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
