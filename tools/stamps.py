@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Developer tool: phase timeline of the lattice kernel from in-kernel cycle stamps.
+"""Developer tool: phase timeline of the row-tile lattice kernel (2d) from in-kernel cycle stamps.
 Build:  hipcc ... -DOLX_EXP_STAMPS -o openlifu-python_amd/lib/libolx_STAMPS.so ; run on the GPU box:
   OLX_LIB_PATH=.../libolx_STAMPS.so python tools/stamps.py [foci]
 """
 import ctypes
 import os
 import sys
+
+os.environ.setdefault("OLX_FIELD_VARIANT", "lattice2d")   # the stamps are compiled into kernel 2d (field_lattice_k)
 
 import numpy as np
 
