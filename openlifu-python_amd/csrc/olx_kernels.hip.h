@@ -1274,7 +1274,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         ky += qstep;
                         while (ky >= KY) { ky -= KY; ++kx; }
                         const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+#ifdef OLX_EXP_L2STORE
+                        dst[u] = qu < npos ? base + ((long long)(io * P.ny + jo) * P.nz & 0xFFFFF) - (long long)(job >> 6) * P.vox : nullptr;  // A/B: stores stay cache resident
+#else
                         dst[u] = qu < npos ? base + (long long)(io * P.ny + jo) * P.nz : nullptr;
+#endif
                         const float* v = sv + (qu < npos ? qu : q) * RS;
                         val[u] = make_float4(v[0], v[1], v[2], v[3]);
                     }
