@@ -1231,15 +1231,17 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 // 36 of them out of the pass loop, which costs > 100 registers)
                 int n0 = 4 * gy;
                 asm volatile("" : "+v"(n0));
+                // staging address of row n = n0 + 16 t + r: one multiply per lane, then immediates; rows of the second plane
+                // (n >= npos) sit one float further and npos rows back
+                float* const a0 = s_out + n0 * RS + c16 * CS + wave * COS_P;
+                const int dplane = 1 - npos * RS;
 #pragma unroll
                 for (int t = 0; t < COS_MT; ++t) {
                     if (t >= ntile) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float w = acc[t][nt][r];
                         const int n = 16 * t + n0 + r;
-                        const int plane = n >= npos ? 1 : 0, pos = n - plane * npos;   // COS_P == 2
-                        if (n < nrow) s_out[pos * RS + c16 * CS + wave * COS_P + plane] = w;
+                        if (n < nrow) a0[(16 * t + r) * RS + (n >= npos ? dplane : 0)] = acc[t][nt][r];
                     }
                 }
             }
