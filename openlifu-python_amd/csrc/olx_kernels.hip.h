@@ -1211,16 +1211,17 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const bool fast = (P.nz % COS_ZB) == 0;
     // |p| / intensity in place, then one staged pass per column tile (complex output is served by kernel 2d: the host
     // does not select this kernel when OLX_OUT_COMPLEX is planned)
+    const float s_p = P.out_scale, s_i = P.out_scale * P.out_scale * P.inten_scale;   // scales applied after the square
 #pragma unroll
     for (int t = 0; t < COS_MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[t][nt][r] * P.out_scale;
-                const float sq = v * v;
-                const float m2 = sq + quad_swap1(sq);
-                acc[t][nt][r] = part == 0 ? __builtin_amdgcn_sqrtf(m2) : m2 * P.inten_scale;
+                const float a = acc[t][nt][r];
+                const float sq = a * a;
+                const float m2 = sq + quad_swap1(sq);      // (S re)^2 + (S im)^2 (partner lane holds the other part)
+                acc[t][nt][r] = part == 0 ? __builtin_amdgcn_sqrtf(m2) * s_p : m2 * s_i;
             }
     // (the column tile is a compile-time argument so that the accumulators keep static indices; the pass loop is rolled)
     auto stage_and_store = [&](auto nt_c) {
