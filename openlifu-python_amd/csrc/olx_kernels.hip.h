@@ -1039,7 +1039,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     // table row / plane stride [words], conflict-free for the row sets that occur (brute-forced per shape)
     constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 378 : (COS_KXW == 3 ? 216 : 184);
     constexpr int RPR = 64 / UW, NROUND = (18 + RPR - 1) / RPR;     // table rows per generation round, rounds
-    constexpr int SB_PER_CHUNK = (LAT_ELEMS_LDS / NT) / 64 > 0 ? (LAT_ELEMS_LDS / NT) / 64 : 1;
+    // super-blocks of B fragments per LDS stage: 2 for every NT but 4 (NT = 2 has LDS to spare at its 2 blocks / CU; two
+    // super-blocks per stage halve the barriers)
+    constexpr int SB_PER_CHUNK = NT >= 4 ? 1 : 2;
     // staging strides [floats]: odd column stride and row stride = 4 (mod 8) spread the 64 lanes of a staging write
     // (16 columns x 4 row groups) over all 32 banks (2-way, which is free for ds_write_b32)
     constexpr int CS = COS_ZB + 1, RS = 16 * CS + 4;
