@@ -1058,7 +1058,13 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const int g = lane >> 4;
     // block -> (x coset, y coset, x part, y part, plane block)
     unsigned b = blockIdx.x;
-    const int kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks;
+    // The two blocks that write the two 64-byte halves of the same 128-byte lines get block ids 8 apart (same XCD, i.e.
+    // the same L2, under round-robin dispatch over the 8 XCDs) instead of adjacent ids (measured -1...-2 %).
+    int kblock;
+    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
+        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
+        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
+    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
     const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
     const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
     const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
