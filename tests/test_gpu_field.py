@@ -475,3 +475,42 @@ def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
         isum += out["intensity"][idx[:, 0], idx[:, 1], idx[:, 2]]
     assert np.array_equal(pm[idx[:, 0], idx[:, 1], idx[:, 2]], pmax)
     assert np.allclose(im[idx[:, 0], idx[:, 1], idx[:, 2]], isum / n_foci, rtol=1e-5)
+
+
+def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch):
+    """Randomised shapes through kernel 2e / 2d's planning corners -- array sizes that pad to super-blocks, pitches of
+    1..6 voxels per axis, grids that cut cosets into unequal parts, ragged plane counts, centred (folded) and shifted
+    grids, 1..20 foci (NT = 1, 2, 4) -- each compared with kernel 2a (exact per pair, no sharing) on the same inputs."""
+    rng = np.random.default_rng(147)
+    seen = set()
+    for case in range(40):
+        nax, nay = int(rng.integers(4, 19)), int(rng.integers(4, 19))
+        mxv, myv = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        h = float(rng.choice([0.5, 0.75, 1.0]))
+        n = [int(rng.integers(9, 70)), int(rng.integers(9, 70)), int(rng.integers(5, 45))]
+        shift = (0.0, 0.0) if case % 2 == 0 else (float(rng.integers(-3, 4)), float(rng.integers(-3, 4)) + 0.5)
+        nf = int(rng.choice([1, 2, 5, 9, 20]))
+        a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+        pos = np.stack([(a.ravel() - (nax - 1) / 2) * mxv * h, (b.ravel() - (nay - 1) / 2) * myv * h, np.zeros(nax * nay)], axis=1)
+        foci = np.column_stack([rng.uniform(-4, 4, nf), rng.uniform(-4, 4, nf), rng.uniform(20, 40, nf)]) * 1e-3
+        if case % 3 == 0:
+            foci[0] = [0, 0, 30e-3]
+        size = np.tile([0.9 * mxv * h, 0.9 * myv * h], (nax * nay, 1))
+        pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, apod=("maxangle", 60.0, 0.0))
+        xs = ((np.arange(n[0]) - (n[0] - 1) / 2) + shift[0]) * h * 1e-3
+        ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h * 1e-3
+        zs = (4.0 + np.arange(n[2]) * h) * 1e-3
+        got = {}
+        for fam in ("lattice", "general"):
+            monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
+            ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, tuple(n), F0, C, RHO, P0)
+            ctx.field_launch()
+            got[fam] = (ctx.field_variant(), np.stack([ctx.field_fetch(f)["pmag"] for f in range(nf)]),
+                        np.stack([ctx.field_fetch(f)["intensity"] for f in range(nf)]))
+        name = got["lattice"][0]
+        seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
+        assert "field_accum_k" in got["general"][0]
+        ref_p, ref_i = got["general"][1], got["general"][2]
+        assert np.abs(got["lattice"][1] - ref_p).max() <= 4e-6 * ref_p.max(), (case, name, nax, nay, mxv, myv, n, nf)
+        assert np.abs(got["lattice"][2] - ref_i).max() <= 8e-6 * ref_i.max(), (case, name)
+    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4"} <= seen, seen
