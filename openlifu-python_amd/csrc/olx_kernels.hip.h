@@ -1046,7 +1046,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     // (16 columns x 4 row groups) over all 32 banks (2-way, which is free for ds_write_b32)
     constexpr int CS = COS_ZB + 1, RS = 16 * CS + 4;
     constexpr int B_BYTES = SB_PER_CHUNK * 4 * NT * 2 * 64 * 16, T_BYTES = COS_NW * 2 * COS_P * COS_PSZ * 4;
-    constexpr int OUT_BYTES = COS_KXW * COS_KYW * RS * 4;      // the whole position grid in one pass
+    constexpr int GROUP = NT >= 4 ? 2 : NT;                      // column tiles staged per epilogue pass
+    constexpr int SLAB = COS_KXW * COS_KYW * RS;                 // floats per staged column tile (whole position grid)
+    constexpr int OUT_BYTES = GROUP * SLAB * 4;
     constexpr int ARENA = B_BYTES + T_BYTES > OUT_BYTES ? B_BYTES + T_BYTES : OUT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[ARENA];
     typedef uint4 (*BArr)[NT][2][64];
@@ -1232,8 +1234,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 acc[t][nt][r] = part == 0 ? __builtin_amdgcn_sqrtf(m2) * s_p : m2 * s_i;
             }
     // (the column tile is a compile-time argument so that the accumulators keep static indices; the pass loop is rolled)
-    auto stage_and_store = [&](auto nt_c) {
-            constexpr int nt = decltype(nt_c)::value;
+    auto stage_and_store = [&](auto nt_c) {          // one pass: GROUP column tiles nt0 .. nt0 + GROUP - 1, two barriers
+            constexpr int nt0 = decltype(nt_c)::value;
             __syncthreads();                         // arena free (K loop / previous read-out done)
             if (active) {
                 // (the row -> position arithmetic is loop-invariant; the opaque copy keeps the compiler from hoisting all
@@ -1250,11 +1252,18 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = 16 * t + n0 + r;
-                        if (n < nrow) a0[(16 * t + r) * RS + (n >= npos ? dplane : 0)] = acc[t][nt][r];
+                        if (n < nrow) {
+                            float* a = a0 + (16 * t + r) * RS + (n >= npos ? dplane : 0);
+#pragma unroll
+                            for (int gq = 0; gq < GROUP; ++gq) a[gq * SLAB] = acc[t][nt0 + gq][r];
+                        }
                     }
                 }
             }
             __syncthreads();
+#pragma unroll
+            for (int gq = 0; gq < GROUP; ++gq) {
+            const int nt = nt0 + gq;
             // read-out.  The host lists the (column, focus, mirror image) store jobs of this column tile densely
             // (count padded to a power of two), so thread -> (piece of 4 planes, job, positions q0, q0 + step, ...) keeps
             // every lane of a store instruction busy whatever the number of targets per column is.
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 const int col = job & 15, m = (job >> 4) & 3;
                 const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
                 float* const base = ((col & 1) ? inten : pmag) + (long long)(job >> 6) * P.vox + kz;
-                const float* sv = s_out + col * CS + 4 * piece;
+                const float* sv = s_out + gq * SLAB + col * CS + 4 * piece;
                 int kx = (int)(((float)q0 + 0.5f) * inv_ky), ky = q0 - kx * KY;     // then carried
                 // RU positions per trip: their LDS reads and address arithmetic first, then RU stores back to back, so that
                 // RU stores are in flight per lane instead of one (a store holds its data registers until it is sent; the
@@ -1306,6 +1315,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     }
                 }
             }
+            }
     };
 #ifdef OLX_EXP_NOEPILOGUE
     {   // A/B build: keep every accumulator live, skip staging + stores
@@ -1318,8 +1328,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     }
 #endif
     stage_and_store(IntC<0>{});
-    if constexpr (NT > 1) stage_and_store(IntC<1>{});
-    if constexpr (NT > 2) { stage_and_store(IntC<2>{}); stage_and_store(IntC<3>{}); }
+    if constexpr (NT > GROUP) stage_and_store(IntC<GROUP>{});
 }
 
 // pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.
