@@ -1525,7 +1525,8 @@ __global__ __launch_bounds__(256) void field_aggregate_p_k(const float* __restri
     const long long stride = (long long)gridDim.x * blockDim.x, v4 = vox >> 2;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = m;
-        for (int f = 0; f < n_foci; ++f) {
+#pragma unroll 8
+        for (int f = 0; f < n_foci; ++f) {          // unrolled: up to 8 independent 16-byte loads in flight per lane
             const float4 p = reinterpret_cast<const float4*>(pmag + (long long)f * vox)[q];
             m.x = fmaxf(m.x, p.x); m.y = fmaxf(m.y, p.y); m.z = fmaxf(m.z, p.z); m.w = fmaxf(m.w, p.w);
             s.x = fmaf(p.x, p.x, s.x); s.y = fmaf(p.y, p.y, s.y); s.z = fmaf(p.z, p.z, s.z); s.w = fmaf(p.w, p.w, s.w);
