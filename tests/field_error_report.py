@@ -1,3 +1,5 @@
+"""Checker script (not a pytest module): field error of every kernel family against the fp64 oracle on an 8-focus Wheel.
+Run from the repo root on the GPU box:  python tests/field_error_report.py"""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "openlifu-python_amd")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from openlifu_amd import _native as nat
