@@ -1,6 +1,7 @@
 """Planning API boundary: ``Protocol`` (beamform / calc_solution) and ``Solution`` (scale / analyze)."""
 from __future__ import annotations
 
+from . import param_constraint as _param
 from . import protocol as _protocol
 from . import solution as _solution
 from . import solution_analysis as _analysis
@@ -17,7 +18,8 @@ get_gridded_transformed_coords = _analysis.get_gridded_transformed_coords
 calc_dist_from_focus = _analysis.calc_dist_from_focus
 get_mask = _analysis.get_mask
 TargetConstraints = _constraints.TargetConstraints
+ParameterConstraint = _param.ParameterConstraint
 
 __all__ = ("Protocol", "Solution", "SolutionAnalysis", "SolutionAnalysisOptions", "TargetConstraints",
            "OnPulseMismatchAction", "get_focus_matrix", "get_offset_grid", "get_gridded_transformed_coords",
-           "calc_dist_from_focus", "get_mask")
+           "calc_dist_from_focus", "get_mask", "ParameterConstraint")

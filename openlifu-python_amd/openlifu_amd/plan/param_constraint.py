@@ -1,0 +1,74 @@
+"""Pass / warn / fail limits on analysis outputs (mirror of openlifu.plan.param_constraint.ParameterConstraint,
+plan/param_constraint.py:17-100).  A value is fine while ``value <operator> limit`` HOLDS; it is a warning or an
+error when the comparison against ``warning_value`` / ``error_value`` fails."""
+from __future__ import annotations
+
+import operator as _op
+from dataclasses import dataclass
+
+from ..util.dict_conversion import DictMixin
+
+PARAM_STATUS_SYMBOLS = {"ok": "✅", "warning": "❗", "error": "❌"}
+
+_SCALAR = {"<": _op.lt, "<=": _op.le, ">": _op.gt, ">=": _op.ge}
+_RANGE = {
+    "within": lambda v, lo, hi: lo < v < hi,
+    "inside": lambda v, lo, hi: lo <= v <= hi,
+    "outside": lambda v, lo, hi: v < lo or v > hi,
+    "outside_inclusive": lambda v, lo, hi: v <= lo or v >= hi,
+}
+
+
+@dataclass
+class ParameterConstraint(DictMixin):
+    operator: str
+    warning_value: float | int | tuple | None = None
+    error_value: float | int | tuple | None = None
+
+    def __post_init__(self):
+        if self.warning_value is None and self.error_value is None:
+            raise ValueError("At least one of warning_value or error_value must be set")
+        for label, v in (("Warning", self.warning_value), ("Error", self.error_value)):
+            if self.operator in _RANGE:
+                if v and (not isinstance(v, tuple) or len(v) != 2 or v[0] >= v[1]):
+                    raise ValueError(f"{label} value must be a sorted tuple of two numbers")
+            elif self.operator in _SCALAR:
+                if v is not None and not isinstance(v, (int, float)):
+                    raise ValueError(f"{label} value must be a single value")
+
+    @staticmethod
+    def compare(value, operator, threshold) -> bool:
+        if operator in _SCALAR:
+            return bool(_SCALAR[operator](value, threshold))
+        if operator in _RANGE:
+            return bool(_RANGE[operator](value, threshold[0], threshold[1]))
+        raise ValueError(f"Unsupported operator: {operator}")
+
+    def is_warning(self, value) -> bool:
+        return self.warning_value is not None and not self.compare(value, self.operator, self.warning_value)
+
+    def is_error(self, value) -> bool:
+        return self.error_value is not None and not self.compare(value, self.operator, self.error_value)
+
+    def get_status(self, value) -> str:
+        return "error" if self.is_error(value) else "warning" if self.is_warning(value) else "ok"
+
+    def get_status_symbol(self, value) -> str:
+        return PARAM_STATUS_SYMBOLS[self.get_status(value)]
+
+    def to_table(self):
+        """Two-row description of the limits as a pandas DataFrame (plan/param_constraint.py:84-96)."""
+        import pandas as pd
+        if self.operator not in _SCALAR and self.operator not in _RANGE:
+            raise ValueError(f"Unsupported operator: {self.operator}")
+        rows = [{"Name": name, "Value": f"value {self.operator} {v}", "Unit": ""}
+                for name, v in (("Warn if not", self.warning_value), ("Error if not", self.error_value)) if v is not None]
+        return pd.DataFrame.from_records(rows)
+
+    @classmethod
+    def from_dict(cls, parameter_dict):
+        d = {k: v for k, v in parameter_dict.items() if k != "class"}
+        for k in ("warning_value", "error_value"):  # JSON turns the (lo, hi) tuples into lists
+            if isinstance(d.get(k), list):
+                d[k] = tuple(d[k])
+        return cls(**d)

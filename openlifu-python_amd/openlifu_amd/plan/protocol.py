@@ -28,6 +28,7 @@ from ..engine import get_engine, gpu_available
 from ..geo import Point
 from ..sim.field import dataset_from_fields, simulate_foci, _ATTRS
 from ..util import dataset as ds
+from .param_constraint import ParameterConstraint
 from .solution import Solution
 from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions
 from .target_constraints import TargetConstraints
@@ -74,7 +75,8 @@ class Protocol:
         d["seg_method"] = seg.SegmentationMethod.from_dict(seg_dict)
         d["target_constraints"] = [TargetConstraints.from_dict(t) for t in d.get("target_constraints", [])]
         d["analysis_options"] = SolutionAnalysisOptions.from_dict(d.get("analysis_options", {}))
-        d["param_constraints"] = d.get("param_constraints", {})
+        d["param_constraints"] = {k: v if isinstance(v, ParameterConstraint) else ParameterConstraint.from_dict(v)
+                                  for k, v in d.get("param_constraints", {}).items()}
         for k in ("virtual_fit_options",):  # out of scope, tolerated in files
             d.pop(k, None)
         return Protocol(**d)
@@ -84,7 +86,9 @@ class Protocol:
                 "pulse": self.pulse.to_dict(), "sequence": self.sequence.to_dict(),
                 "focal_pattern": self.focal_pattern.to_dict(), "sim_setup": asdict(self.sim_setup),
                 "delay_method": self.delay_method.to_dict(), "apod_method": self.apod_method.to_dict(),
-                "seg_method": self.seg_method.to_dict(), "param_constraints": self.param_constraints,
+                "seg_method": self.seg_method.to_dict(),
+                "param_constraints": {k: pc.to_dict() if hasattr(pc, "to_dict") else pc
+                                      for k, pc in self.param_constraints.items()},
                 "target_constraints": [t.to_dict() for t in self.target_constraints],
                 "analysis_options": self.analysis_options.to_dict()}
 

@@ -1,6 +1,6 @@
 """Sonication solution container (mirror of openlifu.plan.solution.Solution,
 plan/solution.py:38-533): delays[F,N], apodizations[F,N], foci, simulation_result, plus
-``scale`` / ``analyze``.  NetCDF persistence is out of scope.
+``scale`` / ``analyze`` and JSON / NetCDF-3 persistence (``util/netcdf.py``).
 
 ``analyze`` / ``scale`` keep the volumes on the GPU: the masked peaks come from one HBM-bound scan
 per query (``olx_field_masked_peak``) over the result that ``calc_solution`` left resident; a
@@ -8,9 +8,11 @@ Solution whose volumes are host-only (e.g. rebuilt from a dict) is uploaded once
 """
 from __future__ import annotations
 
+import base64
 import json
 from dataclasses import dataclass, field
 from datetime import datetime
+from pathlib import Path
 from typing import List, Tuple
 
 import numpy as np
@@ -20,9 +22,15 @@ from ..bf.focal_patterns import FocalPattern
 from ..engine import get_engine, grid_from_coords
 from ..geo import Point
 from ..util import dataset as ds
+from ..util import netcdf
 from ..util.units import getunitconversion
 from ..xdc import Transducer
 from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, beam_bounds_from_samples, get_focus_matrix
+
+
+def _default_nc_path(json_filepath: Path) -> Path:
+    """Same directory, name up to the FIRST dot + ".nc" (plan/solution.py:31-35)."""
+    return json_filepath.parent / (json_filepath.name.split(".")[0] + ".nc")
 
 
 @dataclass
@@ -204,21 +212,26 @@ class Solution:
             self._resident[0].ctx.field_scale(factors)
         self.voltage = v1
 
-    # ---- (de)serialisation: JSON part only (plan/solution.py:390-489) ------------------------------
+    # ---- (de)serialisation (plan/solution.py:390-533) ------------------------------------------
     def to_dict(self, include_simulation_data: bool = False) -> dict:
+        d = {"id": self.id, "name": self.name, "protocol_id": self.protocol_id,
+             "transducer": None if self.transducer is None else self.transducer.to_dict(),
+             "date_created": self.date_created.isoformat(), "description": self.description,
+             "delays": None if self.delays is None else self.delays.tolist(),
+             "apodizations": None if self.apodizations is None else self.apodizations.tolist(),
+             "pulse": self.pulse.to_dict(), "voltage": self.voltage, "sequence": self.sequence.to_dict(),
+             "foci": [p.to_dict() for p in self.foci],
+             "target": None if self.target is None else self.target.to_dict(), "approved": self.approved}
         if include_simulation_data:
-            raise NotImplementedError("NetCDF embedding is outside the hot path")
-        return {"id": self.id, "name": self.name, "protocol_id": self.protocol_id,
-                "transducer": None if self.transducer is None else self.transducer.to_dict(),
-                "date_created": self.date_created.isoformat(), "description": self.description,
-                "delays": None if self.delays is None else self.delays.tolist(),
-                "apodizations": None if self.apodizations is None else self.apodizations.tolist(),
-                "pulse": self.pulse.to_dict(), "voltage": self.voltage, "sequence": self.sequence.to_dict(),
-                "foci": [p.to_dict() for p in self.foci],
-                "target": None if self.target is None else self.target.to_dict(), "approved": self.approved}
+            d["simulation_result"] = self.simulation_result
+        return d
 
     def to_json(self, include_simulation_data: bool = False, compact: bool = False) -> str:
-        d = self.to_dict(include_simulation_data)
+        """With ``include_simulation_data`` the volumes travel as a base64 NetCDF-3 blob, the format the
+        reference embeds (``to_netcdf(engine='scipy')``, plan/solution.py:419-431)."""
+        d = self.to_dict(include_simulation_data=False)
+        if include_simulation_data:
+            d["simulation_result"] = base64.b64encode(netcdf.to_bytes(self.simulation_result)).decode("utf-8")
         return json.dumps(d, separators=(",", ":")) if compact else json.dumps(d, indent=4)
 
     @staticmethod
@@ -236,11 +249,34 @@ class Solution:
         d["foci"] = [Point.from_dict(p) for p in d["foci"]]
         if d.get("target") is not None:
             d["target"] = Point.from_dict(d["target"])
+        if isinstance(d.get("simulation_result"), str):
+            d["simulation_result"] = netcdf.read(base64.b64decode(d["simulation_result"].encode("utf-8")))
         return Solution(**d)
 
     @staticmethod
     def from_json(json_string: str, simulation_result=None) -> "Solution":
         d = json.loads(json_string)
         if simulation_result is not None:
+            if "simulation_result" in d:
+                raise ValueError(
+                    "A simulation result was provided while the json string already contains `simulation_result`. "
+                    "Unclear which to use!")
             d["simulation_result"] = simulation_result
         return Solution.from_dict(d)
+
+    def to_files(self, json_filepath, nc_filepath=None) -> None:
+        """JSON (everything but the volumes) + ``.nc`` (the volumes; same stem unless given),
+        plan/solution.py:491-507.  The ``.nc`` is NetCDF-3 — see ``util/netcdf.py``."""
+        json_filepath = Path(json_filepath)
+        nc_filepath = _default_nc_path(json_filepath) if nc_filepath is None else Path(nc_filepath)
+        json_filepath.parent.mkdir(parents=True, exist_ok=True)
+        nc_filepath.parent.mkdir(parents=True, exist_ok=True)
+        json_filepath.write_text(self.to_json(include_simulation_data=False, compact=False))
+        netcdf.write(self.simulation_result, nc_filepath)
+
+    @staticmethod
+    def from_files(json_filepath, nc_filepath=None) -> "Solution":
+        """plan/solution.py:509-525."""
+        json_filepath = Path(json_filepath)
+        nc_filepath = _default_nc_path(json_filepath) if nc_filepath is None else Path(nc_filepath)
+        return Solution.from_json(json_filepath.read_text(), simulation_result=netcdf.read(nc_filepath))

@@ -117,6 +117,23 @@ def test_detached_solution_is_uploaded_for_analysis():
     assert an2.mainlobe_pnp_MPa == an.mainlobe_pnp_MPa and an2.global_isppa_Wcm2 == an.global_isppa_Wcm2
 
 
+def test_solution_saved_to_files_reloads_and_analyzes_identically(tmp_path):
+    """plan/solution.py:491-525: JSON + .nc round trip of a computed Solution; the reloaded (host-only) volumes
+    are uploaded again and give the same analysis, to_dict included."""
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 40))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup,
+                        focal_pattern=ol.Wheel(center=True, num_spokes=3, spoke_radius=2.0))
+    sol, _, an = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=True)
+    sol.to_files(tmp_path / "s.json")
+    back = ol.Solution.from_files(tmp_path / "s.json")
+    for k in ("p_max", "p_min", "intensity"):
+        assert np.array_equal(back.simulation_result[k].data, sol.simulation_result[k].data)
+    assert np.array_equal(back.delays, sol.delays) and np.array_equal(back.apodizations, sol.apodizations)
+    assert back.voltage == sol.voltage and back.num_foci() == 4
+    assert back.analyze().to_dict() == sol.analyze().to_dict()
+
+
 def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
     """Solution.analyze's device-side reductions vs a NumPy / SciPy recomputation on the fetched volumes,
     following plan/solution.py:135-281 and plan/solution_analysis.py:306-574 step by step."""

@@ -211,6 +211,115 @@ def test_solution_container_checks_and_views():
     assert rt.transducer.numelements() == 4 and rt.foci[0].units == "mm"
 
 
+def test_solution_persistence_json_blob_and_files(tmp_path):
+    """plan/solution.py:411-533: the volumes travel as NetCDF-3 (what the reference embeds with engine='scipy');
+    the reference's own round-trip tests are tests/test_solution.py:59-105."""
+    import base64
+    from openlifu_amd.util import dataset as ds, netcdf
+    coords = ol.SimSetup(spacing=1.0, x_extent=(0, 1), y_extent=(-1, 1), z_extent=(0, 3)).get_coords()
+    rng = np.random.default_rng(147)
+    vols = {}
+    for name, (units, long_name) in {"p_max": ("Pa", "PPP"), "p_min": ("Pa", "PNP"),
+                                     "intensity": ("W/cm^2", "Intensity")}.items():
+        vols[name] = (rng.random((2, 2, 3, 4)).astype(np.float32), coords, {"units": units, "long_name": long_name})
+    sol = ol.Solution(id="sol_1", name="One", delays=rng.random((2, 4)), apodizations=np.ones((2, 4)),
+                      foci=[ol.Point(position=(0, 0, 30)), ol.Point(position=(1, 0, 30))],
+                      target=ol.Point(position=(0, 0, 30)), transducer=ol.Transducer.gen_matrix_array(2, 2),
+                      simulation_result=ds.stack_foci(vols), voltage=12.5)
+
+    def same(a, b):
+        assert list(a.keys()) == list(b.keys()) == ["p_max", "p_min", "intensity"]
+        for k in a.keys():
+            assert b[k].dims == ("focal_point_index", "x", "y", "z") and b[k].data.dtype == np.float32
+            assert np.array_equal(a[k].data, b[k].data) and dict(b[k].attrs) == dict(a[k].attrs)
+            for d in b[k].dims:
+                assert np.array_equal(np.asarray(a[k].coords[d].data), np.asarray(b[k].coords[d].data))
+        assert dict(b["p_min"].coords["z"].attrs) == {"units": "mm", "long_name": "Axial"}
+        assert np.asarray(b["p_min"].coords["focal_point_index"].data).dtype == np.int64
+
+    js = sol.to_json(include_simulation_data=True, compact=True)
+    raw = base64.b64decode(json.loads(js)["simulation_result"])
+    assert raw[:4] == b"CDF\x02"  # NetCDF-3, 64-bit offsets: what scipy's / xarray's scipy engine writes
+    rt = ol.Solution.from_json(js)
+    same(sol.simulation_result, rt.simulation_result)
+    assert rt.voltage == 12.5 and np.array_equal(rt.delays, sol.delays) and rt.target.position[2] == 30
+    rt.simulation_result["p_min"][1].data *= 2  # loaded volumes are writable, caller-owned (Solution.scale idiom)
+    assert "simulation_result" not in json.loads(sol.to_json())
+    with pytest.raises(ValueError, match="Unclear which to use"):
+        ol.Solution.from_json(js, simulation_result=sol.simulation_result)
+
+    jpath = tmp_path / "deep" / "sol_1.v2.json"
+    sol.to_files(jpath)
+    assert (tmp_path / "deep" / "sol_1.nc").exists()  # name up to the first dot (plan/solution.py:31-35)
+    same(sol.simulation_result, ol.Solution.from_files(jpath).simulation_result)
+    sol.to_files(jpath, tmp_path / "elsewhere" / "vol.nc")
+    rt2 = ol.Solution.from_files(jpath, tmp_path / "elsewhere" / "vol.nc")
+    same(sol.simulation_result, rt2.simulation_result)
+    assert rt2.id == "sol_1" and rt2.num_foci() == 2
+    hdf = tmp_path / "h5.nc"
+    hdf.write_bytes(b"\x89HDF\r\n\x1a\n" + bytes(64))
+    with pytest.raises(ValueError, match="NetCDF-4/HDF5"):
+        netcdf.read(hdf)
+    empty = ol.Solution.from_json(ol.Solution().to_json(include_simulation_data=True))
+    assert len(empty.simulation_result) == 0
+
+
+def test_parameter_constraints_and_analysis_report():
+    """The known answers of the reference's tests/test_param_constraints.py:16-79 and
+    tests/test_solution_analysis.py:10-52 (compare table, status ladder, dict / JSON round trips)."""
+    from openlifu_amd.plan import ParameterConstraint as PC, SolutionAnalysis
+    with pytest.raises(ValueError, match="At least one of warning_value or error_value must be set"):
+        PC(operator="<=")
+    with pytest.raises(ValueError, match="Warning value must be a sorted tuple"):
+        PC(operator="within", warning_value=(4.0, 2.0))
+    with pytest.raises(ValueError, match="Error value must be a single value"):
+        PC(operator=">", error_value=(1.0, 2.0))
+    table = [(3, "<", 5, True), (5, "<", 5, False), (5, "<=", 5, True), (6, ">", 5, True), (5, ">=", 5, True),
+             (3, "within", (2, 4), True), (2, "within", (2, 4), False), (1, "inside", (2, 4), False),
+             (2, "inside", (2, 4), True), (3, "inside", (2, 4), True), (1, "outside", (2, 4), True),
+             (2, "outside", (2, 4), False), (2, "outside_inclusive", (2, 4), True),
+             (3, "outside_inclusive", (2, 4), False)]
+    for value, op, threshold, expected in table:
+        assert PC.compare(value, op, threshold) is expected
+    with pytest.raises(ValueError, match="Unsupported operator"):
+        PC.compare(1, "~", 2)
+    thr = PC(operator="<=", warning_value=5.5, error_value=7.0)
+    assert [thr.get_status(v) for v in (3.0, 6.5, 7.5)] == ["ok", "warning", "error"]
+    rng = PC(operator="within", warning_value=(1.0, 4.0), error_value=(0.0, 5.0))
+    assert [rng.get_status(v) for v in (2.5, 0.5, 5.5)] == ["ok", "warning", "error"]
+    assert PC.from_dict(json.loads(json.dumps(rng.to_dict()))) == rng  # (lo, hi) survive the JSON list form
+    assert list(thr.to_table()["Value"]) == ["value <= 5.5", "value <= 7.0"]
+
+    sa = SolutionAnalysis(mainlobe_pnp_MPa=[1.1, 1.2], mainlobe_isppa_Wcm2=[10.0, 12.0],
+                          mainlobe_ispta_mWcm2=[500.0, 520.0], global_pnp_MPa=[1.3, 1.5], global_isppa_Wcm2=[13.0],
+                          p0_MPa=[1.0, 1.1], TIC=0.7, power_W=25.0, MI=1.2, global_ispta_mWcm2=540.0,
+                          param_constraints={"global_pnp_MPa": PC(operator="<=", warning_value=1.4, error_value=1.6)})
+    assert SolutionAnalysis.from_dict(sa.to_dict()) == sa
+    for compact in (True, False):
+        assert SolutionAnalysis.from_json(sa.to_json(compact)) == sa
+    sa2 = SolutionAnalysis.from_json(sa.to_json())
+    for k in ("target_position", "focal_centroid"):
+        for ax in ("lat", "ele", "ax"):
+            setattr(sa2, f"{k}_{ax}_mm", [0.0, 1.0])
+    for db in (3, 6):
+        for ax in ("lat", "ele", "ax"):
+            setattr(sa2, f"beamwidth_{ax}_{db}dB_mm", [1.5, 2.5])
+    sa2.sidelobe_pnp_MPa = [0.5, 0.6]; sa2.sidelobe_isppa_Wcm2 = [5.0, 5.5]
+    sa2.sidelobe_to_mainlobe_pressure_ratio = [0.4, 0.5]; sa2.sidelobe_to_mainlobe_intensity_ratio = [0.5, 0.4]
+    t = sa2.to_table().set_index("id")
+    assert t.loc["global_pnp_MPa", "Value"] == "1.500" and t.loc["global_pnp_MPa", "Status"] == "❗"
+    assert bool(t.loc["global_pnp_MPa", "_warning"]) and not bool(t.loc["global_pnp_MPa", "_error"])
+    assert t.loc["beamwidth_ax_3dB_mm", "Value"] == "2.00" and t.loc["MI", "Value"] == "1.20"
+    assert "voltage_V" not in t.index  # unset scalars are left out
+    t1 = sa2.to_table(focus_index=0).set_index("id")
+    assert t1.loc["global_pnp_MPa", "Value"] == "1.300" and t1.loc["TIC", "Value"] == "N/A"
+    with pytest.raises(ValueError, match="Unknown parameter constraint"):
+        sa2.to_table(constraints={"nonsense": thr})
+    proto = ol.Protocol(param_constraints={"MI": thr})
+    back = ol.Protocol.from_json(proto.to_json())
+    assert back.param_constraints["MI"] == thr
+
+
 def test_protocol_checks_before_touching_the_gpu():
     from openlifu_amd.plan import OnPulseMismatchAction, TargetConstraints
     p = ol.Protocol(target_constraints=[TargetConstraints(dim="x", units="mm", min=-5, max=5)])
