@@ -123,7 +123,8 @@ def test_solution_saved_to_files_reloads_and_analyzes_identically(tmp_path):
     arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
     setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 40))
     proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup,
-                        focal_pattern=ol.Wheel(center=True, num_spokes=3, spoke_radius=2.0))
+                        sequence=ol.Sequence(pulse_count=8, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=3, spoke_radius=2.0))
     sol, _, an = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=True)
     sol.to_files(tmp_path / "s.json")
     back = ol.Solution.from_files(tmp_path / "s.json")
@@ -131,7 +132,13 @@ def test_solution_saved_to_files_reloads_and_analyzes_identically(tmp_path):
         assert np.array_equal(back.simulation_result[k].data, sol.simulation_result[k].data)
     assert np.array_equal(back.delays, sol.delays) and np.array_equal(back.apodizations, sol.apodizations)
     assert back.voltage == sol.voltage and back.num_foci() == 4
-    assert back.analyze().to_dict() == sol.analyze().to_dict()
+    a, b = back.analyze().to_dict(), sol.analyze().to_dict()
+    assert a.keys() == b.keys()
+    for k in a:  # NaN-aware (the axial -6 dB width leaves this small grid); the centroid sums use float atomics
+        if isinstance(a[k], (list, float)):
+            np.testing.assert_allclose(np.asarray(a[k], float), np.asarray(b[k], float), rtol=1e-12, atol=1e-12)
+        else:
+            assert a[k] == b[k]
 
 
 def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
