@@ -209,11 +209,22 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = ctx.profile_end()
+    compute_only = None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        if gather:  # reported beside the headline (never instead of it): the same steps without the exchange
+            k2 = min(args.steps, 200)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                ctx.field_launch()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            compute_only = {"steps": k2, "ms_per_step": float(t[0]) / k2 * 1e3}
 
     if rank == 0:
         pairs_per_step = float(V) * N * F * world
@@ -272,7 +283,9 @@ def main():
                        "kernel": ctx.field_variant(),
                        "reassembly": (f"rccl-{args.reassemble}-overlapped" if gather else
                                       ("none" if (world == 1 or args.reassemble == "none") else "skipped")),
-                       **({"reassembly_note": gather_note} if gather_note else {})},
+                       **({"reassembly_note": gather_note} if gather_note else {}),
+                       **({"without_exchange": dict(compute_only, value=float(V) * N * F * world /
+                                                    (compute_only["ms_per_step"] * 1e-3) / 1e6)} if compute_only else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
