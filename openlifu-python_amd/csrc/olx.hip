@@ -110,6 +110,13 @@ static int fail(olx_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                          \
     } while (0)
 
+// call-scoped device scratch: freed on every return path
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) hipFree(p); }
+    template <class T> T* at(size_t byte_off) const { return reinterpret_cast<T*>(static_cast<unsigned char*>(p) + byte_off); }
+};
+
 extern "C" {
 
 int olx_abi_version(void) { return OLX_ABI_VERSION; }
@@ -272,11 +279,14 @@ int olx_bf_quantize(olx_ctx* c, double bf_clk_hz, int width_bits, uint16_t* tick
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->n_foci, n = c->n_el;
     const size_t fn = (size_t)F * n;
-    unsigned short* d_t = nullptr; unsigned char* d_a = nullptr; double* d_m = nullptr; int* d_o = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_t, sizeof(unsigned short) * fn));
-    HIPCHK(c, hipMalloc((void**)&d_a, fn));
-    HIPCHK(c, hipMalloc((void**)&d_m, sizeof(double) * F));
-    HIPCHK(c, hipMalloc((void**)&d_o, sizeof(int) * F));
+    // one scratch allocation: [F] max apod (fp64) | [F] overflow counts | [F N] ticks | [F N] apod-off bytes
+    unsigned char* scratch = nullptr;
+    const size_t off_o = sizeof(double) * F, off_t = off_o + sizeof(int) * (size_t)((F + 1) & ~1), off_a = off_t + sizeof(unsigned short) * fn;
+    HIPCHK(c, hipMalloc((void**)&scratch, off_a + fn));
+    double* d_m = reinterpret_cast<double*>(scratch);
+    int* d_o = reinterpret_cast<int*>(scratch + off_o);
+    unsigned short* d_t = reinterpret_cast<unsigned short*>(scratch + off_t);
+    unsigned char* d_a = scratch + off_a;
     hipLaunchKernelGGL(bf_quantize_k, dim3(F), dim3(BF_THREADS), 0, c->stream, c->d_delays, c->d_apod, n, bf_clk_hz,
                        (1u << width_bits) - 1u, d_t, d_a, d_m, d_o);
     int rc = OLX_OK;
@@ -286,7 +296,7 @@ int olx_bf_quantize(olx_ctx* c, double bf_clk_hz, int width_bits, uint16_t* tick
     if (!rc && max_apod_out && hipMemcpyAsync(max_apod_out, d_m, sizeof(double) * F, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
     if (!rc && n_overflow_out && hipMemcpyAsync(n_overflow_out, d_o, sizeof(int) * F, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = OLX_EHIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = OLX_EHIP;
-    hipFree(d_t); hipFree(d_a); hipFree(d_m); hipFree(d_o);
+    hipFree(scratch);
     if (rc == OLX_EHIP) return fail(c, OLX_EHIP, "olx_bf_quantize: HIP error");
     return rc;
 }
@@ -357,6 +367,24 @@ static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], d
     L.ax = ax; L.ay = ay; L.nsa = nsa; L.nsb = nsb; L.mx = mx; L.my = my; L.n_pad = nsa * nsb * 64;
     L.x0 = xs[0]; L.y0 = ys[0]; L.px = px; L.py = py; L.min_d2 = min_d2; L.clamp = clamp;
     L.ok = true;
+}
+
+// Kernel 2e: MFMA row tiles (16 rows) one plane pair needs over all cosets and parts -- per (coset, part)
+// ceil(COS_P KX KY / 16) -- for a computed region of wx x wy voxels at lattice pitch (mx, my) voxels.
+static long long coset_tiles16(int wx, int wy, int mx, int my, int nt) {
+    const int kxw = cos_kxw(nt);
+    const int nsx = ((wx + 2 * mx - 1) / (2 * mx) + kxw - 1) / kxw, nsy = ((wy + my - 1) / my + COS_KYW - 1) / COS_KYW;
+    long long t16 = 0;
+    for (int rx = 0; rx < 2 * mx; ++rx)
+        for (int ry = 0; ry < my; ++ry) {
+            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / my + 1 : 0;
+            for (int sx = 0; sx < nsx; ++sx)
+                for (int sy = 0; sy < nsy; ++sy) {
+                    const int KX = (sx + 1) * kxa / nsx - sx * kxa / nsx, KY = (sy + 1) * kya / nsy - sy * kya / nsy;
+                    t16 += (COS_P * KX * KY + 15) / 16;
+                }
+        }
+    return t16;
 }
 
 // Steering-dependent part of the kernel-2 variant choice (runs whenever the steering table changed):
@@ -449,17 +477,8 @@ static int configure_variant(olx_ctx* c) {
         // sweep: 4.6 vs 4.9 ms; 8-focus shard: 0.74 vs 0.58 ms) -- unless the family is pinned for A/B runs
         // Kernel 2e's NT = 4 shape (3 tiles per wave) takes the sweep when its tiles are reasonably full.
         auto coset_fill = [&](int nt) {
-            const olx_ctx::Lattice& A = c->lat;
-            const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), kxw = cos_kxw(nt);
-            const int nsx = ((wx + 2 * A.mx - 1) / (2 * A.mx) + kxw - 1) / kxw, nsy = ((wy + A.my - 1) / A.my + COS_KYW - 1) / COS_KYW;
-            long long t16 = 0;
-            for (int rx = 0; rx < 2 * A.mx; ++rx)
-                for (int ry = 0; ry < A.my; ++ry) {
-                    const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
-                    for (int sx = 0; sx < nsx; ++sx)
-                        for (int sy = 0; sy < nsy; ++sy)
-                            t16 += (COS_P * ((sx + 1) * kxa / nsx - sx * kxa / nsx) * ((sy + 1) * kya / nsy - sy * kya / nsy) + 15) / 16;
-                }
+            const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0);
+            const long long t16 = coset_tiles16(wx, wy, c->lat.mx, c->lat.my, nt);
             return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
         };
         if (c->use_lattice && c->nt >= 4 && c->force_kind != 4 && ((c->flags & OLX_OUT_COMPLEX) || coset_fill(c->nt) < 0.6)) c->use_lattice = false;
@@ -548,21 +567,8 @@ static int configure_variant(olx_ctx* c) {
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
             // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-            long long tiles16 = 0;
-            {
-                const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo, kxw = cos_kxw(c->nt);
-                const int nsx = ((wx + 2 * A.mx - 1) / (2 * A.mx) + kxw - 1) / kxw, nsy = ((wy + A.my - 1) / A.my + COS_KYW - 1) / COS_KYW;
-                for (int rx = 0; rx < 2 * A.mx; ++rx)
-                    for (int ry = 0; ry < A.my; ++ry) {
-                        const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
-                        for (int sx = 0; sx < nsx; ++sx)
-                            for (int sy = 0; sy < nsy; ++sy) {
-                                const int KX = (sx + 1) * kxa / nsx - sx * kxa / nsx, KY = (sy + 1) * kya / nsy - sy * kya / nsy;
-                                tiles16 += (COS_P * KX * KY + 15) / 16;
-                            }
-                    }
-                if (tiles16 > 0 && (double)COS_P * wx * wy / (16.0 * (double)tiles16) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
-            }
+            const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
+            if (tiles16 > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
@@ -606,15 +612,16 @@ static int configure_variant(olx_ctx* c) {
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
             } else {
-            const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
-            snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
-                     "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                     total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
+                snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->lat_mt, c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
             }
-        } else
-        snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
-                 P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
-                 n_img, ntiles);
+        } else {
+            snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
+                     P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
+                     n_img, ntiles);
+        }
     } else if (c->mx * c->my * c->nf == 1) {
         snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
@@ -1099,7 +1106,6 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         HIPCHK(c, hipMalloc((void**)&c->d_inv2z, sizeof(float) * sv));
         HIPCHK(c, hipMemcpy(c->d_inv2z, iz.data(), sizeof(float) * sv, hipMemcpyHostToDevice));
     }
-    (void)nvox;
     HeteroParams& H = c->hp;
     H.n_planes = np; H.nxg = nx; H.nyg = ny; H.xg_begin = c->slab.x_begin;
     H.inv_hx = (float)(1.0 / (g.spacing[0] * rev)); H.inv_hy = (float)(1.0 / (g.spacing[1] * rev));
@@ -1144,7 +1150,12 @@ int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
     if (iters < 1 || !ms_each) return fail(c, OLX_EINVAL, "olx_field_time: iters < 1 or null output");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_time: nothing planned");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<hipEvent_t> ev(iters + 1);
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (auto e : ev) if (e) hipEventDestroy(e); }
+    } T;
+    T.ev.assign(iters + 1, nullptr);
+    std::vector<hipEvent_t>& ev = T.ev;
     for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
     int rc = pack_if_needed(c);
     if (rc) return rc;
@@ -1157,7 +1168,6 @@ int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!rc)
         for (int i = 0; i < iters; ++i) HIPCHK(c, hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]));
-    for (auto& e : ev) hipEventDestroy(e);
     return rc;
 }
 
@@ -1252,10 +1262,11 @@ int olx_field_masked_moments(olx_ctx* c, const double* A, const double* aspect, 
     if (!A || !aspect || !cutoff || !moments_out) return fail(c, OLX_EINVAL, "olx_field_masked_moments: null argument");
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->plan_foci;
-    double* d_A = nullptr; float* d_cut = nullptr; double* d_out = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_A, sizeof(double) * 12 * F));
-    HIPCHK(c, hipMalloc((void**)&d_cut, sizeof(float) * F));
-    HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * 4 * F));
+    DevScratch scratch;   // [12 F] focal-frame rows | [4 F] moments (fp64) | [F] cutoffs
+    HIPCHK(c, hipMalloc(&scratch.p, sizeof(double) * 16 * F + sizeof(float) * F));
+    double* d_A = scratch.at<double>(0);
+    double* d_out = scratch.at<double>(sizeof(double) * 12 * F);
+    float* d_cut = scratch.at<float>(sizeof(double) * 16 * F);
     HIPCHK(c, hipMemcpyAsync(d_A, A, sizeof(double) * 12 * F, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_cut, cutoff, sizeof(float) * F, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 4 * F, c->stream));
@@ -1265,7 +1276,6 @@ int olx_field_masked_moments(olx_ctx* c, const double* A, const double* aspect, 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(moments_out, d_out, sizeof(double) * 4 * F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_A); hipFree(d_cut); hipFree(d_out);
     return OLX_OK;
 }
 
@@ -1277,9 +1287,10 @@ int olx_field_sample(olx_ctx* c, int which, int focus, const double* pts_m, int 
     if (which != 0 && which != 1) return fail(c, OLX_EINVAL, "olx_field_sample: which must be 0 or 1");
     if (which == 1 && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_sample: intensity not planned");
     HIPCHK(c, hipSetDevice(c->device));
-    double* d_pts = nullptr; float* d_o = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_pts, sizeof(double) * 3 * npts));
-    HIPCHK(c, hipMalloc((void**)&d_o, sizeof(float) * npts));
+    DevScratch scratch;   // [3 npts] points (fp64) | [npts] samples
+    HIPCHK(c, hipMalloc(&scratch.p, sizeof(double) * 3 * npts + sizeof(float) * npts));
+    double* d_pts = scratch.at<double>(0);
+    float* d_o = scratch.at<float>(sizeof(double) * 3 * npts);
     HIPCHK(c, hipMemcpyAsync(d_pts, pts_m, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, c->stream));
     PeakParams P; fill_scan_params(c, P, nullptr);
     const float* vol = (which == 0 ? c->d_pmag[c->cur] : c->d_inten) + (size_t)focus * c->fp.vox;
@@ -1287,7 +1298,6 @@ int olx_field_sample(olx_ctx* c, int which, int focus, const double* pts_m, int 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, d_o, sizeof(float) * npts, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_pts); hipFree(d_o);
     return OLX_OK;
 }
 
