@@ -141,6 +141,51 @@ def test_solution_saved_to_files_reloads_and_analyzes_identically(tmp_path):
             assert a[k] == b[k]
 
 
+def test_analyze_ratio_edge_cases_known_answers():
+    """The reference's own known-answer test of Solution.analyze (tests/test_solution.py:173-320): a hand-made
+    3 x 1 x 3 result with one mainlobe and one sidelobe voxel, then the zero / zero, x / zero and zero / x ratios."""
+    from openlifu_amd.plan import SolutionAnalysisOptions
+    from openlifu_amd.util import dataset as ds
+    arr = ol.Transducer(id="trans_456", name="Test Transducer", frequency=1e6, units="m", elements=[
+        ol.Element(index=i + 1, position=[v, v, 0], units="m") for i, v in enumerate((-14, -2, 2, 14))])
+    coords = ds.make_coords({"x": np.array([-0.01, 0, 0.01]), "y": np.array([0.0]), "z": np.array([0.04, 0.05, 0.06])},
+                            {d: {"units": "m"} for d in "xyz"})
+    options = SolutionAnalysisOptions(mainlobe_radius=0.005, sidelobe_radius=0.005, mainlobe_aspect_ratio=(1, 1, 1),
+                                      sidelobe_zmin=0.001, distance_units="m")
+
+    def analyze(main_p, side_p, main_i, side_i):
+        p = np.zeros((1, 3, 1, 3), np.float32); it = np.zeros((1, 3, 1, 3), np.float32)
+        p[0, 1, 0, 1], p[0, 2, 0, 2] = main_p, side_p
+        it[0, 1, 0, 1], it[0, 2, 0, 2] = main_i, side_i
+        sol = ol.Solution(transducer=arr, delays=np.zeros((1, 4)), apodizations=np.ones((1, 4)), pulse=ol.Pulse(frequency=42),
+                          sequence=ol.Sequence(pulse_count=27, pulse_interval=2, pulse_train_interval=2 * 27 + 5),
+                          foci=[ol.Point(id="test_focus_point", position=np.array([0, 0, 0.05]), units="m")],
+                          simulation_result=ds.stack_foci({"p_min": (p, coords, {"units": "Pa"}), "p_max": (p.copy(), coords, {"units": "Pa"}),
+                                                           "intensity": (it, coords, {"units": "W/cm^2"})}))
+        return sol.analyze(options=options)
+
+    a = analyze(1.0e6, 0.5e6, 10.0, 2.0)
+    assert np.isclose(a.mainlobe_pnp_MPa[0], 1.0) and np.isclose(a.sidelobe_pnp_MPa[0], 0.5)
+    assert np.isclose(a.sidelobe_to_mainlobe_pressure_ratio[0], 0.5)
+    assert np.isclose(a.mainlobe_isppa_Wcm2[0], 10.0) and np.isclose(a.sidelobe_isppa_Wcm2[0], 2.0)
+    assert np.isclose(a.sidelobe_to_mainlobe_intensity_ratio[0], 0.2)
+    for f in a.__dataclass_fields__:  # tests/test_solution.py:146-156: floats or lists of floats
+        v = getattr(a, f)
+        assert isinstance(v, (dict, float)) or v is None or (isinstance(v, list) and all(isinstance(x, float) for x in v)), (f, v)
+    a = analyze(1.0e6, 0.0, 10.0, 2.0)
+    assert a.mainlobe_pnp_MPa[0] == 1.0 and a.sidelobe_pnp_MPa[0] == 0.0 and a.sidelobe_to_mainlobe_pressure_ratio[0] == 0.0
+    a = analyze(1.0e6, 0.5e6, 10.0, 0.0)
+    assert a.mainlobe_isppa_Wcm2[0] == 10.0 and a.sidelobe_isppa_Wcm2[0] == 0.0 and a.sidelobe_to_mainlobe_intensity_ratio[0] == 0.0
+    a = analyze(0.0, 0.5e6, 10.0, 2.0)
+    assert a.mainlobe_pnp_MPa[0] == 0.0 and a.sidelobe_pnp_MPa[0] > 0 and a.sidelobe_to_mainlobe_pressure_ratio[0] == np.inf
+    a = analyze(1.0e6, 0.5e6, 0.0, 2.0)
+    assert a.mainlobe_isppa_Wcm2[0] == 0.0 and a.sidelobe_isppa_Wcm2[0] > 0 and a.sidelobe_to_mainlobe_intensity_ratio[0] == np.inf
+    a = analyze(0.0, 0.0, 10.0, 2.0)
+    assert a.mainlobe_pnp_MPa[0] == 0.0 and a.sidelobe_pnp_MPa[0] == 0.0 and np.isnan(a.sidelobe_to_mainlobe_pressure_ratio[0])
+    a = analyze(1.0e6, 0.5e6, 0.0, 0.0)
+    assert a.mainlobe_isppa_Wcm2[0] == 0.0 and a.sidelobe_isppa_Wcm2[0] == 0.0 and np.isnan(a.sidelobe_to_mainlobe_intensity_ratio[0])
+
+
 def test_analyze_centroid_beamwidth_ispta_match_host_recomputation():
     """Solution.analyze's device-side reductions vs a NumPy / SciPy recomputation on the fetched volumes,
     following plan/solution.py:135-281 and plan/solution_analysis.py:306-574 step by step."""

@@ -334,6 +334,50 @@ def test_protocol_checks_before_touching_the_gpu():
         p.check_target([ol.Point()])
 
 
+@pytest.mark.parametrize("action,expected", [("ERROR", None), ("ROUND", 5), ("ROUNDUP", 10), ("ROUNDDOWN", 5)])
+def test_fix_pulse_mismatch_actions(action, expected):
+    """tests/test_protocol.py:84-110: 7 pulses over the 5 foci of a Wheel, every OnPulseMismatchAction."""
+    import logging
+    from openlifu_amd.plan import OnPulseMismatchAction
+    p = ol.Protocol(sequence=ol.Sequence(pulse_count=7, pulse_train_interval=0))
+    foci = ol.focal_patterns.Wheel(center=True, num_spokes=4).get_targets(ol.Point(position=(0, 0, 30)))
+    assert len(foci) == 5
+    logging.disable(logging.CRITICAL)
+    try:
+        if expected is None:
+            with pytest.raises(ValueError, match="not a multiple of the number of foci"):
+                p.fix_pulse_mismatch(OnPulseMismatchAction[action], foci)
+        else:
+            p.fix_pulse_mismatch(OnPulseMismatchAction[action], foci)
+            assert p.sequence.pulse_count == expected
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+@pytest.mark.parametrize("use_gpu", [True, False, None])
+@pytest.mark.parametrize("gpu_is_available", [True, False])
+def test_calc_solution_passes_use_gpu_to_the_seam(monkeypatch, use_gpu, gpu_is_available):
+    """tests/test_protocol.py:112-160: a replaced run_simulation receives gpu = use_gpu, or gpu_available() for None."""
+    import openlifu_amd.plan.protocol as pp
+    from openlifu_amd.sim.field import dataset_from_fields
+    seen = []
+
+    def fake(**kw):
+        seen.append(kw["gpu"])
+        n = [len(kw["params"].coords[d]) for d in "xyz"]
+        return dataset_from_fields({"pmag": np.ones([1] + n, np.float32), "intensity": np.ones([1] + n, np.float32)},
+                                   kw["params"].coords, focus=0), None
+
+    monkeypatch.setattr(pp, "gpu_available", lambda: gpu_is_available)
+    monkeypatch.setattr(pp, "run_simulation", fake)
+    monkeypatch.setattr(pp.Protocol, "beamform_foci", lambda self, arr, foci, params: (np.zeros((len(foci), 4)), np.ones((len(foci), 4)), False))
+    monkeypatch.setattr(pp.Solution, "_bind_device", lambda self: (_ for _ in ()).throw(AssertionError("device touched")))
+    p = ol.Protocol(sim_setup=ol.SimSetup(spacing=2.0, x_extent=(-4, 4), y_extent=(-4, 4), z_extent=(0, 6)))
+    with pytest.raises(AssertionError, match="device touched"):  # the aggregation after the seam is device-side
+        p.calc_solution(ol.Point(position=(0, 0, 30)), ol.Transducer.gen_matrix_array(2, 2), scale=False, use_gpu=use_gpu)
+    assert seen == [gpu_is_available if use_gpu is None else use_gpu]
+
+
 def test_run_simulation_seam_can_be_replaced(monkeypatch):
     """The reference's tests swap `openlifu.plan.protocol.run_simulation` for a mock
     (tests/test_protocol.py:135-142); the same seam exists here and calc_solution honours it."""
