@@ -87,6 +87,21 @@ def test_transducer_table_and_generators(golden):
     assert [e.pin for e in arr.elements] == list(range(1, 13))
 
 
+def test_transducer_transform_literals():
+    """Known answers the reference's tests/test_transducer.py:39-90 hold as literals."""
+    t = ol.Transducer(units="cm").convert_transform(np.array([[1, 0, 0, 2], [0, 1, 0, 3], [0, 0, 1, 4], [0, 0, 0, 1.0]]), units="m")
+    assert np.allclose(t, [[1, 0, 0, 200], [0, 1, 0, 300], [0, 0, 1, 400], [0, 0, 0, 1]])
+    arr = ol.Transducer.gen_matrix_array(nx=3, ny=2, units="cm")
+    assert np.allclose(arr.get_effective_origin(apodizations=np.ones(arr.numelements())), np.zeros(3))
+    for e in range(arr.numelements()):
+        one = np.zeros(arr.numelements()); one[e] = 0.5
+        assert np.allclose(arr.get_effective_origin(apodizations=one, units="um"), arr.get_positions(units="um")[e])
+    tr = ol.Transducer(units="mm")
+    tr.standoff_transform = np.array([[-0.1, 0.9, 0, 20], [0.9, 0.1, 0, 30], [0, 0, 1, 40], [0, 0, 0, 1]])
+    assert np.allclose(tr.get_standoff_transform_in_units("cm"), [[-0.1, 0.9, 0, 2], [0.9, 0.1, 0, 3], [0, 0, 1, 4], [0, 0, 0, 1]])
+    assert isinstance(ol.Transducer.from_json(arr.to_json()).standoff_transform, np.ndarray)
+
+
 def test_transducer_array_flattening(golden):
     g5 = golden.npz("g5_transducer.npz")
     base = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4, kerf=0.5, units="mm", id="mod", sensitivity=2e4)
