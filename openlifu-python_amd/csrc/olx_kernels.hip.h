@@ -1221,17 +1221,23 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const bool fast = (P.nz % COS_ZB) == 0;
     // |p| / intensity in place, then one staged pass per column tile (complex output is served by kernel 2d: the host
     // does not select this kernel when OLX_OUT_COMPLEX is planned)
-    const float s_p = P.out_scale, s_i = P.out_scale * P.out_scale * P.inten_scale;   // scales applied after the square
+    // The |p| lane (part 0) and its partner, the intensity lane (part 1), hold the same (S re)^2 + (S im)^2 for every row, and
+    // only the |p| lane needs its root: per pair of rows the |p| lane takes the root of the first and the partner lane of the
+    // second (handed back through the quad swap) -- one quarter-rate instruction per two rows instead of two.
+    const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;   // scales applied after the square
 #pragma unroll
     for (int t = 0; t < COS_MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = acc[t][nt][r];
-                const float sq = a * a;
-                const float m2 = sq + quad_swap1(sq);      // (S re)^2 + (S im)^2 (partner lane holds the other part)
-                acc[t][nt][r] = part == 0 ? __builtin_amdgcn_sqrtf(m2) * s_p : m2 * s_i;
+            for (int r = 0; r < 4; r += 2) {
+                const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
+                const float sq0 = a0 * a0, sq1 = a1 * a1;
+                const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
+                const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
+                const float ys = quad_swap1(y);
+                acc[t][nt][r] = (part == 0 ? y : m0) * s_lane;
+                acc[t][nt][r + 1] = (part == 0 ? ys : m1) * s_lane;
             }
     // (the column tile is a compile-time argument so that the accumulators keep static indices; the pass loop is rolled)
     auto stage_and_store = [&](auto nt_c) {          // one pass: GROUP column tiles nt0 .. nt0 + GROUP - 1, two barriers
