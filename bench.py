@@ -253,7 +253,9 @@ def main():
             floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
             ceil_pairs = float(V) * N * F / floor_s
             cyc_per_g, pairs_per_g = None, None
-            model = (f"{n_mfma} v_mfma_f32_16x16x32_f16 per launch (3 fp16 hi/lo products, padded row tiles included) at "
+            what = ("1 fp16 hi*hi product per K-step + one K=128 e4m3 instruction (2 units) per two K-steps for both hi/lo corrections"
+                    if "fp8corr" in name else "3 fp16 hi/lo products")
+            model = (f"{n_mfma} matrix-pipe units of one v_mfma_f32_16x16x32_f16 per launch ({what}, padded row tiles included) at "
                      f"16 cycles each on {N_SIMD} SIMDs @{CLK_GHZ} GHz = {floor_s * 1e3:.3f} ms if nothing else issued")
         elif mm:  # kernel 2c: per G 5 plain + 3 transcendental + 4 half-rate (hi/lo split) VALU instructions, plus the
             # issue slots its share of the 3*NT MFMAs blocks (8 cycles each, 0.75*NT MFMAs per 64 terms)

@@ -75,7 +75,7 @@ struct olx_ctx {
         std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
     } lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    bool use_coset = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
+    bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};
     float* d_inten = nullptr; float* d_cplx = nullptr;
@@ -424,6 +424,7 @@ static int configure_variant(olx_ctx* c) {
                         tile_fill(c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), c->lat.my) >= 0.5;
     c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok);
     c->use_lattice = c->use_mfma && lat_ok;
+    c->fp8corr = false;
     c->nt = 1;
     if (c->use_mfma) {
         // ---- kernel 2c column plan.  A column = one distinct steering vector W[sigma_m(e), f]; every
@@ -569,6 +570,21 @@ static int configure_variant(olx_ctx* c) {
             // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
             if (tiles16 > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
+            // fp8 correction products (kernel 2e, NT <= 2): the e4m3 rounding of the two hi x lo terms adds ~2^-16 |w_e G| per
+            // element and term with random signs, i.e. relative to the coherent focal peak sum |w_e G| an error
+            // ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights: measured 5.8e-6 of the peak at
+            // N_eff = 256 (gate 1e-5).  Below that (small arrays, apodization that silences most elements) the fp16
+            // corrections stay (0.8e-6).  OLX_FP8_CORRECTION=0 / 1 pins either.
+            {
+                const char* f8 = getenv("OLX_FP8_CORRECTION");
+                double neff_min = 1e300;
+                for (int f = 0; f < F; ++f) {
+                    double sw1 = 0, sw2 = 0;
+                    for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
+                    neff_min = std::min(neff_min, sw2 > 0 ? sw1 * sw1 / sw2 : 0.0);
+                }
+                c->fp8corr = c->use_coset && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : neff_min >= 255.5);
+            }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
@@ -607,10 +623,12 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
                 }
-                const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * 3 * ntiles;
-                snprintf(nmbuf, sizeof nmbuf, "field_coset_k<nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
+                // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
+                const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                snprintf(nmbuf, sizeof nmbuf, "field_coset_k<nt%d,mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                         total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                         c->fp8corr ? ",fp8corr" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
                 snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
@@ -660,7 +678,8 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g(c->mp.n_el_pad / 16, c->mp.n_tiles, c->nt);
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
-                           c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr, c->d_coords, c->d_bfrag);
+                           c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
+                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -878,8 +897,12 @@ static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
     const CosetParams& Q = c->cp;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
-    if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q);
-    else       hipLaunchKernelGGL((field_coset_k<NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q);
+#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q)
+    if constexpr (cos_fp8(NT)) {
+        if (c->fp8corr) { if (clamp) OLX_COS(true, true); else OLX_COS(false, true); return; }
+    }
+    if (clamp) OLX_COS(true, false); else OLX_COS(false, false);
+#undef OLX_COS
 }
 
 template <int MX, int MY>

@@ -1024,15 +1024,26 @@ constexpr int COS_JOBS = 64;               // store jobs per column tile: 16 (co
 // one column tile leaves registers for 36 accumulators, 3 (table 18 x 12, 5 tiles) with two column tiles, 2 (table
 // 18 x 10, 3 tiles) with four
 constexpr int cos_kxw(int nt) { return nt >= 4 ? 2 : (nt >= 2 ? 3 : 6); }
+// fp8 correction products (NT <= 2; the NT = 4 shape has no registers for the second operand set): the two hi x lo terms of
+// the fp16 hi/lo split only need their hi factor to 2^-4, so both go through ONE v_mfma_scale_f32_16x16x128_f8f6f4 per two
+// K-steps with e4m3 operands -- bytes [lo re, lo im, hi re, hi im] per element against [hi(k0), hi(k1), lo(k0), lo(k1)] of
+// the steering column.  hi parts are <= 2^14 and lo parts < 8 in both operands (host scales), so lo * 2^5 and hi * 2^-6 stay
+// <= 256 (e4m3 overflows to NaN above 448); the instruction's E8M0 block scales (2^1, 2^0) undo the 2^-1 of each product.
+constexpr bool cos_fp8(int nt) { return nt <= 2; }
+constexpr float COS_F8_LO = 32.0f, COS_F8_HI = 1.0f / 64.0f;
+typedef int intx8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-template <int NT, int MX, int MY, bool CLAMP>
+template <int NT, int MX, int MY, bool CLAMP, bool FP8>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
     const int* __restrict__ jobs /*[tiles][MFMA_MAX_NT][COS_JOBS + 1]: dense (column, focus, image) store jobs, [COS_JOBS] = log2 count*/,
     const CosetParams P) {
     constexpr int THREADS = COS_NW * 64;
+    static_assert(!FP8 || cos_fp8(NT), "fp8 correction products need NT <= 2");
     constexpr int COS_KXW = cos_kxw(NT);
     constexpr int UW = 8 + 2 * (COS_KXW - 1);                       // table columns: ud = 2 kx - a in [-7, 2 (KXW - 1)]
     constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // MFMA tiles per wave
@@ -1166,12 +1177,22 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         const float rs = ri * P.g_scale;
                         const float gr = rs * __builtin_amdgcn_cosf(ph);
                         const float gi = rs * __builtin_amdgcn_sinf(ph);
-                        const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
-                        const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
+                        // fp8 corrections: hi rounded to nearest (v_cvt_pk_f16_f32) so that |lo| <= half an ulp
+                        half2_t hi;
+                        if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);
+                        else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                        unsigned lo_word;
+                        if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
+                            int w = __builtin_amdgcn_cvt_pk_fp8_f32((gr - (float)hi[0]) * COS_F8_LO, (gi - (float)hi[1]) * COS_F8_LO, 0, false);
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(gr * COS_F8_HI, gi * COS_F8_HI, w, true);
+                            lo_word = (unsigned)w;
+                        } else {
+                            lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+                        }
                         if (row_ok) {                    // spare lanes / rows past the table do not store
                             const int o = z * COS_PSZ + tw_off + RPR * r * COS_TW;
                             Thi[o] = __builtin_bit_cast(unsigned, hi);
-                            Tlo[o] = __builtin_bit_cast(unsigned, lo);
+                            Tlo[o] = lo_word;
                         }
                     }
                 }
@@ -1179,6 +1200,48 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (FP8) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {         // K-step pairs (ka = 0, 1): two fp16 hi*hi products + ONE fp8 product
+                Half8Bits bh[2][NT];                 // for both correction terms of both K-steps (K = 128 e4m3 values)
+                intx8_t b8[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int ka = 0; ka < 2; ++ka) {
+                        bh[ka][nt].u = s_B[sbl * 4 + 2 * kb + ka][nt][0][lane];
+                        const uint4 q = s_B[sbl * 4 + 2 * kb + ka][nt][1][lane];
+                        b8[nt][4 * ka + 0] = (int)q.x; b8[nt][4 * ka + 1] = (int)q.y; b8[nt][4 * ka + 2] = (int)q.z; b8[nt][4 * ka + 3] = (int)q.w;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < COS_MT; ++t) {
+                    if (t >= ntile) continue;            // block-uniform
+                    Half8Bits ah[2];
+                    intx8_t a8;
+#pragma unroll
+                    for (int ka = 0; ka < 2; ++ka) {
+                        const int kso = 4 * ka - 4 * kb * COS_TW;
+                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + roffT[t] + kso);
+                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tlo + roffT[t] + kso);
+                        const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long l1 = __hip_atomic_load(pl2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        ah[ka].w[0] = (unsigned)h0; ah[ka].w[1] = (unsigned)(h0 >> 32); ah[ka].w[2] = (unsigned)h1; ah[ka].w[3] = (unsigned)(h1 >> 32);
+                        a8[4 * ka + 0] = (int)(unsigned)l0; a8[4 * ka + 1] = (int)(unsigned)(l0 >> 32);
+                        a8[4 * ka + 2] = (int)(unsigned)l1; a8[4 * ka + 3] = (int)(unsigned)(l1 >> 32);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0].h, bh[0][nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1].h, bh[1][nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)      // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
+                        acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
+                }
+            }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {         // unrolled: the K-step's table offset becomes an immediate
                 const int ka = ks & 1, kb = ks >> 1;
@@ -1208,6 +1271,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
                 }
+            }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1346,6 +1410,7 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                             double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]: representative focus, mirror image (-1 = unused)*/,
                             const int* __restrict__ slot_elem /*kernel 2d: element of K slot s (-1 = virtual), NULL = identity*/,
+                            int fp8corr /*kernel 2e, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element*/,
                             float4* __restrict__ coords, uint4* __restrict__ bfrag) {
     const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
     if (!slot_elem && tile == 0 && nt == 0 && lane < 16) {
@@ -1377,6 +1442,16 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
         const _Float16 l = (_Float16)(float)(val - (double)(float)h);
         hi.h[jj] = h;
         lo.h[jj] = l;
+    }
+    if (fp8corr) {
+        Half8Bits q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[2 * e] * COS_F8_HI, (float)hi.h[2 * e + 1] * COS_F8_HI, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo.h[2 * e] * COS_F8_LO, (float)lo.h[2 * e + 1] * COS_F8_LO, w, true);
+            q.w[e] = (unsigned)w;
+        }
+        lo.u = q.u;
     }
     uint4* dst = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 128;
     dst[lane] = hi.u;

@@ -439,7 +439,26 @@ def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
 
 
-@pytest.mark.parametrize("n_foci,expect", [(8, "field_coset_k"), (64, "field_coset_k")])
+def test_fp8_correction_products_are_gated_by_effective_element_count(ctx, monkeypatch):
+    """Kernel 2e's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
+    grow as 1 / sqrt(N_eff): they are used from N_eff = (sum w)^2 / sum w^2 >= 256 up, the fp16 corrections (0.8e-6) below;
+    OLX_FP8_CORRECTION pins either.  Full-volume parity in every mode."""
+    foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 33e-3]])
+    grid, h = (48, 48, 32), (1.0, 1.0, 1.0)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="noclamp,fp8corr>")          # NT = 1
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect="noclamp,fp8corr>")              # NT = 2
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect="noclamp> ")   # few active elements
+    _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect="noclamp> ")                # 64 elements
+    monkeypatch.setenv("OLX_FP8_CORRECTION", "0")
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    xs, ys, zs = centred_grid(48, 1.0)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="noclamp> ", tol=2e-6, complex_out=False)
+    monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="fp8corr", complex_out=False)
+
+
+@pytest.mark.parametrize("n_foci,expect", [(8, "noclamp,fp8corr>"), (64, "field_coset_k<nt4,mx2,my2,flat,noclamp>")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
     """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and one GPU's 8-focus
     shard in bench.py's mirror-orbit order): sampled-voxel parity per focus, the per-focus focal peak, and the
