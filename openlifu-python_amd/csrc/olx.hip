@@ -43,6 +43,7 @@ struct olx_ctx {
     double *d_pos = nullptr, *d_nrm = nullptr, *d_area = nullptr;
     std::vector<double> h_pos;  // [3][N]
     std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
+    std::vector<double> h_foci; unsigned long long foci_version = ~0ull;  // foci of the last olx_bf_solve in the element frame (M == identity)
     bool allow_shared = true;
     // steering
     int n_foci = 0;
@@ -246,6 +247,11 @@ int olx_bf_solve(olx_ctx* c, const double* foci_m, int n_foci, const double* M, 
     if (apod_out) memcpy(apod_out, c->h_apod.data(), sizeof(double) * fn);
     c->n_foci = n_foci;
     c->steer_version++;
+    c->h_foci.clear();
+    if (!M || !memcmp(M, I4, sizeof I4)) {   // focus positions are in the frame of the element table: usable for planning decisions
+        c->h_foci.assign(foci_m, foci_m + 3 * (size_t)n_foci);
+        c->foci_version = c->steer_version;
+    }
     return OLX_OK;
 }
 
@@ -266,6 +272,7 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
     HIPCHK(c, hipMemcpyAsync(c->d_apod, apod, sizeof(double) * fn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_delays.assign(delays_s, delays_s + fn); c->h_apod.assign(apod, apod + fn);
+    c->h_foci.clear();   // external delays: where the foci are is not known
     c->n_foci = n_foci;
     c->steer_version++;
     return OLX_OK;
@@ -571,19 +578,27 @@ static int configure_variant(olx_ctx* c) {
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
             if (tiles16 > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             // fp8 correction products (kernel 2e, NT <= 2): the e4m3 rounding of the two hi x lo terms adds ~2^-16 |w_e G| per
-            // element and term with random signs, i.e. relative to the coherent focal peak sum |w_e G| an error
-            // ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights: measured 5.8e-6 of the peak at
-            // N_eff = 256 (gate 1e-5).  Below that (small arrays, apodization that silences most elements) the fp16
-            // corrections stay (0.8e-6).  OLX_FP8_CORRECTION=0 / 1 pins either.
+            // element and term with random signs -- an absolute error that is about the same everywhere in the volume and, against
+            // the coherent focal peak sum |w_e G|, ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights:
+            // measured 5.8e-6 of the peak at N_eff = 256 (gate: 1e-5 of the volume's maximum).  So they are used only when the
+            // volume is known to contain that peak: the steering table came from olx_bf_solve in the element frame, every
+            // focus lies inside the planned grid and has N_eff >= 256.  Otherwise (external delays, small arrays, apodization
+            // that silences most elements, volumes off the focus) the fp16 corrections stay (0.8e-6).
+            // OLX_FP8_CORRECTION=0 / 1 pins either.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                double neff_min = 1e300;
-                for (int f = 0; f < F; ++f) {
+                bool ok = c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
+                for (int f = 0; ok && f < F; ++f) {
+                    for (int a = 0; a < 3; ++a) {
+                        const double lo = c->grid.origin[a] - 0.5 * c->grid.spacing[a];
+                        const double hi = c->grid.origin[a] + (c->grid.n[a] - 0.5) * c->grid.spacing[a];
+                        if (!(c->h_foci[3 * (size_t)f + a] >= lo && c->h_foci[3 * (size_t)f + a] <= hi)) ok = false;
+                    }
                     double sw1 = 0, sw2 = 0;
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
-                    neff_min = std::min(neff_min, sw2 > 0 ? sw1 * sw1 / sw2 : 0.0);
+                    if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : neff_min >= 255.5);
+                c->fp8corr = c->use_coset && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : ok);
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
