@@ -376,6 +376,55 @@ static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], d
     L.ok = true;
 }
 
+// Foci of an externally supplied steering table (olx_set_steering; the run_simulation seam hands over delays only).  For the
+// reference's geometric delays (bf/delay_methods/direct.py:28-38) tau_e = max(tof) - tof_e, every element satisfies
+// |x - r_e| = S - s_e with s_e = c tau_e and one unknown S per focus; subtracting element 0's equation leaves a LINEAR system in
+// (x, y, S) for a flat array:  -2 (r_e - r_0) . x + 2 (s_e - s_0) S = (s_e^2 - s_0^2) - (|r_e|^2 - |r_0|^2);  z follows from
+// element 0 on the grid's side of the array.  Accepted only if the point reproduces all delays to 1e-6 m (lambda / 3750 at
+// 400 kHz) -- arbitrary delay patterns have no such point and are reported as unknown.
+static bool infer_foci(const olx_ctx* c, std::vector<double>& foci) {
+    const int n = c->n_el, F = c->plan_foci;
+    if (!c->flat || n < 4 || c->h_delays.size() != (size_t)F * n) return false;
+    const double* X = c->h_pos.data(); const double* Y = X + n; const double* Z = Y + n;
+    foci.assign(3 * (size_t)F, 0.0);
+    for (int f = 0; f < F; ++f) {
+        const double* tau = c->h_delays.data() + (size_t)f * n;
+        double A[3][4] = {{0}};   // normal equations [A | b] for u = (x, y, S)
+        const double s0 = c->c * tau[0], q0 = X[0] * X[0] + Y[0] * Y[0];
+        for (int e = 1; e < n; ++e) {
+            const double se = c->c * tau[e];
+            const double row[3] = {-2.0 * (X[e] - X[0]), -2.0 * (Y[e] - Y[0]), 2.0 * (se - s0)};
+            const double rhs = (se * se - s0 * s0) - (X[e] * X[e] + Y[e] * Y[e] - q0);
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) A[i][j] += row[i] * row[j];
+                A[i][3] += row[i] * rhs;
+            }
+        }
+        for (int i = 0; i < 3; ++i) {   // Gaussian elimination with partial pivoting
+            int piv = i;
+            for (int r = i + 1; r < 3; ++r) if (std::fabs(A[r][i]) > std::fabs(A[piv][i])) piv = r;
+            if (!(std::fabs(A[piv][i]) > 1e-300)) return false;
+            if (piv != i) for (int j = 0; j < 4; ++j) std::swap(A[i][j], A[piv][j]);
+            for (int r = 0; r < 3; ++r) {
+                if (r == i) continue;
+                const double m = A[r][i] / A[i][i];
+                for (int j = i; j < 4; ++j) A[r][j] -= m * A[i][j];
+            }
+        }
+        const double x = A[0][3] / A[0][0], y = A[1][3] / A[1][1], S = A[2][3] / A[2][2];
+        const double dz2 = (S - s0) * (S - s0) - (x - X[0]) * (x - X[0]) - (y - Y[0]) * (y - Y[0]);
+        if (!(dz2 > 0) || !std::isfinite(dz2)) return false;
+        const double side = (c->grid.origin[2] + 0.5 * (c->grid.n[2] - 1) * c->grid.spacing[2]) >= Z[0] ? 1.0 : -1.0;
+        const double z = Z[0] + side * std::sqrt(dz2);
+        for (int e = 0; e < n; ++e) {
+            const double d = std::sqrt((x - X[e]) * (x - X[e]) + (y - Y[e]) * (y - Y[e]) + (z - Z[e]) * (z - Z[e]));
+            if (!(std::fabs(d - (S - c->c * tau[e])) <= 1e-6)) return false;
+        }
+        foci[3 * (size_t)f] = x; foci[3 * (size_t)f + 1] = y; foci[3 * (size_t)f + 2] = z;
+    }
+    return true;
+}
+
 // Kernel 2e: MFMA row tiles (16 rows) one plane pair needs over all cosets and parts -- per (coset, part)
 // ceil(COS_P KX KY / 16) -- for a computed region of wx x wy voxels at lattice pitch (mx, my) voxels.
 static long long coset_tiles16(int wx, int wy, int mx, int my, int nt) {
@@ -581,13 +630,18 @@ static int configure_variant(olx_ctx* c) {
             // element and term with random signs -- an absolute error that is about the same everywhere in the volume and, against
             // the coherent focal peak sum |w_e G|, ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights:
             // measured 5.8e-6 of the peak at N_eff = 256 (gate: 1e-5 of the volume's maximum).  So they are used only when the
-            // volume is known to contain that peak: the steering table came from olx_bf_solve in the element frame, every
-            // focus lies inside the planned grid and has N_eff >= 256.  Otherwise (external delays, small arrays, apodization
+            // volume is known to contain that peak: the foci are known (olx_bf_solve in the element frame, or external delays
+            // that infer_foci recognises as geometric), every focus lies inside the planned grid and has N_eff >= 256.
+            // Otherwise (arbitrary external delays, small arrays, apodization
             // that silences most elements, volumes off the focus) the fp16 corrections stay (0.8e-6).
             // OLX_FP8_CORRECTION=0 / 1 pins either.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
                 bool ok = c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
+                if (!ok && !f8 && c->use_coset && cos_fp8(c->nt) && infer_foci(c, c->h_foci)) {   // external delays: geometric?
+                    c->foci_version = c->steer_version;
+                    ok = true;
+                }
                 for (int f = 0; ok && f < F; ++f) {
                     for (int a = 0; a < 3; ++a) {
                         const double lo = c->grid.origin[a] - 0.5 * c->grid.spacing[a];

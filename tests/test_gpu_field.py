@@ -457,14 +457,18 @@ def test_fp8_correction_products_are_gated(ctx, monkeypatch):
     fp8, f16 = "noclamp,fp8corr>", "noclamp> "
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect=fp8, solve=True)             # NT = 1
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True)                 # NT = 2
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16)                             # external delays: foci unknown
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8)     # external geometric delays: the foci are inferred
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True)         # z = 5 .. 28 mm: foci outside
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect=f16, solve=True)   # few active elements
     _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect=f16, solve=True)           # 64 elements
-    monkeypatch.setenv("OLX_FP8_CORRECTION", "0")
     pos, ori, size = synthetic_array(16, 16, 3.0)
-    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
     xs, ys, zs = centred_grid(48, 1.0)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    d = d + np.random.default_rng(147).uniform(0, 2e-7, d.shape)       # external delays that no focus explains (0.3 mm of path)
+    ctx.set_steering(d, a)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
+    monkeypatch.setenv("OLX_FP8_CORRECTION", "0")
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
     check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
     monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
     check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="fp8corr", complex_out=False)
