@@ -682,7 +682,7 @@ __device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DP
 
 #ifdef OLX_EXP_STAMPS
 __device__ unsigned long long g_stamps[4096][8];
-#define OLX_STAMP(k) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)
+#define OLX_STAMP(k) do { if (lane == 0 && wave < 4 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define OLX_STAMP(k)
 #endif
@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
     const int n_sb = P.nsa * P.nsb;
+    OLX_STAMP(0);
 #ifdef OLX_EXP_STAGGER
     if (blockIdx.y == 0 && blockIdx.x < 768) {   // first-round blocks start staggered (A/B: do store bursts of lock-stepped blocks add up?)
         const long long t0 = __builtin_readcyclecounter(), wait = (long long)((blockIdx.x * 7) % 16) * (OLX_EXP_STAGGER);
@@ -1144,6 +1145,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #pragma unroll
         for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
         __syncthreads();
+        if (sb0 == 0) OLX_STAMP(1);
         {
             const int nxt = (sb0 + SB_PER_CHUNK) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
 #pragma unroll
@@ -1200,6 +1202,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (sb == 0) OLX_STAMP(2);
             if constexpr (FP8) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {         // K-step pairs (ka = 0, 1): two fp16 hi*hi products + ONE fp8 product
@@ -1276,8 +1279,10 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (sb == 0) OLX_STAMP(3);
         }
     }
+    OLX_STAMP(4);
     // ---- epilogue.  D layout: lane holds rows 4 (lane >> 4) + r of tile t = rows n = 16 t + 4 gy + r -> (plane, position),
     // column lane & 15 = (o, part).  Staging [position][column][plane of the block], two halves of the position grid.
     const int c16 = lane & 15, part = c16 & 1, gy = lane >> 4;
@@ -1307,6 +1312,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     auto stage_and_store = [&](auto nt_c) {          // one pass: GROUP column tiles nt0 .. nt0 + GROUP - 1, two barriers
             constexpr int nt0 = decltype(nt_c)::value;
             __syncthreads();                         // arena free (K loop / previous read-out done)
+            if (nt0 == 0) OLX_STAMP(5);
             if (active) {
                 // (the row -> position arithmetic is loop-invariant; the opaque copy keeps the compiler from hoisting all
                 // 36 of them out of the pass loop, which costs > 100 registers)
@@ -1331,6 +1337,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 }
             }
             __syncthreads();
+            if (nt0 == 0) OLX_STAMP(6);
 #pragma unroll
             for (int gq = 0; gq < GROUP; ++gq) {
             const int nt = nt0 + gq;
@@ -1354,6 +1361,12 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                 // RU stores are in flight per lane instead of one (a store holds its data registers until it is sent; the
                 // one-store loop spent ~12 k cycles per wave here waiting, which keeps the block's slot on the CU busy)
                 constexpr int RU = 4;
+                // position step as (kx, ky) increments: one conditional wrap per step instead of a divergent loop
+                const int skx = (int)(((float)qstep + 0.5f) * inv_ky), sky = qstep - skx * KY;
+                // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges
+                // them and splits every 16-byte store into a 12-byte and a 4-byte instruction)
+                auto readout = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value != 0;
 #pragma unroll 1
                 for (int q = q0; q < npos; q += RU * qstep) {
                     float4 val[RU]; float* dst[RU];
@@ -1361,8 +1374,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     for (int u = 0; u < RU; ++u) {
                         const int qu = q + u * qstep;
                         const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
-                        ky += qstep;
-                        while (ky >= KY) { ky -= KY; ++kx; }
+                        kx += skx; ky += sky;
+                        if (ky >= KY) { ky -= KY; ++kx; }
                         const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
 #ifdef OLX_EXP_L2STORE
                         dst[u] = qu < npos ? base + ((long long)(io * P.ny + jo) * P.nz & 0xFFFFF) - (long long)(job >> 6) * P.vox : nullptr;  // A/B: stores stay cache resident
@@ -1375,7 +1388,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #pragma unroll
                     for (int u = 0; u < RU; ++u) {
                         if (!dst[u]) continue;
-                        if (fast) {
+                        if constexpr (FAST) {
                             *reinterpret_cast<float4*>(dst[u]) = val[u];
                         } else {
                             const float vv[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
@@ -1384,6 +1397,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         }
                     }
                 }
+                };
+                if (fast) readout(IntC<1>{}); else readout(IntC<0>{});
             }
             }
     };
@@ -1399,6 +1414,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #endif
     stage_and_store(IntC<0>{});
     if constexpr (NT > GROUP) stage_and_store(IntC<GROUP>{});
+    OLX_STAMP(7);
 }
 
 // pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.

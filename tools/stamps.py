@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Developer tool: phase timeline of the row-tile lattice kernel (2d) from in-kernel cycle stamps.
+"""Developer tool: phase timeline of the lattice kernels from in-kernel cycle stamps (one wave in 37 blocks).
 Build:  hipcc ... -DOLX_EXP_STAMPS -o openlifu-python_amd/lib/libolx_STAMPS.so ; run on the GPU box:
-  OLX_LIB_PATH=.../libolx_STAMPS.so python tools/stamps.py [foci]
+  OLX_LIB_PATH=.../libolx_STAMPS.so python tools/stamps.py [foci] [2d]        (default: kernel 2e, "2d": kernel 2d)
 """
 import ctypes
 import os
 import sys
 
-os.environ.setdefault("OLX_FIELD_VARIANT", "lattice2d")   # the stamps are compiled into kernel 2d (field_lattice_k)
+K2D = "2d" in sys.argv[2:]
+if K2D:
+    os.environ.setdefault("OLX_FIELD_VARIANT", "lattice2d")
 
 import numpy as np
 
@@ -34,11 +36,17 @@ lib.olx_exp_read_stamps.argtypes = [ctypes.c_void_p]
 assert lib.olx_exp_read_stamps(buf.ctypes.data) == 0
 ok = buf[:, 0] > 0
 s = buf[ok].astype(np.int64)
-names = ["start->B staged", "t-gen sb0", "4 K-steps sb0", "rest of K loop", "epilogue stage+sync", "read-out stores"]
-d = np.diff(s[:, :7], axis=1)
+if K2D:
+    names = ["start->B staged", "t-gen sb0", "4 K-steps sb0", "rest of K loop", "epilogue stage+sync", "read-out stores"]
+    last = 6
+else:
+    names = ["start->B staged", "t-gen sb0", "4 K-steps sb0", "rest of K loop", "wait for the block (barrier)",
+             "|p| + staging + barrier", "read-out + store issue"]
+    last = 7
+d = np.diff(s[:, :last + 1], axis=1)
 print(f"{ok.sum()} waves sampled; counter ticks (s_memtime), median / p10 / p90")
 for k, nm in enumerate(names):
     print(f"  {nm:24s} {np.median(d[:, k]):10.0f} {np.percentile(d[:, k], 10):10.0f} {np.percentile(d[:, k], 90):10.0f}")
-tot = s[:, 6] - s[:, 0]
+tot = s[:, last] - s[:, 0]
 print(f"  {'wave lifetime':24s} {np.median(tot):10.0f} {np.percentile(tot, 10):10.0f} {np.percentile(tot, 90):10.0f}")
-print(f"  kernel span (first start -> last end): {s[:, 6].max() - s[:, 0].min()}")
+print(f"  kernel span (first start -> last end): {s[:, last].max() - s[:, 0].min()}")
