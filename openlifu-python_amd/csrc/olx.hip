@@ -74,6 +74,8 @@ struct olx_ctx {
         double x0 = 0, y0 = 0, px = 0, py = 0;     // position of lattice index (0, 0) and pitch [m]
         double min_d2 = 0; bool clamp = false;     // incl. the zero-weight virtual elements of the padding
         std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
+        std::vector<int> cell;                     // lattice cell (a, b) -> element
+        int nsbp = 0;                              // super-block rows of the slot map (nsb, or nsb padded to even)
     } lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
@@ -309,6 +311,23 @@ int olx_bf_quantize(olx_ctx* c, double bf_clk_hz, int width_bits, uint16_t* tick
 }
 
 // ---- kernel 2 -----------------------------------------------------------------------------
+// K-slot map of the lattice kernels: slot ((sa nsbp + sbb) 4 + ks) 16 + 4 bb + aa -> element (a, b) = (8 sa + 4 (ks & 1) + aa,
+// 8 sbb + 4 (ks >> 1) + bb), -1 where the array has no element.  sa-major; nsbp = nsb, or nsb padded to an even count for
+// kernel 2e's NT = 2 shape, which shares one geometry table per pair (sa, 2p), (sa, 2p + 1) and skips the padding super-block.
+static void build_slot_map(olx_ctx::Lattice& L, int nsbp) {
+    L.nsbp = nsbp; L.n_pad = L.nsa * nsbp * 64;
+    L.slot_elem.assign((size_t)L.nsa * nsbp * 64, -1);
+    for (int sa = 0; sa < L.nsa; ++sa)
+        for (int sbb = 0; sbb < L.nsb; ++sbb)
+            for (int ks = 0; ks < 4; ++ks)
+                for (int bb = 0; bb < 4; ++bb)
+                    for (int aa = 0; aa < 4; ++aa) {
+                        const int a = 8 * sa + 4 * (ks & 1) + aa, b = 8 * sbb + 4 * (ks >> 1) + bb;
+                        if (a < L.ax && b < L.ay)
+                            L.slot_elem[((size_t)(sa * nsbp + sbb) * 4 + ks) * 16 + 4 * bb + aa] = L.cell[(size_t)a * L.ay + b];
+                    }
+}
+
 // Kernel 2d precondition: the elements fill a regular ax x ay lattice in one z plane and the pitch is a whole number
 // of voxels along x and y.  Fills c->lat (slot map in 8 x 8 super-blocks of four 4 x 4 K-steps, padded with
 // virtual elements) and the clamp / minimum-distance bounds including the virtual lattice points.
@@ -346,22 +365,16 @@ static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], d
         if (a < 0 || a >= ax || b < 0 || b >= ay || cell[(size_t)a * ay + b] >= 0) return;
         cell[(size_t)a * ay + b] = e;
     }
-    L.slot_elem.assign((size_t)nsa * nsb * 64, -1);
-    for (int sbb = 0; sbb < nsb; ++sbb)
-        for (int sa = 0; sa < nsa; ++sa)
-            for (int ks = 0; ks < 4; ++ks)
-                for (int bb = 0; bb < 4; ++bb)
-                    for (int aa = 0; aa < 4; ++aa) {
-                        const int a = 8 * sa + 4 * (ks & 1) + aa, b = 8 * sbb + 4 * (ks >> 1) + bb;
-                        if (a < ax && b < ay)
-                            L.slot_elem[((size_t)(sbb * nsa + sa) * 4 + ks) * 16 + 4 * bb + aa] = cell[(size_t)a * ay + b];
-                    }
+    L.ax = ax; L.ay = ay; L.nsa = nsa; L.nsb = nsb;
+    L.cell.swap(cell);
+    build_slot_map(L, nsb);
+    const int nsbp = (nsb + 1) & ~1;               // the bounds below also cover the padding rows of kernel 2e's pair tables
     // distance bounds over every lattice point of the padded array (virtual ones included: their G must stay finite)
     const double ez = c->h_pos[2 * (size_t)n];
     double min_d2 = 1e300; bool clamp = false;
     const double guard = 2.0 * dmin;
     for (int a = 0; a < 8 * nsa; ++a)
-        for (int b = 0; b < 8 * nsb; ++b) {
+        for (int b = 0; b < 8 * nsbp; ++b) {          // (kernel 2e's pair table also covers the padding rows)
             const double p[3] = {xs[0] + a * px, ys[0] + b * py, ez};
             double d2 = 0;
             for (int k = 0; k < 3; ++k) {
@@ -371,7 +384,7 @@ static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], d
             min_d2 = std::min(min_d2, d2);
             if (d2 < guard * guard) clamp = true;
         }
-    L.ax = ax; L.ay = ay; L.nsa = nsa; L.nsb = nsb; L.mx = mx; L.my = my; L.n_pad = nsa * nsb * 64;
+    L.mx = mx; L.my = my;
     L.x0 = xs[0]; L.y0 = ys[0]; L.px = px; L.py = py; L.min_d2 = min_d2; L.clamp = clamp;
     L.ok = true;
 }
@@ -539,6 +552,17 @@ static int configure_variant(olx_ctx* c) {
             return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
         };
         if (c->use_lattice && c->nt >= 4 && c->force_kind != 4 && ((c->flags & OLX_OUT_COMPLEX) || coset_fill(c->nt) < 0.6)) c->use_lattice = false;
+        // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
+        // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
+        // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
+        c->use_coset = false;
+        if (c->use_lattice) {
+            const char* fv = getenv("OLX_FIELD_VARIANT");
+            c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
+            if (coset_fill(c->nt) > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
+            const int want = (c->use_coset && c->nt == 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
+            if (want != c->lat.nsbp) build_slot_map(c->lat, want);
+        }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();
         std::vector<int> colinfo((size_t)ntiles * MAXC * 2, -1), targets((size_t)ntiles * MAXC * 4, -1);
@@ -608,7 +632,7 @@ static int configure_variant(olx_ctx* c) {
             L.tiles_x = ((P.nx - L.x_lo + 4 * A.mx - 1) / (4 * A.mx)) * 2 * A.mx;   // 2 x rows two pitches apart per tile
             L.tiles_y = ((P.ny - L.y_lo + 4 * A.my - 1) / (4 * A.my)) * A.my;       // 4 y rows one pitch apart
             L.kgroups = (P.nz + 2 * c->lat_mt - 1) / (2 * c->lat_mt);
-            L.nsa = A.nsa; L.nsb = A.nsb;
+            L.nsa = A.nsa; L.nsb = A.nsb; L.nsbp = A.nsbp;
             // dx(i, a) = (origin - x0) + (i - mx a) h: whole voxels go into the integer part, the rest is |f| <= h/2
             const double offx = c->grid.origin[0] - A.x0, offy = c->grid.origin[1] - A.y0;
             L.ux0 = (int)std::llround(offx / c->grid.spacing[0]); L.uy0 = (int)std::llround(offy / c->grid.spacing[1]);
@@ -619,13 +643,8 @@ static int configure_variant(olx_ctx* c) {
             L.hz = P.hz; L.dmin2 = P.dmin2; L.flat_ez = P.flat_ez;
             L.g_scale = M.g_scale; L.out_scale = M.out_scale; L.inten_scale = P.inten_scale;
             L.vox = P.vox; L.flags = P.flags;
-            // kernel 2e: whole cosets per wave (no row-tile padding, one 18 x 18 table per plane); 2d stays for A/B runs
             const char* fv = getenv("OLX_FIELD_VARIANT");
-            c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
-            // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
-            // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
-            if (tiles16 > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             // fp8 correction products (kernel 2e, NT <= 2): the e4m3 rounding of the two hi x lo terms adds ~2^-16 |w_e G| per
             // element and term with random signs -- an absolute error that is about the same everywhere in the volume and, against
             // the coherent focal peak sum |w_e G|, ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights:
@@ -661,7 +680,7 @@ static int configure_variant(olx_ctx* c) {
                 const int kxw = cos_kxw(c->nt);
                 Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
                 Q.kblocks = (P.nz + COS_ZB - 1) / COS_ZB;
-                Q.nsa = L.nsa; Q.nsb = L.nsb; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
+                Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
                 Q.vox = L.vox; Q.flags = L.flags;

@@ -663,6 +663,7 @@ struct LatParams {
     int tiles_x, tiles_y;      // row tiles per axis: blocks of 4 pitches x (2 mx | my) residues
     int kgroups;               // ceil(nz / (2 MT))
     int nsa, nsb;              // element super-blocks (8 x 8) per lattice axis
+    int nsbp;                  // rows of the K-slot map (= nsb here; kernel 2e's NT = 2 shape pads it to an even count)
     int ux0, uy0;              // dx(i, a) = fx0 + (i_global + ux0 - mx a) hx   (integer part folded into ux0)
     float fx0, fy0;            // [wavelengths], |f| <= h/2
     float hx_hi, hx_lo, hy_hi, hy_lo, hz;  // spacing [wavelengths]; hi + lo = the fp64 value to ~2^-48
@@ -750,7 +751,8 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int n_sb = P.nsa * P.nsb;
+    const int nsbp = P.nsbp;                    // (= nsb: this kernel is never planned with the padded K-slot map)
+    const int n_sb = P.nsa * nsbp;
     OLX_STAMP(0);
     // B fragments: chunk c+1 is fetched into registers while chunk c is contracted (the loads stay in flight across
     // the K-steps), then handed to LDS between two barriers -- no wave waits for global memory inside the loop.
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
         if (sb0 == 0) OLX_STAMP(1);
         for (int sbl = 0; sbl < sb_here; ++sbl) {
             const int sb = sb0 + sbl;
-            const int sbb = sb / P.nsa, sa = sb - sbb * P.nsa;
+            const int sa = sb / nsbp, sbb = sb - sa * nsbp;      // sa-major order (host slot map)
             // ---- G table of this super-block: 110 offsets x ZW planes (2 rounds of 64 lanes per plane)
 #ifndef OLX_EXP_NOTGEN
 #pragma unroll
@@ -1008,6 +1010,7 @@ struct CosetParams {
     int nsx, nsy;              // parts the coset's positions are cut into along x / y
     int kblocks;               // plane blocks of COS_ZB planes
     int nsa, nsb;
+    int nsbp;                  // rows of the K-slot map: nsb, padded to an even count for the NT = 2 shape (shared pair tables)
     int ux0, uy0;
     float fx0, fy0, hx_hi, hx_lo, hy_hi, hy_lo, hz;
     float dmin2, flat_ez, g_scale, out_scale, inten_scale;
@@ -1048,8 +1051,14 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     constexpr int UW = 8 + 2 * (COS_KXW - 1);                       // table columns: ud = 2 kx - a in [-7, 2 (KXW - 1)]
     constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // MFMA tiles per wave
     // table row / plane stride [words], conflict-free for the row sets that occur (brute-forced per shape)
-    constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 378 : (COS_KXW == 3 ? 216 : 184);
-    constexpr int RPR = 64 / UW, NROUND = (18 + RPR - 1) / RPR;     // table rows per generation round, rounds
+    // SHARE (NT = 2; the 18 x 18 table of NT = 1 has no LDS for it): the tables of the two super-blocks (sa, 2p) and (sa, 2p + 1)
+    // overlap in 10 of their 18 rows (offsets wd = ky - b), so ONE 26-row table serves both: 26 instead of 36 rows to evaluate
+    constexpr bool SHARE = NT == 2;                                 // (NT = 4: measured +1 %, it spills 7 registers)
+    constexpr int TROWS = SHARE ? 26 : 18, ROW0 = SHARE ? 15 : 7;   // table rows; row of offset wd = 0
+    // (plane strides keep the residues mod 64 of the brute-forced 216 / 184 of the 18-row tables)
+    constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 378 : (COS_KXW == 3 ? 344 : 184);
+    static_assert(TROWS * COS_TW <= COS_PSZ, "table does not fit its plane stride");
+    constexpr int RPR = 64 / UW, NROUND = (TROWS + RPR - 1) / RPR;  // table rows per generation round, rounds
     // super-blocks of B fragments per LDS stage: 2 for every NT but 4 (NT = 2 has LDS to spare at its 2 blocks / CU; two
     // super-blocks per stage halve the barriers)
     constexpr int SB_PER_CHUNK = NT >= 4 ? 1 : 2;
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const int wl = lane / UW, ui = lane - UW * wl;
     const bool gen_lane = wl < RPR;
     const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
-    const int Wlane = jbase + P.uy0 + P.my * (wl - 7);
+    const int Wlane = jbase + P.uy0 + P.my * (wl - ROW0);
     const int tw_off = wl * COS_TW + (UW - 1 - ui);   // + RPR r TW per round
     unsigned* const Thi = s_T + (wave * 2 + 0) * COS_P * COS_PSZ;
     unsigned* const Tlo = s_T + (wave * 2 + 1) * COS_P * COS_PSZ;
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
         n = n < nrow ? n : (nrow > 0 ? nrow - 1 : 0);
         const int plane = n >= npos ? 1 : 0, pos = n - plane * npos;             // COS_P == 2
         const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;   // exact for these small integers
-        roffT[t] = plane * COS_PSZ + (ky - g + 7) * COS_TW + (UW - 8 - 2 * kx);
+        roffT[t] = plane * COS_PSZ + (ky - g + ROW0) * COS_TW + (UW - 8 - 2 * kx);
     }
     floatx4_t acc[COS_MT][NT];
 #pragma unroll
@@ -1122,7 +1131,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int n_sb = P.nsa * P.nsb;
+    const int nsbp = P.nsbp;                    // SHARE: nsb padded to an even count, so chunks = table pairs never straddle sa
+    const int n_sb = P.nsa * nsbp;
     OLX_STAMP(0);
 #ifdef OLX_EXP_STAGGER
     if (blockIdx.y == 0 && blockIdx.x < 768) {   // first-round blocks start staggered (A/B: do store bursts of lock-stepped blocks add up?)
@@ -1155,18 +1165,23 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             }
         }
         if (!active) continue;
-        for (int sbl = 0; sbl < sb_here; ++sbl) {
+#pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
+        for (int sbl = 0; sbl < SB_PER_CHUNK; ++sbl) {
+            if (SB_PER_CHUNK > 1 && sbl >= sb_here) break;
             const int sb = sb0 + sbl;
-            const int sbb = sb / P.nsa, sa = sb - sbb * P.nsa;
-            // ---- G table of this super-block: 18 x 18 offsets x 2 planes, 6 rounds of 3 table rows
-            {
+            const int sa = sb / nsbp, sbb = sb - sa * nsbp;      // sa-major order (host slot map)
+            if constexpr (SHARE) { if (sbb >= P.nsb) continue; }   // padding super-block of an odd count: zero weights, nothing to do
+            static_assert(!SHARE || SB_PER_CHUNK == 2, "a chunk is one table pair");
+            const int sl = SHARE ? sbl : 0;                      // position in the table pair (chunks start at even sbb)
+            // ---- G table: TROWS x UW offsets x 2 planes (SHARE: once per super-block pair)
+            if (sl == 0) {
                 const float U = (float)(Ulane - 8 * P.mx * sa);
                 const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
                 const float dx2 = dx * dx;
                 const int Wsb = Wlane - 8 * P.my * sbb;
 #pragma unroll 2
                 for (int r = 0; r < NROUND; ++r) {
-                    const bool row_ok = gen_lane && RPR * r + wl < 18;  // the last round may run past the 18 table rows
+                    const bool row_ok = gen_lane && RPR * r + wl < TROWS;  // the last round may run past the table
                     const float W = (float)(Wsb + RPR * P.my * r);
                     const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
                     const float r2 = fmaf(dy, dy, dx2);
@@ -1224,7 +1239,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     intx8_t a8;
 #pragma unroll
                     for (int ka = 0; ka < 2; ++ka) {
-                        const int kso = 4 * ka - 4 * kb * COS_TW;
+                        const int kso = 4 * ka - (4 * kb + 8 * sl) * COS_TW;   // the pair's second super-block reads 8 table rows lower
                         const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + roffT[t] + kso);
                         const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tlo + roffT[t] + kso);
                         const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1254,7 +1269,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     bh[nt].u = s_B[sbl * 4 + ks][nt][0][lane];
                     bl[nt].u = s_B[sbl * 4 + ks][nt][1][lane];
                 }
-                const int kso = 4 * ka - 4 * kb * COS_TW;
+                const int kso = 4 * ka - (4 * kb + 8 * sl) * COS_TW;   // the pair's second super-block reads 8 table rows lower
 #pragma unroll
                 for (int t = 0; t < COS_MT; ++t) {
                     if (t >= ntile) continue;            // block-uniform

@@ -447,6 +447,17 @@ def test_lattice_not_used_when_pitch_is_not_a_whole_number_of_voxels(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 40, 32), (0.7, 0.7, 0.7), expect="field_shared_k")
 
 
+def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
+    """Kernel 2e's NT = 2 shape shares one geometry table per pair of 8 x 8 element super-blocks along y; 20 element rows
+    are 3 super-block rows, so the K-slot map is padded with an empty fourth that the kernel skips (and 2d / NT = 1 / NT = 4
+    never see).  Off-axis foci so that every column is distinct."""
+    foci = np.array([[1e-3, 2e-3, 30e-3], [-3e-3, 1e-3, 26e-3], [2e-3, -4e-3, 22e-3]])      # 3 x 4 mirror images = 12 columns: NT = 2
+    _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci, expect="field_coset_k<nt2")
+    many = np.column_stack([np.linspace(-4, 4, 9), np.linspace(3, -3, 9), np.linspace(20, 30, 9)]) * 1e-3     # shifted grid: no mirror images
+    _lattice_case(ctx, 9, 23, (2.0, 2.0), (30, 50, 20), (1.0, 1.0, 1.0), origin_shift=(1.0, -2.0), foci=many, expect="field_coset_k<nt2")
+    _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
+
+
 def test_fp8_correction_products_are_gated(ctx, monkeypatch):
     """Kernel 2e's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
     grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  The host uses them only when the volume is known to hold that
