@@ -560,7 +560,7 @@ static int configure_variant(olx_ctx* c) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             if (coset_fill(c->nt) > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
-            const int want = (c->use_coset && c->nt == 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
+            const int want = (c->use_coset && c->nt <= 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
             if (want != c->lat.nsbp) build_slot_map(c->lat, want);
         }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;

@@ -1051,17 +1051,17 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     constexpr int UW = 8 + 2 * (COS_KXW - 1);                       // table columns: ud = 2 kx - a in [-7, 2 (KXW - 1)]
     constexpr int COS_MT = (COS_P * COS_KXW * COS_KYW + 15) / 16;   // MFMA tiles per wave
     // table row / plane stride [words], conflict-free for the row sets that occur (brute-forced per shape)
-    // SHARE (NT = 2; the 18 x 18 table of NT = 1 has no LDS for it): the tables of the two super-blocks (sa, 2p) and (sa, 2p + 1)
+    // SHARE (NT <= 2): the tables of the two super-blocks (sa, 2p) and (sa, 2p + 1)
     // overlap in 10 of their 18 rows (offsets wd = ky - b), so ONE 26-row table serves both: 26 instead of 36 rows to evaluate
-    constexpr bool SHARE = NT == 2;                                 // (NT = 4: measured +1 %, it spills 7 registers)
+    constexpr bool SHARE = NT <= 2;                                 // (NT = 4: measured +1 %, it spills 7 registers)
     constexpr int TROWS = SHARE ? 26 : 18, ROW0 = SHARE ? 15 : 7;   // table rows; row of offset wd = 0
-    // (plane strides keep the residues mod 64 of the brute-forced 216 / 184 of the 18-row tables)
-    constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 378 : (COS_KXW == 3 ? 344 : 184);
+    // (plane strides keep the residues mod 64 of the brute-forced 378 / 216 / 184 of the 18-row tables)
+    constexpr int COS_TW = COS_KXW == 6 ? 20 : (COS_KXW == 3 ? 12 : 10), COS_PSZ = COS_KXW == 6 ? 570 : (COS_KXW == 3 ? 344 : 184);
     static_assert(TROWS * COS_TW <= COS_PSZ, "table does not fit its plane stride");
     constexpr int RPR = 64 / UW, NROUND = (TROWS + RPR - 1) / RPR;  // table rows per generation round, rounds
     // super-blocks of B fragments per LDS stage: 2 for every NT but 4 (NT = 2 has LDS to spare at its 2 blocks / CU; two
     // super-blocks per stage halve the barriers)
-    constexpr int SB_PER_CHUNK = NT >= 4 ? 1 : 2;
+    constexpr int SB_PER_CHUNK = NT == 2 ? 2 : 1;                // (NT = 1: its 26 x 18 pair tables leave LDS for one super-block of B only)
     // staging strides [floats]: odd column stride and row stride = 4 (mod 8) spread the 64 lanes of a staging write
     // (16 columns x 4 row groups) over all 32 banks (2-way, which is free for ds_write_b32)
     constexpr int CS = COS_ZB + 1, RS = 16 * CS + 4;
@@ -1171,8 +1171,10 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             const int sb = sb0 + sbl;
             const int sa = sb / nsbp, sbb = sb - sa * nsbp;      // sa-major order (host slot map)
             if constexpr (SHARE) { if (sbb >= P.nsb) continue; }   // padding super-block of an odd count: zero weights, nothing to do
-            static_assert(!SHARE || SB_PER_CHUNK == 2, "a chunk is one table pair");
-            const int sl = SHARE ? sbl : 0;                      // position in the table pair (chunks start at even sbb)
+            // position in the table pair: the chunk index when a chunk is a pair (compile-time after unrolling: it goes into
+            // the immediate table offsets), else the parity of sbb (then the table pointers move)
+            const int sl = !SHARE ? 0 : (SB_PER_CHUNK == 2 ? sbl : (sbb & 1));
+            const int sl_imm = SB_PER_CHUNK == 2 ? sl : 0;
             // ---- G table: TROWS x UW offsets x 2 planes (SHARE: once per super-block pair)
             if (sl == 0) {
                 const float U = (float)(Ulane - 8 * P.mx * sa);
@@ -1218,6 +1220,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (sb == 0) OLX_STAMP(2);
+            const unsigned* const Th = Thi - (SB_PER_CHUNK == 2 ? 0 : 8 * sl * COS_TW);
+            const unsigned* const Tl = Tlo - (SB_PER_CHUNK == 2 ? 0 : 8 * sl * COS_TW);
             if constexpr (FP8) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {         // K-step pairs (ka = 0, 1): two fp16 hi*hi products + ONE fp8 product
@@ -1239,9 +1243,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     intx8_t a8;
 #pragma unroll
                     for (int ka = 0; ka < 2; ++ka) {
-                        const int kso = 4 * ka - (4 * kb + 8 * sl) * COS_TW;   // the pair's second super-block reads 8 table rows lower
-                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + roffT[t] + kso);
-                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tlo + roffT[t] + kso);
+                        const int kso = 4 * ka - (4 * kb + 8 * sl_imm) * COS_TW;   // the pair's second super-block reads 8 table rows lower
+                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Th + roffT[t] + kso);
+                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tl + roffT[t] + kso);
                         const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1269,13 +1273,13 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     bh[nt].u = s_B[sbl * 4 + ks][nt][0][lane];
                     bl[nt].u = s_B[sbl * 4 + ks][nt][1][lane];
                 }
-                const int kso = 4 * ka - (4 * kb + 8 * sl) * COS_TW;   // the pair's second super-block reads 8 table rows lower
+                const int kso = 4 * ka - (4 * kb + 8 * sl_imm) * COS_TW;   // the pair's second super-block reads 8 table rows lower
 #pragma unroll
                 for (int t = 0; t < COS_MT; ++t) {
                     if (t >= ntile) continue;            // block-uniform
                     Half8Bits ah, al;
-                    const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + roffT[t] + kso);
-                    const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tlo + roffT[t] + kso);
+                    const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Th + roffT[t] + kso);
+                    const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(Tl + roffT[t] + kso);
                     const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
