@@ -140,7 +140,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU); RCCL is driven by libolx
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo reports its connections on C stdout; stdout belongs to the one JSON line, so it points at stderr meanwhile
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()  # forces the pair connections (and their messages) now
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     el = tuple(int(v) for v in args.elements.split("x"))
     arr, setup, foci = synthetic_workload(args.grid, args.spacing_mm, el, args.pitch_mm, args.foci_per_gpu, seed=rank)
