@@ -1002,6 +1002,10 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
 //     conflict-free for the row sets that occur (brute-forced, 1.03 LDS cycles per access).
 //   * 8 waves = 16 consecutive planes per block; the epilogue transposes through LDS in two halves of the position
 //     grid and writes 64-byte z runs.
+//   * NT <= 2 (SHARE): the tables of the super-blocks (sa, 2p) and (sa, 2p + 1) overlap in 10 of 18 rows, so one 26-row
+//     table per PAIR is evaluated and the second super-block reads it 8 rows lower (K-slot map sa-major, rows padded to even).
+//   * NT <= 2, FP8: the two hi x lo correction products of the fp16 split take e4m3 operands -- one
+//     v_mfma_scale_f32_16x16x128_f8f6f4 per two K-steps instead of four fp16 MFMAs (cos_fp8 below; host-gated).
 // ------------------------------------------------------------------------------------
 struct CosetParams {
     int nx, ny, nz;
