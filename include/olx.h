@@ -123,7 +123,12 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  *   (xdc/transducer.py:105-106), rho/c = reference medium values (kwave_if.py:52-56).
  * launch: asynchronous on the context's stream.  fetch: blocking D2H of one focus
  *   volume into caller-owned host arrays [nx*ny*nz] (cplx: 2 floats per voxel); any
- *   pointer may be NULL. */
+ *   pointer may be NULL.
+ * accuracy: fp32 results within 1e-5 of the volume's maximum |p| against the fp64 definition
+ *   (typically 1e-6).  For matrix arrays on a commensurate grid the library may compute two
+ *   small correction products in fp8 (6e-6) when the steering table's foci are known to lie
+ *   inside the grid and drive >= 256 elements effectively; environment OLX_FP8_CORRECTION=0
+ *   keeps the 1e-6 path everywhere.  olx_field_variant() names the kernel in use. */
 int olx_field_plan(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab /*NULL = whole grid*/,
                    int n_foci, double freq, double c, double rho, double p0_pa, unsigned flags);
 int olx_field_launch(olx_ctx *ctx);
