@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """Build libolx.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
 
-  python openlifu-python_amd/build.py [--force]
+  python openlifu-python_amd/build.py [--force] [-DOLX_EXP_...] [--out lib/libolx_exp.so]
 
-hipcc cross-compiles without a GPU; the .so lands in openlifu-python_amd/lib/ (git-ignored,
-travels with gpurun snapshots)."""
+hipcc cross-compiles without a GPU.  Every csrc/*.hip is one translation unit (the host side olx.hip plus
+one k_*.hip per kernel-2 family), compiled in parallel to build/*.o and linked into
+openlifu-python_amd/lib/libolx.so (git-ignored, travels with gpurun snapshots).  A unit is rebuilt when it or any
+header it could include (csrc/*.h, include/olx.h) is newer than its object."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "olx.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "olx_kernels.hip.h"), os.path.join(HERE, "..", "include", "olx.h")]
+CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libolx.so")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-         "-I/opt/rocm/include"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
 def hipcc() -> str:
@@ -27,14 +29,34 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm 7.x expected under /opt/rocm)")
 
 
-def build(force: bool = False) -> str:
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + SRC + ["-ldl"]
-    subprocess.check_call(cmd)
-    return OUT
+def build(force: bool = False, defines=(), out: str = OUT) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "olx.h")]
+    tag = "" if not defines else "_" + "_".join(d.lstrip("-D").replace("=", "") for d in defines)
+    objdir = os.path.join(HERE, "build" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    cc = hipcc()
+    jobs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append([cc] + FLAGS + list(defines) + ["-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, jobs), jobs):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if jobs or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs):
+        subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = sys.argv[1:]
+    out = OUT
+    if "--out" in args:
+        out = os.path.join(HERE, args[args.index("--out") + 1])
+    print(build(force="--force" in args, defines=[a for a in args if a.startswith("-D")], out=out))

@@ -1,0 +1,288 @@
+// kernels 2a (field_accum_k) and 2b (field_shared_k): exact per-pair accumulate on the VALU
+// gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#include "k_types.hip.h"
+#include "olx_ctx.h"
+#include "olx_launch.h"
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// kernel 2: pressure-field accumulate, exact per voxel-element pair, fp32.
+//
+// Work map: the [nx,ny,nz] slab is rows of nz voxels (z fastest).  A lane owns ZPL
+// consecutive z voxels of one row, so dx, dy and rho^2 = dx^2 + dy^2 are formed once per
+// (lane, element) and shared by its ZPL voxels; 64/ (nz/ZPL) rows per wave.  Lanes of a
+// wave write ZPL*4-byte pieces that tile whole rows: for nz = 256, ZPL = 4 a wave stores
+// one contiguous 1 KiB row with one dwordx4 store per lane.
+// Element data is wave-uniform: read with scalar loads (s_load_dwordx8) from the packed
+// table, served by the scalar cache -- no VGPR, LDS or vector-memory traffic in the loop.
+// Per pair: v_rsq_f32 (1/d), v_sin_f32 + v_cos_f32 on the phase in REVOLUTIONS
+// (t = d + frac(f tau), d in wavelengths), ~5 plain VALU.  Transcendental issue is the bound
+// (DESIGN.md section 5); HBM sees only the output stream.
+//   FLAT : every element has the same z -> (z_v - z_e)^2 hoisted out of the element loop.
+//   CLAMP: apply d >= dmin (needed only if a voxel can come within dmin of an element;
+//          decided on the host from the element / slab bounding boxes).
+// ------------------------------------------------------------------------------------
+
+
+template <int ZPL, bool FLAT, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
+    const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
+    float* __restrict__ cplx, const FieldParams P) {
+    const int f = blockIdx.y;
+    const int cpr = (P.nz + ZPL - 1) / ZPL;  // chunks per row
+    const long long lane_id = (long long)blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const long long rows = (long long)P.nx * P.ny;
+    const long long row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int i = (int)(row / P.ny), j = (int)(row - (long long)i * P.ny);
+    const int k0 = chunk * ZPL;
+    const float x = (float)(i + P.x_begin) * P.hx;
+    const float y = (float)j * P.hy;
+    float z[ZPL], re[ZPL], im[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        z[q] = (float)(k0 + q) * P.hz;
+        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+        re[q] = 0.f; im[q] = 0.f;
+    }
+    const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
+#pragma unroll 2
+    for (int e = 0; e < P.n_el; ++e) {
+        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
+        const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
+        const float phi = t[e * TAB_STRIDE + 4];
+        const float dx = x - ex, dy = y - ey;
+        const float r2 = fmaf(dy, dy, dx * dx);
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            float d2;
+            if (FLAT) {
+                d2 = r2 + z[q];
+            } else {
+                const float dz = z[q] - ez;
+                d2 = fmaf(dz, dz, r2);
+            }
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float ph = fmaf(d2, ri, phi);  // d [wavelengths] + phi = phase [revolutions]
+            const float s = __builtin_amdgcn_sinf(ph);
+            const float c = __builtin_amdgcn_cosf(ph);
+            const float a = w * ri;
+            re[q] = fmaf(a, c, re[q]);
+            im[q] = fmaf(a, s, im[q]);
+        }
+    }
+    // epilogue: fused |p|, intensity, optional complex
+    const long long base = (long long)f * P.vox + row * P.nz + k0;
+    float pm[ZPL], it[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
+        pm[q] = __builtin_sqrtf(m2);
+        it[q] = m2 * P.inten_scale;
+    }
+    const bool full = (k0 + ZPL <= P.nz);
+    if (ZPL == 4 && full && (P.nz & 3) == 0) {
+        if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+        if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+        if (P.flags & 4u) {
+            float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
+            c4[0] = make_float4(re[0], im[0], re[1], im[1]);
+            c4[1] = make_float4(re[2], im[2], re[3], im[3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            if (k0 + q < P.nz) {
+                if (P.flags & 1u) pmag[base + q] = pm[q];
+                if (P.flags & 2u) inten[base + q] = it[q];
+                if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 2b: shared-geometry accumulate.  The geometry term G(v,e) = exp(j k d)/d does not
+// depend on the focus, and for an element set that is mirror-symmetric about the grid's
+// centre plane(s) G(v,e) = G(sigma v, sigma e).  One lane therefore evaluates G once
+// (the 3 transcendentals) and feeds NOUT = MX*MY*NF complex accumulators
+//     P_f(sigma_m v) += W[sigma_m e, f] * G(v, e)
+// with 4 plain fma each (weights wave-uniform in SGPRs).  MX/MY = 2 folds the x / y mirror
+// (lanes cover only the upper half of that axis and also write the mirrored voxel),
+// NF = foci per tile (blockIdx.y = tile).  Exact: no approximation is involved, only
+// re-association of which (voxel, element) pair is evaluated where.
+// Table entry (tile, e) = { x_e, y_e, z_e, 0, (wr_k, wi_k) k < NOUT },  k = f_local*NM + cx + DX*cy,
+// NM = DX*DY distinct mirror columns (perm[m] passed to the pack kernel lists exactly those).
+// Coordinates on a mirrored axis are taken relative to the grid centre and formed as
+// (2 i - (n-1)) * h/2 so that x(n-1-i) == -x(i) bit for bit.
+// ------------------------------------------------------------------------------------
+
+// DX / DY (1 or 2) = distinct weight columns along a folded axis: when the steering itself is
+// mirror-symmetric (W[sigma e] == W[e] bit for bit, e.g. an on-axis focus) the mirrored voxel's
+// value is the same sum, so it is accumulated once (D = 1) and stored twice.
+template <int ZPL, int MX, int MY, int DX, int DY, int NF, bool FLAT, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
+    const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
+    float* __restrict__ cplx, const SharedParams P) {
+    static_assert(DX <= MX && DY <= MY, "distinct columns cannot exceed the fold");
+    constexpr int NM = DX * DY, NOUT = NM * NF, STRIDE = 4 + 2 * NOUT;
+    const int tile = blockIdx.y;
+    const unsigned cpr = (unsigned)(P.nz + ZPL - 1) / ZPL;
+    const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const int x_lo = (MX == 2) ? P.nx / 2 : 0, y_lo = (MY == 2) ? P.ny / 2 : 0;
+    const unsigned hyn = (unsigned)(P.ny - y_lo);
+    const unsigned rows = (unsigned)(P.nx - x_lo) * hyn;
+    const unsigned row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int ii = (int)(row / hyn);
+    const int i = ii + x_lo, j = (int)(row - (unsigned)ii * hyn) + y_lo;
+    const int k0 = chunk * ZPL;
+    const float x = (MX == 2) ? (float)(2 * i - (P.nx - 1)) * (0.5f * P.hx) : (float)(i + P.x_begin) * P.hx;
+    const float y = (MY == 2) ? (float)(2 * j - (P.ny - 1)) * (0.5f * P.hy) : (float)j * P.hy;
+    float z[ZPL], re[ZPL][NOUT], im[ZPL][NOUT];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        z[q] = (float)(k0 + q) * P.hz;
+        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) { re[q][k] = 0.f; im[q][k] = 0.f; }
+    }
+    const float* t = tab + (size_t)tile * P.n_el * STRIDE;
+#ifdef OLX_EXP_UNROLL
+#pragma unroll OLX_EXP_UNROLL
+#endif
+    for (int e = 0; e < P.n_el; ++e) {
+        const float* te = t + (size_t)e * STRIDE;
+        const float dx = x - te[0], dy = y - te[1];
+        const float ez = te[2];
+        const float r2 = fmaf(dy, dy, dx * dx);
+        float gr[ZPL], gi[ZPL];
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            float d2;
+            if (FLAT) {
+                d2 = r2 + z[q];
+            } else {
+                const float dz = z[q] - ez;
+                d2 = fmaf(dz, dz, r2);
+            }
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float ph = d2 * ri;  // distance in wavelengths = phase in revolutions
+            gr[q] = ri * __builtin_amdgcn_cosf(ph);
+            gi[q] = ri * __builtin_amdgcn_sinf(ph);
+        }
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const float wr = te[4 + 2 * k], wi = te[5 + 2 * k];
+#pragma unroll
+            for (int q = 0; q < ZPL; ++q) {
+                re[q][k] = fmaf(gr[q], wr, re[q][k]);
+                re[q][k] = fmaf(-gi[q], wi, re[q][k]);
+                im[q][k] = fmaf(gr[q], wi, im[q][k]);
+                im[q][k] = fmaf(gi[q], wr, im[q][k]);
+            }
+        }
+    }
+    const bool full = (k0 + ZPL <= P.nz) && (P.nz % ZPL == 0);
+#pragma unroll
+    for (int kk = 0; kk < MX * MY * NF; ++kk) {      // every stored volume slice: (focus, mirror image)
+        const int f = tile * NF + kk / (MX * MY);
+        if (f >= P.n_foci) continue;
+        const int ms = kk % (MX * MY);                // store mirror: bit 0 = x (if MX == 2), next = y
+        const bool fx = (MX == 2) && (ms & 1), fy = (MY == 2) && ((MX == 2) ? (ms >> 1) : (ms & 1));
+        // weight column that holds this image's sum (collapsed along axes with symmetric steering)
+        const int cx = (DX == 2 && fx) ? 1 : 0, cy = (DY == 2 && fy) ? 1 : 0;
+        const int k = (kk / (MX * MY)) * NM + cx + DX * cy;
+        const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+        const long long base = (long long)f * P.vox + ((long long)io * P.ny + jo) * P.nz + k0;
+        float pm[ZPL], it[ZPL];
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            const float m2 = fmaf(re[q][k], re[q][k], im[q][k] * im[q][k]);
+            pm[q] = __builtin_sqrtf(m2);
+            it[q] = m2 * P.inten_scale;
+        }
+        if (ZPL == 4 && full) {
+            if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+            if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+            if (P.flags & 4u) {
+                float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
+                c4[0] = make_float4(re[0][k], im[0][k], re[1][k], im[1][k]);
+                c4[1] = make_float4(re[2][k], im[2][k], re[3][k], im[3][k]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ZPL; ++q) {
+                if (k0 + q < P.nz) {
+                    if (P.flags & 1u) pmag[base + q] = pm[q];
+                    if (P.flags & 2u) inten[base + q] = it[q];
+                    if (P.flags & 4u) { cplx[2 * (base + q)] = re[q][k]; cplx[2 * (base + q) + 1] = im[q][k]; }
+                }
+            }
+        }
+    }
+}
+
+
+}  // namespace olx
+
+using namespace olx;
+
+template <int MX, int MY, int DX, int DY, int NF>
+static void launch_shared(olx_ctx* c, float* pm) {
+    const SharedParams& S = c->sp;
+    constexpr int ZPL = 4;
+    const long long cpr = (S.nz + ZPL - 1) / ZPL;
+    const long long lanes = (long long)(S.nx - (MX == 2 ? S.nx / 2 : 0)) * (S.ny - (MY == 2 ? S.ny / 2 : 0)) * cpr;
+    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), (c->plan_foci + NF - 1) / NF);
+    dim3 blk(FIELD_THREADS);
+    if (c->flat) {
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+    } else {
+        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+    }
+}
+
+static bool dispatch_shared(olx_ctx* c, float* pm) {
+#define OLX_CASE(MX_, MY_, DX_, DY_, NF_) \
+    if (c->mx == MX_ && c->my == MY_ && c->dx == DX_ && c->dy == DY_ && c->nf == NF_) { launch_shared<MX_, MY_, DX_, DY_, NF_>(c, pm); return true; }
+    // no fold: foci tiles only
+    OLX_CASE(1, 1, 1, 1, 2) OLX_CASE(1, 1, 1, 1, 4) OLX_CASE(1, 1, 1, 1, 8)
+    // one fold
+    OLX_CASE(2, 1, 1, 1, 1) OLX_CASE(2, 1, 1, 1, 2) OLX_CASE(2, 1, 1, 1, 4) OLX_CASE(2, 1, 1, 1, 8)
+    OLX_CASE(2, 1, 2, 1, 1) OLX_CASE(2, 1, 2, 1, 2) OLX_CASE(2, 1, 2, 1, 4)
+    OLX_CASE(1, 2, 1, 1, 1) OLX_CASE(1, 2, 1, 1, 2) OLX_CASE(1, 2, 1, 1, 4) OLX_CASE(1, 2, 1, 1, 8)
+    OLX_CASE(1, 2, 1, 2, 1) OLX_CASE(1, 2, 1, 2, 2) OLX_CASE(1, 2, 1, 2, 4)
+    // two folds
+    OLX_CASE(2, 2, 1, 1, 1) OLX_CASE(2, 2, 1, 1, 2) OLX_CASE(2, 2, 1, 1, 4) OLX_CASE(2, 2, 1, 1, 8)
+    OLX_CASE(2, 2, 2, 1, 1) OLX_CASE(2, 2, 2, 1, 2) OLX_CASE(2, 2, 2, 1, 4)
+    OLX_CASE(2, 2, 1, 2, 1) OLX_CASE(2, 2, 1, 2, 2) OLX_CASE(2, 2, 1, 2, 4)
+    OLX_CASE(2, 2, 2, 2, 1) OLX_CASE(2, 2, 2, 2, 2)
+#undef OLX_CASE
+    return false;
+}
+
+template <bool FLAT, bool CLAMP>
+static void launch_field(olx_ctx* c, float* pm) {
+    const FieldParams& P = c->fp;
+    constexpr int ZPL = 4;
+    const long long cpr = (P.nz + ZPL - 1) / ZPL;
+    const long long lanes = (long long)P.nx * P.ny * cpr;
+    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci);
+    hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm,
+                       c->d_inten, c->d_cplx, P);
+}
+
+bool olx_launch_shared(olx_ctx* c, float* pm) { return dispatch_shared(c, pm); }
+
+void olx_launch_accum(olx_ctx* c, float* pm) {
+    if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
+    else         { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }
+}

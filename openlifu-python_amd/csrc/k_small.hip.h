@@ -1,0 +1,520 @@
+// Small kernels of the openlifu hot path, compiled into the host translation unit (olx.hip):
+//  kernel 1  bf_solve_k / bf_quantize_k   per-element geometric delay / apodization solve (fp64), hardware hand-off
+//            steer_pack_k, steer_pack_shared_k, mfma_pack_k   fp64 steering + element table -> kernel-2 operands
+//  scans     field_aggregate(_p)_k, field_scale_k, field_masked_peak_k, field_masked_moments_k, field_sample_k,
+//            offset_grid_k, tof_spread_k, field_weighted_sum_k   (HBM-bound streaming)
+// gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4.
+#pragma once
+#include "k_types.hip.h"
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// kernel 1: F blocks (one per focus) x 256 threads striding over elements.
+// Element table is SoA fp64 (pos[3][N], nrm[3][N]) so that lane e reads pos[a][e]:
+// consecutive lanes -> consecutive 8-byte words (coalesced).  The focus and the 4x4
+// transform are staged once per block in LDS and broadcast from there.
+// Restates  xdc/element.py:239-246 (distance), :248-260 (angle),
+//           bf/delay_methods/direct.py:36-38, bf/apod_methods/maxangle.py:37-38,
+//           bf/apod_methods/piecewiselinear.py:46-48.
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(BF_THREADS) void bf_solve_k(
+    const double* __restrict__ pos,  // [3][N]
+    const double* __restrict__ nrm,  // [3][N]
+    int n, const double* __restrict__ foci /*[F][3]*/, const double* __restrict__ M /*[16]*/,
+    double c, int apod_kind, double angle_scale, double p0, double p1,
+    double* __restrict__ delays /*[F][N]*/, double* __restrict__ apod /*[F][N]*/) {
+    __shared__ double s_focus[3];
+    __shared__ double s_M[16];
+    __shared__ double s_red[BF_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid < 3) s_focus[tid] = foci[3 * f + tid];
+    if (tid >= 64 && tid < 80) s_M[tid - 64] = M[tid - 64];
+    __syncthreads();
+    const double fx = s_focus[0], fy = s_focus[1], fz = s_focus[2];
+    double* dl = delays + (size_t)f * n;
+    double* ap = apod + (size_t)f * n;
+    double lmax = -1.0;
+    for (int e = tid; e < n; e += BF_THREADS) {
+        const double px = pos[e], py = pos[n + e], pz = pos[2 * n + e];
+        // gpos = (M . [p,1])[:3]
+        const double gx = s_M[0] * px + s_M[1] * py + s_M[2] * pz + s_M[3];
+        const double gy = s_M[4] * px + s_M[5] * py + s_M[6] * pz + s_M[7];
+        const double gz = s_M[8] * px + s_M[9] * py + s_M[10] * pz + s_M[11];
+        const double vx = fx - gx, vy = fy - gy, vz = fz - gz;
+        const double d = sqrt(vx * vx + vy * vy + vz * vz);
+        const double tof = d / c;
+        dl[e] = tof;
+        lmax = fmax(lmax, tof);
+        double a;
+        if (apod_kind == 0) {
+            a = p0;
+        } else {
+            const double nx0 = nrm[e], ny0 = nrm[n + e], nz0 = nrm[2 * n + e];
+            // v2 = (M . pose)[:3,2] = M[:3,:3] . normal
+            double wx = s_M[0] * nx0 + s_M[1] * ny0 + s_M[2] * nz0;
+            double wy = s_M[4] * nx0 + s_M[5] * ny0 + s_M[6] * nz0;
+            double wz = s_M[8] * nx0 + s_M[9] * ny0 + s_M[10] * nz0;
+            const double wn = sqrt(wx * wx + wy * wy + wz * wz);
+            wx /= wn; wy /= wn; wz /= wn;
+            const double ux = vx / d, uy = vy / d, uz = vz / d;
+            const double cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+            double sn = sqrt(cx * cx + cy * cy + cz * cz);
+            const double theta_deg = asin(sn) * angle_scale;  // 180/pi (np.degrees) or 1
+            if (apod_kind == 1) {
+                a = (theta_deg <= p0) ? 1.0 : 0.0;
+            } else {
+                const double fr = (p0 - theta_deg) / (p0 - p1);
+                a = fmax(0.0, fmin(1.0, fr));
+            }
+        }
+        ap[e] = a;
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) s_red[tid >> 6] = lmax;
+    __syncthreads();
+    double bmax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < BF_THREADS / 64; ++w) bmax = fmax(bmax, s_red[w]);
+    for (int e = tid; e < n; e += BF_THREADS) dl[e] = bmax - dl[e];  // same thread wrote dl[e]
+}
+
+// ------------------------------------------------------------------------------------
+// hardware hand-off of the steering table (io/LIFUTXDevice.py:1357-1372, 1874): per focus and
+// element the beamformer-clock delay count int(delay * 1.0 * bf_clk) -- the reference's own fp64 expression,
+// truncated toward zero, so the ticks are bit-exact -- and the apodization-off bit int(1 - apod)
+// (LIFUTXDevice.py:1811); per focus max(apod) (the duty-cycle factor of :1358) and the number of delays that
+// do not fit `width` bits (set_register_value would raise, :1500-1501).  F blocks x 256 threads.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BF_THREADS) void bf_quantize_k(const double* __restrict__ delays, const double* __restrict__ apod,
+                                                             int n, double bf_clk, unsigned max_ticks,
+                                                             unsigned short* __restrict__ ticks, unsigned char* __restrict__ apod_off,
+                                                             double* __restrict__ max_apod, int* __restrict__ n_overflow) {
+    __shared__ double s_red[BF_THREADS / 64];
+    __shared__ int s_ovf[BF_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    double amax = -1.0e300;
+    int ovf = 0;
+    for (int e = tid; e < n; e += BF_THREADS) {
+        const size_t o = (size_t)f * n + e;
+        const double prod = delays[o] * 1.0 * bf_clk;
+        const long long t = (long long)prod;                 // int(): toward zero
+        if (t < 0 || t > (long long)max_ticks) ++ovf;
+        ticks[o] = (unsigned short)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
+        const double a = apod[o];
+        apod_off[o] = (unsigned char)(int)(1.0 - a);
+        amax = fmax(amax, a);
+    }
+    amax = wave_max(amax);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ovf += __shfl_xor(ovf, off, 64);
+    if ((tid & 63) == 0) { s_red[tid >> 6] = amax; s_ovf[tid >> 6] = ovf; }
+    __syncthreads();
+    if (tid == 0) {
+        double m = s_red[0]; int v = s_ovf[0];
+#pragma unroll
+        for (int w = 1; w < BF_THREADS / 64; ++w) { m = fmax(m, s_red[w]); v += s_ovf[w]; }
+        max_apod[f] = m;
+        n_overflow[f] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// steering pack: fp64 (pos, area, delays, apod) -> the fp32 table kernel 2 streams through
+// the scalar cache.  Entry (f, e) = 8 floats (32 B, one s_load_dwordx8):
+//   { (x_e - ox)/lambda, (y_e - oy)/lambda, (z_e - oz)/lambda, w_ef, phi_ef, 0, 0, 0 }
+// Lengths are in WAVELENGTHS (x f0/c) so that the phase in revolutions is the distance itself:
+// t = d2 * rsq(d2) + phi is ONE fma.  w_ef = a_ef P0 S_e / lambda^2 [Pa] (amplitude w/d with d in
+// wavelengths);  phi_ef = frac(f0 tau_ef) [revolutions].
+// Differences and products are formed in fp64 and rounded once.
+// ------------------------------------------------------------------------------------
+
+__global__ void steer_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
+                             const double* __restrict__ delays, const double* __restrict__ apod,
+                             double ox, double oy, double oz, double freq, double p0_over_lambda,
+                             double rev, const int* __restrict__ kfirst, const int* __restrict__ klast,
+                             float* __restrict__ tab) {
+    const int f = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const size_t o = ((size_t)f * n + e);
+    const double cyc = freq * delays[o];
+    float* t = tab + o * TAB_STRIDE;
+    t[0] = (float)((pos[e] - ox) * rev);
+    t[1] = (float)((pos[n + e] - oy) * rev);
+    t[2] = (float)((pos[2 * n + e] - oz) * rev);
+    t[3] = (float)(apod[o] * area[e] * p0_over_lambda * rev);
+    t[4] = (float)(cyc - floor(cyc));
+    t[5] = kfirst ? __int_as_float(kfirst[e]) : 0.f;  // kernel 2h: planes strictly above / below the element
+    t[6] = klast ? __int_as_float(klast[e]) : 0.f;
+    t[7] = 0.f;
+}
+
+// pack for kernel 2b: complex weights W[sigma_m(e), f] = a P0 S / lambda * exp(j 2 pi frac(f0 tau)),
+// evaluated in fp64 and rounded once.  perm[m][e] = index of the mirror image of element e.
+__global__ void steer_pack_shared_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
+                                    const double* __restrict__ delays, const double* __restrict__ apod,
+                                    const int* __restrict__ perm, double ox, double oy, double oz, double freq,
+                                    double p0_over_lambda, double rev, int n_foci, int nf, int nm,
+                                    float* __restrict__ tab) {
+    const int tile = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int nout = nf * nm, stride = 4 + 2 * nout;
+    float* t = tab + ((size_t)tile * n + e) * stride;
+    t[0] = (float)((pos[e] - ox) * rev);
+    t[1] = (float)((pos[n + e] - oy) * rev);
+    t[2] = (float)((pos[2 * n + e] - oz) * rev);
+    t[3] = 0.f;
+    for (int k = 0; k < nout; ++k) {
+        const int f = tile * nf + k / nm, m = k % nm;
+        float wr = 0.f, wi = 0.f;
+        if (f < n_foci) {
+            const int es = perm[m * n + e];
+            const size_t o = (size_t)f * n + es;
+            const double cyc = freq * delays[o];
+            const double ph = 6.283185307179586476925286766559 * (cyc - floor(cyc));
+            const double w = apod[o] * area[es] * p0_over_lambda * rev;
+            wr = (float)(w * cos(ph));
+            wi = (float)(w * sin(ph));
+        }
+        t[4 + 2 * k] = wr;
+        t[5 + 2 * k] = wi;
+    }
+}
+
+// pack for kernel 2c: element coordinates (wavelengths, padded) and B fragments in MFMA lane order.
+// grid (n_el_pad/16, tiles, NT), block 64: thread = lane.  Column o (< 8*NT) of tile T carries the steering
+// vector of its representative (focus, mirror image): W[perm[image][e], focus]; unused columns are zero.
+__global__ void mfma_pack_k(const double* __restrict__ pos, const double* __restrict__ area, int n, int n_pad,
+                            const double* __restrict__ delays, const double* __restrict__ apod,
+                            const int* __restrict__ perm, double ox, double oy, double oz, double freq,
+                            double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci,
+                            const int* __restrict__ colinfo /*[tiles][32][2]: representative focus, mirror image (-1 = unused)*/,
+                            const int* __restrict__ slot_elem /*kernel 2d: element of K slot s (-1 = virtual), NULL = identity*/,
+                            int fp8corr /*kernel 2e, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element*/,
+                            float4* __restrict__ coords, uint4* __restrict__ bfrag) {
+    const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
+    if (!slot_elem && tile == 0 && nt == 0 && lane < 16) {
+        const int e = 16 * ks + lane;
+        coords[e] = (e < n) ? make_float4((float)((pos[e] - ox) * rev), (float)((pos[n + e] - oy) * rev),
+                                          (float)((pos[2 * n + e] - oz) * rev), 0.f)
+                            : make_float4(1.0e4f, 1.0e4f, 1.0e4f, 0.f);  // padding: far away, zero weight
+    }
+    const int g = lane >> 4, c = lane & 15, o = nt * 8 + (c >> 1), part_c = c & 1;
+    const int col_focus = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2];
+    const int col_mirror = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2 + 1];
+    Half8Bits hi, lo;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 8 * g + jj, slot = 16 * ks + (k >> 1), part_k = k & 1;
+        const int e = slot_elem ? slot_elem[slot] : (slot < n ? slot : -1);
+        double val = 0.0;
+        const int f = col_focus;
+        if (e >= 0 && f >= 0 && f < n_foci) {
+            const int es = perm[col_mirror * n + e];
+            const size_t off = (size_t)f * n + es;
+            const double cyc = freq * delays[off];
+            const double ph = 6.283185307179586476925286766559 * (cyc - floor(cyc));
+            const double w = apod[off] * area[es] * w_scale;
+            const double wr = w * cos(ph), wi = w * sin(ph);
+            val = part_k == 0 ? (part_c == 0 ? wr : wi) : (part_c == 0 ? -wi : wr);
+        }
+        const _Float16 h = (_Float16)(float)val;
+        const _Float16 l = (_Float16)(float)(val - (double)(float)h);
+        hi.h[jj] = h;
+        lo.h[jj] = l;
+    }
+    if (fp8corr) {
+        Half8Bits q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[2 * e] * COS_F8_HI, (float)hi.h[2 * e + 1] * COS_F8_HI, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo.h[2 * e] * COS_F8_LO, (float)lo.h[2 * e + 1] * COS_F8_LO, w, true);
+            q.w[e] = (unsigned)w;
+        }
+        lo.u = q.u;
+    }
+    uint4* dst = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 128;
+    dst[lane] = hi.u;
+    dst[64 + lane] = lo.u;
+}
+
+// ------------------------------------------------------------------------------------
+// aggregation over foci (plan/protocol.py:384-387) and per-focus scaling
+// (plan/solution.py:331-337).  HBM-bound streaming: float4 per lane, grid-stride.
+// ------------------------------------------------------------------------------------
+__global__ void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+                                  int n_foci, long long vox, float inv /* 1 / total foci (all ranks) */,
+                                  float* __restrict__ pmax, float* __restrict__ imean) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        float m = 0.f, s = 0.f;
+        for (int f = 0; f < n_foci; ++f) {
+            if (pmag) m = fmaxf(m, pmag[(long long)f * vox + v]);
+            if (inten) s += inten[(long long)f * vox + v];
+        }
+        if (pmax) pmax[v] = m;
+        if (imean) imean[v] = s * inv;
+    }
+}
+
+// Same aggregate from the |p| volumes alone: the intensity of a launched (not uploaded) result is scale(v) |p|^2 by
+// construction (kwave_if.py:140-141), so the mean intensity is scale(v) mean_f |p_f|^2 and the intensity volumes
+// need not be read back -- half the HBM traffic of field_aggregate_k (4 B per voxel and focus, float4 per lane).
+__global__ __launch_bounds__(256) void field_aggregate_p_k(const float* __restrict__ pmag, int n_foci, long long vox, float inv,
+                                                            float inten_scale, const float* __restrict__ inv2z,
+                                                            float* __restrict__ pmax, float* __restrict__ imean) {
+    const long long stride = (long long)gridDim.x * blockDim.x, v4 = vox >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = m;
+#pragma unroll 8
+        for (int f = 0; f < n_foci; ++f) {          // unrolled: up to 8 independent 16-byte loads in flight per lane
+            const float4 p = reinterpret_cast<const float4*>(pmag + (long long)f * vox)[q];
+            m.x = fmaxf(m.x, p.x); m.y = fmaxf(m.y, p.y); m.z = fmaxf(m.z, p.z); m.w = fmaxf(m.w, p.w);
+            s.x = fmaf(p.x, p.x, s.x); s.y = fmaf(p.y, p.y, s.y); s.z = fmaf(p.z, p.z, s.z); s.w = fmaf(p.w, p.w, s.w);
+        }
+        reinterpret_cast<float4*>(pmax)[q] = m;
+        if (imean) {
+            float4 k = make_float4(inten_scale, inten_scale, inten_scale, inten_scale);
+            if (inv2z) k = reinterpret_cast<const float4*>(inv2z)[q];
+            reinterpret_cast<float4*>(imean)[q] = make_float4(s.x * k.x * inv, s.y * k.y * inv, s.z * k.z * inv, s.w * k.w * inv);
+        }
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {   // tail
+        float m = 0.f, s = 0.f;
+        for (int f = 0; f < n_foci; ++f) { const float p = pmag[(long long)f * vox + v]; m = fmaxf(m, p); s = fmaf(p, p, s); }
+        pmax[v] = m;
+        if (imean) imean[v] = s * (inv2z ? inv2z[v] : inten_scale) * inv;
+    }
+}
+
+__global__ void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
+                              float* __restrict__ cplx, const float* __restrict__ scale,
+                              long long vox) {
+    const int f = blockIdx.y;
+    const float s = scale[f];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        const long long o = (long long)f * vox + v;
+        if (pmag) pmag[o] *= s;
+        if (inten) inten[o] *= s * s;
+        if (cplx) { cplx[2 * o] *= s; cplx[2 * o + 1] *= s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// masked peak per focus (get_mask + max; plan/solution_analysis.py:384-442).  HBM-bound
+// scan of one float per voxel; the focal-frame affine is evaluated in fp64 so that the
+// mask edge matches the fp64 oracle.  Non-negative floats order like their bit patterns,
+// so the cross-block reduction is an integer atomicMax.
+// ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restrict__ vol,
+                                                            const double* __restrict__ A,
+                                                            const PeakParams P,
+                                                            unsigned* __restrict__ out) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ float s_red[4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float* v = vol + (long long)f * P.vol_stride;
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nyz = (long long)P.ny * P.nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / P.nz, iz = rem - iy * P.nz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        bool sel = true;
+        if (P.op != 4) {
+            const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+            const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+            const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+            const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+            sel = (P.op == 0) ? (dist < P.radius) : (P.op == 1) ? (dist <= P.radius)
+                : (P.op == 2) ? (dist > P.radius) : (dist >= P.radius);
+        }
+        if (P.use_zmin) sel = sel && (z > P.zmin);
+        if (sel) m = fmaxf(m, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        atomicMax(out + f, __float_as_uint(m));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// masked first moments per focus (find_centroid, plan/solution_analysis.py:306-317): over voxels inside
+// the focal ellipsoid (dist < radius) whose |p| exceeds cutoff_f:  S0 = sum p, S1 = sum p * (x, y, z).
+// fp64 sums, block-reduced, one atomicAdd(double) per block and component.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void field_masked_moments_k(const float* __restrict__ vol,
+                                                               const double* __restrict__ A,
+                                                               const float* __restrict__ cutoff,
+                                                               const PeakParams P, double* __restrict__ out /*[F][4]*/) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ double s_red[4][4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float* v = vol + (long long)f * P.vol_stride;
+    const float cut = cutoff[f];
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nyz = (long long)P.ny * P.nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / P.nz, iz = rem - iy * P.nz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+        const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+        const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+        const float p = v[i];
+        if (sqrt(q0 * q0 + q1 * q1 + q2 * q2) < P.radius && p > cut) {
+            s0 += p; sx += p * x; sy += p * y; sz += p * z;
+        }
+    }
+    double comp[4] = {s0, sx, sy, sz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) comp[k] += __shfl_xor(comp[k], off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = comp[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(out + 4 * f + threadIdx.x, s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
+                                                                s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------
+// trilinear samples of one resident volume at arbitrary points (interp_transformed_axis,
+// plan/solution_analysis.py:444-486: xarray linear interpolation, NaN outside the grid).
+// ------------------------------------------------------------------------------------
+__global__ void field_sample_k(const float* __restrict__ vol, const double* __restrict__ pts, int npts,
+                               const PeakParams P, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const double c[3] = {(pts[3 * i] - P.ox) / P.hx, (pts[3 * i + 1] - P.oy) / P.hy, (pts[3 * i + 2] - P.oz) / P.hz};
+    const int n[3] = {P.nx, P.ny, P.nz};
+    int i0[3]; double w[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double tol = 1e-9 * (n[a] > 1 ? n[a] - 1 : 1);
+        if (!(c[a] >= -tol && c[a] <= n[a] - 1 + tol)) inside = false;
+        double cc = fmin(fmax(c[a], 0.0), (double)(n[a] - 1));
+        i0[a] = (int)fmin(floor(cc), (double)max(n[a] - 2, 0));
+        w[a] = cc - i0[a];
+    }
+    if (!inside) { out[i] = __builtin_nanf(""); return; }
+    double acc = 0;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const int ix = min(i0[0] + dx, P.nx - 1), iy = min(i0[1] + dy, P.ny - 1), iz = min(i0[2] + dz, P.nz - 1);
+                const double ww = (dx ? w[0] : 1 - w[0]) * (dy ? w[1] : 1 - w[1]) * (dz ? w[2] : 1 - w[2]);
+                acc += ww * vol[((long long)ix * P.ny + iy) * P.nz + iz];
+            }
+    out[i] = (float)acc;
+}
+
+// ------------------------------------------------------------------------------------
+// offset grid (get_gridded_transformed_coords / get_offset_grid / calc_dist_from_focus,
+// plan/solution_analysis.py:344-403): per voxel q = A . [x, y, z, 1] in fp64 (A = first three rows of
+// inv(get_focus_matrix)), optionally dist = sqrt(sum (q_a / aspect_a)^2).  Pure HBM write stream: 24 (+8) bytes
+// per voxel, coordinates come from the three axis vectors (a few KB, cache resident).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void offset_grid_k(const double* __restrict__ xs, const double* __restrict__ ys,
+                                                      const double* __restrict__ zs, int nx, int ny, int nz,
+                                                      const double* __restrict__ A, double ia0, double ia1, double ia2,
+                                                      double* __restrict__ coords, double* __restrict__ dist) {
+    __shared__ double sA[12];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[threadIdx.x];
+    __syncthreads();
+    const long long vox = (long long)nx * ny * nz, nyz = (long long)ny * nz;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / nz, iz = rem - iy * nz;
+        const double x = xs[ix], y = ys[iy], z = zs[iz];
+        // same association as the reference's np.dot row: ((a0 x + a1 y) + a2 z) + a3, no fused contraction
+        const double q0 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[0], x), __dmul_rn(sA[1], y)), __dmul_rn(sA[2], z)), sA[3]);
+        const double q1 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[4], x), __dmul_rn(sA[5], y)), __dmul_rn(sA[6], z)), sA[7]);
+        const double q2 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(sA[8], x), __dmul_rn(sA[9], y)), __dmul_rn(sA[10], z)), sA[11]);
+        if (coords) { coords[3 * i] = q0; coords[3 * i + 1] = q1; coords[3 * i + 2] = q2; }
+        if (dist) {
+            const double d0 = q0 * ia0, d1 = q1 * ia1, d2 = q2 * ia2;
+            dist[i] = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// time-of-flight spread (SimSetup.get_max_cycle_offset, sim/sim_setup.py:132-143): per voxel
+// tof_e = ||r_v - r_e|| / c0 + delay_e, dtof = max_e tof - min_e tof; result = max over voxels (fp64, the reference's
+// arithmetic).  Element positions / delays are wave-uniform scalar loads; block max via __shfl_xor, then one
+// atomicMax on the bit pattern (non-negative doubles order like their uint64 images).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tof_spread_k(const double* __restrict__ xs, const double* __restrict__ ys,
+                                                     const double* __restrict__ zs, int nx, int ny, int nz,
+                                                     const double* __restrict__ pos /*[3][N]*/, const double* __restrict__ delays,
+                                                     int n, double c0, unsigned long long* __restrict__ out) {
+    __shared__ double s_red[4];
+    const long long vox = (long long)nx * ny * nz, nyz = (long long)ny * nz;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    double best = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / nz, iz = rem - iy * nz;
+        const double x = xs[ix], y = ys[iy], z = zs[iz];
+        double tmax = -1.0e300, tmin = 1.0e300;
+        for (int e = 0; e < n; ++e) {
+            const double dx = x - pos[e], dy = y - pos[n + e], dz = z - pos[2 * n + e];
+            const double t = __dadd_rn(__ddiv_rn(sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz))), c0),
+                                       delays ? delays[e] : 0.0);
+            tmax = fmax(tmax, t); tmin = fmin(tmin, t);
+        }
+        best = fmax(best, tmax - tmin);
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        atomicMax(out, (unsigned long long)__double_as_longlong(best));
+    }
+}
+
+// weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
+__global__ void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
+                                     long long vox, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+        float s = 0.f;
+        for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * vox + v];
+        out[v] = s;
+    }
+}
+
+
+}  // namespace olx

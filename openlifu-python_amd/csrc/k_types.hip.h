@@ -1,0 +1,31 @@
+// Device-side vector types and small helpers shared by the kernel translation units (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "olx_params.h"
+
+namespace olx {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+typedef int intx8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+__device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2]: no LDS traffic)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+#ifdef OLX_EXP_STAMPS
+static __device__ unsigned long long g_stamps[4096][8];   // per translation unit; read back by olx_exp_read_stamps (k_coset.hip)
+#define OLX_STAMP(k) do { if (lane == 0 && wave < 4 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define OLX_STAMP(k)
+#endif
+
+}  // namespace olx

@@ -1,124 +1,17 @@
 // C-ABI of the MI355X-native openlifu hot path (declared in include/olx.h).
-// Host side: context, device buffers, launch logic, RCCL (dlopen) reassembly.
-#include "../../include/olx.h"
+// Host side: context, device buffers, launch logic, RCCL (dlopen) reassembly.  The kernel-2 families live in
+// their own translation units (k_*.hip, launchers in olx_launch.h); the small kernels are compiled here.
+#include "olx_ctx.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
-#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
-#include <cstdarg>
-#include <cstdio>
 #include <cstring>
-#include <string>
-#include <vector>
 
-#include "olx_kernels.hip.h"
-
-using namespace olx;
-
-// ---- RCCL, bound at run time so that single-GPU use never loads it -------------------
-typedef struct { char internal[OLX_UNIQUE_ID_BYTES]; } olx_nccl_id;
-typedef void* olx_nccl_comm;
-struct RcclApi {
-    void* handle = nullptr;
-    int (*GetUniqueId)(olx_nccl_id*) = nullptr;
-    int (*CommInitRank)(olx_nccl_comm*, int, olx_nccl_id, int) = nullptr;
-    int (*CommDestroy)(olx_nccl_comm) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int /*dtype*/, olx_nccl_comm, hipStream_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
-    int (*ReduceScatter)(const void*, void*, size_t /*recvcount*/, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-};
-static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
-static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
-
-struct olx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // element table (device fp64 SoA + host copy for variant decisions)
-    int n_el = 0;
-    double *d_pos = nullptr, *d_nrm = nullptr, *d_area = nullptr;
-    std::vector<double> h_pos;  // [3][N]
-    std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
-    std::vector<double> h_foci; unsigned long long foci_version = ~0ull;  // foci of the last olx_bf_solve in the element frame (M == identity)
-    bool allow_shared = true;
-    // steering
-    int n_foci = 0;
-    double *d_delays = nullptr, *d_apod = nullptr;
-    size_t steer_cap = 0;
-    double *d_foci = nullptr, *d_M = nullptr;
-    size_t foci_cap = 0;
-    unsigned long long steer_version = 0, packed_version = ~0ull;
-    // field plan
-    bool planned = false;
-    bool uploaded = false;  // volumes came from olx_field_upload: not launchable
-    olx_grid grid{};
-    olx_slab slab{};
-    int plan_foci = 0;
-    double freq = 0, c = 0, rho = 0, p0_pa = 0;
-    unsigned flags = 0;
-    FieldParams fp{};
-    bool flat = false, clamp = false;
-    // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
-    bool use_mfma = false; int nt = 1; MfmaParams mp{}; float4* d_coords = nullptr; uint4* d_bfrag = nullptr; int* d_colinfo = nullptr; int* d_targets = nullptr; size_t colinfo_cap = 0;
-    size_t coords_cap = 0, bfrag_cap = 0; double min_dist = 0, mfma_wscale = 0; int force_kind = 0;  // 0 auto, 1 general, 2 shared, 3 mfma
-    int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
-    float* d_tab = nullptr; size_t tab_cap = 0;
-    // lattice variant (kernel 2d): matrix array whose pitch is a whole number of voxels
-    struct Lattice {
-        bool ok = false;
-        int ax = 0, ay = 0, nsa = 0, nsb = 0, mx = 1, my = 1, n_pad = 0;
-        double x0 = 0, y0 = 0, px = 0, py = 0;     // position of lattice index (0, 0) and pitch [m]
-        double min_d2 = 0; bool clamp = false;     // incl. the zero-weight virtual elements of the padding
-        std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
-        std::vector<int> cell;                     // lattice cell (a, b) -> element
-        int nsbp = 0;                              // super-block rows of the slot map (nsb, or nsb padded to even)
-    } lat;
-    bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
-    static constexpr int NBUF = 2;
-    float* d_pmag[NBUF] = {nullptr, nullptr};
-    float* d_inten = nullptr; float* d_cplx = nullptr;
-    float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
-    double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
-    float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
-    // heterogeneous medium (kernel 2h)
-    bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
-    float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;
-    size_t out_cap = 0; int nbuf = 1; int cur = 0;
-    std::string variant;
-    std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
-    // comm
-    RcclApi rccl; olx_nccl_comm comm = nullptr; int nranks = 1, rank = 0;
-    hipStream_t comm_stream = nullptr; hipEvent_t ev_field[NBUF] = {nullptr, nullptr};
-    hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
-    float* d_gather = nullptr; size_t gather_cap = 0;
-    hipEvent_t ev_agg = nullptr, ev_red = nullptr; bool reduce_pending = false;
-};
-
-static int fail(olx_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) c->err = buf;
-    return code;
-}
-#define HIPCHK(c, call)                                                                  \
-    do {                                                                                 \
-        hipError_t e_ = (call);                                                          \
-        if (e_ != hipSuccess)                                                            \
-            return fail((c), e_ == hipErrorOutOfMemory ? OLX_ENOMEM : OLX_EHIP, "%s: %s", #call, \
-                        hipGetErrorString(e_));                                          \
-    } while (0)
-
-// call-scoped device scratch: freed on every return path
-struct DevScratch {
-    void* p = nullptr;
-    ~DevScratch() { if (p) hipFree(p); }
-    template <class T> T* at(size_t byte_off) const { return reinterpret_cast<T*>(static_cast<unsigned char*>(p) + byte_off); }
-};
+#include "k_small.hip.h"
+#include "olx_launch.h"
 
 extern "C" {
 
@@ -926,132 +819,6 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
 
 }  // extern "C"
 
-template <int MX, int MY, int DX, int DY, int NF>
-static void launch_shared(olx_ctx* c, float* pm) {
-    const SharedParams& S = c->sp;
-    constexpr int ZPL = 4;
-    const long long cpr = (S.nz + ZPL - 1) / ZPL;
-    const long long lanes = (long long)(S.nx - (MX == 2 ? S.nx / 2 : 0)) * (S.ny - (MY == 2 ? S.ny / 2 : 0)) * cpr;
-    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), (c->plan_foci + NF - 1) / NF);
-    dim3 blk(FIELD_THREADS);
-    if (c->flat) {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-    } else {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-        else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
-    }
-}
-
-template <int MT, int NT, int MX, int MY>
-static void launch_mfma(olx_ctx* c, float* pm) {
-    const MfmaParams& M = c->mp;
-    const long long rpr = (M.nz + MT * 16 - 1) / (MT * 16);
-    const long long runs = (long long)(M.nx - (MX == 2 ? M.nx / 2 : 0)) * (M.ny - (MY == 2 ? M.ny / 2 : 0)) * rpr;
-    dim3 grid((unsigned)((runs + 3) / 4), M.n_tiles), blk(FIELD_THREADS);
-#define OLX_MF(FL, CL) hipLaunchKernelGGL((field_mfma_k<MT, NT, MX, MY, FL, CL>), grid, blk, 0, c->stream, c->d_coords, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, M)
-    if (c->flat) { if (c->clamp) OLX_MF(true, true); else OLX_MF(true, false); }
-    else         { if (c->clamp) OLX_MF(false, true); else OLX_MF(false, false); }
-#undef OLX_MF
-}
-
-template <int MX, int MY>
-static void dispatch_mfma_nt(olx_ctx* c, float* pm) {
-    const bool big = c->mp.nz >= 48;
-    if (big) { if (c->nt == 1) launch_mfma<4, 1, MX, MY>(c, pm); else if (c->nt == 2) launch_mfma<4, 2, MX, MY>(c, pm); else launch_mfma<4, 4, MX, MY>(c, pm); }
-    else     { if (c->nt == 1) launch_mfma<1, 1, MX, MY>(c, pm); else if (c->nt == 2) launch_mfma<1, 2, MX, MY>(c, pm); else launch_mfma<1, 4, MX, MY>(c, pm); }
-}
-
-template <int MT, int NT, int MX, int MY>
-static void launch_lattice(olx_ctx* c, float* pm, bool clamp) {
-    const LatParams& L = c->lp;
-    constexpr int NW = LAT_THREADS / 64;
-    const long long blocks = (long long)L.tiles_x * L.tiles_y * ((L.kgroups + NW - 1) / NW);
-    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(LAT_THREADS);
-    if (clamp) hipLaunchKernelGGL((field_lattice_k<MT, NT, MX, MY, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, L);
-    else       hipLaunchKernelGGL((field_lattice_k<MT, NT, MX, MY, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, L);
-}
-
-template <int MX, int MY>
-static void dispatch_lattice_nt(olx_ctx* c, float* pm) {
-    const bool clamp = c->clamp || c->lat.clamp;
-    if (c->nt == 1) launch_lattice<4, 1, MX, MY>(c, pm, clamp);
-    else if (c->nt == 2) launch_lattice<4, 2, MX, MY>(c, pm, clamp);
-    else launch_lattice<4, 4, MX, MY>(c, pm, clamp);
-}
-
-template <int NT, int MX, int MY>
-static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
-    const CosetParams& Q = c->cp;
-    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
-    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q)
-    if constexpr (cos_fp8(NT)) {
-        if (c->fp8corr) { if (clamp) OLX_COS(true, true); else OLX_COS(false, true); return; }
-    }
-    if (clamp) OLX_COS(true, false); else OLX_COS(false, false);
-#undef OLX_COS
-}
-
-template <int MX, int MY>
-static void dispatch_coset_nt(olx_ctx* c, float* pm) {
-    const bool clamp = c->clamp || c->lat.clamp;
-    if (c->nt == 1) launch_coset<1, MX, MY>(c, pm, clamp); else if (c->nt == 2) launch_coset<2, MX, MY>(c, pm, clamp);
-    else launch_coset<4, MX, MY>(c, pm, clamp);
-}
-
-static void dispatch_lattice(olx_ctx* c, float* pm) {
-    if (c->use_coset) {
-        if (c->mx == 2 && c->my == 2) dispatch_coset_nt<2, 2>(c, pm);
-        else if (c->mx == 2) dispatch_coset_nt<2, 1>(c, pm);
-        else if (c->my == 2) dispatch_coset_nt<1, 2>(c, pm);
-        else dispatch_coset_nt<1, 1>(c, pm);
-        return;
-    }
-    if (c->mx == 2 && c->my == 2) dispatch_lattice_nt<2, 2>(c, pm);
-    else if (c->mx == 2) dispatch_lattice_nt<2, 1>(c, pm);
-    else if (c->my == 2) dispatch_lattice_nt<1, 2>(c, pm);
-    else dispatch_lattice_nt<1, 1>(c, pm);
-}
-
-static void dispatch_mfma(olx_ctx* c, float* pm) {
-    if (c->use_lattice) { dispatch_lattice(c, pm); return; }
-    if (c->mx == 2 && c->my == 2) dispatch_mfma_nt<2, 2>(c, pm);
-    else if (c->mx == 2) dispatch_mfma_nt<2, 1>(c, pm);
-    else if (c->my == 2) dispatch_mfma_nt<1, 2>(c, pm);
-    else dispatch_mfma_nt<1, 1>(c, pm);
-}
-
-static bool dispatch_shared(olx_ctx* c, float* pm) {
-#define OLX_CASE(MX_, MY_, DX_, DY_, NF_) \
-    if (c->mx == MX_ && c->my == MY_ && c->dx == DX_ && c->dy == DY_ && c->nf == NF_) { launch_shared<MX_, MY_, DX_, DY_, NF_>(c, pm); return true; }
-    // no fold: foci tiles only
-    OLX_CASE(1, 1, 1, 1, 2) OLX_CASE(1, 1, 1, 1, 4) OLX_CASE(1, 1, 1, 1, 8)
-    // one fold
-    OLX_CASE(2, 1, 1, 1, 1) OLX_CASE(2, 1, 1, 1, 2) OLX_CASE(2, 1, 1, 1, 4) OLX_CASE(2, 1, 1, 1, 8)
-    OLX_CASE(2, 1, 2, 1, 1) OLX_CASE(2, 1, 2, 1, 2) OLX_CASE(2, 1, 2, 1, 4)
-    OLX_CASE(1, 2, 1, 1, 1) OLX_CASE(1, 2, 1, 1, 2) OLX_CASE(1, 2, 1, 1, 4) OLX_CASE(1, 2, 1, 1, 8)
-    OLX_CASE(1, 2, 1, 2, 1) OLX_CASE(1, 2, 1, 2, 2) OLX_CASE(1, 2, 1, 2, 4)
-    // two folds
-    OLX_CASE(2, 2, 1, 1, 1) OLX_CASE(2, 2, 1, 1, 2) OLX_CASE(2, 2, 1, 1, 4) OLX_CASE(2, 2, 1, 1, 8)
-    OLX_CASE(2, 2, 2, 1, 1) OLX_CASE(2, 2, 2, 1, 2) OLX_CASE(2, 2, 2, 1, 4)
-    OLX_CASE(2, 2, 1, 2, 1) OLX_CASE(2, 2, 1, 2, 2) OLX_CASE(2, 2, 1, 2, 4)
-    OLX_CASE(2, 2, 2, 2, 1) OLX_CASE(2, 2, 2, 2, 2)
-#undef OLX_CASE
-    return false;
-}
-
-template <bool FLAT, bool CLAMP>
-static void launch_field(olx_ctx* c, float* pm) {
-    const FieldParams& P = c->fp;
-    constexpr int ZPL = 4;
-    const long long cpr = (P.nz + ZPL - 1) / ZPL;
-    const long long lanes = (long long)P.nx * P.ny * cpr;
-    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci);
-    hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm,
-                       c->d_inten, c->d_cplx, P);
-}
-
 extern "C" {
 
 int olx_field_launch(olx_ctx* c) {
@@ -1070,18 +837,11 @@ int olx_field_launch(olx_ctx* c) {
     float* pm = c->d_pmag[b];
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    if (c->hetero) {
-        const FieldParams& P = c->fp;
-        const long long nblk = (long long)((P.nx + 7) / 8) * ((P.ny + 7) / 8) * ((P.nz + 15) / 16);  // 8x8 tile x 16 z
-        dim3 grid((unsigned)nblk, c->plan_foci), blk(FIELD_THREADS);
-        if (c->clamp) hipLaunchKernelGGL((field_hetero_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
-        else          hipLaunchKernelGGL((field_hetero_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
-    } else if (c->use_mfma) {
-        dispatch_mfma(c, pm);
-    } else if (c->mx * c->my * c->nf > 1) {
-        if (!dispatch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
-    } else if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }
-    else                { if (c->clamp) launch_field<false, true>(c, pm); else launch_field<false, false>(c, pm); }
+    if (c->hetero) olx_launch_hetero(c, pm);
+    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+    else if (c->mx * c->my * c->nf > 1) {
+        if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
+    } else olx_launch_accum(c, pm);
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
     c->cur = b;
@@ -1671,10 +1431,3 @@ int olx_allgather_fetch(olx_ctx* c, int rank, float* out) {
 }
 
 }  // extern "C"
-
-#ifdef OLX_EXP_STAMPS
-// developer build only (tools/stamps.py): per-wave phase time stamps of the lattice kernel
-extern "C" int olx_exp_read_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_stamps), sizeof(unsigned long long) * 4096 * 8);
-}
-#endif

@@ -1,0 +1,118 @@
+// Host-side context of the C-ABI (include/olx.h): device buffers, plan state, variant decisions.
+// Shared by olx.hip and the kernel translation units' launchers.
+#pragma once
+#include "../../include/olx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "olx_params.h"
+
+using namespace olx;
+
+// ---- RCCL, bound at run time so that single-GPU use never loads it -------------------
+typedef struct { char internal[OLX_UNIQUE_ID_BYTES]; } olx_nccl_id;
+typedef void* olx_nccl_comm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(olx_nccl_id*) = nullptr;
+    int (*CommInitRank)(olx_nccl_comm*, int, olx_nccl_id, int) = nullptr;
+    int (*CommDestroy)(olx_nccl_comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int /*dtype*/, olx_nccl_comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t /*recvcount*/, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
+static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
+
+struct olx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // element table (device fp64 SoA + host copy for variant decisions)
+    int n_el = 0;
+    double *d_pos = nullptr, *d_nrm = nullptr, *d_area = nullptr;
+    std::vector<double> h_pos;  // [3][N]
+    std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
+    std::vector<double> h_foci; unsigned long long foci_version = ~0ull;  // foci of the last olx_bf_solve in the element frame (M == identity)
+    bool allow_shared = true;
+    // steering
+    int n_foci = 0;
+    double *d_delays = nullptr, *d_apod = nullptr;
+    size_t steer_cap = 0;
+    double *d_foci = nullptr, *d_M = nullptr;
+    size_t foci_cap = 0;
+    unsigned long long steer_version = 0, packed_version = ~0ull;
+    // field plan
+    bool planned = false;
+    bool uploaded = false;  // volumes came from olx_field_upload: not launchable
+    olx_grid grid{};
+    olx_slab slab{};
+    int plan_foci = 0;
+    double freq = 0, c = 0, rho = 0, p0_pa = 0;
+    unsigned flags = 0;
+    FieldParams fp{};
+    bool flat = false, clamp = false;
+    // shared-geometry variant (kernel 2b): mirror folds and foci per tile; 1,1,1 = kernel 2a
+    bool use_mfma = false; int nt = 1; MfmaParams mp{}; float4* d_coords = nullptr; uint4* d_bfrag = nullptr; int* d_colinfo = nullptr; int* d_targets = nullptr; size_t colinfo_cap = 0;
+    size_t coords_cap = 0, bfrag_cap = 0; double min_dist = 0, mfma_wscale = 0; int force_kind = 0;  // 0 auto, 1 general, 2 shared, 3 mfma
+    int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
+    float* d_tab = nullptr; size_t tab_cap = 0;
+    // lattice variant (kernel 2d): matrix array whose pitch is a whole number of voxels
+    struct Lattice {
+        bool ok = false;
+        int ax = 0, ay = 0, nsa = 0, nsb = 0, mx = 1, my = 1, n_pad = 0;
+        double x0 = 0, y0 = 0, px = 0, py = 0;     // position of lattice index (0, 0) and pitch [m]
+        double min_d2 = 0; bool clamp = false;     // incl. the zero-weight virtual elements of the padding
+        std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
+        std::vector<int> cell;                     // lattice cell (a, b) -> element
+        int nsbp = 0;                              // super-block rows of the slot map (nsb, or nsb padded to even)
+    } lat;
+    bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
+    bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
+    static constexpr int NBUF = 2;
+    float* d_pmag[NBUF] = {nullptr, nullptr};
+    float* d_inten = nullptr; float* d_cplx = nullptr;
+    float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
+    double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
+    float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
+    // heterogeneous medium (kernel 2h)
+    bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
+    float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;
+    size_t out_cap = 0; int nbuf = 1; int cur = 0;
+    std::string variant;
+    std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
+    // comm
+    RcclApi rccl; olx_nccl_comm comm = nullptr; int nranks = 1, rank = 0;
+    hipStream_t comm_stream = nullptr; hipEvent_t ev_field[NBUF] = {nullptr, nullptr};
+    hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
+    float* d_gather = nullptr; size_t gather_cap = 0;
+    hipEvent_t ev_agg = nullptr, ev_red = nullptr; bool reduce_pending = false;
+};
+
+static inline int fail(olx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail((c), e_ == hipErrorOutOfMemory ? OLX_ENOMEM : OLX_EHIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                          \
+    } while (0)
+
+// call-scoped device scratch: freed on every return path
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) hipFree(p); }
+    template <class T> T* at(size_t byte_off) const { return reinterpret_cast<T*>(static_cast<unsigned char*>(p) + byte_off); }
+};
+

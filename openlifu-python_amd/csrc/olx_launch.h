@@ -1,0 +1,11 @@
+// Launchers of the kernel-2 families, one translation unit each (k_*.hip).  Each enqueues ONE launch of the
+// planned variant on the context's stream, writing |p| to `pm` (the current output buffer) and the other planned
+// outputs to the context's buffers; errors surface through hipGetLastError in olx_field_launch.
+#pragma once
+struct olx_ctx;
+void olx_launch_accum(olx_ctx* c, float* pm);        // 2a  field_accum_k
+bool olx_launch_shared(olx_ctx* c, float* pm);       // 2b  field_shared_k (false: no instantiation for the planned shape)
+void olx_launch_mfma(olx_ctx* c, float* pm);         // 2c  field_mfma_k
+void olx_launch_lattice(olx_ctx* c, float* pm);      // 2d  field_lattice_k
+void olx_launch_coset(olx_ctx* c, float* pm);        // 2e  field_coset_k
+void olx_launch_hetero(olx_ctx* c, float* pm);       // 2h  field_hetero_k
