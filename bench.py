@@ -3,21 +3,23 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of kernel 2 that
-accumulates the complex pressure of this GPU's `--foci-per-gpu` foci (default 8 = one GPU's share of
-BASELINE.json's 64-focus Wheel sweep, configs[2]) of a 256-element matrix array over a 256^3 grid,
-with the element table and the steering table already resident in HBM.  `--foci-per-gpu 1` is the
-single-focus accumulate.  For N > 1 (launched by torch.distributed.run, one rank per GPU) rank r takes
-foci [8r, 8r+8) of the sweep (weak scaling; the compute needs no collective).  `--reassemble` selects
-what crosses xGMI per step, on a side stream overlapped with the next step's compute:
-  aggregate (default)  local max/mean over the rank's foci + RCCL reduce-scatter of ONE volume pair (rank r ends
-                       up owning its 1/N of the global aggregate; olx_field_allreduce_aggregate would replicate it) --
-                       the aggregated result of Protocol.calc_solution (plan/protocol.py:382-387), the only
-                       cross-rank dependency the sharded path has;
-  allgather            every per-focus |p| volume to every rank (north_star's reassembly; 67 MB per
-                       focus per peer: xGMI-bound, see DESIGN.md section 6);
-  none                 volumes stay sharded in each rank's HBM.
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of kernel 2 that accumulates the
+complex pressure of this GPU's `--foci-per-gpu` foci (default 8 = one GPU's share of BASELINE.json's 64-focus Wheel
+sweep, configs[2]) of a 256-element matrix array over a 256^3 grid, element table and steering table already resident
+in HBM, plus -- for N > 1 -- the reassembly exchange.  The foci of a rank are whatever the PRODUCT's shard planner
+(openlifu_amd.dist.plan_foci_orbits: whole mirror orbits per GPU) assigns it, driven through the product's
+`ShardedField` (plan_foci_sweep / step); `--foci-per-gpu 1` is the single-focus accumulate (configs[1] / configs[3]).
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU; weak scaling: 8 foci per GPU, 64 at N = 8) the timed
+step uses `--reassemble allgather` by default -- north_star's reassembly, every per-focus |p| volume to every rank over
+RCCL/xGMI on a side stream, overlapped with the next step's compute; the same run then reports `aggregate`
+(reduce-scatter of max |p| / mean intensity, plan/protocol.py:382-387) and the compute without any exchange beside it.
 torch is used only for the rendezvous / barrier (gloo); the product path is ctypes -> HIP.
+
+Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `--corrections fp8` (bench default, an explicit
+opt-in through the plan flag OLX_FIELD_FP8_CORRECTION) computes the two hi x lo correction products in e4m3
+(<= 6e-6 of the focal peak); `--corrections fp16` is the library default (<= 2e-6).  At N = 1 the line carries BOTH
+timings (`precision_safe` = the fp16 one) and a `parity` block measured in this run against the fp64 C oracle.
 
 Prints ONE JSON line (rank 0).  `value` = V * N_el * F_total / time [Mvoxel-elements/s].
 """
@@ -41,67 +43,136 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # wave-instruction per SIMD at 8 waves/SIMD: plain f32 VALU 2.45, v_sin/v_cos/v_rsq 8.17
 CYC_PLAIN, CYC_TRANS = 2.45, 8.17
 N_SIMD, CLK_GHZ = 1024, 2.4
+F0, C0, RHO0, SENS = 400e3, 1500.0, 1000.0, 1e5
 
 
-def synthetic_workload(grid_n: int, spacing_mm: float, el=(16, 16), pitch_mm=3.0, n_foci=1, seed=0):
-    """SURVEY 8(d) inputs: flat matrix array (gen_matrix_array semantics), cubic grid centred in x,y,
-    z from 5 mm, foci = Wheel(center, 5 mm) about (0,0,40) mm when n_foci > 1."""
+def synthetic_workload(grid_n: int, spacing_mm: float, el=(16, 16), pitch_mm=3.0, offset_mm=(0.0, 0.0)):
+    """SURVEY 8(d) inputs: flat matrix array (gen_matrix_array semantics), cubic grid centred in x,y, z from 5 mm,
+    BASELINE configs[2]'s 64-focus sweep = Wheel(center, 63 spokes, 5 mm) about (0,0,40) mm (+ offset_mm)."""
     import openlifu_amd as ol
     arr = ol.Transducer.gen_matrix_array(nx=el[0], ny=el[1], pitch=pitch_mm, kerf=0.1 * pitch_mm, units="mm",
-                                         sensitivity=1e5)
+                                         sensitivity=SENS)
     half = (grid_n - 1) / 2 * spacing_mm
     setup = ol.SimSetup(spacing=spacing_mm, x_extent=(-half, half), y_extent=(-half, half),
                         z_extent=(5.0, 5.0 + (grid_n - 1) * spacing_mm))
-    target = ol.Point(position=(0, 0, 40), units="mm")
-    # BASELINE configs[2]: Wheel(center, 63 spokes, 5 mm) = 64 foci; rank r owns foci [r*F, r*F + F) (mod 64)
-    sweep = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0).get_targets(target)
-    # shard order: centre, spoke 0, then mirror partners (i, 63 - i) side by side, so that a shard holds whole
-    # mirror orbits -- their steering vectors coincide up to the array's symmetry and kernel 2c accumulates each once
-    order = [0, 1] + [k for i in range(1, 32) for k in (1 + i, 1 + 63 - i)]
-    foci = [sweep[order[(seed * n_foci + k) % len(order)]] for k in range(n_foci)]
-    return arr, setup, foci
+    target = ol.Point(position=(offset_mm[0], offset_mm[1], 40), units="mm")
+    pattern = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0)
+    return arr, setup, target, pattern
 
 
-def cpu_baseline(arr, setup, foci, budget_s: float):
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pos_m, area, coords, focus_m, budget_s: float):
     """Times the fp64 NumPy oracle (oracle/field_oracle.py, kind "port": the reference has no NumPy
     field code to time) on a bounded centred sub-cube of the same workload, single thread."""
     from oracle import bf_oracle as bo, field_oracle as fo
-    pos_m, _, area, _, _ = arr.element_table()
-    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci[0].get_position(units="m"), 1500.0)
-    coords = [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), focus_m, C0)
 
     def sub(n):
         return [c[(len(c) - n) // 2:(len(c) - n) // 2 + n] for c in coords]
 
     t = time.perf_counter()
-    fo.field_on_grid(*sub(16), pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    fo.field_on_grid(*sub(16), pos_m, area, d, a, F0, C0, SENS)
     rate = 16 ** 3 * len(pos_m) / (time.perf_counter() - t)
     n = int(min(len(coords[0]), max(16, round((budget_s * rate / len(pos_m)) ** (1 / 3)))))
     t = time.perf_counter()
-    fo.field_on_grid(*sub(n), pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    fo.field_on_grid(*sub(n), pos_m, area, d, a, F0, C0, SENS)
     dt = time.perf_counter() - t
     return {"value": n ** 3 * len(pos_m) / dt / 1e6, "unit": "Mvoxel-elements/s", "cores": 1, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"fp64 NumPy oracle, centred {n}^3 sub-cube x {len(pos_m)} elements, 1 focus, {dt:.1f} s"}
 
 
-def cpu_baseline_c(arr, setup, foci, budget_s: float):
+def cpu_baseline_c(pos_m, area, coords, focus_m, budget_s: float):
     """Same definition in C + OpenMP on every host core (oracle/field_oracle.c)."""
     from oracle import bf_oracle as bo, c_oracle as co
-    pos_m, _, area, _, _ = arr.element_table()
-    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci[0].get_position(units="m"), 1500.0)
-    coords = [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+    d, a = bo.beamform(pos_m, np.zeros_like(pos_m), focus_m, C0)
     n = min(len(coords[0]), 64)
     sub = [c[(len(c) - n) // 2:(len(c) - n) // 2 + n] for c in coords]
     t = time.perf_counter()
-    co.field_on_grid(*sub, pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    co.field_on_grid(*sub, pos_m, area, d, a, F0, C0, SENS)
     rate = n ** 3 * len(pos_m) / (time.perf_counter() - t)
     n2 = int(min(len(coords[0]), max(n, round((budget_s * rate / len(pos_m)) ** (1 / 3)))))
     sub = [c[(len(c) - n2) // 2:(len(c) - n2) // 2 + n2] for c in coords]
     t = time.perf_counter()
-    co.field_on_grid(*sub, pos_m, area, d, a, 400e3, 1500.0, 1e5)
+    co.field_on_grid(*sub, pos_m, area, d, a, F0, C0, SENS)
     dt = time.perf_counter() - t
     return {"value": n2 ** 3 * len(pos_m) / dt / 1e6, "unit": "Mvoxel-elements/s", "cores": co.max_threads(),
-            "kind": "port", "sample": f"fp64 C/OpenMP oracle, centred {n2}^3 sub-cube x {len(pos_m)} elements, {dt:.1f} s"}
+            "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"fp64 C/OpenMP oracle, centred {n2}^3 sub-cube x {len(pos_m)} elements, {dt:.1f} s"}
+
+
+def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), medium=None):
+    """Post-timing parity of the resident result against the fp64 C oracle: `n_samples` random voxels of up to three
+    focus volumes, error normalised by each focus' own peak (the volume maximum for a focus inside the grid)."""
+    from oracle import bf_oracle as bo, c_oracle as co
+    xs, ys, zs = coords
+    rng = np.random.default_rng(147)
+    idx = np.stack([rng.integers(0, len(c), n_samples) for c in coords], axis=1)
+    pts = np.stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2]]], axis=1)
+    worst, checked = 0.0, []
+    for f in check:
+        if f >= len(foci_m):
+            continue
+        d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci_m[f], C0)
+        ref = np.abs(co.field_at_points(pts, pos_m, area, d, a, F0, C0, SENS))
+        peak = max(np.abs(co.field_at_points([foci_m[f]], pos_m, area, d, a, F0, C0, SENS))[0], ref.max())
+        got = ctx.field_fetch(f, want=("pmag",))["pmag"][idx[:, 0], idx[:, 1], idx[:, 2]]
+        worst = max(worst, float(np.abs(got - ref).max() / peak))
+        checked.append(int(f))
+    return {"max_err_over_peak": worst, "gate": 1e-5, "sampled_voxels_per_focus": n_samples, "foci_checked": checked,
+            "oracle": "oracle/field_oracle.c (fp64, C/OpenMP)",
+            "full_volume_test": "tests/test_gpu_field.py::test_headline_shard_256cubed_full_volume_parity"}
+
+
+def issue_model(name, V, N, F):
+    """Issue ceiling of the kernel variant in use: (peak pairs/s, model text)."""
+    import re
+    m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
+    mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
+    ml = re.search(r"field_(?:lattice|coset|toep)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+    if ml:  # lattice kernels: table arithmetic amortised; the matrix pipe is the ceiling (MFMA and VALU issue add up here)
+        n_mfma = int(ml.group(5))
+        floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
+        what = ("1 fp16 hi*hi product per K-step + one K=128 e4m3 instruction (2 units) per two K-steps for both hi/lo corrections"
+                if "fp8corr" in name else "3 fp16 hi/lo products")
+        return float(V) * N * F / floor_s, (f"{n_mfma} matrix-pipe units of one v_mfma_f32_16x16x32_f16 per launch ({what}, padded row tiles "
+                                            f"included) at 16 cycles each on {N_SIMD} SIMDs @{CLK_GHZ} GHz = {floor_s * 1e3:.3f} ms if nothing else issued")
+    if mm:
+        ntc, _, nfoci, nimg, ntile = (int(v) for v in mm.groups())
+        cyc, pairs = 5 * CYC_PLAIN + 3 * CYC_TRANS + 4 * 4.2 + 6.0 * ntc, nfoci * nimg / ntile
+        model = (f"per G: 5 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + 4 half-rate @4.2 + {0.75 * ntc:.2f} MFMA "
+                 f"issue slots @8 cycles, serving {pairs:.0f} pairs")
+    elif m:
+        mx, my, dx, dy, nf = (int(v) for v in m.groups())
+        cyc, pairs = 4 * CYC_PLAIN + 3 * CYC_TRANS + dx * dy * nf * 2 * 4.2, mx * my * nf
+        model = (f"per G: 4 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + {dx * dy * nf} x 2 v_pk_fma @4.2 cycles, "
+                 f"serving {pairs} pairs")
+    else:
+        cyc, pairs, model = 6 * CYC_PLAIN + 3 * CYC_TRANS, 1, f"per pair: 6 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} cycles"
+    return N_SIMD * CLK_GHZ * 1e9 * 64 * pairs / cyc, model + "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"
+
+
+def static_traffic(kernel_name: str, grid_n: int):
+    """HBM bytes per launch from the committed PMC summaries (profiles/traffic.json), matched on the kernel variant
+    string: a STATIC figure from tools/profile_round.sh's counter passes, not measured in this run; None when the
+    variant in use has no committed counter pass."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    for ent in json.load(open(tpath)).get("entries", []):
+        if ent.get("grid") == grid_n and kernel_name.startswith(ent.get("kernel_prefix", "\0")):
+            return ent["hbm_bytes_per_launch"], f"static: {ent['source']} (rocprofv3 --pmc passes of tools/profile_round.sh on this kernel variant, not this run)"
+    return None, None
 
 
 def main():
@@ -113,16 +184,23 @@ def main():
                     help="before the W warm-up steps, keep the GPU busy this long so that DVFS has left the idle clock "
                          "(the first ~20 launches after idle run 15-20 %% slower, tools/launch_series.py); 0 disables")
     ap.add_argument("--foci-per-gpu", type=int, default=8)
-    ap.add_argument("--reassemble", choices=["aggregate", "allgather", "none"], default="aggregate")
+    ap.add_argument("--reassemble", choices=["allgather", "aggregate", "none"], default=None,
+                    help="default: allgather for N > 1 (north_star), none for N = 1")
+    ap.add_argument("--corrections", choices=["fp8", "fp16"], default="fp8",
+                    help="hi x lo correction products of the fp16 operand split: fp8 = opt-in e4m3 products (<= 6e-6 of the "
+                         "focal peak), fp16 = the library default (<= 2e-6); the other one is timed beside it at N = 1")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--spacing-mm", type=float, default=0.25)
     ap.add_argument("--elements", type=str, default="16x16")
     ap.add_argument("--pitch-mm", type=float, default=3.0)
+    ap.add_argument("--offset-mm", type=str, default="0,0",
+                    help="lateral offset of the sweep's target: a non-zero value breaks the mirror symmetry the headline shard enjoys")
     ap.add_argument("--force-comm", action="store_true", help="exercise the RCCL path even with 1 rank")
     ap.add_argument("--medium", choices=["water", "skull"], default="water",
-                    help="skull: BASELINE configs[4] synthetic skull-slab mask, heterogeneous layered-ray kernel")
+                    help="skull: BASELINE configs[4] synthetic skull-slab mask, heterogeneous layered-ray kernel, x-slabs per GPU")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (debug: oversubscribe one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the post-timing legs (other correction mode, parity, calc_solution)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,9 +210,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    reassemble = args.reassemble or ("allgather" if world > 1 else "none")
 
     import openlifu_amd as ol  # loads libolx.so (system ROCm runtime) before any torch import
-    from openlifu_amd import _native as nat
+    from openlifu_amd import _native as nat, dist as od
     from openlifu_amd.engine import grid_from_coords
 
     dist = None
@@ -153,21 +232,34 @@ def main():
             os.close(saved_stdout)
 
     el = tuple(int(v) for v in args.elements.split("x"))
-    arr, setup, foci = synthetic_workload(args.grid, args.spacing_mm, el, args.pitch_mm, args.foci_per_gpu, seed=rank)
-    F, N = len(foci), arr.numelements()
+    off = tuple(float(v) for v in args.offset_mm.split(","))
+    arr, setup, target, pattern = synthetic_workload(args.grid, args.spacing_mm, el, args.pitch_mm, off)
+    sweep = pattern.get_targets(target)
+    sweep_m = np.array([f.get_position(units="m") for f in sweep])
+    origin, spacing, n = grid_from_coords(setup.get_coords())
+    coords_m = [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+    centre = tuple(origin[a] + 0.5 * (n[a] - 1) * spacing[a] for a in (0, 1))
+    # weak scaling: the 64-focus sweep cut into orbit-aware shards of `foci_per_gpu`; an N-GPU run takes the first N of them
+    fpg = max(1, min(args.foci_per_gpu, len(sweep_m)))
+    shards_all = od.plan_foci_orbits(sweep_m, -(-len(sweep_m) // fpg), centre_xy=centre)
+    run_idx = np.concatenate([shards_all[r % len(shards_all)] for r in range(world)])
+    run_foci = sweep_m[run_idx]
+    N = arr.numelements()
+    V = int(np.prod(n))
     eng = ol.get_engine(local_rank if args.device is None else args.device)
     ctx = eng.ctx
-    eng.bind(arr)
-    ctx.bf_solve(np.array([f.get_position(units="m") for f in foci]), 1500.0)  # kernel 1: steering stays resident
-    gather = (world > 1 or args.force_comm) and args.reassemble != "none"
+    sf = od.ShardedField(eng, world, rank)
+    gather = (world > 1 or args.force_comm) and reassemble != "none"
     gather_note = None
     if gather:
         ok = 1
         try:
-            uid = [ctx.comm_unique_id() if rank == 0 else None]  # (libolx keeps RCCL's banner off stdout)
-            if dist is not None:
-                dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0], world, rank)
+            def exchange(uid):
+                box = [uid]
+                if dist is not None:
+                    dist.broadcast_object_list(box, src=0)
+                return box[0]
+            sf.init_comm(exchange)  # (libolx keeps RCCL's banner off stdout)
         except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
             ok, gather_note = 0, f"RCCL init failed: {e}"
         if dist is not None:  # every rank must take the same branch, or the collectives below would hang
@@ -176,146 +268,179 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 0 and ok:
                 gather_note = "RCCL init failed on another rank"
-                ctx.comm_destroy()
+                sf.close()
             ok = int(flag[0])
         gather = bool(ok)
-    origin, spacing, n = grid_from_coords(setup.get_coords())
-    ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
-    V = int(np.prod(n))
+    out_flags = nat.OUT_PMAG | nat.OUT_INTENSITY
+    skull = None
     if args.medium == "skull":  # 8 mm <= z < 14 mm + 2 mm sin(2 pi x / 40 mm) cos(2 pi y / 40 mm)
-        xs, ys, zs = (np.asarray(c.data, dtype=np.float32) * 1e-3 for c in setup.get_coords().values())
-        zsurf = 14e-3 + 2e-3 * np.sin(2 * np.pi * xs / 40e-3)[:, None] * np.cos(2 * np.pi * ys / 40e-3)[None, :]
-        skull = (zs[None, None, :] >= 8e-3) & (zs[None, None, :] < zsurf[:, :, None])
-        ctx.field_set_medium(np.where(skull, 2800.0, 1500.0).astype(np.float32), np.where(skull, 6.0, 0.0).astype(np.float32),
-                             np.where(skull, 1900.0, 1000.0).astype(np.float32))
-        del skull
+        from openlifu_amd.seg.seg_methods import skull_slab_volumes
+        skull = skull_slab_volumes(*coords_m)
 
-    def step():
-        ctx.field_launch()
-        if gather and args.reassemble == "aggregate":
-            ctx.field_reduce_scatter_aggregate()
-        elif gather:
-            ctx.field_allgather()
+    def plan(fp8: bool):
+        if skull is not None:   # configs[4]: all foci of the run on every rank's x-slab, label volume replicated
+            dl, ap = eng.beamform(arr, run_foci[:fpg], C0)            # kernel 1
+            sf.plan_slab_sweep(arr, dl, ap, origin, spacing, n, F0, C0, RHO0, SENS, flags=out_flags, medium=skull)
+            return fpg
+        mine = sf.plan_foci_sweep(arr, run_foci, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS,
+                                  flags=out_flags, fp8_correction=fp8)
+        return len(mine)
 
     def barrier():
         ctx.sync()
         if dist is not None:
             dist.barrier()
 
+    def timed(mode: str, steps: int, warmup: int):
+        """(wall seconds for `steps` steps: max over ranks, per-launch kernel ms of this rank)."""
+        for _ in range(warmup):
+            sf.step(mode)
+        barrier()
+        ctx.profile_begin(steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sf.step(mode)
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kern = ctx.profile_end()
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed, kern
+
+    F = plan(args.corrections == "fp8")
     if args.clock_ramp_ms > 0:  # not steps: the same launches, discarded, until the shader clock has ramped up
         t_ramp = time.perf_counter()
         while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
             ctx.field_launch()
             ctx.sync()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_begin(args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = ctx.profile_end()
-    compute_only = None
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        if gather:  # reported beside the headline (never instead of it): the same steps without the exchange
-            k2 = min(args.steps, 200)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(k2):
-                ctx.field_launch()
-            barrier()
-            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            compute_only = {"steps": k2, "ms_per_step": float(t[0]) / k2 * 1e3}
+    mode = reassemble if gather else "none"
+    elapsed, kern_ms = timed(mode, args.steps, args.warmup)
+    kernel_name = ctx.field_variant()
+    k_ms = float(np.mean(kern_ms))
+    F_total = F * world if skull is None else F   # slab mode: the same F foci on every rank's slab
+    V_step = float(V)                              # voxels of the whole grid covered per step (slabs tile it)
+    pairs_per_step = V_step * N * F_total
+    value = pairs_per_step * args.steps / elapsed / 1e6
+    beside = {}
+    if dist is not None and gather:  # reported beside the headline (never instead of it): other exchange, no exchange
+        k2 = min(args.steps, 200)
+        other = "aggregate" if mode == "allgather" else "allgather"
+        if skull is None:
+            e2, _ = timed(other, k2, 10)
+            beside[f"with_{other}"] = {"steps": k2, "ms_per_step": e2 / k2 * 1e3, "value": pairs_per_step * k2 / e2 / 1e6}
+        e3, _ = timed("none", k2, 10)
+        beside["without_exchange"] = {"steps": k2, "ms_per_step": e3 / k2 * 1e3, "value": pairs_per_step * k2 / e3 / 1e6}
 
     if rank == 0:
-        pairs_per_step = float(V) * N * F * world
-        value = pairs_per_step * args.steps / elapsed / 1e6
-        # roofline of the dominant kernel (field_accum_k): algorithmic HBM bytes per launch =
-        # 8 B per voxel per focus (|p| + intensity float32 outputs) + the 32 B/entry packed table
-        alg_bytes = 8.0 * V * F + 32.0 * N * F
-        k_ms = float(np.mean(kern_ms))
+        # roofline of the dominant kernel: algorithmic HBM bytes per launch = 8 B per voxel per focus (|p| + intensity
+        # float32 outputs) + the 32 B/entry packed steering table (SURVEY 8(d)); a slab launch covers V / world voxels
+        vox_launch = V if skull is None else V // world
+        alg_bytes = 8.0 * vox_launch * F + 32.0 * N * F
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            key = f"{args.elements}_{args.grid}_{F}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        # VALU-issue ceiling of the kernel variant in use: how many logical (voxel, element,
-        # focus) pairs one evaluation of the geometry term G serves, and what that evaluation costs to issue.
-        import re
-        name = ctx.field_variant()
-        m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
-        mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-        ml = re.search(r"field_(?:lattice|coset)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
-        if ml:  # kernel 2d: the table arithmetic is amortised over 8 voxel rows x 64 elements; the matrix pipe is the ceiling.
-            # On this chip MFMA and VALU issue add up (tools/ubench_clock.hip), so the MFMA-only time is a strict floor.
-            n_mfma = int(ml.group(5))
-            floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
-            ceil_pairs = float(V) * N * F / floor_s
-            cyc_per_g, pairs_per_g = None, None
-            what = ("1 fp16 hi*hi product per K-step + one K=128 e4m3 instruction (2 units) per two K-steps for both hi/lo corrections"
-                    if "fp8corr" in name else "3 fp16 hi/lo products")
-            model = (f"{n_mfma} matrix-pipe units of one v_mfma_f32_16x16x32_f16 per launch ({what}, padded row tiles included) at "
-                     f"16 cycles each on {N_SIMD} SIMDs @{CLK_GHZ} GHz = {floor_s * 1e3:.3f} ms if nothing else issued")
-        elif mm:  # kernel 2c: per G 5 plain + 3 transcendental + 4 half-rate (hi/lo split) VALU instructions, plus the
-            # issue slots its share of the 3*NT MFMAs blocks (8 cycles each, 0.75*NT MFMAs per 64 terms)
-            ntc, _, nfoci, nimg, ntile = (int(v) for v in mm.groups())
-            cyc_per_g = 5 * CYC_PLAIN + 3 * CYC_TRANS + 4 * 4.2 + 6.0 * ntc
-            pairs_per_g = nfoci * nimg / ntile
-            model = (f"per G: 5 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + 4 half-rate @4.2 + {0.75 * ntc:.2f} MFMA "
-                     f"issue slots @8 cycles, serving {pairs_per_g:.0f} pairs")
-        elif m:
-            mx, my, dx, dy, nf = (int(v) for v in m.groups())
-            cyc_per_g = 4 * CYC_PLAIN + 3 * CYC_TRANS + dx * dy * nf * 2 * 4.2
-            pairs_per_g, model = mx * my * nf, (f"per G: 4 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} + "
-                                               f"{dx * dy * nf} x 2 v_pk_fma @4.2 cycles, serving {mx * my * nf} pairs")
-        else:
-            cyc_per_g, pairs_per_g, model = 6 * CYC_PLAIN + 3 * CYC_TRANS, 1, f"per pair: 6 plain @{CYC_PLAIN} + 3 transcendental @{CYC_TRANS} cycles"
-        if cyc_per_g is not None:
-            ceil_pairs = N_SIMD * CLK_GHZ * 1e9 * 64 * pairs_per_g / cyc_per_g
+        traffic, traffic_src = static_traffic(kernel_name, args.grid)
+        ceil_pairs, model = issue_model(kernel_name, vox_launch, N, F)
+        fp8_on = "fp8corr" in kernel_name
+        lattice = "field_coset_k" in kernel_name or "field_lattice_k" in kernel_name or "field_toep_k" in kernel_name or "field_mfma_k" in kernel_name
+        dtype = ("f32-acc/f16x2+e4m3-corr" if fp8_on else ("f32-acc/f16x3" if lattice else "f32"))
         out = {
             "metric": "Mvoxel-elements/s pressure-field accumulate", "value": value, "unit": "Mvoxel-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if skull is None else "strong", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic",
             "config": {"workload": f"{N}-element {args.elements} matrix array x {args.grid}^3 grid "
                                    f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
-                                   f"(BASELINE configs[2] shard), |p|+intensity out",
-                       "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": 400e3,
+                                   f"(BASELINE configs[2] shard, planned by openlifu_amd.dist.plan_foci_orbits), |p|+intensity out"
+                                   if skull is None else
+                                   f"{N}-element {args.elements} matrix array x {args.grid}^3 grid ({args.spacing_mm} mm), skull-slab "
+                                   f"medium (BASELINE configs[4]), {F} foci, x-slabs of {n[0] // world} planes per GPU",
+                       "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": F0,
+                       "focus_indices_rank0": [int(v) for v in run_idx[:F]], "target_offset_mm": list(off),
                        "medium": args.medium, "clock_ramp_ms": args.clock_ramp_ms,
-                       "kernel": ctx.field_variant(),
-                       "reassembly": (f"rccl-{args.reassemble}-overlapped" if gather else
-                                      ("none" if (world == 1 or args.reassemble == "none") else "skipped")),
-                       **({"reassembly_note": gather_note} if gather_note else {}),
-                       **({"without_exchange": dict(compute_only, value=float(V) * N * F * world /
-                                                    (compute_only["ms_per_step"] * 1e-3) / 1e6)} if compute_only else {})},
+                       "corrections": "fp8 (opt-in, OLX_FIELD_FP8_CORRECTION)" if fp8_on else "fp16 (library default)",
+                       "kernel": kernel_name,
+                       "reassembly": (f"rccl-{mode}-overlapped" if gather else
+                                      ("none" if (world == 1 or reassemble == "none") else "skipped")),
+                       **({"rccl_library": ctx.rccl_path()} if gather else {}),
+                       **({"reassembly_note": gather_note} if gather_note else {}), **beside},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kern_ms)),
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the accumulate is issue bound (matrix pipe + VALU), not HBM bound "
                                  "(SURVEY 8(d), DESIGN.md 5); see issue_ceiling"},
-            "issue_ceiling": {"achieved_Mpairs_s": float(V) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
-                             "frac": float(V) * N * F / (k_ms * 1e-3) / ceil_pairs,
-                             "model": model + ("" if ml else "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)")},
+            "issue_ceiling": {"achieved_Mpairs_s": float(vox_launch) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
+                              "frac": float(vox_launch) * N * F / (k_ms * 1e-3) / ceil_pairs, "model": model},
         }
+        if world == 1 and not args.no_extras and skull is None:
+            pos_m, _, area, _, _ = arr.element_table()
+            out["parity"] = {args.corrections: sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])}
+            # kernel 1 (SURVEY 8(d)): microseconds per F x N solve, HIP events around 50 repeats
+            us = ctx.bf_time(50)
+            out["kernel1"] = {"us_per_solve": float(np.median(us)), "foci": F, "elements": N, "dtype": "f64"}
+            # the other correction mode on the same workload, same box, right after
+            other_fp8 = args.corrections != "fp8"
+            plan(other_fp8)
+            k2 = min(args.steps, 300)
+            e2, km2 = timed("none", k2, 20)
+            name2 = ctx.field_variant()
+            a2 = alg_bytes / (float(np.mean(km2)) * 1e-3) / 1e9
+            out["fp8_optin" if other_fp8 else "precision_safe"] = {
+                "kernel": name2, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name2 else "f32-acc/f16x3",
+                "kernel_ms_avg": float(np.mean(km2)), "ms_per_step": e2 / k2 * 1e3, "steps": k2,
+                "value": pairs_per_step * k2 / e2 / 1e6, "roofline_frac": a2 / HBM_PEAK_GBS}
+            out["parity"]["fp8" if other_fp8 else "fp16"] = sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])
+            out["end_to_end"] = end_to_end(ol, arr, setup, target, sweep, run_idx[:F], args)
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(arr, setup, foci, args.cpu_seconds)
-            out["cpu_baseline_c"] = cpu_baseline_c(arr, setup, foci, min(args.cpu_seconds, 10.0))
+            pos_m, _, area, _, _ = arr.element_table()
+            out["cpu_baseline"] = cpu_baseline(pos_m, area, coords_m, run_foci[0], args.cpu_seconds)
+            out["cpu_baseline_c"] = cpu_baseline_c(pos_m, area, coords_m, run_foci[0], min(args.cpu_seconds, 10.0))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
-        if gather:
-            ctx.comm_destroy()
+        sf.close()
         dist.destroy_process_group()
+
+
+def end_to_end(ol, arr, setup, target, sweep, idx, args):
+    """Wall time of the product's API call for the same shard: Protocol.calc_solution(simulate=True, scale=True) --
+    beamform, accumulate, scale, aggregate and analyze on the device -- and the device->host bandwidth of materialising
+    the per-focus volumes the caller then reads (fresh, caller-owned NumPy arrays)."""
+    foci = [sweep[int(i)] for i in idx]
+    pattern = ol.focal_patterns.SinglePoint(target_pressure=1e6) if len(foci) == 1 else _ListPattern(ol, foci)
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=F0, duration=2e-5), sequence=ol.Sequence(pulse_count=len(foci) * 2, pulse_train_interval=0),
+                        focal_pattern=pattern, sim_setup=setup)
+    proto.calc_solution(target, arr, simulate=True, scale=True)          # warm (allocations, first-touch)
+    t0 = time.perf_counter()
+    sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
+    t1 = time.perf_counter()
+    nbytes = 0
+    for k in ("p_min", "intensity"):
+        nbytes += np.asarray(sol.simulation_result[k].data).nbytes
+    t2 = time.perf_counter()
+    return {"calc_solution_ms": (t1 - t0) * 1e3, "foci": len(foci), "what": "Protocol.calc_solution(simulate=True, scale=True): "
+            "kernel 1 + kernel 2 + device-side scale / aggregate / analyze; aggregate volumes fetched, per-focus volumes left lazy",
+            "fetch_ms": (t2 - t1) * 1e3, "fetch_bytes": int(nbytes), "fetch_GBps": nbytes / max(t2 - t1, 1e-9) / 1e9,
+            "fetch_what": "first .data access of simulation_result['p_min'] and ['intensity'] (device -> fresh NumPy arrays)",
+            "mainlobe_pnp_MPa": [float(v) for v in an.mainlobe_pnp_MPa[:2]]}
+
+
+def _ListPattern(ol, foci):
+    """FocalPattern that returns a fixed list of foci (the shard the planner assigned)."""
+    from dataclasses import dataclass
+
+    @dataclass
+    class ShardPattern(ol.focal_patterns.FocalPattern):
+        def get_targets(self, target):
+            return [f.copy() for f in foci]
+
+        def num_foci(self):
+            return len(foci)
+    return ShardPattern(target_pressure=1e6)
 
 
 if __name__ == "__main__":

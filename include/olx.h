@@ -47,6 +47,8 @@ extern "C" {
 #define OLX_OUT_PMAG 1u      /* |p| [Pa]  -> p_max and p_min of kwave_if.py:131-139 */
 #define OLX_OUT_INTENSITY 2u /* 1e-4 |p|^2 / (2 rho c) [W/cm^2]  (kwave_if.py:140-144) */
 #define OLX_OUT_COMPLEX 4u   /* (re, im) interleaved, float32 */
+/* accuracy / speed option of olx_field_plan (OR-ed into flags; see the accuracy note there) */
+#define OLX_FIELD_FP8_CORRECTION 8u
 
 typedef struct olx_ctx olx_ctx;
 
@@ -99,6 +101,10 @@ int olx_set_elements(olx_ctx *ctx, const double *pos_m, const double *normal,
 int olx_bf_solve(olx_ctx *ctx, const double *foci_m, int n_foci, const double *M, double c,
                  int apod_kind, double p0, double p1, double *delays_out, double *apod_out);
 
+/* Times `iters` repeats of the last olx_bf_solve's kernel (same foci / transform / options, results rewritten with
+ * equal values) with HIP events on the context's stream; us_each[iters] = microseconds per F x N solve (bench.py). */
+int olx_bf_time(olx_ctx *ctx, int iters, float *us_each);
+
 /* Upload externally computed delays / apodizations [F*N] as the steering table
  * (run_simulation's `delays`, `apod` arguments, sim/kwave_if.py:81-83, 98-99). */
 int olx_set_steering(olx_ctx *ctx, const double *delays_s, const double *apod, int n_foci);
@@ -124,15 +130,20 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  * launch: asynchronous on the context's stream.  fetch: blocking D2H of one focus
  *   volume into caller-owned host arrays [nx*ny*nz] (cplx: 2 floats per voxel); any
  *   pointer may be NULL.
- * accuracy: fp32 results within 1e-5 of the volume's maximum |p| against the fp64 definition
- *   (typically 1e-6).  For matrix arrays on a commensurate grid the library may compute two
- *   small correction products in fp8 (6e-6) when the steering table's foci are known to lie
- *   inside the grid and drive >= 256 elements effectively; environment OLX_FP8_CORRECTION=0
- *   keeps the 1e-6 path everywhere.  olx_field_variant() names the kernel in use. */
+ * accuracy: fp32 results within 2e-6 of the volume's maximum |p| against the fp64 definition (measured
+ *   0.8e-6 ... 1.9e-6; gate in tests 1e-5).  OPT-IN: with OLX_FIELD_FP8_CORRECTION in `flags`, matrix
+ *   arrays on a commensurate grid compute the two small correction products of the fp16 hi/lo split
+ *   in fp8 (e4m3): ~12 % faster, error <= 6e-6 of the FOCAL PEAK.  The library honours the request only
+ *   when every focus of the steering table is known to lie inside the planned slab and drives >= 256
+ *   elements effectively ((sum w)^2 / sum w^2); otherwise it silently keeps the 2e-6 path.  Nothing
+ *   selects fp8 unasked.  olx_field_variant() names the kernel in use ("fp8corr" when active). */
 int olx_field_plan(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab /*NULL = whole grid*/,
                    int n_foci, double freq, double c, double rho, double p0_pa, unsigned flags);
 int olx_field_launch(olx_ctx *ctx);
 int olx_field_fetch(olx_ctx *ctx, int focus, float *pmag, float *intensity, float *cplx);
+/* All planned focus volumes at once ([F * slab voxels] floats each, either may be NULL): one pipelined transfer through a
+ * ring of pinned chunks whose copy-out into the caller's (pageable, caller-owned) arrays runs on several host threads. */
+int olx_field_fetch_all(olx_ctx *ctx, float *pmag, float *intensity);
 /* One-shot convenience: plan + launch + fetch of all foci ([F * slab voxels] each). */
 int olx_field(olx_ctx *ctx, const olx_grid *grid, int n_foci, double freq, double c, double rho,
               double p0_pa, float *pmag_out, float *intensity_out);
@@ -232,13 +243,20 @@ int olx_field_allgather(olx_ctx *ctx);
 int olx_allgather_fetch(olx_ctx *ctx, int rank, float *pmag_out);
 /* Aggregated result with the foci sharded over ranks (plan/protocol.py:382-387): local max / sum over
  * this rank's foci, then RCCL all-reduce (max for |p|, sum for the intensity mean) of one volume each,
- * asynchronously on the side stream; the mean divides by n_foci * nranks (equal foci per rank).
+ * asynchronously on the side stream; the mean divides by n_foci * nranks (equal foci per rank) unless
+ * olx_field_aggregate_counts gave the genuine counts of padded shards.
  * olx_field_reduce_scatter_aggregate is the sharded form: an in-place reduce-scatter after which rank r owns voxels
  * [r V/N, (r+1) V/N) of the global aggregate (the rest of its buffer holds its local partial result) -- half the
  * xGMI traffic; it falls back to the all-reduce when V is not divisible by N.
  * olx_aggregate_fetch waits for either and copies the volumes to the host (either may be NULL). */
 int olx_field_allreduce_aggregate(olx_ctx *ctx);
 int olx_field_reduce_scatter_aggregate(olx_ctx *ctx);
+/* Shards padded to equal size (RCCL all-gather needs equal counts; dist.plan_foci_orbits repeats a rank's last focus):
+ * only the first local_valid planned foci of this rank enter its local max / sum, and the intensity mean divides by
+ * global_total (the number of genuine foci over all ranks).  Valid until the next olx_field_plan. */
+int olx_field_aggregate_counts(olx_ctx *ctx, int local_valid, int global_total);
+/* File the RCCL entry points were bound from ("" before the first olx_comm_* call). */
+const char *olx_rccl_path(const olx_ctx *ctx);
 int olx_aggregate_fetch(olx_ctx *ctx, float *pmag_max_out, float *intensity_mean_out);
 
 #ifdef __cplusplus

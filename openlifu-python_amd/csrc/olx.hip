@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "k_small.hip.h"
 #include "olx_launch.h"
@@ -142,11 +143,32 @@ int olx_bf_solve(olx_ctx* c, const double* foci_m, int n_foci, const double* M, 
     if (apod_out) memcpy(apod_out, c->h_apod.data(), sizeof(double) * fn);
     c->n_foci = n_foci;
     c->steer_version++;
+    c->bf_c = cs; c->bf_kind = apod_kind; c->bf_scale = angle_scale; c->bf_p0 = p0; c->bf_p1 = p1; c->bf_valid = true;
     c->h_foci.clear();
     if (!M || !memcmp(M, I4, sizeof I4)) {   // focus positions are in the frame of the element table: usable for planning decisions
         c->h_foci.assign(foci_m, foci_m + 3 * (size_t)n_foci);
         c->foci_version = c->steer_version;
     }
+    return OLX_OK;
+}
+
+int olx_bf_time(olx_ctx* c, int iters, float* us_each) {
+    if (!c) return OLX_EINVAL;
+    if (iters < 1 || !us_each) return fail(c, OLX_EINVAL, "olx_bf_time: iters < 1 or null output");
+    if (!c->bf_valid || c->n_foci <= 0) return fail(c, OLX_ESTATE, "olx_bf_time: no olx_bf_solve to repeat");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev(iters + 1, nullptr);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    for (int i = 0; i < iters; ++i) {   // same foci, transform and options as the last solve: the outputs are rewritten with equal values
+        hipLaunchKernelGGL(bf_solve_k, dim3(c->n_foci), dim3(BF_THREADS), 0, c->stream, c->d_pos, c->d_nrm, c->n_el,
+                           c->d_foci, c->d_M, c->bf_c, c->bf_kind, c->bf_scale, c->bf_p0, c->bf_p1, c->d_delays, c->d_apod);
+        HIPCHK(c, hipEventRecord(ev[i + 1], c->stream));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) { float ms = 0; e = hipEventElapsedTime(&ms, ev[i], ev[i + 1]); us_each[i] = ms * 1e3f; }
+    for (auto& v : ev) hipEventDestroy(v);
+    if (e != hipSuccess) return fail(c, OLX_EHIP, "olx_bf_time: %s", hipGetErrorString(e));
     return OLX_OK;
 }
 
@@ -168,6 +190,7 @@ int olx_set_steering(olx_ctx* c, const double* delays_s, const double* apod, int
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_delays.assign(delays_s, delays_s + fn); c->h_apod.assign(apod, apod + fn);
     c->h_foci.clear();   // external delays: where the foci are is not known
+    c->bf_valid = false;
     c->n_foci = n_foci;
     c->steer_version++;
     return OLX_OK;
@@ -538,26 +561,27 @@ static int configure_variant(olx_ctx* c) {
             L.vox = P.vox; L.flags = P.flags;
             const char* fv = getenv("OLX_FIELD_VARIANT");
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
-            // fp8 correction products (kernel 2e, NT <= 2): the e4m3 rounding of the two hi x lo terms adds ~2^-16 |w_e G| per
-            // element and term with random signs -- an absolute error that is about the same everywhere in the volume and, against
-            // the coherent focal peak sum |w_e G|, ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive weights:
-            // measured 5.8e-6 of the peak at N_eff = 256 (gate: 1e-5 of the volume's maximum).  So they are used only when the
-            // volume is known to contain that peak: the foci are known (olx_bf_solve in the element frame, or external delays
-            // that infer_foci recognises as geometric), every focus lies inside the planned grid and has N_eff >= 256.
-            // Otherwise (arbitrary external delays, small arrays, apodization
-            // that silences most elements, volumes off the focus) the fp16 corrections stay (0.8e-6).
-            // OLX_FP8_CORRECTION=0 / 1 pins either.
+            // fp8 correction products (kernel 2e, NT <= 2), OPT-IN (OLX_FIELD_FP8_CORRECTION in the plan flags): the e4m3
+            // rounding of the two hi x lo terms adds ~2^-16 |w_e G| per element and term with random signs -- an absolute error
+            // that falls off only slowly with depth and, against the coherent focal peak sum |w_e G|, is ~ 1 / sqrt(N_eff),
+            // N_eff = (sum w)^2 / sum w^2 over the focus' drive weights: 5.8e-6 of the peak at N_eff = 256 (gate: 1e-5 of the
+            // volume's maximum).  Even when asked for they are used only if the planned SLAB is known to contain that peak:
+            // the foci are known (olx_bf_solve in the element frame, or external delays that infer_foci recognises as
+            // geometric), every focus lies inside the slab and has N_eff >= 256.  Otherwise, and by default, the fp16
+            // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                bool ok = c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
-                if (!ok && !f8 && c->use_coset && cos_fp8(c->nt) && infer_foci(c, c->h_foci)) {   // external delays: geometric?
+                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && cos_fp8(c->nt);
+                bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
+                if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                     c->foci_version = c->steer_version;
                     ok = true;
                 }
                 for (int f = 0; ok && f < F; ++f) {
                     for (int a = 0; a < 3; ++a) {
-                        const double lo = c->grid.origin[a] - 0.5 * c->grid.spacing[a];
-                        const double hi = c->grid.origin[a] + (c->grid.n[a] - 0.5) * c->grid.spacing[a];
+                        const int b0 = a == 0 ? c->slab.x_begin : 0, cnt = a == 0 ? c->slab.x_count : c->grid.n[a];
+                        const double lo = c->grid.origin[a] + (b0 - 0.5) * c->grid.spacing[a];
+                        const double hi = c->grid.origin[a] + (b0 + cnt - 0.5) * c->grid.spacing[a];
                         if (!(c->h_foci[3 * (size_t)f + a] >= lo && c->h_foci[3 * (size_t)f + a] <= hi)) ok = false;
                     }
                     double sw1 = 0, sw2 = 0;
@@ -693,12 +717,14 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         if (g->n[a] < 1 || !(g->spacing[a] > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: bad grid axis %d", a);
     if (!(freq > 0) || !(cs > 0) || !(rho > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: freq, c, rho must be > 0");
     if (!(flags & (OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX))) return fail(c, OLX_EINVAL, "olx_field_plan: no outputs selected");
+    if (flags & ~(OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX | OLX_FIELD_FP8_CORRECTION)) return fail(c, OLX_EINVAL, "olx_field_plan: unknown flag bits 0x%x", flags);
     olx_slab s{0, g->n[0]};
     if (slab) s = *slab;
     if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_plan: slab outside grid");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->grid = *g; c->slab = s; c->plan_foci = n_foci; c->hetero = false;
+    c->agg_local = -1; c->agg_total = 0;   // aggregate over all planned foci unless olx_field_aggregate_counts says otherwise
     c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags;
     const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
     const size_t total = (size_t)vox * n_foci;
@@ -872,6 +898,89 @@ int olx_profile_end(olx_ctx* c, float* ms_each, int capacity, int* n_recorded) {
     return OLX_OK;
 }
 
+}  // extern "C"
+
+// Device -> caller-owned host memory.  The caller's arrays are ordinary pageable NumPy memory (ownership contract of the
+// seam: fresh, writable, caller-owned -- SURVEY 8(b)); a plain hipMemcpy of such memory is staged by the runtime through
+// a small pinned buffer (~25 GB/s, and it touches every destination page from ONE thread).  Modes (OLX_FETCH_MODE, for
+// A/B measurements; default "staged"):
+//   pageable  hipMemcpyAsync straight into the caller's pages (the round-1 path)
+//   register  hipHostRegister the destination, one DMA, unregister (pinning walks / faults the pages in the kernel)
+//   staged    a ring of pinned chunks: chunk i+1 is DMA'd while worker threads copy chunk i into the destination,
+//             so the first touch of the destination pages and the copy-out run on several host cores
+struct FetchRing {
+    static constexpr int NCH = 3;
+    static constexpr size_t CHUNK = (size_t)16 << 20;
+    void* buf[NCH] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[NCH] = {nullptr, nullptr, nullptr};
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        for (int i = 0; i < NCH; ++i) {
+            if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        ok = true;
+        return true;
+    }
+    void destroy() {
+        for (int i = 0; i < NCH; ++i) { if (buf[i]) hipHostFree(buf[i]); if (ev[i]) hipEventDestroy(ev[i]); buf[i] = nullptr; ev[i] = nullptr; }
+        ok = false;
+    }
+};
+static FetchRing g_ring[16];   // one per device ordinal (contexts of one device share it; one caller thread per context)
+
+static void parallel_copy(void* dst, const void* src, size_t bytes, int nthreads) {
+    if (nthreads <= 1 || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+    for (int t = 0; t < nthreads; ++t) {
+        const size_t off = per * t;
+        if (off >= bytes) break;
+        const size_t cnt = std::min(per, bytes - off);
+        th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, cnt); });
+    }
+    for (auto& t : th) t.join();
+}
+
+static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
+    const char* mode_env = getenv("OLX_FETCH_MODE");
+    const int mode = !mode_env ? 2 : !strcmp(mode_env, "pageable") ? 0 : !strcmp(mode_env, "register") ? 1 : 2;
+    if (mode == 1 && bytes >= ((size_t)1 << 20)) {
+        if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) {
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipHostUnregister(dst);
+            if (e != hipSuccess) return fail(c, OLX_EHIP, "fetch (registered): %s", hipGetErrorString(e));
+            return OLX_OK;
+        }
+        (void)hipGetLastError();   // fall through to the pageable copy
+    }
+    FetchRing& R = g_ring[c->device & 15];
+    if (mode == 2 && bytes >= 2 * FetchRing::CHUNK && R.init()) {
+        const int nthr = [] { const char* t = getenv("OLX_FETCH_THREADS"); int n = t ? atoi(t) : 4; return n < 1 ? 1 : (n > 16 ? 16 : n); }();
+        const size_t nchunk = (bytes + FetchRing::CHUNK - 1) / FetchRing::CHUNK;
+        for (size_t i = 0; i < nchunk + FetchRing::NCH - 1; ++i) {
+            if (i < nchunk) {   // enqueue chunk i (its ring slot was drained NCH - 1 iterations ago)
+                const size_t off = i * FetchRing::CHUNK, cnt = std::min(FetchRing::CHUNK, bytes - off);
+                HIPCHK(c, hipMemcpyAsync(R.buf[i % FetchRing::NCH], (const char*)src + off, cnt, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipEventRecord(R.ev[i % FetchRing::NCH], c->stream));
+            }
+            if (i >= FetchRing::NCH - 1) {   // drain chunk j while later chunks are in flight
+                const size_t j = i - (FetchRing::NCH - 1), off = j * FetchRing::CHUNK, cnt = std::min(FetchRing::CHUNK, bytes - off);
+                HIPCHK(c, hipEventSynchronize(R.ev[j % FetchRing::NCH]));
+                parallel_copy((char*)dst + off, R.buf[j % FetchRing::NCH], cnt, nthr);
+            }
+        }
+        return OLX_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+extern "C" {
+
 int olx_field_fetch(olx_ctx* c, int focus, float* pmag, float* intensity, float* cplx) {
     if (!c) return OLX_EINVAL;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_fetch: nothing planned");
@@ -879,12 +988,26 @@ int olx_field_fetch(olx_ctx* c, int focus, float* pmag, float* intensity, float*
     if (intensity && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_fetch: intensity not planned");
     if (cplx && !(c->flags & OLX_OUT_COMPLEX)) return fail(c, OLX_ESTATE, "olx_field_fetch: complex output not planned");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t vox = (size_t)c->fp.vox, off = vox * focus;
-    if (pmag) HIPCHK(c, hipMemcpyAsync(pmag, c->d_pmag[c->cur] + off, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
-    if (intensity) HIPCHK(c, hipMemcpyAsync(intensity, c->d_inten + off, sizeof(float) * vox, hipMemcpyDeviceToHost, c->stream));
-    if (cplx) HIPCHK(c, hipMemcpyAsync(cplx, c->d_cplx + 2 * off, sizeof(float) * 2 * vox, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return OLX_OK;
+    const size_t vox = (size_t)c->fp.vox, off = vox * focus;
+    int rc = OLX_OK;
+    if (pmag) rc = fetch_to_host(c, pmag, c->d_pmag[c->cur] + off, sizeof(float) * vox);
+    if (!rc && intensity) rc = fetch_to_host(c, intensity, c->d_inten + off, sizeof(float) * vox);
+    if (!rc && cplx) rc = fetch_to_host(c, cplx, c->d_cplx + 2 * off, sizeof(float) * 2 * vox);
+    return rc;
+}
+
+int olx_field_fetch_all(olx_ctx* c, float* pmag, float* intensity) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_fetch_all: nothing planned");
+    if (intensity && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_fetch_all: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t total = (size_t)c->fp.vox * c->plan_foci;
+    int rc = OLX_OK;
+    if (pmag) rc = fetch_to_host(c, pmag, c->d_pmag[c->cur], sizeof(float) * total);
+    if (!rc && intensity) rc = fetch_to_host(c, intensity, c->d_inten, sizeof(float) * total);
+    return rc;
 }
 
 int olx_field(olx_ctx* c, const olx_grid* g, int n_foci, double freq, double cs, double rho, double p0_pa,
@@ -1265,8 +1388,12 @@ struct StdoutToStderr {
 static int load_rccl(olx_ctx* c) {
     RcclApi& r = c->rccl;
     if (r.handle) return OLX_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) { r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+    // The system ROCm's RCCL first: libolx.so is built against and runs on /opt/rocm's HIP runtime; a bare "librccl.so.1"
+    // can resolve to another ROCm build earlier on the search path (e.g. the copy bundled with a PyTorch wheel in the
+    // launcher's process).  OLX_RCCL_PATH overrides; olx_rccl_path() reports what was bound.
+    const char* envp = getenv("OLX_RCCL_PATH");
+    const char* names[] = {envp ? envp : "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+    for (const char* nm : names) { r.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (r.handle) break; }
     if (!r.handle) return fail(c, OLX_ECOMM, "RCCL not found: %s", dlerror());
     r.GetUniqueId = (int (*)(olx_nccl_id*))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(olx_nccl_comm*, int, olx_nccl_id, int))dlsym(r.handle, "ncclCommInitRank");
@@ -1277,6 +1404,8 @@ static int load_rccl(olx_ctx* c) {
     r.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclReduceScatter");  // optional
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail(c, OLX_ECOMM, "RCCL symbols missing");
+    Dl_info info;
+    c->rccl_path = (dladdr((void*)r.AllGather, &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
     return OLX_OK;
 }
 #define NCCLCHK(c, call)                                                                              \
@@ -1284,6 +1413,8 @@ static int load_rccl(olx_ctx* c) {
         int r_ = (call);                                                                              \
         if (r_ != 0) return fail((c), OLX_ECOMM, "%s: %s", #call, (c)->rccl.GetErrorString(r_));      \
     } while (0)
+
+const char* olx_rccl_path(const olx_ctx* c) { return c ? c->rccl_path.c_str() : ""; }
 
 int olx_comm_unique_id(olx_ctx* c, void* id_bytes) {
     if (!c || !id_bytes) return OLX_EINVAL;
@@ -1375,13 +1506,16 @@ static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red, 0));
         c->reduce_pending = false;
     }
-    const float inv_n = 1.0f / ((float)c->plan_foci * (float)c->nranks);
+    // genuine foci of this rank come first in its shard (padding repeats the last one, dist.plan_foci_orbits): only they enter
+    // the local max / sum, and the mean divides by the GLOBAL number of genuine foci (olx_field_aggregate_counts)
+    const int n_local = c->agg_local >= 0 ? std::min(c->agg_local, c->plan_foci) : c->plan_foci;
+    const float inv_n = 1.0f / (c->agg_total > 0 ? (float)c->agg_total : (float)c->plan_foci * (float)c->nranks);
     if (!c->uploaded && (vox & 3) == 0)   // launched result: intensity == scale(v) |p|^2, aggregate from |p| alone (half the reads)
-        hipLaunchKernelGGL(field_aggregate_p_k, dim3(4096), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->plan_foci, (long long)vox,
+        hipLaunchKernelGGL(field_aggregate_p_k, dim3(4096), dim3(256), 0, c->stream, c->d_pmag[c->cur], n_local, (long long)vox,
                            inv_n, c->fp.inten_scale, c->hetero ? c->d_inv2z : nullptr, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
     else
         hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], with_i ? c->d_inten : nullptr,
-                           c->plan_foci, (long long)vox, inv_n, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
+                           n_local, (long long)vox, inv_n, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));
@@ -1400,6 +1534,13 @@ static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
     }
     HIPCHK(c, hipEventRecord(c->ev_red, c->comm_stream));
     c->reduce_pending = true;
+    return OLX_OK;
+}
+
+int olx_field_aggregate_counts(olx_ctx* c, int local_valid, int global_total) {
+    if (!c) return OLX_EINVAL;
+    if (local_valid < 0 || global_total < 1) return fail(c, OLX_EINVAL, "olx_field_aggregate_counts: need local_valid >= 0 and global_total >= 1");
+    c->agg_local = local_valid; c->agg_total = global_total;
     return OLX_OK;
 }
 

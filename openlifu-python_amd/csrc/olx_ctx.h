@@ -93,6 +93,10 @@ struct olx_ctx {
     hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
     float* d_gather = nullptr; size_t gather_cap = 0;
     hipEvent_t ev_agg = nullptr, ev_red = nullptr; bool reduce_pending = false;
+    int agg_local = -1, agg_total = 0;        // olx_field_aggregate_counts: genuine local foci / global focus count (padding excluded)
+    std::string rccl_path;                     // file the RCCL symbols were bound from
+    // parameters of the last olx_bf_solve (olx_bf_time repeats it)
+    bool bf_valid = false; double bf_c = 0, bf_scale = 1, bf_p0 = 0, bf_p1 = 0; int bf_kind = 0;
 };
 
 static inline int fail(olx_ctx* c, int code, const char* fmt, ...) {

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("OLX_LIB_PATH") or os.path.join(os.path.dirname(_PKG_D
 OLX_OK, OLX_EINVAL, OLX_ESTATE, OLX_EHIP, OLX_ENOMEM, OLX_ECOMM = 0, -1, -2, -3, -4, -5
 APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2
 OUT_PMAG, OUT_INTENSITY, OUT_COMPLEX = 1, 2, 4
+FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/olx.h declares (tests/test_abi.py checks the header against this list)
@@ -29,7 +30,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch",
+    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all",
 ]
 
 
@@ -95,6 +96,10 @@ def load(require_gpu: bool = True):
         lib.olx_field_allreduce_aggregate.argtypes = [vp]
         lib.olx_field_reduce_scatter_aggregate.argtypes = [vp]
         lib.olx_aggregate_fetch.argtypes = [vp, fp, fp]
+        lib.olx_field_aggregate_counts.argtypes = [vp, c_int, c_int]
+        lib.olx_rccl_path.argtypes = [vp]; lib.olx_rccl_path.restype = c_char_p
+        lib.olx_bf_time.argtypes = [vp, c_int, fp]
+        lib.olx_field_fetch_all.argtypes = [vp, fp, fp]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -248,7 +253,7 @@ class Context:
         self._shape = (nx, int(n[1]), int(n[2]))
         self._grid_shape = (int(n[0]), int(n[1]), int(n[2]))
         self._vox = nx * int(n[1]) * int(n[2])
-        self._flags = int(flags) | OUT_PMAG
+        self._flags = (int(flags) | OUT_PMAG) & 7
         self._plan_foci = F
 
     def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9):
@@ -273,6 +278,30 @@ class Context:
         if it is not None: out["intensity"] = it
         if cx is not None: out["complex"] = cx[..., 0] + 1j * cx[..., 1]
         return out
+
+    def field_fetch_all(self, want=("pmag", "intensity")):
+        """All planned focus volumes in one pipelined transfer -> dict of float32 [F, nx, ny, nz] (fresh, caller-owned)."""
+        shape = (self._plan_foci,) + self._shape
+        pm = np.empty(shape, dtype=np.float32) if "pmag" in want else None
+        it = np.empty(shape, dtype=np.float32) if "intensity" in want else None
+        self._chk(self._lib.olx_field_fetch_all(self._h, _fptr(pm), _fptr(it)))
+        out = {}
+        if pm is not None: out["pmag"] = pm
+        if it is not None: out["intensity"] = it
+        return out
+
+    def bf_time(self, iters: int = 20) -> np.ndarray:
+        """Microseconds per repeat of the last bf_solve's kernel (HIP events)."""
+        us = np.empty(int(iters), dtype=np.float32)
+        self._chk(self._lib.olx_bf_time(self._h, int(iters), _fptr(us)))
+        return us
+
+    def aggregate_counts(self, local_valid: int, global_total: int):
+        self._chk(self._lib.olx_field_aggregate_counts(self._h, int(local_valid), int(global_total)))
+
+    def rccl_path(self) -> str:
+        v = self._lib.olx_rccl_path(self._h)
+        return v.decode() if v else ""
 
     def field_upload(self, origin_m, spacing_m, n, pmag, intensity=None):
         """Bind host volumes [F, nx, ny, nz] as the resident result (for analysis of loaded Solutions)."""

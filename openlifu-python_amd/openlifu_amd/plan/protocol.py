@@ -26,7 +26,7 @@ from ..bf.apod_methods import ApodizationMethod
 from ..bf.delay_methods import Direct
 from ..engine import get_engine, gpu_available
 from ..geo import Point
-from ..sim.field import dataset_from_fields, simulate_foci, _ATTRS
+from ..sim.field import dataset_from_fields, lazy_stack, simulate_foci, _ATTRS
 from ..util import dataset as ds
 from .param_constraint import ParameterConstraint
 from .solution import Solution
@@ -165,12 +165,20 @@ class Protocol:
         custom_seam = run_simulation is not sim.run_simulation  # patched seam (reference tests mock it)
         if simulate and not custom_seam:
             self.logger.info(f"Simulate for {len(foci)} foci...")
+            # opt-in speed option, SimSetup.options["fp8_correction"] = "1" (sim_setup.py:51 "Additional simulation options")
+            fp8 = str(getattr(sim_options, "options", {}).get("fp8_correction", "0")).lower() in ("1", "true", "yes")
+            # the per-focus volumes stay in HBM (scale / aggregate / analyze below run there); the Dataset hands them to
+            # the host on first access.  Real xarray objects cannot defer, so with xarray installed they are fetched now.
             fields = simulate_foci(transducer, params, delays, apod, self.pulse.frequency,
-                                   self.pulse.amplitude * voltage, steering_resident=resident)
+                                   self.pulse.amplitude * voltage, steering_resident=resident, fp8_correction=fp8,
+                                   lazy=not ds.HAVE_XARRAY)
             coords = params.coords
-            pm = fields["pmag"]
-            stacked = ds.stack_foci({"p_max": (pm, coords, _ATTRS["p_max"]), "p_min": (pm.copy(), coords, _ATTRS["p_min"]),
-                                     "intensity": (fields["intensity"], coords, _ATTRS["intensity"])})
+            if not ds.HAVE_XARRAY:
+                stacked = lazy_stack(fields, coords)
+            else:  # pragma: no cover - xarray is absent in the build image
+                pm = fields["pmag"]
+                stacked = ds.stack_foci({"p_max": (pm, coords, _ATTRS["p_max"]), "p_min": (pm.copy(), coords, _ATTRS["p_min"]),
+                                         "intensity": (fields["intensity"], coords, _ATTRS["intensity"])})
         elif simulate:
             cycles = np.min([np.round(self.pulse.duration * self.pulse.frequency), 20])
             outs = [run_simulation(arr=transducer, params=params, delays=delays[i], apod=apod[i],

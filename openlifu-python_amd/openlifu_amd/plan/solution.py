@@ -96,13 +96,27 @@ class Solution:
         return self.get_pulsetrain_dutycycle() * between
 
     # ---- device-side analysis -----------------------------------------------------------------
+    def _device_is_current(self) -> bool:
+        """True while the GPU still holds THIS solution's volumes and the host cannot have changed them: the result
+        token matches and ``p_min`` / ``intensity`` are lazy arrays nobody has read yet.  Once a volume has been
+        materialised on the host the caller may have edited it in place (the reference's own ``scale`` does), so the
+        host copy is the authority from then on and the device copy is refreshed from it before every scan."""
+        r = getattr(self, "_resident", None)
+        if r is None or r[0] is not get_engine() or r[1] != r[0].result_token:
+            return False
+        res = self.simulation_result
+        return all(isinstance(res[k], ds.LazyDataArray) and not res[k].materialized for k in ("p_min", "intensity"))
+
     def _bind_device(self):
-        """Make sure the GPU holds this solution's volumes; returns (engine, origin, spacing, n)."""
+        """Make sure the GPU holds this solution's CURRENT volumes; returns (engine, origin, spacing, n)."""
         res = self.simulation_result
         origin, spacing, n = grid_from_coords({d: res.coords[d] for d in res["p_min"].dims if d != "focal_point_index"})
         eng = get_engine()
-        if self._resident is None or self._resident[0] is not eng or self._resident[1] != eng.result_token:
-            eng.upload_result(origin, spacing, n, res["p_min"].data, res["intensity"].data)
+        if not self._device_is_current():
+            pm, it = np.asarray(res["p_min"].data), np.asarray(res["intensity"].data)   # (reads any still-lazy volume first)
+            if "p_max" in res:
+                _ = res["p_max"].data
+            eng.upload_result(origin, spacing, n, pm, it)
             self._resident = (eng, eng.result_token)
         return eng, origin, spacing, n
 
@@ -203,12 +217,16 @@ class Solution:
         apod_factors, v0, v1 = self.compute_scaling_factors(focal_pattern, analysis)
         factors = v1 / v0 * apod_factors
         res = self.simulation_result
+        on_device = self._device_is_current()
+        for name, power in (("p_min", 1), ("p_max", 1), ("intensity", 2)):
+            da = res[name]
+            if on_device and isinstance(da, ds.LazyDataArray) and not da.materialized:
+                continue                      # still in HBM only: scaled there below, read (scaled) whenever the caller asks
+            for i in range(self.num_foci()):
+                da[i].data *= factors[i] ** power
         for i in range(self.num_foci()):
-            res["p_min"][i].data *= factors[i]
-            res["p_max"][i].data *= factors[i]
-            res["intensity"][i].data *= factors[i] ** 2
             self.apodizations[i] = self.apodizations[i] * apod_factors[i]
-        if self._resident is not None and self._resident[1] == self._resident[0].result_token:
+        if on_device:
             self._resident[0].ctx.field_scale(factors)
         self.voltage = v1
 

@@ -40,14 +40,31 @@ def _medium(params):
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
-                  steering_resident=False, slab=None):
-    """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz]."""
+                  steering_resident=False, slab=None, fp8_correction=False, lazy=False):
+    """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz], or with ``lazy`` a
+    ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""
     coords = params.coords
     origin, spacing, n = grid_from_coords(coords)
     c, rho, medium = _medium(params)
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
-                              slab=slab, steering_resident=steering_resident, medium=medium)
+                              slab=slab, steering_resident=steering_resident, medium=medium,
+                              fp8_correction=fp8_correction, lazy=lazy)
+
+
+def lazy_stack(result, coords, dim="focal_point_index"):
+    """Dataset{p_max, p_min, intensity}[focal_point_index, x, y, z] (plan/protocol.py:341-347) over a DeviceResult:
+    three independent LazyDataArrays (p_max and p_min are separate host arrays once read, as callers scale them
+    independently, plan/solution.py:333-334)."""
+    from collections import OrderedDict
+    dims = (dim,) + tuple(coords.dims if hasattr(coords, "dims") else coords.keys())
+    c = OrderedDict([(dim, np.arange(result.shape[0]))])
+    c.update(coords)
+    out = {}
+    for name, key in (("p_max", "pmag"), ("p_min", "pmag"), ("intensity", "intensity")):
+        out[name] = result.lazy_array(key, lambda fetch, name=name: ds.LazyDataArray(
+            result.shape, np.float32, fetch, coords=c, dims=dims, name=name, attrs=_ATTRS[name]))
+    return ds.make_dataset(out)
 
 
 def dataset_from_fields(fields, coords, focus=None):

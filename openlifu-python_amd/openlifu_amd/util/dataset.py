@@ -32,12 +32,14 @@ except ImportError:
 class DataArray:
     def __init__(self, data, coords=None, dims=None, name=None, attrs=None):
         self.data = np.asarray(data)
+        self._init_labels(self.data.ndim, coords, dims, name, attrs)
+
+    def _init_labels(self, ndim, coords, dims, name, attrs):
         if dims is None:
-            dims = tuple(coords.keys())[: self.data.ndim] if coords is not None else tuple(
-                f"dim_{i}" for i in range(self.data.ndim))
+            dims = tuple(coords.keys())[:ndim] if coords is not None else tuple(f"dim_{i}" for i in range(ndim))
         self.dims = tuple(dims)
-        if len(self.dims) != self.data.ndim:
-            raise ValueError(f"dims {self.dims} do not match data of rank {self.data.ndim}")
+        if len(self.dims) != ndim:
+            raise ValueError(f"dims {self.dims} do not match data of rank {ndim}")
         self.coords = OrderedDict()
         if coords is not None:
             for k, v in coords.items():
@@ -56,18 +58,18 @@ class DataArray:
 
     @property
     def sizes(self):
-        return OrderedDict(zip(self.dims, self.data.shape))
+        return OrderedDict(zip(self.dims, self.shape))
 
     @property
     def ndim(self):
-        return self.data.ndim
+        return len(self.shape)
 
     @property
     def size(self):
-        return self.data.size
+        return int(np.prod(self.shape, dtype=np.int64))
 
     def __len__(self):
-        return len(self.data)
+        return self.shape[0]
 
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.data, dtype=dtype)
@@ -139,6 +141,51 @@ class DataArray:
 
     def __repr__(self):
         return f"<openlifu_amd.DataArray {self.name!r} dims={self.dims} shape={self.shape} attrs={list(self.attrs)}>"
+
+
+class LazyDataArray(DataArray):
+    """A DataArray whose values still live in HBM: shape / dims / coords / attrs are known, ``.data`` brings the values
+    to the host on FIRST access (``fetch()`` -> a fresh, writable, caller-owned ndarray) and is an ordinary NumPy array
+    from then on.  ``Protocol.calc_solution`` returns the per-focus volumes this way: scaling, aggregation and analysis
+    run on the device, so a caller that only looks at the analysis never pays for 3 x F volumes of PCIe traffic
+    (DESIGN.md section 6).  ``materialized`` tells whether the host copy exists (and may have been edited)."""
+
+    def __init__(self, shape, dtype, fetch, coords=None, dims=None, name=None, attrs=None):
+        self._shape = tuple(int(v) for v in shape)
+        self._dtype = np.dtype(dtype)
+        self._fetch = fetch
+        self._host = None
+        self._init_labels(len(self._shape), coords, dims, name, attrs)
+
+    @property
+    def materialized(self) -> bool:
+        return self._host is not None
+
+    @property
+    def data(self):
+        if self._host is None:
+            host = np.asarray(self._fetch())
+            if host.shape != self._shape:
+                raise ValueError(f"device result of shape {host.shape}, expected {self._shape}")
+            self._host, self._fetch = host, None
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        self._host, self._fetch = np.asarray(value), None
+        self._shape = self._host.shape
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def __repr__(self):
+        where = "host" if self.materialized else "device"
+        return f"<openlifu_amd.LazyDataArray {self.name!r} dims={self.dims} shape={self.shape} on {where}>"
 
 
 class Coordinates(OrderedDict):

@@ -160,15 +160,24 @@ class Element:
         self.position = np.array([x, y, z])
         self.orientation = np.array([az, el, roll])
 
+    def interp_impulse_response(self, dt=None):
+        """(response resampled to ``dt`` by linear interpolation, zero-mean time axis) -- xdc/element.py:84-93."""
+        dt = self.impulse_dt if dt is None else dt
+        t0 = self.impulse_dt * np.arange(len(self.impulse_response))
+        resp = np.interp(np.arange(0, t0[-1] + dt, dt), t0, self.impulse_response)
+        t = np.arange(len(resp)) * dt
+        return resp, t - np.mean(t)
+
     def calc_output(self, input_signal, dt):
         """xdc/element.py:144-154.  NOTE: like the reference, multiplies the caller's
-        array IN PLACE when sensitivity is set and there is no impulse response."""
+        array IN PLACE when sensitivity is set and there is no impulse response.  An array impulse response is
+        convolved in (resampled to ``dt``); the reference's own branch raises there (see Transducer.calc_output)."""
         if self.impulse_response is None:
             out = input_signal
         elif len(self.impulse_response) == 1:
             out = input_signal * self.impulse_response[0]
         else:
-            raise NotImplementedError("array impulse responses are outside the hot path")
+            out = np.convolve(input_signal, self.interp_impulse_response(dt)[0], mode="full")
         if self.sensitivity is not None:
             out *= self.sensitivity
         return out

@@ -88,16 +88,30 @@ class Transducer:
     def copy(self):
         return copy.deepcopy(self)
 
+    def interp_impulse_response(self, dt=None):
+        """(response resampled to ``dt`` by linear interpolation, zero-mean time axis) -- xdc/transducer.py:84-93."""
+        dt = self.impulse_dt if dt is None else dt
+        t0 = self.impulse_dt * np.arange(len(self.impulse_response))
+        resp = np.interp(np.arange(0, t0[-1] + dt, dt), t0, self.impulse_response)
+        t = np.arange(len(resp)) * dt
+        return resp, t - np.mean(t)
+
     def calc_output(self, input_signal, dt, delays: np.ndarray = None, apod: np.ndarray = None):
         """Per-element drive signal [N, T] (xdc/transducer.py:95-112): ``a_e * sensitivity * signal``
         preceded by ``int(delay/dt)`` zeros.  Like the reference, ``input_signal`` is scaled IN PLACE
-        by ``sensitivity`` when no impulse response is set (transducer.py:100-106)."""
+        by ``sensitivity`` when no impulse response is set (transducer.py:100-106).
+
+        With an array impulse response the drive is first convolved with the response resampled to ``dt``
+        (``np.convolve(signal, interp_impulse_response(dt)[0], 'full')``).  That is what transducer.py:100-104 sets
+        out to do; the reference itself passes the (response, time) tuple to np.convolve there and raises ValueError
+        (tests/golden/g11_impulse_response.json records it), so a transducer file with an impulse response cannot
+        get through ``Solution.analyze`` upstream -- here it can."""
         n = self.numelements()
         delays = np.zeros(n) if delays is None else delays
         apod = np.ones(n) if apod is None else apod
-        if self.impulse_response is not None:
-            raise NotImplementedError("array impulse responses are outside the hot path")
         sig = input_signal
+        if self.impulse_response is not None:
+            sig = np.convolve(input_signal, self.interp_impulse_response(dt)[0], mode="full")
         if self.sensitivity is not None:
             sig *= self.sensitivity
         outs = [np.concatenate([np.zeros(int(d / dt)), a * el.calc_output(sig, dt)])

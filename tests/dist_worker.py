@@ -41,6 +41,19 @@ def main():
     got = od.assemble_foci(all_gather_np(local), F)
     assert got.shape == full.shape and np.array_equal(got, full), "foci reassembly mismatch"
 
+    # --- orbit-aware foci sharding (what ShardedField.plan_foci_sweep uses): the spokes of the 4-spoke wheel pair up
+    shards = od.plan_foci_orbits(foci, world)
+    local = full[shards[rank]]
+    got = od.assemble_foci_sharded(all_gather_np(local), shards, F)
+    assert np.array_equal(got, full), "orbit-sharded reassembly mismatch"
+    valid = od.shard_valid_counts(shards, F)
+    mine = full[shards[rank][:valid[rank]]]                 # genuine foci only: the padded aggregate (olx_field_aggregate_counts)
+    tmax = torch.from_numpy(mine.max(axis=0).copy()) if len(mine) else torch.zeros(full.shape[1:])
+    tsum = torch.from_numpy((mine.astype(np.float64) ** 2).sum(axis=0)) if len(mine) else torch.zeros(full.shape[1:], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    assert np.array_equal(tmax.numpy(), full.max(axis=0))
+    assert np.allclose(tsum.numpy() / F, (full.astype(np.float64) ** 2).mean(axis=0), rtol=1e-12)
+
     # --- slab sharding (nx = 7 planes over `world` ranks: shifted trailing slab)
     per, plan = od.plan_slabs(len(xs), world)
     begin = plan[rank][0]

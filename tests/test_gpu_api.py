@@ -327,3 +327,64 @@ def test_max_cycle_offset_matches_numpy_restatement():
         got = setup.get_max_cycle_offset(arr, delays=dl, zmin=zmin)
         assert np.isclose(got, ref, rtol=1e-13), (got, ref)
     assert np.isclose(setup.get_max_cycle_offset(arr, frequency=1e6, delays=delays), ref / 400e3 * 1e6 * 0 + setup.get_max_cycle_offset(arr, delays=delays) * 2.5)
+
+
+def test_results_stay_on_the_device_until_read_and_host_edits_win():
+    """calc_solution leaves the per-focus volumes in HBM (LazyDataArray): scale / aggregate / analyze run there and the
+    host arrays appear on first ``.data`` access -- fresh, writable, independent.  From then on the host copy is the
+    authority: an in-place edit of simulation_result (the reference supports it; its own Solution.scale does it,
+    plan/solution.py:331-337) must show up in the next analyze(), not be shadowed by the resident device copy.  A second
+    calc_solution on the same engine must not invalidate arrays of the first that nobody has read yet."""
+    from openlifu_amd.util import dataset as ds
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 40))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup,
+                        sequence=ol.Sequence(pulse_count=6, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=2, spoke_radius=2.0, target_pressure=1.0, units="MPa"))
+    sol, agg, an = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=True)
+    res = sol.simulation_result
+    assert all(isinstance(res[k], ds.LazyDataArray) and not res[k].materialized for k in ("p_min", "p_max", "intensity"))
+    assert res["p_min"].shape == (3, 21, 21, 36) and res["p_min"].dims[0] == "focal_point_index"
+    assert np.allclose(an.mainlobe_pnp_MPa, 1.0, rtol=1e-4)          # scaled on the device
+    sol_b, _, an_b = proto.calc_solution(ol.Point(position=(1, 0, 28)), arr, scale=False)   # reuses the device buffers
+    assert all(res[k].materialized for k in ("p_min", "p_max", "intensity"))                # retired to the host in time
+    pm = res["p_min"].data
+    assert pm.flags.writeable and pm.dtype == np.float32 and pm is not res["p_max"].data
+    assert np.array_equal(pm, res["p_max"].data) and np.isclose(pm.max() * 1e-6, max(an.global_pnp_MPa), rtol=1e-6)
+    assert np.array_equal(agg["p_min"].data, pm.max(axis=0))
+    assert sol.analyze().mainlobe_pnp_MPa == an.mainlobe_pnp_MPa                           # uploaded again from the host copy
+    pm[1] *= 2.0                                                                           # host edit after the fact
+    res["intensity"].data[1] *= 4.0
+    an2 = sol.analyze()
+    assert np.isclose(an2.mainlobe_pnp_MPa[1], 2.0 * an.mainlobe_pnp_MPa[1], rtol=1e-6)
+    assert np.isclose(an2.mainlobe_isppa_Wcm2[1], 4.0 * an.mainlobe_isppa_Wcm2[1], rtol=1e-6)
+    assert an2.mainlobe_pnp_MPa[0] == an.mainlobe_pnp_MPa[0]
+    # scale() of a solution whose volumes live on the host mutates them in place (API contract) and stays consistent
+    before = res["p_min"].data.copy()
+    sol.scale(proto.focal_pattern)
+    an3 = sol.analyze()
+    assert np.allclose(an3.mainlobe_pnp_MPa, 1.0, rtol=1e-4) and not np.array_equal(res["p_min"].data, before)
+    # the second solution is still lazy and reads back what its own analysis saw
+    assert not sol_b.simulation_result["p_min"].materialized
+    assert np.isclose(sol_b.simulation_result["p_min"].data.max() * 1e-6, max(an_b.global_pnp_MPa), rtol=1e-6)
+
+
+def test_fetch_paths_agree(monkeypatch):
+    """olx_field_fetch_all (pipelined pinned ring, the default) == per-focus fetches, in every OLX_FETCH_MODE."""
+    from openlifu_amd import _native as nat
+    pos, size, _ = bo.gen_matrix_array(16, 16, 3.0, 0.3)
+    with nat.Context(0) as ctx:
+        ctx.set_elements(pos * 1e-3, np.tile([0, 0, 1.0], (256, 1)), size[:, 0] * size[:, 1] * 1e-6)
+        ctx.bf_solve(np.array([[0, 0, 30e-3], [2e-3, 1e-3, 28e-3], [-1e-3, 3e-3, 33e-3]]), 1500.0)
+        ctx.field_plan((-32e-3, -32e-3, 5e-3), (0.5e-3,) * 3, (128, 128, 160), 400e3, 1500.0, 1000.0, 1e5)   # 3 x 10.5 MB x 2
+        ctx.field_launch()
+        monkeypatch.setenv("OLX_FETCH_MODE", "pageable")
+        ref = [ctx.field_fetch(f) for f in range(3)]
+        for mode in ("staged", "register", "pageable"):
+            monkeypatch.setenv("OLX_FETCH_MODE", mode)
+            out = ctx.field_fetch_all()
+            assert out["pmag"].flags.writeable and out["pmag"].shape == (3, 128, 128, 160)
+            for f in range(3):
+                assert np.array_equal(out["pmag"][f], ref[f]["pmag"]) and np.array_equal(out["intensity"][f], ref[f]["intensity"])
+                one = ctx.field_fetch(f)
+                assert np.array_equal(one["pmag"], ref[f]["pmag"])

@@ -31,11 +31,13 @@ def setup_ctx(ctx, pos, ori, size, foci_m, apod=("uniform", 1.0, 0.0), solve=Fal
     return pos_m, area, delays, ap
 
 
-def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P, complex_out=True):
-    """complex_out=False plans |p| + intensity only (kernel 2e serves that; complex output goes through 2d / 2c)."""
+def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P, complex_out=True, fp8=False):
+    """complex_out=False plans |p| + intensity only (kernel 2e serves that; complex output goes through 2d / 2c).
+    fp8=True opts in to the e4m3 correction products (OLX_FIELD_FP8_CORRECTION)."""
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (len(xs), len(ys), len(zs)), F0, C, RHO, P0,
-                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.OUT_COMPLEX if complex_out else 0))
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.OUT_COMPLEX if complex_out else 0) |
+                   (nat.FIELD_FP8_CORRECTION if fp8 else 0))
     if want_variant:
         assert want_variant in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
@@ -230,6 +232,13 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     ints = np.stack([ctx.field_fetch(f)["intensity"] for f in range(3)])
     assert np.array_equal(pm, local.max(axis=0)) and np.allclose(im, ints.mean(axis=0), rtol=1e-6)
     assert np.array_equal(pm_rs, pm) and np.array_equal(im_rs, im)
+    assert ctx.rccl_path().startswith("/opt/rocm"), ctx.rccl_path()     # the system ROCm's RCCL, not a wheel's copy
+    # padded shards (F not divisible by the ranks): only the first `local_valid` foci enter the local max / sum and the mean
+    # divides by the GLOBAL number of genuine foci (olx_field_aggregate_counts) -- here: focus 2 is padding, 2 foci in total
+    ctx.aggregate_counts(2, 2)
+    ctx.field_allreduce_aggregate()
+    pm2, im2 = ctx.aggregate_fetch()
+    assert np.array_equal(pm2, local[:2].max(axis=0)) and np.allclose(im2, ints[:2].mean(axis=0), rtol=1e-6)
     ctx.comm_destroy()
     # the driver class on world = 1 (no communicator): foci mode and slab mode agree with each other
     arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
@@ -390,7 +399,7 @@ def test_mirror_partner_foci_share_columns(ctx):
 
 
 def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0.0), z0=5e-3, foci=None, apod=("uniform", 1.0, 0.0),
-                  slab=None, expect="field_coset_k", solve=False):
+                  slab=None, expect="field_coset_k", solve=False, fp8=False):
     """Flat nax x nay array with pitch (px, py) [mm]; grid of grid_n voxels with spacing [mm] centred on the array
     (+ origin_shift voxels); full-volume parity against the oracle."""
     px, py = pitch_xy
@@ -407,16 +416,18 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     xs, ys = coords
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     if slab is None:
-        check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect, complex_out=False)
+        check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect, complex_out=False, fp8=fp8)
         if expect == "field_coset_k":      # the same case with complex output: served by kernel 2d
             check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant="field_lattice_k")
         return
-    ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab)
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab,
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
     assert expect in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     for f in range(len(foci)):
         got = ctx.field_fetch(f)["pmag"]
         ref = np.abs(co.field_on_grid(xs[slab[0]:slab[0] + slab[1]], ys, zs, pos_m, area, d[f], ap[f], F0, C, P0, dmin=0.5 * min(h)))
+        # normalised by the SLAB's own maximum (the bound olx.h states per planned volume)
         assert got.shape == ref.shape and np.abs(got - ref).max() / ref.max() <= TOL_P
 
 
@@ -458,42 +469,90 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
     _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
 
 
-def test_fp8_correction_products_are_gated(ctx, monkeypatch):
+def test_fp8_correction_products_are_opt_in_and_gated(ctx, monkeypatch):
     """Kernel 2e's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
-    grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  The host uses them only when the volume is known to hold that
-    peak -- steering from olx_bf_solve, every focus inside the grid -- and N_eff >= 256; the fp16 corrections (0.8e-6)
-    otherwise.  OLX_FP8_CORRECTION pins either.  Full-volume parity in every mode."""
+    grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  They are OPT-IN (plan flag OLX_FIELD_FP8_CORRECTION): never
+    selected unasked -- neither on the olx_bf_solve path nor at the run_simulation seam -- and, when asked for, used only
+    if the planned SLAB is known to hold the focal peak (foci known and inside the slab) and N_eff >= 256; the fp16
+    corrections (0.8e-6) otherwise.  OLX_FP8_CORRECTION pins either for A/B runs.  Full-volume parity in every mode."""
     foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 33e-3]])
     grid, h = (48, 48, 32), (1.0, 1.0, 1.0)      # z = 5 .. 36 mm: both foci inside
     fp8, f16 = "noclamp,fp8corr>", "noclamp> "
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect=fp8, solve=True)             # NT = 1
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True)                 # NT = 2
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8)     # external geometric delays: the foci are inferred
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True)         # z = 5 .. 28 mm: foci outside
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect=f16, solve=True)   # few active elements
-    _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect=f16, solve=True)           # 64 elements
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, solve=True)                 # default: never fp8
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16)                             # nor at the external-delay seam
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect=fp8, solve=True, fp8=True)   # NT = 1
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True, fp8=True)       # NT = 2
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, fp8=True)   # external geometric delays: the foci are inferred
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True, fp8=True)   # z = 5 .. 28 mm: foci outside
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect=f16, solve=True, fp8=True)   # few active elements
+    _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect=f16, solve=True, fp8=True)     # 64 elements
+    # x-slabs (the multi-GPU shard unit): only the slab that holds BOTH foci (x = -0.5 mm and 2.5 mm: voxels 23 and 26) may use
+    # fp8; a slab next to them keeps fp16 and its error is bounded against its OWN maximum
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(16, 16), expect=fp8, solve=True, fp8=True)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(0, 16), expect=f16, solve=True, fp8=True)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(32, 16), expect=f16, solve=True, fp8=True)
     pos, ori, size = synthetic_array(16, 16, 3.0)
     xs, ys, zs = centred_grid(48, 1.0)
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
     d = d + np.random.default_rng(147).uniform(0, 2e-7, d.shape)       # external delays that no focus explains (0.3 mm of path)
     ctx.set_steering(d, a)
-    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False, fp8=True)
     monkeypatch.setenv("OLX_FP8_CORRECTION", "0")
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
-    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False, fp8=True)
     monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
     check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="fp8corr", complex_out=False)
 
 
-@pytest.mark.parametrize("n_foci,expect", [(8, "noclamp,fp8corr>"), (64, "field_coset_k<nt4,mx2,my2,flat,noclamp>")])
-def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, expect):
-    """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and one GPU's 8-focus
-    shard in bench.py's mirror-orbit order): sampled-voxel parity per focus, the per-focus focal peak, and the
-    aggregate over foci (max |p|, mean intensity, plan/protocol.py:382-387) against the fetched volumes."""
-    pos, ori, size = synthetic_array(16, 16, 3.0)
+def _wheel_shard(n_foci, rank=0):
+    """One GPU's shard of BASELINE configs[2]'s 64-focus Wheel sweep as the PRODUCT plans it (dist.plan_foci_orbits:
+    whole mirror orbits per shard), foci in metres."""
+    from openlifu_amd import dist as od
     sweep = bo.wheel_targets([0, 0, 40.0], True, 63, 5.0) * 1e-3
-    order = [0, 1] + [k for i in range(1, 32) for k in (1 + i, 1 + 63 - i)]
-    foci = sweep[order[:n_foci]]
+    if n_foci == 64:
+        return sweep
+    shards = od.plan_foci_orbits(sweep, 64 // n_foci, centre_xy=(0.0, 0.0))
+    return sweep[shards[rank]]
+
+
+@pytest.mark.parametrize("fp8", [True, False])
+def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
+    """The bench.py headline configuration (256 el x 256^3, rank 0's 8-focus shard of the Wheel sweep, |p| + intensity),
+    FULL-volume parity against the fp64 C oracle for three foci -- the on-axis centre, spoke 0 (on the x axis) and a
+    diagonal spoke -- with the fp8 correction products opted in (the bench default; stated bound 6e-6 of the focal
+    peak, gate 1e-5) and with the default fp16 corrections (bound 2e-6).  16.7 M voxels x 256 elements per focus on
+    every host core."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(8)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    xs, ys, zs = centred_grid(256, 0.25)
+    h = (xs[1] - xs[0],) * 3
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0,
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+    name = ctx.field_variant()
+    assert "field_coset_k<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name
+    ctx.field_launch()
+    worst = 0.0
+    for f in (0, 1, 4):
+        out = ctx.field_fetch(f)
+        ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0]))
+        peak = ref.max()
+        err = np.abs(out["pmag"] - ref).max() / peak
+        worst = max(worst, err)
+        assert err <= (6.5e-6 if fp8 else 2e-6), (f, err)
+        iref = fo.intensity_wcm2(ref, RHO, C)
+        assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
+    print(f"full-volume 256^3 parity, fp8={fp8}: max error {worst:.2e} of the volume maximum")
+
+
+@pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp> 16 columns"),
+                                                 (64, 0, "field_coset_k<nt4,mx2,my2,flat,noclamp>")])
+def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, rank, expect):
+    """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and two of the eight
+    8-focus shards the product's orbit-aware planner hands to the GPUs): sampled-voxel parity per focus, the per-focus
+    focal peak, and the aggregate over foci (max |p|, mean intensity, plan/protocol.py:382-387) against the fetched volumes."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(n_foci, rank)
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
     xs, ys, zs = centred_grid(256, 0.25)
     h = (xs[1] - xs[0],) * 3

@@ -415,3 +415,67 @@ def test_run_simulation_seam_can_be_replaced(monkeypatch):
     with pytest.raises(AssertionError, match="device touched"):  # aggregation is device-side; reached only after the seam ran
         p.calc_solution(ol.Point(position=(0, 0, 30)), ol.Transducer.gen_matrix_array(2, 2), scale=False, voltage=4.0)
     assert len(calls) == 3 and calls[0] == ((4,), (4,), 5e5, 2.0)
+
+
+# ---- impulse responses (golden G11 from the real reference) ----------------------------------------
+def test_impulse_response_interpolation_and_drive_signal(golden):
+    """interp_impulse_response bit-for-bit against the reference (Transducer and Element, native / resampled / coarser
+    time steps), and calc_output's array-impulse-response branch = the convolution the reference's branch sets out to
+    do (xdc/transducer.py:100-104; upstream it raises, which the fixture records)."""
+    import openlifu_amd as ol
+    g = golden.npz("g11_impulse_response.npz")
+    assert golden.json("g11_impulse_response.json")["reference_calc_output_with_array_impulse_response_raises"] == {
+        "transducer": "ValueError", "element": "ValueError"}
+    arr = ol.Transducer.gen_matrix_array(nx=2, ny=3, pitch=4, kerf=0.5, units="mm", sensitivity=2.5,
+                                         impulse_response=g["ir"], impulse_dt=float(g["ir_dt"]))
+    dt = float(g["dt"])
+    for tag, d in (("native", None), ("resampled", dt), ("coarse", 3.3e-7)):
+        resp, tt = arr.interp_impulse_response(d)
+        assert np.array_equal(resp, g[f"tx_interp_{tag}"]) and np.array_equal(tt, g[f"tx_interp_t_{tag}"])
+    el = ol.Element(impulse_response=g["ir"], impulse_dt=float(g["ir_dt"]), sensitivity=0.5)
+    resp, tt = el.interp_impulse_response(dt)
+    assert np.array_equal(resp, g["el_interp"]) and np.array_equal(tt, g["el_interp_t"])
+    assert np.array_equal(ol.Element(impulse_response=0.75, sensitivity=2.0).calc_output(g["signal"].copy(), dt), g["el_scalar_out"])
+    assert np.allclose(el.calc_output(g["signal"].copy(), dt), g["el_intended_out"], rtol=1e-15, atol=0)
+    out = arr.calc_output(g["signal"].copy(), dt, delays=g["delays"], apod=g["apod"])
+    filt = g["tx_intended_filtered"]
+    assert out.shape == (6, len(filt) + int(g["delays"].max() / dt))
+    for e in range(6):
+        lead = int(g["delays"][e] / dt)
+        assert not out[e, :lead].any() and np.allclose(out[e, lead:lead + len(filt)], g["apod"][e] * filt, rtol=1e-15, atol=0)
+    with pytest.raises(ValueError):
+        ol.Transducer.gen_matrix_array(nx=2, ny=2, impulse_response=[1.0, 2.0])          # array response needs impulse_dt
+
+
+# ---- threshold / skull segmentation (SURVEY 8(f)3) -------------------------------------------------------------------
+def test_threshold_segmentation_labels_and_params():
+    from openlifu_amd.seg import MATERIALS, Material, SegmentationMethod, seg_methods as sm
+    from openlifu_amd.util import dataset as ds
+    coords = {"x": np.arange(3.0), "y": np.arange(2.0), "z": np.arange(4.0)}
+    img = np.array([-1000.0, -150.0, 40.0, 299.9, 300.0, 1800.0] * 4).reshape(3, 2, 4)
+    vol = ds.make_dataarray(img, coords=coords, dims=("x", "y", "z"))
+    seg = SegmentationMethod.from_dict({"class": "ThresholdSegmentation", "bounds": [-200.0, 300.0],
+                                        "labels": ["air", "tissue", "skull"], "ref_material": "water"})
+    params = seg.seg_params(vol)
+    c = np.asarray(params["sound_speed"].data)
+    expect = np.where(img < -200, MATERIALS["air"].sound_speed, np.where(img < 300, MATERIALS["tissue"].sound_speed, MATERIALS["skull"].sound_speed))
+    assert np.array_equal(c, expect) and params["sound_speed"].attrs["ref_value"] == 1500.0
+    assert set(params.keys() if hasattr(params, "keys") else params.data_vars) >= {"sound_speed", "density", "attenuation"}
+    assert SegmentationMethod.from_dict(seg.to_dict()).bounds == [-200.0, 300.0]
+    sk = SegmentationMethod.from_dict({"class": "SkullThreshold", "skull_threshold": 250.0})
+    assert isinstance(sk, sm.SkullThreshold) and sk.labels == ["water", "skull"] and SegmentationMethod.from_dict(sk.to_dict()).skull_threshold == 250.0
+    rho = np.asarray(sk.seg_params(vol)["density"].data)
+    assert np.array_equal(rho, np.where(img >= 250.0, 1900.0, 1000.0))
+    with pytest.raises(ValueError):
+        sm.ThresholdSegmentation(bounds=[300.0, 100.0], labels=["water", "tissue", "skull"])
+    with pytest.raises(ValueError):
+        sm.ThresholdSegmentation(bounds=[300.0], labels=["water", "bone"])
+    with pytest.raises(ValueError):
+        sm.ThresholdSegmentation(bounds=[300.0], labels=["water"])
+    # the synthetic phantom of SURVEY 8(d): slab between 8 mm and a wavy surface around 14 mm
+    xs = np.linspace(-20e-3, 20e-3, 41); zs = 5e-3 + np.arange(16) * 1e-3
+    v = sm.skull_slab_volumes(xs, xs, zs)
+    zsurf = 14e-3 + 2e-3 * np.sin(2 * np.pi * xs / 40e-3)[:, None] * np.cos(2 * np.pi * xs / 40e-3)[None, :]
+    mask = (zs[None, None, :] >= 8e-3) & (zs[None, None, :] < zsurf[:, :, None])
+    assert np.array_equal(v["sound_speed"], np.where(mask, 2800.0, 1500.0).astype(np.float32))
+    assert np.array_equal(v["attenuation"], np.where(mask, 6.0, 0.0).astype(np.float32)) and v["density"].max() == 1900.0

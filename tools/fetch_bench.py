@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): device -> caller-owned NumPy bandwidth of olx_field_fetch_all per OLX_FETCH_MODE
+(pageable / register / staged x threads) for the bench.py headline result (8 foci x 256^3 x {|p|, intensity} = 1.07 GB).
+  python tools/fetch_bench.py [--grid 256] [--foci 8]"""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "openlifu-python_amd")]
+from openlifu_amd import _native as nat
+
+ap = argparse.ArgumentParser(); ap.add_argument("--grid", type=int, default=256); ap.add_argument("--foci", type=int, default=8)
+a = ap.parse_args()
+n = 16
+xe = (np.arange(n) - (n - 1) / 2) * 3e-3
+pos = np.stack([np.repeat(xe, n), np.tile(xe, n), np.zeros(n * n)], axis=1)
+with nat.Context(0) as ctx:
+    ctx.set_elements(pos, np.tile([0, 0, 1.0], (n * n, 1)), np.full(n * n, 7.29e-6))
+    th = 2 * np.pi * np.arange(a.foci) / 63
+    ctx.bf_solve(np.stack([5e-3 * np.cos(th), 5e-3 * np.sin(th), np.full(a.foci, 40e-3)], axis=1), 1500.0)
+    h = 64e-3 / a.grid
+    ctx.field_plan((-(a.grid - 1) / 2 * h, -(a.grid - 1) / 2 * h, 5e-3), (h,) * 3, (a.grid,) * 3, 400e3, 1500.0, 1000.0, 1e5)
+    ctx.field_launch(); ctx.sync()
+    nbytes = 2 * 4 * a.foci * a.grid ** 3
+    for mode, thr in (("pageable", 1), ("register", 1), ("staged", 1), ("staged", 2), ("staged", 4), ("staged", 8)):
+        os.environ["OLX_FETCH_MODE"] = mode; os.environ["OLX_FETCH_THREADS"] = str(thr)
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); out = ctx.field_fetch_all(); ts.append(time.perf_counter() - t); del out
+        print(f"{mode:9s} threads {thr}: {nbytes / min(ts) / 1e9:6.1f} GB/s best, {nbytes / max(ts) / 1e9:6.1f} GB/s worst ({min(ts) * 1e3:.0f} ms for {nbytes / 1e6:.0f} MB incl. np.empty first touch)")

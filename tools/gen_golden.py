@@ -313,6 +313,37 @@ def main():
         g10["overflow_error"] = type(e).__name__
     json.dump(g10, open(os.path.join(OUT, "g10_tx_handoff.json"), "w"))
 
+    # ---- G11: impulse responses (xdc/transducer.py:84-104, xdc/element.py:84-93, 144-154) ---------------------------
+    # interp_impulse_response is executed as is.  calc_output's array branch hands the (response, time) TUPLE that
+    # interp_impulse_response returns to np.convolve, which raises in the reference (recorded below); the fixture
+    # therefore holds the convolution that branch evidently intends: np.convolve(signal, interp(dt)[0], 'full').
+    ir = np.array([0.0, 0.6, 1.0, 0.35, -0.25, -0.1, 0.02])
+    ir_dt, dt = 1.0e-7, 1.25e-7
+    sig = Pulse(frequency=400e3, amplitude=1.0, duration=1e-5).calc_pulse(np.arange(0, 1e-5, dt))
+    arr_ir = Transducer.gen_matrix_array(nx=2, ny=3, pitch=4, kerf=0.5, units="mm", sensitivity=2.5,
+                                         impulse_response=ir, impulse_dt=ir_dt)
+    g11 = {"ir": ir, "ir_dt": ir_dt, "dt": dt, "signal": sig, "delays": np.array([0, 1e-6, 2.4e-6, 0.3e-6, 0, 5e-7]),
+           "apod": np.array([1, 0.5, 1, 0, 0.25, 1.0])}
+    for tag, d in (("native", None), ("resampled", dt), ("coarse", 3.3e-7)):
+        resp, tt = arr_ir.interp_impulse_response(d)
+        g11[f"tx_interp_{tag}"] = resp; g11[f"tx_interp_t_{tag}"] = tt
+    el_ir = Element(impulse_response=ir, impulse_dt=ir_dt, sensitivity=0.5)
+    resp, tt = el_ir.interp_impulse_response(dt)
+    g11["el_interp"] = resp; g11["el_interp_t"] = tt
+    g11["el_scalar_out"] = Element(impulse_response=0.75, sensitivity=2.0).calc_output(sig.copy(), dt)
+    raised = {}
+    for label, fn in (("transducer", lambda: arr_ir.calc_output(sig.copy(), dt, delays=g11["delays"], apod=g11["apod"])),
+                      ("element", lambda: el_ir.calc_output(sig.copy(), dt))):
+        try:
+            fn(); raised[label] = "none"
+        except Exception as e:  # noqa: BLE001
+            raised[label] = type(e).__name__
+    g11["tx_intended_filtered"] = np.convolve(sig, arr_ir.interp_impulse_response(dt)[0], mode="full") * 2.5
+    g11["el_intended_out"] = np.convolve(sig, el_ir.interp_impulse_response(dt)[0], mode="full") * 0.5
+    np.savez_compressed(os.path.join(OUT, "g11_impulse_response.npz"), **g11)
+    json.dump({"reference_calc_output_with_array_impulse_response_raises": raised},
+              open(os.path.join(OUT, "g11_impulse_response.json"), "w"))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
