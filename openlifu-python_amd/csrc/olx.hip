@@ -906,41 +906,47 @@ int olx_profile_end(olx_ctx* c, float* ms_each, int capacity, int* n_recorded) {
 // A/B measurements; default "staged"):
 //   pageable  hipMemcpyAsync straight into the caller's pages (the round-1 path)
 //   register  hipHostRegister the destination, one DMA, unregister (pinning walks / faults the pages in the kernel)
-//   staged    a ring of pinned chunks: chunk i+1 is DMA'd while worker threads copy chunk i into the destination,
-//             so the first touch of the destination pages and the copy-out run on several host cores
-struct FetchRing {
-    static constexpr int NCH = 3;
-    static constexpr size_t CHUNK = (size_t)16 << 20;
-    void* buf[NCH] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev[NCH] = {nullptr, nullptr, nullptr};
-    bool ok = false;
+//   staged    the transfer is cut into one contiguous part per worker thread (OLX_FETCH_THREADS, default 8); each worker
+//             streams its part through its own two pinned chunks on its own stream -- DMA of chunk i+1 overlaps the
+//             copy-out of chunk i -- so the first touch of the destination pages and the copy-out run on several cores
+struct FetchLane {                 // one per worker thread: its own stream and two pinned chunks
+    static constexpr size_t CHUNK = (size_t)8 << 20;
+    hipStream_t stream = nullptr;
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
     bool init() {
-        if (ok) return true;
-        for (int i = 0; i < NCH; ++i) {
+        if (stream) return true;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < 2; ++i) {
             if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) return false;
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
         }
-        ok = true;
         return true;
     }
-    void destroy() {
-        for (int i = 0; i < NCH; ++i) { if (buf[i]) hipHostFree(buf[i]); if (ev[i]) hipEventDestroy(ev[i]); buf[i] = nullptr; ev[i] = nullptr; }
-        ok = false;
-    }
 };
-static FetchRing g_ring[16];   // one per device ordinal (contexts of one device share it; one caller thread per context)
+static constexpr int FETCH_MAX_THREADS = 32;
+static FetchLane g_lanes[16][FETCH_MAX_THREADS];   // [device ordinal][worker]; one caller thread per context
 
-static void parallel_copy(void* dst, const void* src, size_t bytes, int nthreads) {
-    if (nthreads <= 1 || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
-    const size_t per = ((bytes / nthreads) + 4095) & ~(size_t)4095;
-    for (int t = 0; t < nthreads; ++t) {
-        const size_t off = per * t;
-        if (off >= bytes) break;
-        const size_t cnt = std::min(per, bytes - off);
-        th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, cnt); });
+// Worker t moves bytes [lo, hi) of the transfer: DMA of chunk i+1 into its second pinned buffer is in flight while it
+// copies chunk i into the destination (first touch of those destination pages happens on this thread).
+static hipError_t fetch_lane_run(int device, FetchLane& L, char* dst, const char* src, size_t lo, size_t hi) {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    const size_t n = (hi - lo + FetchLane::CHUNK - 1) / FetchLane::CHUNK;
+    auto issue = [&](size_t i) {
+        const size_t off = lo + i * FetchLane::CHUNK, cnt = std::min(FetchLane::CHUNK, hi - off);
+        hipError_t r = hipMemcpyAsync(L.buf[i & 1], src + off, cnt, hipMemcpyDeviceToHost, L.stream);
+        return r != hipSuccess ? r : hipEventRecord(L.ev[i & 1], L.stream);
+    };
+    if (n) { e = issue(0); if (e != hipSuccess) return e; }
+    for (size_t i = 0; i < n; ++i) {
+        if (i + 1 < n) { e = issue(i + 1); if (e != hipSuccess) return e; }
+        e = hipEventSynchronize(L.ev[i & 1]);
+        if (e != hipSuccess) return e;
+        const size_t off = lo + i * FetchLane::CHUNK, cnt = std::min(FetchLane::CHUNK, hi - off);
+        memcpy(dst + off, L.buf[i & 1], cnt);
     }
-    for (auto& t : th) t.join();
+    return hipSuccess;
 }
 
 static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -956,23 +962,28 @@ static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
         }
         (void)hipGetLastError();   // fall through to the pageable copy
     }
-    FetchRing& R = g_ring[c->device & 15];
-    if (mode == 2 && bytes >= 2 * FetchRing::CHUNK && R.init()) {
-        const int nthr = [] { const char* t = getenv("OLX_FETCH_THREADS"); int n = t ? atoi(t) : 4; return n < 1 ? 1 : (n > 16 ? 16 : n); }();
-        const size_t nchunk = (bytes + FetchRing::CHUNK - 1) / FetchRing::CHUNK;
-        for (size_t i = 0; i < nchunk + FetchRing::NCH - 1; ++i) {
-            if (i < nchunk) {   // enqueue chunk i (its ring slot was drained NCH - 1 iterations ago)
-                const size_t off = i * FetchRing::CHUNK, cnt = std::min(FetchRing::CHUNK, bytes - off);
-                HIPCHK(c, hipMemcpyAsync(R.buf[i % FetchRing::NCH], (const char*)src + off, cnt, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipEventRecord(R.ev[i % FetchRing::NCH], c->stream));
+    if (mode == 2 && bytes >= 4 * FetchLane::CHUNK) {
+        int nthr = 8;
+        if (const char* t = getenv("OLX_FETCH_THREADS")) nthr = atoi(t);
+        const int hw = (int)std::thread::hardware_concurrency();
+        nthr = std::max(1, std::min({nthr, FETCH_MAX_THREADS, hw > 0 ? hw : 1, (int)(bytes / (2 * FetchLane::CHUNK))}));
+        FetchLane* lanes = g_lanes[c->device & 15];
+        bool ready = true;
+        for (int t = 0; t < nthr; ++t) ready = ready && lanes[t].init();
+        if (ready) {
+            const size_t per = ((bytes / nthr) + 4095) & ~(size_t)4095;
+            std::vector<hipError_t> rc(nthr, hipSuccess);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthr; ++t) {
+                const size_t lo = std::min(per * t, bytes), hi = t == nthr - 1 ? bytes : std::min(per * (t + 1), bytes);
+                th.emplace_back([&, t, lo, hi] { rc[t] = fetch_lane_run(c->device, lanes[t], (char*)dst, (const char*)src, lo, hi); });
             }
-            if (i >= FetchRing::NCH - 1) {   // drain chunk j while later chunks are in flight
-                const size_t j = i - (FetchRing::NCH - 1), off = j * FetchRing::CHUNK, cnt = std::min(FetchRing::CHUNK, bytes - off);
-                HIPCHK(c, hipEventSynchronize(R.ev[j % FetchRing::NCH]));
-                parallel_copy((char*)dst + off, R.buf[j % FetchRing::NCH], cnt, nthr);
-            }
+            for (auto& t : th) t.join();
+            for (int t = 0; t < nthr; ++t)
+                if (rc[t] != hipSuccess) return fail(c, OLX_EHIP, "fetch (staged, worker %d): %s", t, hipGetErrorString(rc[t]));
+            return OLX_OK;
         }
-        return OLX_OK;
+        (void)hipGetLastError();
     }
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -120,17 +120,32 @@ class Solution:
             self._resident = (eng, eng.result_token)
         return eng, origin, spacing, n
 
+    def _focus_frames(self):
+        """[F, 12]: first three rows of inv(get_focus_matrix(focus, effective origin)) per focus (row-major)."""
+        pos_m = self.transducer.get_positions(units="m")
+        A = np.zeros((self.num_foci(), 12))
+        for i, focus in enumerate(self.foci):
+            ap = np.asarray(self.apodizations[i])
+            o_m = (ap.reshape(-1, 1) * pos_m).sum(axis=0) / ap.sum()       # Transducer.get_effective_origin (transducer.py:191-201)
+            A[i] = np.linalg.inv(get_focus_matrix(focus.get_position(units="m"), origin=o_m))[:3].ravel()
+        return A
+
+    def _mainlobe_peaks(self, options: SolutionAnalysisOptions) -> SolutionAnalysis:
+        an = SolutionAnalysis()
+        eng, _, _, _ = self._bind_device()
+        to_m = getunitconversion(options.distance_units, "m")
+        peaks = eng.ctx.field_masked_peak(self._focus_frames(), options.mainlobe_aspect_ratio, options.mainlobe_radius * to_m, "<", "pmag")
+        an.mainlobe_pnp_MPa = [float(v) * 1e-6 for v in peaks]
+        return an
+
     def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None) -> SolutionAnalysis:
         """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
         options = SolutionAnalysisOptions() if options is None else options
         an = SolutionAnalysis()
         eng, _, _, _ = self._bind_device()
         to_m = getunitconversion(options.distance_units, "m")
-        A = np.zeros((self.num_foci(), 12))
+        A = self._focus_frames()
         for i, focus in enumerate(self.foci):
-            f_m = focus.get_position(units="m")
-            o_m = self.transducer.get_effective_origin(apodizations=self.apodizations[i], units="m")
-            A[i] = np.linalg.inv(get_focus_matrix(f_m, origin=o_m))[:3].ravel()
             f_mm = focus.get_position(units="mm")
             an.target_position_lat_mm.append(f_mm[0]); an.target_position_ele_mm.append(f_mm[1])
             an.target_position_ax_mm.append(f_mm[2])
@@ -213,7 +228,9 @@ class Solution:
     def scale(self, focal_pattern: FocalPattern, analysis_options: SolutionAnalysisOptions | None = None) -> None:
         """Scale in place to the target pressure (plan/solution.py:313-338): host arrays are mutated
         (the API contract) and the resident device copy is scaled by ``field_scale_k``."""
-        analysis = self.analyze(options=analysis_options)
+        # only the per-focus mainlobe peak of |p| enters the factors (compute_scaling_factors reads nothing else of the
+        # analysis the reference runs here, plan/solution.py:313-317): one masked scan instead of the whole report
+        analysis = self._mainlobe_peaks(SolutionAnalysisOptions() if analysis_options is None else analysis_options)
         apod_factors, v0, v1 = self.compute_scaling_factors(focal_pattern, analysis)
         factors = v1 / v0 * apod_factors
         res = self.simulation_result

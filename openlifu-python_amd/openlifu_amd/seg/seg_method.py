@@ -86,7 +86,22 @@ class SegmentationMethod(ABC):
         return self._map_params(self._segment(volume), materials=self.materials if materials is None else materials)
 
     def ref_params(self, coords):
-        return self._map_params(self._ref_segment(coords))
+        """Uniform reference medium on ``coords`` (seg_method.py:104-107).  Every voxel of every parameter volume holds the
+        reference material's value, so the volumes are declared constant and only allocated if somebody reads them
+        (same values, shapes, dims and attrs as ``_map_params(_ref_segment(coords))``)."""
+        if ds.HAVE_XARRAY:  # pragma: no cover - real xarray objects cannot defer
+            return self._map_params(self._ref_segment(coords))
+        dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
+        shape = [len(coords[d]) for d in dims]
+        reference = self.materials[self.ref_material]
+        cmap = {d: coords[d] for d in dims}
+        volumes = {pid: ds.LazyDataArray.uniform(shape, float(getattr(reference, pid)), coords=cmap, dims=dims, name=pid,
+                                                 attrs={"units": info["units"], "long_name": info["name"],
+                                                        "ref_value": reference.get_param(pid)})
+                   for pid, info in PARAM_INFO.items()}
+        params = ds.make_dataset(volumes)
+        params.attrs["ref_material"] = reference
+        return params
 
     def _ref_segment(self, coords):
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())

@@ -32,6 +32,14 @@ def _medium(params):
         if key not in params:
             vols[key] = None
             continue
+        declared = getattr(params[key], "uniform_value", None)
+        if declared is not None:                  # constant volume nobody has touched: no 134 MB scan
+            if declared != ref:
+                uniform = False
+                vols[key] = np.asarray(params[key].data)
+            else:
+                vols[key] = None
+            continue
         vol = np.asarray(params[key].data)
         if vol.size and (vol.min() != ref or vol.max() != ref):
             uniform = False

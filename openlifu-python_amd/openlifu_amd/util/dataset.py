@@ -150,16 +150,31 @@ class LazyDataArray(DataArray):
     run on the device, so a caller that only looks at the analysis never pays for 3 x F volumes of PCIe traffic
     (DESIGN.md section 6).  ``materialized`` tells whether the host copy exists (and may have been edited)."""
 
-    def __init__(self, shape, dtype, fetch, coords=None, dims=None, name=None, attrs=None):
+    def __init__(self, shape, dtype, fetch, coords=None, dims=None, name=None, attrs=None, uniform_value=None):
         self._shape = tuple(int(v) for v in shape)
         self._dtype = np.dtype(dtype)
         self._fetch = fetch
         self._host = None
+        self._uniform = uniform_value
         self._init_labels(len(self._shape), coords, dims, name, attrs)
 
     @property
     def materialized(self) -> bool:
         return self._host is not None
+
+    @property
+    def uniform_value(self):
+        """The single value every entry holds, for arrays declared constant (``uniform``) that nobody has read -- and
+        thereby possibly edited -- yet; None otherwise."""
+        return self._uniform if self._host is None else None
+
+    @classmethod
+    def uniform(cls, shape, value, coords=None, dims=None, name=None, attrs=None, dtype=np.float64):
+        """A constant volume that is only allocated if somebody reads it (the parameter volumes of a uniform medium:
+        5 x 134 MB of identical numbers at 256^3, seg/seg_method.py:84-115)."""
+        shape = tuple(int(v) for v in shape)
+        return cls(shape, dtype, lambda: np.full(shape, value, dtype=dtype), coords=coords, dims=dims, name=name,
+                   attrs=attrs, uniform_value=value)
 
     @property
     def data(self):

@@ -130,8 +130,17 @@ class Transducer:
         return [el.get_corners(units=units, matrix=transform) for el in self.elements]
 
     def get_positions(self, transform: np.ndarray | None = None, units: str | None = None):
+        """[N, 3] element positions (xdc/transducer.py:203-207): (M . [p * scl, 1])[:3] per element, evaluated for all
+        elements at once when they share one length unit (the normal state: __post_init__ rescales them)."""
         units = self.units if units is None else units
-        return np.array([el.get_position(units=units, matrix=transform) for el in self.elements])
+        el_units = {el.units for el in self.elements}
+        if len(el_units) != 1:
+            return np.array([el.get_position(units=units, matrix=transform) for el in self.elements])
+        pos = np.array([el.position for el in self.elements], dtype=np.float64).reshape(-1, 3) * getunitconversion(el_units.pop(), units)
+        if transform is None:
+            return pos
+        M = np.asarray(transform, dtype=np.float64)
+        return pos @ M[:3, :3].T + M[:3, 3]
 
     def get_effective_origin(self, apodizations: np.ndarray, units: str | None = None):
         """Apodization-weighted centroid of the active aperture (xdc/transducer.py:191-201)."""

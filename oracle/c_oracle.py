@@ -33,6 +33,11 @@ def lib():
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_grid_hetero.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp,
                                                ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_grid_hetero_layers.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ctypes.c_int, dp, dp, dp,
+                                                      ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        ip = ctypes.POINTER(ctypes.c_int)
+        _lib.olo_hetero_layers.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip]
+        _lib.olo_hetero_layers.restype = ctypes.c_int
         _lib.olo_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -81,9 +86,33 @@ def medium_terms(c_vol, alpha_db_cm_mhz, c0, freq, alpha_power=0.9):
     return np.ascontiguousarray(sig), np.ascontiguousarray(a)
 
 
+def hetero_layers(sig, ab, planes_per_layer):
+    """[(lo, hi)] plane ranges of the layers of the two-level quadrature (definition: oracle/field_oracle.c)."""
+    sig = np.ascontiguousarray(sig, dtype=np.float64); ab = np.ascontiguousarray(ab, dtype=np.float64)
+    nx, ny, nz = sig.shape
+    lo = np.zeros(nz, dtype=np.int32); hi = np.zeros(nz, dtype=np.int32)
+    ip = ctypes.POINTER(ctypes.c_int)
+    nl = lib().olo_hetero_layers(_p(sig), _p(ab), nx, ny, nz, int(planes_per_layer), lo.ctypes.data_as(ip), hi.ctypes.data_as(ip))
+    return [(int(lo[g]), int(hi[g])) for g in range(nl)]
+
+
 def field_on_grid_hetero(xs_m, ys_m, zs_m, sig, ab, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0, dmin=None,
-                         nthreads=0):
-    """Heterogeneous straight-ray layered model (definition: oracle/field_oracle.c)."""
+                         nthreads=0, planes_per_layer=1, two_level=None):
+    """Heterogeneous straight-ray layered model (definition: oracle/field_oracle.c).  planes_per_layer = 1: one sample per
+    grid plane (olo_field_grid_hetero); G > 1: the two-level quadrature with layers of <= G planes
+    (olo_field_grid_hetero_layers), which kernel 2h evaluates."""
+    if (planes_per_layer != 1) if two_level is None else two_level:
+        xs = np.ascontiguousarray(xs_m, dtype=np.float64); ys = np.ascontiguousarray(ys_m, dtype=np.float64)
+        zs = np.ascontiguousarray(zs_m, dtype=np.float64)
+        if dmin is None:
+            dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
+        pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+        sig = np.ascontiguousarray(sig, dtype=np.float64); ab = np.ascontiguousarray(ab, dtype=np.float64)
+        assert sig.shape == (len(xs), len(ys), len(zs)) == ab.shape
+        re = np.empty(sig.shape); im = np.empty_like(re)
+        lib().olo_field_grid_hetero_layers(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), int(planes_per_layer),
+                                           _p(pos), _p(w), _p(phi), len(w), k, dmin, nthreads, _p(re), _p(im))
+        return re + 1j * im
     xs = np.ascontiguousarray(xs_m, dtype=np.float64); ys = np.ascontiguousarray(ys_m, dtype=np.float64)
     zs = np.ascontiguousarray(zs_m, dtype=np.float64)
     if dmin is None:

@@ -153,3 +153,115 @@ int olo_field_grid_hetero(const double *xs, int nx, const double *ys, int ny, co
     }
     return 0;
 }
+
+/* ---- heterogeneous medium, two-level (layered) quadrature: the definition kernel 2h evaluates --------
+ * PARITY UNPINNED, like the model above, of which this is the G-plane generalisation (planes_per_layer = 1 reproduces it).
+ *
+ * The non-trivial grid planes (sig or a non-zero somewhere) are grouped into LAYERS: every maximal run of consecutive
+ * non-trivial planes is cut into chunks of at most G planes.  Layer g = planes [lo_g, hi_g] carries the column sums
+ *     Ssig_g(i,j) = sum_{k in g} sig(i,j,k),   Sa_g(i,j) = sum_{k in g} a(i,j,k)
+ * and the mid height z_g = (z_lo + z_hi) / 2.  For the ray element e -> voxel v, with B = the planes strictly between them:
+ *   - a layer whose planes ALL lie in B contributes its column sums, sampled (bilinear, border-extended) ONCE where the ray
+ *     crosses z_g  -- the layer is treated as a thin phase / absorption screen at its mid height;
+ *   - the planes of B in a layer that is only partly between (the layer the voxel itself sits in, or the one an element
+ *     plane cuts) contribute individually, exactly as in the one-level model;
+ *   - the voxel's own half layer is sampled at the voxel.
+ * E = l (sum of the above for sig), A = l (same for a), l = hz d / |z_v - z_e|.  Cost per ray: ~ (planes / G) + G samples
+ * instead of one per plane; the lateral walk of a ray inside a layer (slope x G hz / 2) is what the screen neglects. */
+static inline void bilinear_map(const double *ms, const double *ma, int nx, int ny, double u, double v, double *s_out, double *a_out) {
+    u = u < 0 ? 0 : (u > nx - 1 ? nx - 1 : u);
+    v = v < 0 ? 0 : (v > ny - 1 ? ny - 1 : v);
+    int i0 = (int)floor(u), j0 = (int)floor(v);
+    if (i0 > nx - 2) i0 = nx - 2 < 0 ? 0 : nx - 2;
+    if (j0 > ny - 2) j0 = ny - 2 < 0 ? 0 : ny - 2;
+    const int i1 = i0 + 1 < nx ? i0 + 1 : i0, j1 = j0 + 1 < ny ? j0 + 1 : j0;
+    const double fu = u - i0, fv = v - j0;
+#define AT2(arr, i, j) arr[(size_t)(i) * ny + (j)]
+    *s_out = (1 - fu) * ((1 - fv) * AT2(ms, i0, j0) + fv * AT2(ms, i0, j1)) + fu * ((1 - fv) * AT2(ms, i1, j0) + fv * AT2(ms, i1, j1));
+    *a_out = (1 - fu) * ((1 - fv) * AT2(ma, i0, j0) + fv * AT2(ma, i0, j1)) + fu * ((1 - fv) * AT2(ma, i1, j0) + fv * AT2(ma, i1, j1));
+#undef AT2
+}
+
+#include <stdlib.h>
+
+/* Layer plan shared with the tests: layer_lo / layer_hi [<= nz] receive the plane ranges, returns the number of layers. */
+int olo_hetero_layers(const double *sig, const double *ab, int nx, int ny, int nz, int planes_per_layer, int *layer_lo, int *layer_hi) {
+    const int G = planes_per_layer < 1 ? 1 : planes_per_layer;
+    int nl = 0, run = 0;
+    for (int k = 0; k < nz; ++k) {
+        int any = 0;
+        for (size_t ij = 0; ij < (size_t)nx * ny && !any; ++ij)
+            if (sig[ij * nz + k] != 0.0 || ab[ij * nz + k] != 0.0) any = 1;
+        if (!any) { run = 0; continue; }
+        if (run == 0 || run == G) { layer_lo[nl] = k; layer_hi[nl] = k; ++nl; run = 1; }
+        else { layer_hi[nl - 1] = k; ++run; }
+    }
+    return nl;
+}
+
+int olo_field_grid_hetero_layers(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                                 const double *sig, const double *ab, int planes_per_layer, const double *pos, const double *w,
+                                 const double *phi, int n, double k, double dmin, int nthreads, double *re_out, double *im_out) {
+    const double hx = nx > 1 ? xs[1] - xs[0] : 1.0, hy = ny > 1 ? ys[1] - ys[0] : 1.0, hz = nz > 1 ? zs[1] - zs[0] : 1.0;
+    int *lo = (int *)malloc(sizeof(int) * (size_t)nz), *hi = (int *)malloc(sizeof(int) * (size_t)nz);
+    const int nl = olo_hetero_layers(sig, ab, nx, ny, nz, planes_per_layer, lo, hi);
+    const size_t nxy = (size_t)nx * ny;
+    double *ms = (double *)calloc((size_t)(nl > 0 ? nl : 1) * nxy, sizeof(double)), *ma = (double *)calloc((size_t)(nl > 0 ? nl : 1) * nxy, sizeof(double));
+    for (int g = 0; g < nl; ++g)
+        for (size_t ij = 0; ij < nxy; ++ij) {
+            double s = 0, a = 0;
+            for (int kk = lo[g]; kk <= hi[g]; ++kk) { s += sig[ij * nz + kk]; a += ab[ij * nz + kk]; }
+            ms[(size_t)g * nxy + ij] = s; ma[(size_t)g * nxy + ij] = a;
+        }
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long ij = 0; ij < (long)nxy; ++ij) {
+        const int i = (int)(ij / ny), j = (int)(ij % ny);
+        for (int kv = 0; kv < nz; ++kv) {
+            const double x = xs[i], y = ys[j], z = zs[kv];
+            double sr = 0, si = 0;
+            for (int e = 0; e < n; ++e) {
+                const double ex = pos[3 * e], ey = pos[3 * e + 1], ez = pos[3 * e + 2];
+                const double dx = x - ex, dy = y - ey, dz = z - ez;
+                double d = sqrt(dx * dx + dy * dy + dz * dz);
+                if (d < dmin) d = dmin;
+                double E = 0, A = 0;
+                if (dz != 0) {
+                    const double l = hz * d / fabs(dz);
+                    double ssum = 0.5 * sig[(size_t)ij * nz + kv], asum = 0.5 * ab[(size_t)ij * nz + kv];
+                    for (int g = 0; g < nl; ++g) {
+                        int full = 1;
+                        for (int kk = lo[g]; kk <= hi[g] && full; ++kk) {
+                            const double t = (zs[kk] - ez) / dz;
+                            if (!(t > 0 && t < 1) || kk == kv) full = 0;
+                        }
+                        double s1, a1;
+                        if (full) {
+                            const double t = (0.5 * (zs[lo[g]] + zs[hi[g]]) - ez) / dz;
+                            bilinear_map(ms + (size_t)g * nxy, ma + (size_t)g * nxy, nx, ny, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                            ssum += s1; asum += a1;
+                            continue;
+                        }
+                        for (int kk = lo[g]; kk <= hi[g]; ++kk) {
+                            const double t = (zs[kk] - ez) / dz;
+                            if (!(t > 0 && t < 1) || kk == kv) continue;
+                            bilinear2(sig, ab, nx, ny, nz, kk, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                            ssum += s1; asum += a1;
+                        }
+                    }
+                    E = l * ssum; A = l * asum;
+                }
+                double s, c;
+                sincos(k * (d + E) + phi[e], &s, &c);
+                const double amp = w[e] / d * exp(-A);
+                sr += amp * c; si += amp * s;
+            }
+            re_out[(size_t)ij * nz + kv] = sr;
+            im_out[(size_t)ij * nz + kv] = si;
+        }
+    }
+    free(lo); free(hi); free(ms); free(ma);
+    return 0;
+}

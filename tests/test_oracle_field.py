@@ -90,3 +90,36 @@ def test_plausible_beamwidth_vs_reference_fixture():
     for db, ref in ((3, 4.57e-3), (6, 6.65e-3)):
         above = x[p >= p.max() * 10 ** (-db / 20)]
         assert abs((above.max() - above.min()) - ref) < 0.12 * ref
+
+
+def test_hetero_two_level_quadrature_definition():
+    """The layered (two-level) heterogeneous definition kernel 2h evaluates: with one plane per layer it IS the one-level
+    model; the slab known-answer holds for every layer thickness (a laterally uniform slab has no lateral walk to neglect);
+    on a wavy phantom the screens differ from the one-level result by per-cent-level amounts (steep rays walk laterally
+    inside a layer -- which is why one plane per layer stays the default and thicker layers are an opt-in speed option)."""
+    from oracle import c_oracle as co
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    rng = np.random.default_rng(147)
+    pos = np.column_stack([rng.uniform(-6e-3, 6e-3, 12), rng.uniform(-6e-3, 6e-3, 12), np.zeros(12)])
+    area = np.full(12, 4e-6); d = rng.uniform(0, 2e-6, 12); a = rng.uniform(0.3, 1.0, 12)
+    xs = np.linspace(-8e-3, 8e-3, 17); ys = np.linspace(-6e-3, 6e-3, 13); zs = 2e-3 + np.arange(30) * 0.5e-3
+    vol = skull_slab_volumes(xs * 2.5, ys * 2.5, 6e-3 + (zs - 2e-3) * 1.2)     # phantom squeezed onto this small grid: planes 4..15 or so
+    sig, ab = co.medium_terms(vol["sound_speed"], vol["attenuation"], 1500.0, 400e3)
+    layers = co.hetero_layers(sig, ab, 4)
+    nontriv = [k for k in range(30) if sig[:, :, k].any() or ab[:, :, k].any()]
+    assert [k for lo, hi in layers for k in range(lo, hi + 1)] == nontriv and all(hi - lo + 1 <= 4 for lo, hi in layers)
+    assert co.hetero_layers(sig, ab, 1) == [(k, k) for k in nontriv]
+    one = co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos, area, d, a, 400e3, 1500.0, 1e5)
+    same = co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos, area, d, a, 400e3, 1500.0, 1e5, planes_per_layer=1, two_level=True)
+    assert np.abs(same - one).max() <= 1e-12 * np.abs(one).max()
+    for G in (3, 8):
+        lay = co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos, area, d, a, 400e3, 1500.0, 1e5, planes_per_layer=G)
+        assert 0 < np.abs(lay - one).max() <= 0.12 * np.abs(one).max()
+    # laterally uniform slab: exact for any G (amplitude x exp(-alpha L), phase + k L (c0/c - 1); single on-axis element)
+    sig_u = np.zeros((17, 13, 30)); ab_u = np.zeros_like(sig_u)
+    sig_u[:, :, 6:17] = 1500.0 / 2800.0 - 1.0; ab_u[:, :, 6:17] = 30.0
+    e0 = np.array([[0.0, 0.0, 0.0]])
+    ref = co.field_on_grid_hetero(xs, ys, zs, sig_u, ab_u, e0, [4e-6], [0.0], [1.0], 400e3, 1500.0, 1e5)
+    for G in (2, 5, 11, 64):
+        lay = co.field_on_grid_hetero(xs, ys, zs, sig_u, ab_u, e0, [4e-6], [0.0], [1.0], 400e3, 1500.0, 1e5, planes_per_layer=G)
+        assert np.abs(lay - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -21,7 +21,7 @@ with nat.Context(0) as ctx:
     ctx.field_plan((-(a.grid - 1) / 2 * h, -(a.grid - 1) / 2 * h, 5e-3), (h,) * 3, (a.grid,) * 3, 400e3, 1500.0, 1000.0, 1e5)
     ctx.field_launch(); ctx.sync()
     nbytes = 2 * 4 * a.foci * a.grid ** 3
-    for mode, thr in (("pageable", 1), ("register", 1), ("staged", 1), ("staged", 2), ("staged", 4), ("staged", 8)):
+    for mode, thr in (("pageable", 1), ("staged", 2), ("staged", 4), ("staged", 8), ("staged", 12), ("staged", 16), ("staged", 24)):
         os.environ["OLX_FETCH_MODE"] = mode; os.environ["OLX_FETCH_THREADS"] = str(thr)
         ts = []
         for _ in range(3):
