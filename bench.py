@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="exercise the RCCL path even with 1 rank")
     ap.add_argument("--medium", choices=["water", "skull"], default="water",
                     help="skull: BASELINE configs[4] synthetic skull-slab mask, heterogeneous layered-ray kernel, x-slabs per GPU")
+    ap.add_argument("--hetero-planes-per-layer", type=int, default=1,
+                    help="--medium skull: quadrature of the ray integrals (1 = one sample per grid plane, the default model; G > 1 = "
+                         "opt-in layered screens, olx_field_medium_layering)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (debug: oversubscribe one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the post-timing legs (other correction mode, parity, calc_solution)")
@@ -276,6 +279,7 @@ def main():
     if args.medium == "skull":  # 8 mm <= z < 14 mm + 2 mm sin(2 pi x / 40 mm) cos(2 pi y / 40 mm)
         from openlifu_amd.seg.seg_methods import skull_slab_volumes
         skull = skull_slab_volumes(*coords_m)
+        skull["planes_per_layer"] = args.hetero_planes_per_layer
 
     def plan(fp8: bool):
         if skull is not None:   # configs[4]: all foci of the run on every rank's x-slab, label volume replicated

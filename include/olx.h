@@ -156,6 +156,13 @@ int olx_field(olx_ctx *ctx, const olx_grid *grid, int n_foci, double freq, doubl
  * the voxel's own rho c.  Valid until the next olx_field_plan. */
 int olx_field_set_medium(olx_ctx *ctx, const float *sound_speed, const float *attenuation,
                          const float *density, double alpha_power);
+/* Quadrature of the ray integrals for the NEXT olx_field_set_medium calls of this context (default 1): with
+ * planes_per_layer = G > 1 every run of consecutive non-trivial grid planes is cut into layers of <= G planes and a layer
+ * lying wholly between element and voxel is sampled ONCE at its mid height with the column sums of its planes (a thin
+ * phase / absorption screen; the planes of the layer a voxel sits in are still sampled one by one).  ~G x fewer gathers
+ * per ray; the lateral walk of a ray inside a layer is neglected (per-cent-level change of the field on the skull-slab
+ * phantom at G = 8).  Definition: oracle/field_oracle.c olo_field_grid_hetero_layers. */
+int olx_field_medium_layering(olx_ctx *ctx, int planes_per_layer);
 
 /* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
  * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]

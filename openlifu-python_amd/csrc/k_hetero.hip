@@ -7,28 +7,51 @@
 namespace olx {
 
 // ------------------------------------------------------------------------------------
-// kernel 2h: heterogeneous medium, straight-ray layered model (definition: oracle/field_oracle.c,
-// DESIGN.md section 7).  Per (voxel, element) the ray is sampled where it crosses each NON-TRIVIAL grid plane
-// (planes whose excess slowness and absorption are identically zero are skipped; the host lists the others)
-// lying between the element and the voxel: bilinear gather (clamped to the border) of {sig, a'} (float2, plane-major [np][nx][ny],
-// L2 / Infinity-Cache resident) -> E' = l' sum sig (extra path, wavelengths), A = l' sum a' (nepers),
-// l' = hz d / |dz|.  Then the usual term with phase d + E' + phi and amplitude w exp(-A) / d.
-// Table entry: kernel-2a layout with slots 5 / 6 = first / last plane index strictly above / below the
-// element (bit-cast ints, decided on the host in fp64).  Work map as kernel 2a (ZPL z voxels per lane).
+// kernel 2h: heterogeneous medium, straight-ray layered model (definition: oracle/field_oracle.c
+// olo_field_grid_hetero / olo_field_grid_hetero_layers).  Per (voxel, element) the ray is sampled
+// where it crosses each NON-TRIVIAL grid plane (planes whose excess slowness and absorption are identically zero are
+// skipped; the host lists the others) lying between the element and the voxel: bilinear sample (clamped to the border)
+// of {sig, a'} -> E' = l' sum sig (extra path, wavelengths), A = l' sum a' (nepers), l' = hz d / |dz|.  Then the usual
+// term with phase d + E' + phi and amplitude w exp(-A) / d.
+//
+//  * The ray integrals E', A depend on (voxel, element) only -- not on the focus.  One lane therefore evaluates them
+//    ONCE and feeds NF foci (template; the steering table of a launch tile carries NF (w, phi) pairs per element):
+//    per extra focus only the phase add, sin, cos and two fma are repeated, not the ~33 gathers of a skull layer.
+//  * LAYERS (opt-in, olx_field_medium_layering G > 1): two-level quadrature.  Runs of non-trivial planes are cut into
+//    layers of <= G planes carrying the column sums of their planes; a layer that lies wholly between element and voxel
+//    is sampled once at its mid height (a thin phase / absorption screen), the planes of a layer that is only partly
+//    between (the one the voxel sits in) individually.  G = 1 (default) is the one-sample-per-plane model.
+//
+// The medium is stored as a PRE-GATHERED bilinear stencil: texel (p, i, j) = 8 floats { sig, a' } x {(i,j), (i,j+1),
+// (i+1,j), (i+1,j+1)} (edge-clamped), 32 B aligned, so one sample = two 16-B loads from one cache line instead of four
+// 8-B gathers from two rows.  Work map: a wave = an 8 x 8 (x, y) tile of voxels x ZPL consecutive z per lane, the four
+// waves of a block = four consecutive z chunks of the same tile; for a fixed plane and element the crossing points of
+// the wave's 64 rays form a compact (shrunken) image of the tile, so the gathers of one wave-instruction fall into a
+// few cache lines.  Table entry (tile, e) = { x, y, z, kfirst, klast, 0, 0, 0, (w_f, phi_f) f < NF } with kfirst /
+// klast = first / last plane index strictly above / below the element (bit-cast ints, decided on the host in fp64).
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ void hetero_sample(const float4* __restrict__ plane, float tt, float dxu, float dyv, float eu, float ev,
+                                              float umax, float vmax, int nyg, float& ss, float& as) {
+    const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), umax);   // border values extend outwards
+    const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), vmax);
+    const int i0 = (int)u, j0 = (int)v;
+    const float fu = u - (float)i0, fv = v - (float)j0;
+    const float4* tx = plane + ((size_t)i0 * nyg + j0) * 2;
+    const float4 lo = tx[0], hi = tx[1];     // {s00,a00,s01,a01}, {s10,a10,s11,a11}
+    const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
+    const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
+    ss += fmaf(fu, s1 - s0, s0);
+    as += fmaf(fu, a1 - a0, a0);
+}
 
-// Work map of kernel 2h: a wave = an 8 x 8 (x, y) tile of voxels x ZPL consecutive z per lane, the four
-// waves of a block = four consecutive z chunks of the same tile.  For a fixed plane and element the
-// crossing points of the wave's 64 rays then form a compact (shrunken) image of the tile, so the gathers
-// of one wave-instruction fall into a few cache lines.  The medium is stored as a PRE-GATHERED bilinear
-// stencil: texel (p, i, j) = 8 floats { sig, a' } x {(i,j), (i,j+1), (i+1,j), (i+1,j+1)} (edge-clamped),
-// 32 B aligned, so one sample = two 16-B loads from one cache line instead of four 8-B gathers from two rows.
-template <int ZPL, bool CLAMP>
+template <int ZPL, int NF, bool CLAMP, bool LAYERS>
 __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
-    const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_k,
-    const int* __restrict__ plane_of_k, const float* __restrict__ inv2z, float* __restrict__ pmag,
+    const float* __restrict__ tab, const float4* __restrict__ med, const float4* __restrict__ med_layer,
+    const int* __restrict__ plane_k, const int* __restrict__ plane_of_k, const int* __restrict__ layer_lo,
+    const int* __restrict__ layer_hi, const float* __restrict__ inv2z, float* __restrict__ pmag,
     float* __restrict__ inten, float* __restrict__ cplx, const FieldParams P, const HeteroParams H) {
-    const int f = blockIdx.y;
+    constexpr int STRIDE = HET_TAB_HEAD + 2 * NF;
+    const int ftile = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_y = (P.ny + 7) >> 3, zblocks = (P.nz + 4 * ZPL - 1) / (4 * ZPL);
     const int zb = blockIdx.x % zblocks;
@@ -39,27 +62,29 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
     const bool live = i < P.nx && j < P.ny && k0 < P.nz;
     const int ic = min(i, P.nx - 1), jc = min(j, P.ny - 1);
     const float x = (float)(ic + P.x_begin) * P.hx, y = (float)jc * P.hy;
-    float z[ZPL], re[ZPL], im[ZPL], sv[ZPL], av[ZPL];
+    float z[ZPL], re[ZPL][NF], im[ZPL][NF], sv[ZPL], av[ZPL];
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
         const int kq = min(k0 + q, P.nz - 1);
         z[q] = (float)kq * P.hz;
-        re[q] = 0.f; im[q] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { re[q][f] = 0.f; im[q][f] = 0.f; }
         const int pq = plane_of_k[kq];                   // the voxel's own half layer
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pq >= 0) m = med[(((size_t)pq * H.nxg + (ic + H.xg_begin)) * H.nyg + jc) * 2];
         sv[q] = 0.5f * m.x; av[q] = 0.5f * m.y;
     }
-    const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
+    const size_t plane_sz = (size_t)H.nxg * H.nyg * 2;
+    const float umax = (float)(H.nxg - 1), vmax = (float)(H.nyg - 1);
+    const float* t = tab + (size_t)ftile * P.n_el * STRIDE;
     for (int e = 0; e < P.n_el; ++e) {
-        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1], ez = t[e * TAB_STRIDE + 2];
-        const float w = t[e * TAB_STRIDE + 3], phi = t[e * TAB_STRIDE + 4];
-        const int kfirst = __float_as_int(t[e * TAB_STRIDE + 5]), klast = __float_as_int(t[e * TAB_STRIDE + 6]);
+        const float* te = t + (size_t)e * STRIDE;
+        const float ex = te[0], ey = te[1], ez = te[2];
+        const int kfirst = __float_as_int(te[3]), klast = __float_as_int(te[4]);
         const float dx = x - ex, dy = y - ey;
         const float r2 = fmaf(dy, dy, dx * dx);
         const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
         const float dxu = dx * H.inv_hx, dyv = dy * H.inv_hy;
-        const float umax = (float)(H.nxg - 1), vmax = (float)(H.nyg - 1);
         float dz[ZPL], idz[ZPL], ss[ZPL], as[ZPL];
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
@@ -68,29 +93,48 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
             ss[q] = sv[q]; as[q] = av[q];
         }
         // planes between element and voxel: k in [kfirst, kv) (voxel above) or (kv, klast] (voxel below).
-        // k0..k0+ZPL-1 are wave-uniform, so the trip bounds are too.
-        for (int p = 0; p < H.n_planes; ++p) {
-            const int k = plane_k[p];                    // wave-uniform
-            const bool any_above = k >= kfirst && k < k0 + ZPL - 1, any_below = k <= klast && k > k0;
-            if (!any_above && !any_below) continue;
-            const float zk = (float)k * P.hz - ez;
-            const float4* plane = med + (size_t)p * H.nxg * H.nyg * 2;
+        // k0..k0+ZPL-1 are wave-uniform, so every trip bound and branch below is too.
+        if constexpr (LAYERS) {
+            for (int g = 0; g < H.n_layers; ++g) {
+                const int lo = layer_lo[g], hi = layer_hi[g];
+                if ((hi < kfirst || lo >= k0 + ZPL - 1) && (lo > klast || hi <= k0)) continue;   // no plane of it is between for any q
+                const float zg = 0.5f * (float)(lo + hi) * P.hz - ez;
+                bool part = false;
 #pragma unroll
-            for (int q = 0; q < ZPL; ++q) {
-                const int kv = k0 + q;
-                const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);   // wave-uniform
-                if (!between) continue;
-                const float tt = zk * idz[q];
-                const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), umax);   // border values extend outwards
-                const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), vmax);
-                const int i0 = (int)u, j0 = (int)v;
-                const float fu = u - (float)i0, fv = v - (float)j0;
-                const float4* tx = plane + ((size_t)i0 * H.nyg + j0) * 2;
-                const float4 lo = tx[0], hi = tx[1];     // {s00,a00,s01,a01}, {s10,a10,s11,a11}
-                const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
-                const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
-                ss[q] += fmaf(fu, s1 - s0, s0);
-                as[q] += fmaf(fu, a1 - a0, a0);
+                for (int q = 0; q < ZPL; ++q) {
+                    const int kv = k0 + q;
+                    const bool full = (lo >= kfirst && hi < kv) || (lo > kv && hi <= klast);
+                    if (full) hetero_sample(med_layer + (size_t)g * plane_sz, zg * idz[q], dxu, dyv, eu, ev, umax, vmax, H.nyg, ss[q], as[q]);
+                    else part = true;
+                }
+                if (!part) continue;
+                for (int k = lo; k <= hi; ++k) {          // the layer the voxels sit in (or an element plane cuts): plane by plane
+                    const float zk = (float)k * P.hz - ez;
+                    const float4* plane = med + (size_t)plane_of_k[k] * plane_sz;
+#pragma unroll
+                    for (int q = 0; q < ZPL; ++q) {
+                        const int kv = k0 + q;
+                        const bool full = (lo >= kfirst && hi < kv) || (lo > kv && hi <= klast);
+                        const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);
+                        if (full || !between) continue;
+                        hetero_sample(plane, zk * idz[q], dxu, dyv, eu, ev, umax, vmax, H.nyg, ss[q], as[q]);
+                    }
+                }
+            }
+        } else {
+            for (int p = 0; p < H.n_planes; ++p) {
+                const int k = plane_k[p];                    // wave-uniform
+                const bool any_above = k >= kfirst && k < k0 + ZPL - 1, any_below = k <= klast && k > k0;
+                if (!any_above && !any_below) continue;
+                const float zk = (float)k * P.hz - ez;
+                const float4* plane = med + (size_t)p * plane_sz;
+#pragma unroll
+                for (int q = 0; q < ZPL; ++q) {
+                    const int kv = k0 + q;
+                    const bool between = (k >= kfirst && k < kv) || (k <= klast && k > kv);   // wave-uniform
+                    if (!between) continue;
+                    hetero_sample(plane, zk * idz[q], dxu, dyv, eu, ev, umax, vmax, H.nyg, ss[q], as[q]);
+                }
             }
         }
 #pragma unroll
@@ -100,34 +144,94 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
             const float ri = __builtin_amdgcn_rsqf(d2);
             const float d = d2 * ri;
             const float l = dz[q] != 0.f ? P.hz * d * fabsf(idz[q]) : 0.f;   // path per layer [wavelengths]
-            const float ph = fmaf(l, ss[q], d) + phi;
-            const float a = w * ri * __expf(-l * as[q]);
-            re[q] = fmaf(a, __builtin_amdgcn_cosf(ph), re[q]);
-            im[q] = fmaf(a, __builtin_amdgcn_sinf(ph), im[q]);
+            const float ph0 = fmaf(l, ss[q], d);
+            const float a0 = ri * __expf(-l * as[q]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {               // the ray integrals above serve every focus of the tile
+                const float ph = ph0 + te[HET_TAB_HEAD + 2 * f + 1];
+                const float a = a0 * te[HET_TAB_HEAD + 2 * f];
+                re[q][f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[q][f]);
+                im[q][f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[q][f]);
+            }
         }
     }
     if (!live) return;
     const long long vrow = ((long long)i * P.ny + j) * P.nz + k0;
-    const long long base = (long long)f * P.vox + vrow;
 #pragma unroll
-    for (int q = 0; q < ZPL; ++q) {
-        if (k0 + q >= P.nz) continue;
-        const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
-        if (P.flags & 1u) pmag[base + q] = __builtin_sqrtf(m2);
-        if (P.flags & 2u) inten[base + q] = m2 * (inv2z ? inv2z[vrow + q] : P.inten_scale);
-        if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
+    for (int f = 0; f < NF; ++f) {
+        const int fg = ftile * NF + f;
+        if (fg >= H.n_foci) break;
+        const long long base = (long long)fg * P.vox + vrow;
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            if (k0 + q >= P.nz) continue;
+            const float m2 = fmaf(re[q][f], re[q][f], im[q][f] * im[q][f]);
+            if (P.flags & 1u) pmag[base + q] = __builtin_sqrtf(m2);
+            if (P.flags & 2u) inten[base + q] = m2 * (inv2z ? inv2z[vrow + q] : P.inten_scale);
+            if (P.flags & 4u) { cplx[2 * (base + q)] = re[q][f]; cplx[2 * (base + q) + 1] = im[q][f]; }
+        }
     }
 }
 
+// steering pack for kernel 2h: fp64 (pos, area, delays, apod) -> [tiles][n][HET_TAB_HEAD + 2 NF] floats (see above);
+// lengths in wavelengths, w = a P0 S / lambda^2, phi = frac(f0 tau) [revolutions]; foci past the last one get w = 0.
+__global__ void steer_pack_hetero_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
+                                    const double* __restrict__ delays, const double* __restrict__ apod, double ox, double oy,
+                                    double oz, double freq, double p0_over_lambda, double rev, const int* __restrict__ kfirst,
+                                    const int* __restrict__ klast, int n_foci, int nf, float* __restrict__ tab) {
+    const int tile = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float* t = tab + ((size_t)tile * n + e) * (HET_TAB_HEAD + 2 * nf);
+    t[0] = (float)((pos[e] - ox) * rev);
+    t[1] = (float)((pos[n + e] - oy) * rev);
+    t[2] = (float)((pos[2 * n + e] - oz) * rev);
+    t[3] = __int_as_float(kfirst[e]);
+    t[4] = __int_as_float(klast[e]);
+    t[5] = 0.f; t[6] = 0.f; t[7] = 0.f;
+    for (int fl = 0; fl < nf; ++fl) {
+        const int f = tile * nf + fl;
+        float w = 0.f, ph = 0.f;
+        if (f < n_foci) {
+            const size_t o = (size_t)f * n + e;
+            const double cyc = freq * delays[o];
+            w = (float)(apod[o] * area[e] * p0_over_lambda * rev);
+            ph = (float)(cyc - floor(cyc));
+        }
+        t[HET_TAB_HEAD + 2 * fl] = w;
+        t[HET_TAB_HEAD + 2 * fl + 1] = ph;
+    }
+}
 
 }  // namespace olx
 
 using namespace olx;
 
-void olx_launch_hetero(olx_ctx* c, float* pm) {
+void olx_pack_hetero(olx_ctx* c) {
+    const double lambda = c->c / c->freq;
+    const int tiles = (c->plan_foci + c->nf - 1) / c->nf;
+    dim3 g((c->n_el + 127) / 128, tiles);
+    hipLaunchKernelGGL(steer_pack_hetero_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays, c->d_apod,
+                       c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq, c->p0_pa / lambda, c->freq / c->c,
+                       c->d_kfirst, c->d_klast, c->plan_foci, c->nf, c->d_tab);
+}
+
+template <int NF>
+static void launch_hetero_nf(olx_ctx* c, float* pm) {
     const FieldParams& P = c->fp;
     const long long nblk = (long long)((P.nx + 7) / 8) * ((P.ny + 7) / 8) * ((P.nz + 15) / 16);  // 8x8 tile x 16 z
-    dim3 grid((unsigned)nblk, c->plan_foci), blk(FIELD_THREADS);
-    if (c->clamp) hipLaunchKernelGGL((field_hetero_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
-    else          hipLaunchKernelGGL((field_hetero_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_plane_k, c->d_plane_of_k, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp);
+    dim3 grid((unsigned)nblk, (c->plan_foci + NF - 1) / NF), blk(FIELD_THREADS);
+    const bool layers = c->hp.n_layers > 0;
+#define OLX_HET(CL, LY) hipLaunchKernelGGL((field_hetero_k<4, NF, CL, LY>), grid, blk, 0, c->stream, c->d_tab, c->d_med, c->d_med_layer, \
+                                           c->d_plane_k, c->d_plane_of_k, c->d_layer_lo, c->d_layer_hi, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp)
+    if (layers) { if (c->clamp) OLX_HET(true, true); else OLX_HET(false, true); }
+    else        { if (c->clamp) OLX_HET(true, false); else OLX_HET(false, false); }
+#undef OLX_HET
+}
+
+void olx_launch_hetero(olx_ctx* c, float* pm) {
+    if (c->nf >= 8) launch_hetero_nf<8>(c, pm);
+    else if (c->nf >= 4) launch_hetero_nf<4>(c, pm);
+    else if (c->nf >= 2) launch_hetero_nf<2>(c, pm);
+    else launch_hetero_nf<1>(c, pm);
 }

@@ -54,7 +54,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -388,10 +388,24 @@ static int configure_variant(olx_ctx* c) {
             }
         return true;
     };
-    if (c->hetero) {  // kernel 2h: no folds, no shared geometry
-        c->mx = c->my = c->dx = c->dy = c->nf = c->nt = 1; c->use_mfma = false; c->use_lattice = false;
-        char hb[96];
-        snprintf(hb, sizeof hb, "field_hetero_k<4,%s> (%d non-trivial planes)", c->clamp ? "clamp" : "noclamp", c->hp.n_planes);
+    if (c->hetero) {  // kernel 2h: no folds; the ray integrals of a (voxel, element) pair are shared by up to 8 foci per launch tile
+        c->mx = c->my = c->dx = c->dy = c->nt = 1; c->use_mfma = false; c->use_lattice = false;
+        c->nf = 1;
+        while (c->nf * 2 <= F && c->nf < 8) c->nf *= 2;
+        const size_t need = (size_t)((F + c->nf - 1) / c->nf) * n * (HET_TAB_HEAD + 2 * c->nf);
+        if (c->tab_cap < need) {
+            if (c->d_tab) hipFree(c->d_tab);
+            c->d_tab = nullptr; c->tab_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_tab, sizeof(float) * need));
+            c->tab_cap = need;
+        }
+        c->hp.n_foci = F;
+        char hb[160];
+        if (c->hp.n_layers > 0)
+            snprintf(hb, sizeof hb, "field_hetero_k<4,nf%d,%s,layers> (%d non-trivial planes in %d layers of <= %d)", c->nf,
+                     c->clamp ? "clamp" : "noclamp", c->hp.n_planes, c->hp.n_layers, c->planes_per_layer);
+        else
+            snprintf(hb, sizeof hb, "field_hetero_k<4,nf%d,%s> (%d non-trivial planes)", c->nf, c->clamp ? "clamp" : "noclamp", c->hp.n_planes);
         c->variant = hb;
         return OLX_OK;
     }
@@ -677,7 +691,9 @@ static int pack_if_needed(olx_ctx* c) {
     if (c->packed_version == c->steer_version) return OLX_OK;
     { int rc = configure_variant(c); if (rc) return rc; }
     const double lambda = c->c / c->freq;
-    if (c->use_mfma) {
+    if (c->hetero) {
+        olx_pack_hetero(c);
+    } else if (c->use_mfma) {
         const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
         const double oy = c->my == 2 ? c->grid.origin[1] + 0.5 * (c->grid.n[1] - 1) * c->grid.spacing[1] : c->grid.origin[1];
         dim3 g(c->mp.n_el_pad / 16, c->mp.n_tiles, c->nt);
@@ -689,8 +705,7 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
-                           c->p0_pa / lambda, c->freq / c->c, c->hetero ? c->d_kfirst : nullptr,
-                           c->hetero ? c->d_klast : nullptr, c->d_tab);
+                           c->p0_pa / lambda, c->freq / c->c, nullptr, nullptr, c->d_tab);
     } else {
         // mirrored axes: table coordinates relative to the grid centre plane
         const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
@@ -1089,8 +1104,51 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         while (kl >= 0 && !(g.origin[2] + kl * g.spacing[2] < ez)) --kl;
         kfirst[e] = kf; klast[e] = kl;
     }
-    for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast})
+    for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,
+                     (void**)&c->d_med_layer, (void**)&c->d_layer_lo, (void**)&c->d_layer_hi})
         if (*q) { hipFree(*q); *q = nullptr; }
+    // two-level quadrature (opt-in, olx_field_medium_layering): every maximal run of consecutive non-trivial planes is cut
+    // into layers of <= G planes; a layer's stencil holds the column sums of its planes (fp64 sums, rounded once)
+    std::vector<int> layer_lo, layer_hi;
+    if (c->planes_per_layer > 1) {
+        int run = 0;
+        for (int q = 0; q < np; ++q) {
+            const bool contiguous = q > 0 && plane_k[q] == plane_k[q - 1] + 1;
+            if (!contiguous || run == c->planes_per_layer) { layer_lo.push_back(plane_k[q]); layer_hi.push_back(plane_k[q]); run = 1; }
+            else { layer_hi.back() = plane_k[q]; ++run; }
+        }
+        const int nl = (int)layer_lo.size();
+        std::vector<float> lay((size_t)std::max(nl, 1) * nx * ny * 8, 0.f);
+        std::vector<double> acc((size_t)nx * ny * 2);
+        for (int g = 0; g < nl; ++g) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int k = layer_lo[g]; k <= layer_hi[g]; ++k)
+                for (int i = 0; i < nx; ++i)
+                    for (int j = 0; j < ny; ++j) {
+                        const size_t o = ((size_t)i * ny + j) * nz + k;
+                        if (sound_speed) acc[((size_t)i * ny + j) * 2] += c0 / (double)sound_speed[o] - 1.0;
+                        if (attenuation) acc[((size_t)i * ny + j) * 2 + 1] += (double)attenuation[o] * afac;
+                    }
+            for (int i = 0; i < nx; ++i)
+                for (int j = 0; j < ny; ++j) {
+                    float* tx = &lay[(((size_t)g * nx + i) * ny + j) * 8];
+                    const int i1 = std::min(i + 1, nx - 1), j1 = std::min(j + 1, ny - 1);
+                    const int cs[4][2] = {{i, j}, {i, j1}, {i1, j}, {i1, j1}};
+                    for (int q = 0; q < 4; ++q) {
+                        tx[2 * q] = (float)acc[((size_t)cs[q][0] * ny + cs[q][1]) * 2];
+                        tx[2 * q + 1] = (float)acc[((size_t)cs[q][0] * ny + cs[q][1]) * 2 + 1];
+                    }
+                }
+        }
+        HIPCHK(c, hipMalloc((void**)&c->d_med_layer, sizeof(float) * lay.size()));
+        HIPCHK(c, hipMalloc((void**)&c->d_layer_lo, sizeof(int) * std::max(nl, 1)));
+        HIPCHK(c, hipMalloc((void**)&c->d_layer_hi, sizeof(int) * std::max(nl, 1)));
+        HIPCHK(c, hipMemcpy(c->d_med_layer, lay.data(), sizeof(float) * lay.size(), hipMemcpyHostToDevice));
+        if (nl) {
+            HIPCHK(c, hipMemcpy(c->d_layer_lo, layer_lo.data(), sizeof(int) * nl, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->d_layer_hi, layer_hi.data(), sizeof(int) * nl, hipMemcpyHostToDevice));
+        }
+    }
     HIPCHK(c, hipMalloc((void**)&c->d_med, sizeof(float) * med.size()));
     HIPCHK(c, hipMalloc((void**)&c->d_plane_k, sizeof(int) * std::max(np, 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_plane_of_k, sizeof(int) * nz));
@@ -1112,12 +1170,19 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         HIPCHK(c, hipMemcpy(c->d_inv2z, iz.data(), sizeof(float) * sv, hipMemcpyHostToDevice));
     }
     HeteroParams& H = c->hp;
-    H.n_planes = np; H.nxg = nx; H.nyg = ny; H.xg_begin = c->slab.x_begin;
+    H.n_planes = np; H.n_layers = (int)layer_lo.size(); H.n_foci = c->plan_foci; H.nxg = nx; H.nyg = ny; H.xg_begin = c->slab.x_begin;
     H.inv_hx = (float)(1.0 / (g.spacing[0] * rev)); H.inv_hy = (float)(1.0 / (g.spacing[1] * rev));
     H.u0 = 0.f; H.v0 = 0.f;  // table origin == grid origin for kernel 2h
     c->hetero = true;
     c->packed_version = ~0ull;
     return configure_variant(c);
+}
+
+int olx_field_medium_layering(olx_ctx* c, int planes_per_layer) {
+    if (!c) return OLX_EINVAL;
+    if (planes_per_layer < 1 || planes_per_layer > 4096) return fail(c, OLX_EINVAL, "olx_field_medium_layering: planes_per_layer must be in [1, 4096]");
+    c->planes_per_layer = planes_per_layer;
+    return OLX_OK;
 }
 
 int olx_field_upload(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_foci, const float* pmag,

@@ -84,6 +84,8 @@ struct olx_ctx {
     // heterogeneous medium (kernel 2h)
     bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
     float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;
+    int planes_per_layer = 1;                  // olx_field_medium_layering: 1 = one sample per plane (default)
+    float4* d_med_layer = nullptr; int *d_layer_lo = nullptr, *d_layer_hi = nullptr;
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
     std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;

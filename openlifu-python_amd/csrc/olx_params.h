@@ -102,8 +102,12 @@ constexpr int cos_kxw(int nt) { return nt >= 4 ? 2 : (nt >= 2 ? 3 : 6); }
 constexpr bool cos_fp8(int nt) { return nt <= 2; }
 constexpr float COS_F8_LO = 32.0f, COS_F8_HI = 1.0f / 64.0f;
 
+constexpr int HET_TAB_HEAD = 8;            // floats of a kernel-2h table entry before its (w, phi) pairs
+
 struct HeteroParams {
     int n_planes;          // non-trivial planes
+    int n_layers;          // layers of the two-level quadrature (0 = one sample per plane)
+    int n_foci;            // planned foci (the last launch tile may be partly empty)
     float u0, v0;          // (table origin - grid x0) / hx, same for y: index-space offset of the table frame
     float inv_hx, inv_hy;  // 1 / spacing [1/wavelengths]
     int nxg, nyg;          // whole-grid lateral size of the medium planes

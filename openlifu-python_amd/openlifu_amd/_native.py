@@ -30,7 +30,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all",
+    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering",
 ]
 
 
@@ -100,6 +100,7 @@ def load(require_gpu: bool = True):
         lib.olx_rccl_path.argtypes = [vp]; lib.olx_rccl_path.restype = c_char_p
         lib.olx_bf_time.argtypes = [vp, c_int, fp]
         lib.olx_field_fetch_all.argtypes = [vp, fp, fp]
+        lib.olx_field_medium_layering.argtypes = [vp, c_int]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -256,8 +257,10 @@ class Context:
         self._flags = (int(flags) | OUT_PMAG) & 7
         self._plan_foci = F
 
-    def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9):
-        """Per-voxel medium volumes [nx,ny,nz] of the WHOLE planned grid (None = reference value)."""
+    def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9, planes_per_layer=1):
+        """Per-voxel medium volumes [nx,ny,nz] of the WHOLE planned grid (None = reference value).  ``planes_per_layer``
+        > 1 opts in to the two-level (layered screen) quadrature of the ray integrals (olx_field_medium_layering)."""
+        self._chk(self._lib.olx_field_medium_layering(self._h, int(planes_per_layer)))
         arrs = []
         for a in (sound_speed, attenuation, density):
             arrs.append(None if a is None else np.ascontiguousarray(a, dtype=np.float32))

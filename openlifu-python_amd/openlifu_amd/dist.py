@@ -201,7 +201,8 @@ class ShardedField:
         ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=nat.OUT_PMAG if flags is None else flags,
                        slab=self.slab)
         if medium is not None:
-            ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"))
+            ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"),
+                                 planes_per_layer=int(medium.get("planes_per_layer", 1)))
         eng.result_token += 1
         return self.slab
 

@@ -171,7 +171,8 @@ class Protocol:
             # the host on first access.  Real xarray objects cannot defer, so with xarray installed they are fetched now.
             fields = simulate_foci(transducer, params, delays, apod, self.pulse.frequency,
                                    self.pulse.amplitude * voltage, steering_resident=resident, fp8_correction=fp8,
-                                   lazy=not ds.HAVE_XARRAY)
+                                   lazy=not ds.HAVE_XARRAY,
+                                   hetero_planes_per_layer=int(getattr(sim_options, "options", {}).get("hetero_planes_per_layer", 1)))
             coords = params.coords
             if not ds.HAVE_XARRAY:
                 stacked = lazy_stack(fields, coords)

@@ -48,12 +48,14 @@ def _medium(params):
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
-                  steering_resident=False, slab=None, fp8_correction=False, lazy=False):
+                  steering_resident=False, slab=None, fp8_correction=False, lazy=False, hetero_planes_per_layer=1):
     """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz], or with ``lazy`` a
     ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""
     coords = params.coords
     origin, spacing, n = grid_from_coords(coords)
     c, rho, medium = _medium(params)
+    if medium is not None and int(hetero_planes_per_layer) > 1:   # opt-in layered-screen quadrature (DESIGN.md section 7)
+        medium["planes_per_layer"] = int(hetero_planes_per_layer)
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
                               slab=slab, steering_resident=steering_resident, medium=medium,

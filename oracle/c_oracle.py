@@ -36,6 +36,9 @@ def lib():
         _lib.olo_field_grid_hetero_layers.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ctypes.c_int, dp, dp, dp,
                                                       ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         ip = ctypes.POINTER(ctypes.c_int)
+        _lib.olo_field_columns_hetero_layers.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ctypes.c_int, ip,
+                                                         ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                         ctypes.c_int, dp, dp]
         _lib.olo_hetero_layers.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip]
         _lib.olo_hetero_layers.restype = ctypes.c_int
         _lib.olo_max_threads.restype = ctypes.c_int
@@ -123,6 +126,25 @@ def field_on_grid_hetero(xs_m, ys_m, zs_m, sig, ab, pos_m, area_m2, delays_s, ap
     re = np.empty(sig.shape); im = np.empty_like(re)
     lib().olo_field_grid_hetero(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), _p(pos), _p(w), _p(phi),
                                 len(w), k, dmin, nthreads, _p(re), _p(im))
+    return re + 1j * im
+
+
+def field_columns_hetero(xs_m, ys_m, zs_m, sig, ab, columns, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0, dmin=None,
+                         nthreads=0, planes_per_layer=1):
+    """The heterogeneous definition (two-level form; G = 1 is the one-level model) on selected grid columns only:
+    columns [ncol, 2] = (i, j) indices -> complex [ncol, nz].  For full-size grids, where the whole volume is out of reach."""
+    xs = np.ascontiguousarray(xs_m, dtype=np.float64); ys = np.ascontiguousarray(ys_m, dtype=np.float64)
+    zs = np.ascontiguousarray(zs_m, dtype=np.float64)
+    if dmin is None:
+        dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
+    pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+    sig = np.ascontiguousarray(sig, dtype=np.float64); ab = np.ascontiguousarray(ab, dtype=np.float64)
+    assert sig.shape == (len(xs), len(ys), len(zs)) == ab.shape
+    cols = np.ascontiguousarray(columns, dtype=np.int32).reshape(-1, 2)
+    re = np.empty((len(cols), len(zs))); im = np.empty_like(re)
+    lib().olo_field_columns_hetero_layers(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), int(planes_per_layer),
+                                          cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(cols), _p(pos), _p(w), _p(phi), len(w),
+                                          k, dmin, nthreads, _p(re), _p(im))
     return re + 1j * im
 
 

@@ -199,10 +199,59 @@ int olo_hetero_layers(const double *sig, const double *ab, int nx, int ny, int n
     return nl;
 }
 
-int olo_field_grid_hetero_layers(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
-                                 const double *sig, const double *ab, int planes_per_layer, const double *pos, const double *w,
-                                 const double *phi, int n, double k, double dmin, int nthreads, double *re_out, double *im_out) {
+/* One voxel of the two-level definition (maps: [nl][nx*ny] column sums; lo / hi: layer plane ranges). */
+static inline void hetero_layers_voxel(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz, const double *sig,
+                                       const double *ab, const int *lo, const int *hi, int nl, const double *ms, const double *ma,
+                                       const double *pos, const double *w, const double *phi, int n, double k, double dmin,
+                                       int i, int j, int kv, double *re, double *im) {
     const double hx = nx > 1 ? xs[1] - xs[0] : 1.0, hy = ny > 1 ? ys[1] - ys[0] : 1.0, hz = nz > 1 ? zs[1] - zs[0] : 1.0;
+    const size_t nxy = (size_t)nx * ny, ij = (size_t)i * ny + j;
+    const double x = xs[i], y = ys[j], z = zs[kv];
+    double sr = 0, si = 0;
+    for (int e = 0; e < n; ++e) {
+        const double ex = pos[3 * e], ey = pos[3 * e + 1], ez = pos[3 * e + 2];
+        const double dx = x - ex, dy = y - ey, dz = z - ez;
+        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < dmin) d = dmin;
+        double E = 0, A = 0;
+        if (dz != 0) {
+            const double l = hz * d / fabs(dz);
+            double ssum = 0.5 * sig[ij * nz + kv], asum = 0.5 * ab[ij * nz + kv];
+            for (int g = 0; g < nl; ++g) {
+                int full = 1;
+                for (int kk = lo[g]; kk <= hi[g] && full; ++kk) {
+                    const double t = (zs[kk] - ez) / dz;
+                    if (!(t > 0 && t < 1) || kk == kv) full = 0;
+                }
+                double s1, a1;
+                if (full) {
+                    const double t = (0.5 * (zs[lo[g]] + zs[hi[g]]) - ez) / dz;
+                    bilinear_map(ms + (size_t)g * nxy, ma + (size_t)g * nxy, nx, ny, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                    ssum += s1; asum += a1;
+                    continue;
+                }
+                for (int kk = lo[g]; kk <= hi[g]; ++kk) {
+                    const double t = (zs[kk] - ez) / dz;
+                    if (!(t > 0 && t < 1) || kk == kv) continue;
+                    bilinear2(sig, ab, nx, ny, nz, kk, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                    ssum += s1; asum += a1;
+                }
+            }
+            E = l * ssum; A = l * asum;
+        }
+        double s, c;
+        sincos(k * (d + E) + phi[e], &s, &c);
+        const double amp = w[e] / d * exp(-A);
+        sr += amp * c; si += amp * s;
+    }
+    *re = sr; *im = si;
+}
+
+/* columns[ncol][2] = (i, j) grid columns; NULL = every column of the grid.  Outputs [ncol (or nx*ny)][nz]. */
+int olo_field_columns_hetero_layers(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                                    const double *sig, const double *ab, int planes_per_layer, const int *columns, long ncol,
+                                    const double *pos, const double *w, const double *phi, int n, double k, double dmin,
+                                    int nthreads, double *re_out, double *im_out) {
     int *lo = (int *)malloc(sizeof(int) * (size_t)nz), *hi = (int *)malloc(sizeof(int) * (size_t)nz);
     const int nl = olo_hetero_layers(sig, ab, nx, ny, nz, planes_per_layer, lo, hi);
     const size_t nxy = (size_t)nx * ny;
@@ -213,55 +262,24 @@ int olo_field_grid_hetero_layers(const double *xs, int nx, const double *ys, int
             for (int kk = lo[g]; kk <= hi[g]; ++kk) { s += sig[ij * nz + kk]; a += ab[ij * nz + kk]; }
             ms[(size_t)g * nxy + ij] = s; ma[(size_t)g * nxy + ij] = a;
         }
+    const long total = columns ? ncol : (long)nxy;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(dynamic, 8)
-    for (long ij = 0; ij < (long)nxy; ++ij) {
-        const int i = (int)(ij / ny), j = (int)(ij % ny);
+#pragma omp parallel for schedule(dynamic, 4) collapse(2)
+    for (long q = 0; q < total; ++q)
         for (int kv = 0; kv < nz; ++kv) {
-            const double x = xs[i], y = ys[j], z = zs[kv];
-            double sr = 0, si = 0;
-            for (int e = 0; e < n; ++e) {
-                const double ex = pos[3 * e], ey = pos[3 * e + 1], ez = pos[3 * e + 2];
-                const double dx = x - ex, dy = y - ey, dz = z - ez;
-                double d = sqrt(dx * dx + dy * dy + dz * dz);
-                if (d < dmin) d = dmin;
-                double E = 0, A = 0;
-                if (dz != 0) {
-                    const double l = hz * d / fabs(dz);
-                    double ssum = 0.5 * sig[(size_t)ij * nz + kv], asum = 0.5 * ab[(size_t)ij * nz + kv];
-                    for (int g = 0; g < nl; ++g) {
-                        int full = 1;
-                        for (int kk = lo[g]; kk <= hi[g] && full; ++kk) {
-                            const double t = (zs[kk] - ez) / dz;
-                            if (!(t > 0 && t < 1) || kk == kv) full = 0;
-                        }
-                        double s1, a1;
-                        if (full) {
-                            const double t = (0.5 * (zs[lo[g]] + zs[hi[g]]) - ez) / dz;
-                            bilinear_map(ms + (size_t)g * nxy, ma + (size_t)g * nxy, nx, ny, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
-                            ssum += s1; asum += a1;
-                            continue;
-                        }
-                        for (int kk = lo[g]; kk <= hi[g]; ++kk) {
-                            const double t = (zs[kk] - ez) / dz;
-                            if (!(t > 0 && t < 1) || kk == kv) continue;
-                            bilinear2(sig, ab, nx, ny, nz, kk, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
-                            ssum += s1; asum += a1;
-                        }
-                    }
-                    E = l * ssum; A = l * asum;
-                }
-                double s, c;
-                sincos(k * (d + E) + phi[e], &s, &c);
-                const double amp = w[e] / d * exp(-A);
-                sr += amp * c; si += amp * s;
-            }
-            re_out[(size_t)ij * nz + kv] = sr;
-            im_out[(size_t)ij * nz + kv] = si;
+            const int i = columns ? columns[2 * q] : (int)(q / ny), j = columns ? columns[2 * q + 1] : (int)(q % ny);
+            hetero_layers_voxel(xs, nx, ys, ny, zs, nz, sig, ab, lo, hi, nl, ms, ma, pos, w, phi, n, k, dmin, i, j, kv,
+                                &re_out[(size_t)q * nz + kv], &im_out[(size_t)q * nz + kv]);
         }
-    }
     free(lo); free(hi); free(ms); free(ma);
     return 0;
+}
+
+int olo_field_grid_hetero_layers(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                                 const double *sig, const double *ab, int planes_per_layer, const double *pos, const double *w,
+                                 const double *phi, int n, double k, double dmin, int nthreads, double *re_out, double *im_out) {
+    return olo_field_columns_hetero_layers(xs, nx, ys, ny, zs, nz, sig, ab, planes_per_layer, NULL, 0, pos, w, phi, n, k, dmin,
+                                           nthreads, re_out, im_out);
 }

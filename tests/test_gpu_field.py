@@ -383,6 +383,72 @@ def test_heterogeneous_medium_layered_ray_model(ctx):
     assert np.array_equal(ctx.field_fetch(0, want=("complex",))["complex"], p0)
 
 
+def test_heterogeneous_foci_share_ray_integrals_and_layers(ctx):
+    """Kernel 2h evaluates the ray integrals of a (voxel, element) pair once for up to 8 foci of a launch tile (nf1/2/4/8
+    shapes, last tile partly empty), optionally with the two-level layered quadrature (olx_field_medium_layering, G = 3 and
+    8 against oracle/field_oracle.c's olo_field_grid_hetero_layers; G = 1 against the one-level definition), and in
+    x-slabs (the multi-GPU shard unit of BASELINE configs[4]: medium replicated, slab results identical to the whole)."""
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    foci = np.column_stack([np.linspace(-4, 4, 11), np.linspace(3, -3, 11), np.linspace(24, 32, 11)]) * 1e-3
+    xs = np.linspace(-12e-3, 12e-3, 25); ys = np.linspace(-10e-3, 10e-3, 21); zs = 3e-3 + np.arange(44) * 0.75e-3
+    cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    sig, ab = co.medium_terms(cvol, avol, C, F0)
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    for nfoci, G, expect in ((1, 1, "nf1,noclamp>"), (2, 1, "nf2"), (5, 1, "nf4"), (11, 1, "nf8"), (11, 3, "nf8,noclamp,layers"), (3, 8, "nf2,noclamp,layers")):
+        pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci[:nfoci], apod=("maxangle", 55.0, 0.0))
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
+        ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G)
+        assert expect in ctx.field_variant(), ctx.field_variant()
+        ctx.field_launch()
+        whole = np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)])
+        for f in sorted({0, nfoci // 2, nfoci - 1}):
+            ref = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0, planes_per_layer=G))
+            assert np.abs(whole[f] - ref).max() / ref.max() <= 2e-5, (nfoci, G, f)
+        if nfoci == 11:   # x-slabs: bit-identical to the same voxels of the whole-grid launch
+            parts = []
+            for b, cnt in ((0, 9), (9, 8), (17, 8)):
+                ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0, slab=(b, cnt))
+                ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G)
+                ctx.field_launch()
+                parts.append(np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)]))
+            assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+@pytest.mark.parametrize("G", [1, 8])
+def test_c5_skull_slab_256cubed_sampled(ctx, G):
+    """BASELINE config 5 at full size (256 el, 256^3 at 0.25 mm, SURVEY 8(d) skull-slab phantom made by the product's
+    SkullThreshold segmenter), 4 foci in one launch: sampled-voxel parity against the fp64 oracle of the same quadrature
+    (one sample per plane, and 8-plane layered screens), voxels below the slab equal to the homogeneous field, and one
+    of the four x-slabs a 4-GPU run computes equal to the whole-grid result."""
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(8)[[0, 1, 2, 4]]
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    xs, ys, zs = centred_grid(256, 0.25)
+    vol = skull_slab_volumes(xs, ys, zs)
+    hh = (xs[1] - xs[0],) * 3
+    ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG)
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G)
+    assert ("nf4,noclamp,layers" if G > 1 else "nf4,noclamp>") in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    got = [ctx.field_fetch(f, want=("pmag",))["pmag"] for f in (0, 3)]
+    rng = np.random.default_rng(147)
+    cols = np.column_stack([rng.integers(0, 256, 20), rng.integers(0, 256, 20)])
+    cols[:6] = [[127, 127], [128, 140], [100, 128], [160, 90], [127, 200], [40, 60]]      # through and around the focal region
+    idx = np.column_stack([rng.integers(0, 256, 600), rng.integers(0, 256, 600), rng.integers(0, 256, 600)])
+    sig, ab = co.medium_terms(vol["sound_speed"], vol["attenuation"], C, F0)
+    for gi, f in enumerate((0, 3)):     # whole z columns (through the slab and the focus), all 256 planes each
+        ref = np.abs(co.field_columns_hetero(xs, ys, zs, sig, ab, cols, pos_m, area, d[f], a[f], F0, C, P0, planes_per_layer=G))
+        mine = got[gi][cols[:, 0], cols[:, 1], :]
+        assert np.abs(mine - ref).max() / max(ref.max(), mine.max()) <= 3e-5, (G, f)
+    homog = np.abs(co.field_at_points(np.column_stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2] % 11]]), pos_m, area, d[0], a[0], F0, C, P0))
+    assert np.abs(got[0][idx[:, 0], idx[:, 1], idx[:, 2] % 11] - homog).max() / homog.max() <= TOL_P     # z < 7.75 mm: water only
+    ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG, slab=(64, 64))
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G)
+    ctx.field_launch()
+    assert np.array_equal(ctx.field_fetch(3, want=("pmag",))["pmag"], got[1][64:128])
+
+
 def test_mirror_partner_foci_share_columns(ctx):
     """A Wheel's spokes come in mirror orbits: the steering vector of spoke -theta seen through the y-mirror
     equals spoke +theta's, so kernel 2c accumulates one column for both and stores it to both volumes.  The
