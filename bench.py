@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--hetero-planes-per-layer", type=int, default=1,
                     help="--medium skull: quadrature of the ray integrals (1 = one sample per grid plane, the default model; G > 1 = "
                          "opt-in layered screens, olx_field_medium_layering)")
+    ap.add_argument("--hetero-model", choices=["auto", "marched", "sampled"], default="auto",
+                    help="--medium skull: ray-integral model (olx_field_medium_model): marched = running ray sums, one look-up per ray "
+                         "(kernel 2m, what auto picks for this phantom); sampled = one sample per non-trivial plane (kernel 2h)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (debug: oversubscribe one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the post-timing legs (other correction mode, parity, calc_solution)")
@@ -280,6 +283,7 @@ def main():
         from openlifu_amd.seg.seg_methods import skull_slab_volumes
         skull = skull_slab_volumes(*coords_m)
         skull["planes_per_layer"] = args.hetero_planes_per_layer
+        skull["model"] = args.hetero_model
 
     def plan(fp8: bool):
         if skull is not None:   # configs[4]: all foci of the run on every rank's x-slab, label volume replicated

@@ -163,6 +163,19 @@ int olx_field_set_medium(olx_ctx *ctx, const float *sound_speed, const float *at
  * per ray; the lateral walk of a ray inside a layer is neglected (per-cent-level change of the field on the skull-slab
  * phantom at G = 8).  Definition: oracle/field_oracle.c olo_field_grid_hetero_layers. */
 int olx_field_medium_layering(olx_ctx *ctx, int planes_per_layer);
+/* Ray-integral model for the NEXT olx_field_set_medium calls of this context (default OLX_MEDIUM_AUTO):
+ *   OLX_MEDIUM_SAMPLED  one bilinear sample on EVERY non-trivial plane between element and voxel (kernel 2h; with
+ *                       olx_field_medium_layering > 1 its two-level form).  Definition: olo_field_grid_hetero(_layers).
+ *   OLX_MEDIUM_MARCHED  running ray sums carried from one non-trivial plane to the next on the grid, ONE bilinear look-up per
+ *                       (voxel, element) (kernel 2m, ~20 x faster on the skull-slab phantom).  Differs from SAMPLED only by the
+ *                       re-interpolation of the running sum at each non-trivial plane.  Needs every element strictly below the
+ *                       first non-trivial plane, >= 2 voxels along x and y and planes_per_layer = 1; olx_field_set_medium
+ *                       fails with OLX_EINVAL otherwise.  Definition: oracle/field_oracle.c olo_field_columns_hetero_march.
+ *   OLX_MEDIUM_AUTO     MARCHED when its preconditions hold, else SAMPLED (olx_field_variant names the kernel in use). */
+#define OLX_MEDIUM_AUTO 0
+#define OLX_MEDIUM_SAMPLED 1
+#define OLX_MEDIUM_MARCHED 2
+int olx_field_medium_model(olx_ctx *ctx, int model);
 
 /* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
  * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]

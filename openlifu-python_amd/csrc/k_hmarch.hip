@@ -1,0 +1,190 @@
+// kernel 2m (field_hmarch_k): heterogeneous medium, MARCHED ray integrals -- one bilinear look-up per (voxel, element)
+// gfx950 (CDNA4, wave64) only.  Definition: oracle/field_oracle.c olo_field_columns_hetero_march, DESIGN.md section 7.
+#include "k_types.hip.h"
+#include "olx_ctx.h"
+#include "olx_launch.h"
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// Kernel 2h samples the medium on EVERY non-trivial plane between element and voxel (~32 bilinear gathers per ray on
+// the skull-slab phantom, ~30 VALU instructions each: 137 ms per focus at 256 el x 256^3).  Here the ray sums are
+// carried upwards through the non-trivial planes m_0 < m_1 < ... ON THE GRID, per element:
+//     U_0(i,j) = med(i,j,m_0),   U_p(i,j) = B[U_{p-1}](crossing of the ray e -> (i,j,m_p) with plane m_{p-1}) + med(i,j,m_p)
+// (B = bilinear, border values extended outwards) and a voxel of plane k takes ONE look-up into U_{p*}, p* = the last
+// non-trivial plane strictly below k.  Work per ray: one gather instead of one per plane.  Precondition (host-checked):
+// every element lies strictly below plane m_0 -- rays then cross the non-trivial planes upwards only, and voxels level with
+// or below an element see none.
+//
+// The host walks the planes in order and issues one launch per SEGMENT = a run of voxel planes that read the same U_p:
+//   * planes (m_p, m_{p+1}) -- trivial planes, any count -- and the final run above the last non-trivial plane: look-ups
+//     only (ES = 1: the four waves of a block are four consecutive planes of one 8 x 8 lateral tile, so their gathers
+//     share cache lines);
+//   * each non-trivial plane m_{p+1} on its own: the look-up value + the plane's own medium term IS U_{p+1}, so the same
+//     launch writes the next running sums (U is double-buffered) -- over the WHOLE lateral grid even in an x-slab launch,
+//     because rays cross slab boundaries (field outputs stay masked to the slab).  One plane is only 1024 tiles, so the
+//     elements are split over the block's four waves (ES = 4) and their partial sums meet in LDS.
+// U layout: [element][i][j] float2 {sum sig, sum a'}; a look-up = two 16-byte loads (rows i0, i0 + 1; 8-byte aligned).
+// The ray sums are focus-independent: up to NF = 8 foci of a launch tile share every look-up (only sin, cos and two fma
+// per extra focus).  Table entry as in kernel 2h: { x, y, z, kfirst, klast, 0, 0, 0, (w_f, phi_f) f < NF }.
+// ------------------------------------------------------------------------------------
+struct MarchSeg {
+    int k_lo, k_hi;      // voxel planes of this launch (inclusive)
+    int k_src;           // grid plane the source sums U_src live on (-1: none -- nothing non-trivial below these planes)
+    int write;           // 1: k_lo == k_hi is a non-trivial plane; write U_dst (launch covers the whole lateral grid)
+    int i0, ni;          // lateral extent of the launch in GLOBAL x indices: the slab, or the whole grid when writing
+};
+
+typedef float float4u_t __attribute__((ext_vector_type(4), aligned(8)));
+
+template <int NF, int ES, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_hmarch_k(
+    const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_of_k,
+    const float2* __restrict__ U_src, float2* __restrict__ U_dst, const float* __restrict__ inv2z,
+    float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx, const FieldParams P,
+    const HeteroParams H, const MarchSeg S) {
+    constexpr int STRIDE = HET_TAB_HEAD + 2 * NF;
+    constexpr int PB = 4 / ES;                              // planes per block
+    __shared__ float s_red[ES > 1 ? (ES - 1) * 2 * NF * 64 : 1];
+    const int ftile = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_y = (P.ny + 7) >> 3, zblocks = (S.k_hi - S.k_lo + PB) / PB;
+    const int zb = blockIdx.x % zblocks, tile = blockIdx.x / zblocks;
+    const int ti = tile / tiles_y, tj = tile - ti * tiles_y;
+    const int ig = S.i0 + ti * 8 + (lane >> 3), j = tj * 8 + (lane & 7);   // global x index, y index
+    const int k = S.k_lo + zb * PB + wave / ES, es = wave % ES;
+    const bool in_grid = ig < S.i0 + S.ni && j < P.ny;
+    const bool live_k = k <= S.k_hi;                        // wave-uniform (ES > 1: PB = 1, always true)
+    const int ic = min(ig, S.i0 + S.ni - 1), jc = min(j, P.ny - 1), kc = min(k, S.k_hi);
+    const float x = (float)ic * P.hx, y = (float)jc * P.hy, z = (float)kc * P.hz;
+    // the voxel's own half layer
+    float sv = 0.f, av = 0.f;
+    {
+        const int pq = plane_of_k[kc];                      // wave-uniform
+        if (pq >= 0) {
+            const float4 m = med[(((size_t)pq * H.nxg + ic) * H.nyg + jc) * 2];
+            sv = 0.5f * m.x; av = 0.5f * m.y;
+        }
+    }
+    float re[NF], im[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { re[f] = 0.f; im[f] = 0.f; }
+    const size_t plane_sz = (size_t)H.nxg * H.nyg;
+    const float umax = (float)(H.nxg - 1), vmax = (float)(H.nyg - 1);
+    const int imax = H.nxg - 2, jmax = H.nyg - 2;           // host guarantees nxg, nyg >= 2
+    const float zsrc = (float)S.k_src * P.hz;
+    const float* t = tab + (size_t)ftile * P.n_el * STRIDE;
+    const bool writer = S.write && ftile == 0 && in_grid;
+    if (live_k) {
+        for (int e = es; e < P.n_el; e += ES) {
+            const float* te = t + (size_t)e * STRIDE;
+            const float ex = te[0], ey = te[1], ez = te[2];
+            const float dx = x - ex, dy = y - ey, dz = z - ez;
+            const float r2 = fmaf(dy, dy, dx * dx);
+            const float idz = dz != 0.f ? __builtin_amdgcn_rcpf(dz) : 0.f;      // wave-uniform
+            float ss = 0.f, as = 0.f;
+            if (S.k_src >= 0 && dz > 0.f) {                 // wave-uniform branch
+                const float tt = (zsrc - ez) * idz;
+                const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
+                const float u = __builtin_amdgcn_fmed3f(fmaf(tt, dx * H.inv_hx, eu), 0.f, umax);   // border values extend outwards
+                const float v = __builtin_amdgcn_fmed3f(fmaf(tt, dy * H.inv_hy, ev), 0.f, vmax);
+                const int i0 = min((int)u, imax), j0 = min((int)v, jmax);
+                const float fu = u - (float)i0, fv = v - (float)j0;
+                const float2* r0 = U_src + (size_t)e * plane_sz + (size_t)i0 * H.nyg + j0;
+                const float4u_t lo = *reinterpret_cast<const float4u_t*>(r0);            // {s00, a00, s01, a01}
+                const float4u_t hi = *reinterpret_cast<const float4u_t*>(r0 + H.nyg);    // {s10, a10, s11, a11}
+                const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
+                const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
+                ss = fmaf(fu, s1 - s0, s0);
+                as = fmaf(fu, a1 - a0, a0);
+            }
+            if (writer) U_dst[(size_t)e * plane_sz + (size_t)ig * H.nyg + j] = make_float2(ss + 2.f * sv, as + 2.f * av);
+            float d2 = fmaf(dz, dz, r2);
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float d = d2 * ri;
+            const float l = P.hz * d * fabsf(idz);           // path per layer [wavelengths]; 0 level with the element
+            const float ph0 = fmaf(l, ss + sv, d);
+            const float a0 = ri * __expf(-l * (as + av));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {                   // the ray sums above serve every focus of the tile
+                const float ph = ph0 + te[HET_TAB_HEAD + 2 * f + 1];
+                const float a = a0 * te[HET_TAB_HEAD + 2 * f];
+                re[f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[f]);
+                im[f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[f]);
+            }
+        }
+    }
+    if constexpr (ES > 1) {                                  // partial sums of the element subsets meet in wave 0
+        if (es > 0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                s_red[(((es - 1) * NF + f) * 2 + 0) * 64 + lane] = re[f];
+                s_red[(((es - 1) * NF + f) * 2 + 1) * 64 + lane] = im[f];
+            }
+        }
+        __syncthreads();
+        if (es > 0) return;
+#pragma unroll
+        for (int q = 0; q < ES - 1; ++q)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                re[f] += s_red[((q * NF + f) * 2 + 0) * 64 + lane];
+                im[f] += s_red[((q * NF + f) * 2 + 1) * 64 + lane];
+            }
+    }
+    const int il = ig - P.x_begin;                           // slab-local x
+    if (!live_k || !in_grid || il < 0 || il >= P.nx) return;
+    const long long vrow = ((long long)il * P.ny + j) * P.nz + k;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int fg = ftile * NF + f;
+        if (fg >= H.n_foci) break;
+        const long long o = (long long)fg * P.vox + vrow;
+        const float m2 = fmaf(re[f], re[f], im[f] * im[f]);
+        if (P.flags & 1u) pmag[o] = __builtin_sqrtf(m2);
+        if (P.flags & 2u) inten[o] = m2 * (inv2z ? inv2z[vrow] : P.inten_scale);
+        if (P.flags & 4u) { cplx[2 * o] = re[f]; cplx[2 * o + 1] = im[f]; }
+    }
+}
+
+}  // namespace olx
+
+using namespace olx;
+
+template <int NF>
+static void launch_hmarch_nf(olx_ctx* c, float* pm) {
+    const FieldParams& P = c->fp;
+    const int nz = P.nz, np = (int)c->h_plane_k.size();
+    const int ftiles = (c->plan_foci + NF - 1) / NF;
+    auto go = [&](int k_lo, int k_hi, int p_src, bool write) {
+        if (k_hi < k_lo) return;
+        MarchSeg S;
+        S.k_lo = k_lo; S.k_hi = k_hi; S.k_src = p_src >= 0 ? c->h_plane_k[p_src] : -1; S.write = write ? 1 : 0;
+        S.i0 = write ? 0 : c->slab.x_begin; S.ni = write ? c->hp.nxg : P.nx;
+        const float2* src = p_src >= 0 ? c->d_U[p_src & 1] : nullptr;
+        float2* dst = write ? c->d_U[(p_src + 1) & 1] : nullptr;
+        const long long tiles = (long long)((S.ni + 7) / 8) * ((P.ny + 7) / 8);
+#define OLX_HM(ES_, CL) hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL>), dim3((unsigned)(tiles * ((k_hi - k_lo + 4 / ES_) / (4 / ES_))), ftiles), \
+                                           dim3(FIELD_THREADS), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
+                                           c->d_inten, c->d_cplx, P, c->hp, S)
+        if (write) { if (c->clamp) OLX_HM(4, true); else OLX_HM(4, false); }
+        else       { if (c->clamp) OLX_HM(1, true); else OLX_HM(1, false); }
+#undef OLX_HM
+    };
+    if (np == 0) { go(0, nz - 1, -1, false); return; }
+    go(0, c->h_plane_k[0] - 1, -1, false);                   // below the first non-trivial plane: homogeneous rays
+    go(c->h_plane_k[0], c->h_plane_k[0], -1, true);          // U_0 = the plane's own term
+    for (int p = 0; p + 1 < np; ++p) {
+        go(c->h_plane_k[p] + 1, c->h_plane_k[p + 1] - 1, p, false);
+        go(c->h_plane_k[p + 1], c->h_plane_k[p + 1], p, true);
+    }
+    go(c->h_plane_k[np - 1] + 1, nz - 1, np - 1, false);
+}
+
+void olx_launch_hmarch(olx_ctx* c, float* pm) {
+    if (c->nf >= 8) launch_hmarch_nf<8>(c, pm);
+    else if (c->nf >= 4) launch_hmarch_nf<4>(c, pm);
+    else if (c->nf >= 2) launch_hmarch_nf<2>(c, pm);
+    else launch_hmarch_nf<1>(c, pm);
+}

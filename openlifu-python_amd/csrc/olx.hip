@@ -54,7 +54,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1]};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -401,7 +401,10 @@ static int configure_variant(olx_ctx* c) {
         }
         c->hp.n_foci = F;
         char hb[160];
-        if (c->hp.n_layers > 0)
+        if (c->marched)
+            snprintf(hb, sizeof hb, "field_hmarch_k<nf%d,%s> (%d non-trivial planes, marched ray sums, %d launches)", c->nf,
+                     c->clamp ? "clamp" : "noclamp", c->hp.n_planes, 2 * c->hp.n_planes + 1);
+        else if (c->hp.n_layers > 0)
             snprintf(hb, sizeof hb, "field_hetero_k<4,nf%d,%s,layers> (%d non-trivial planes in %d layers of <= %d)", c->nf,
                      c->clamp ? "clamp" : "noclamp", c->hp.n_planes, c->hp.n_layers, c->planes_per_layer);
         else
@@ -878,7 +881,7 @@ int olx_field_launch(olx_ctx* c) {
     float* pm = c->d_pmag[b];
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    if (c->hetero) olx_launch_hetero(c, pm);
+    if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
     else if (c->use_mfma) { if (c->use_lattice) { if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
@@ -1104,9 +1107,28 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         while (kl >= 0 && !(g.origin[2] + kl * g.spacing[2] < ez)) --kl;
         kfirst[e] = kf; klast[e] = kl;
     }
+    // marched ray sums (kernel 2m) need rays that cross the non-trivial planes upwards only, and a 2 x 2 stencil
+    bool march_ok = c->planes_per_layer == 1 && nx >= 2 && ny >= 2;
+    if (np > 0)
+        for (int e = 0; e < n && march_ok; ++e)
+            if (!(c->h_pos[2 * (size_t)n + e] < g.origin[2] + plane_k[0] * g.spacing[2])) march_ok = false;
+    if (c->medium_model == OLX_MEDIUM_MARCHED && !march_ok)
+        return fail(c, OLX_EINVAL, "olx_field_set_medium: OLX_MEDIUM_MARCHED needs every element strictly below the first non-trivial "
+                                    "plane, >= 2 voxels along x and y and planes_per_layer = 1");
+    c->marched = march_ok && c->medium_model != OLX_MEDIUM_SAMPLED;
+    c->h_plane_k = plane_k;
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,
                      (void**)&c->d_med_layer, (void**)&c->d_layer_lo, (void**)&c->d_layer_hi})
         if (*q) { hipFree(*q); *q = nullptr; }
+    if (c->marched) {
+        const size_t need = (size_t)n * nx * ny;
+        if (c->U_cap < need) {
+            for (float2*& u : c->d_U) { if (u) hipFree(u); u = nullptr; }
+            c->U_cap = 0;
+            for (float2*& u : c->d_U) HIPCHK(c, hipMalloc((void**)&u, sizeof(float2) * need));
+            c->U_cap = need;
+        }
+    }
     // two-level quadrature (opt-in, olx_field_medium_layering): every maximal run of consecutive non-trivial planes is cut
     // into layers of <= G planes; a layer's stencil holds the column sums of its planes (fp64 sums, rounded once)
     std::vector<int> layer_lo, layer_hi;
@@ -1182,6 +1204,14 @@ int olx_field_medium_layering(olx_ctx* c, int planes_per_layer) {
     if (!c) return OLX_EINVAL;
     if (planes_per_layer < 1 || planes_per_layer > 4096) return fail(c, OLX_EINVAL, "olx_field_medium_layering: planes_per_layer must be in [1, 4096]");
     c->planes_per_layer = planes_per_layer;
+    return OLX_OK;
+}
+
+int olx_field_medium_model(olx_ctx* c, int model) {
+    if (!c) return OLX_EINVAL;
+    if (model != OLX_MEDIUM_AUTO && model != OLX_MEDIUM_SAMPLED && model != OLX_MEDIUM_MARCHED)
+        return fail(c, OLX_EINVAL, "olx_field_medium_model: unknown model %d", model);
+    c->medium_model = model;
     return OLX_OK;
 }
 

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("OLX_LIB_PATH") or os.path.join(os.path.dirname(_PKG_D
 OLX_OK, OLX_EINVAL, OLX_ESTATE, OLX_EHIP, OLX_ENOMEM, OLX_ECOMM = 0, -1, -2, -3, -4, -5
 APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2
 OUT_PMAG, OUT_INTENSITY, OUT_COMPLEX = 1, 2, 4
+MEDIUM_MODELS = {"auto": 0, "sampled": 1, "marched": 2}   # OLX_MEDIUM_*
 FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
 UNIQUE_ID_BYTES = 128
 
@@ -30,7 +31,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering",
+    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model",
 ]
 
 
@@ -101,6 +102,7 @@ def load(require_gpu: bool = True):
         lib.olx_bf_time.argtypes = [vp, c_int, fp]
         lib.olx_field_fetch_all.argtypes = [vp, fp, fp]
         lib.olx_field_medium_layering.argtypes = [vp, c_int]
+        lib.olx_field_medium_model.argtypes = [vp, c_int]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -257,10 +259,15 @@ class Context:
         self._flags = (int(flags) | OUT_PMAG) & 7
         self._plan_foci = F
 
-    def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9, planes_per_layer=1):
-        """Per-voxel medium volumes [nx,ny,nz] of the WHOLE planned grid (None = reference value).  ``planes_per_layer``
-        > 1 opts in to the two-level (layered screen) quadrature of the ray integrals (olx_field_medium_layering)."""
+    def field_set_medium(self, sound_speed=None, attenuation=None, density=None, alpha_power=0.9, planes_per_layer=1, model="auto"):
+        """Per-voxel medium volumes [nx,ny,nz] of the WHOLE planned grid (None = reference value).  ``model``: "marched"
+        (running ray sums, one look-up per ray: kernel 2m), "sampled" (one sample per non-trivial plane: kernel 2h) or
+        "auto" (marched when its preconditions hold, olx_field_medium_model).  ``planes_per_layer`` > 1 opts in to the
+        two-level (layered screen) quadrature of the sampled model (olx_field_medium_layering)."""
+        if model not in MEDIUM_MODELS:
+            raise ValueError(f"medium model must be one of {sorted(MEDIUM_MODELS)}, got {model!r}")
         self._chk(self._lib.olx_field_medium_layering(self._h, int(planes_per_layer)))
+        self._chk(self._lib.olx_field_medium_model(self._h, MEDIUM_MODELS[model]))
         arrs = []
         for a in (sound_speed, attenuation, density):
             arrs.append(None if a is None else np.ascontiguousarray(a, dtype=np.float32))

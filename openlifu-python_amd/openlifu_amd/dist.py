@@ -202,7 +202,7 @@ class ShardedField:
                        slab=self.slab)
         if medium is not None:
             ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"),
-                                 planes_per_layer=int(medium.get("planes_per_layer", 1)))
+                                 planes_per_layer=int(medium.get("planes_per_layer", 1)), model=medium.get("model", "auto"))
         eng.result_token += 1
         return self.slab
 

@@ -145,7 +145,7 @@ class Engine:
         self.ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=flags, slab=slab)
         if medium is not None:  # heterogeneous medium: layered straight-ray kernel
             self.ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"),
-                                      planes_per_layer=int(medium.get("planes_per_layer", 1)))
+                                      planes_per_layer=int(medium.get("planes_per_layer", 1)), model=medium.get("model", "auto"))
         self.ctx.field_launch()
         self.result_token += 1
         if lazy and "complex" not in want:

@@ -48,7 +48,8 @@ def _medium(params):
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
-                  steering_resident=False, slab=None, fp8_correction=False, lazy=False, hetero_planes_per_layer=1):
+                  steering_resident=False, slab=None, fp8_correction=False, lazy=False, hetero_planes_per_layer=1,
+                  hetero_model="auto"):
     """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz], or with ``lazy`` a
     ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""
     coords = params.coords
@@ -56,6 +57,8 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
     c, rho, medium = _medium(params)
     if medium is not None and int(hetero_planes_per_layer) > 1:   # opt-in layered-screen quadrature
         medium["planes_per_layer"] = int(hetero_planes_per_layer)
+    if medium is not None:   # "auto": marched ray sums (kernel 2m) when the elements lie below the medium, else sampled (2h)
+        medium["model"] = hetero_model
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
                               slab=slab, steering_resident=steering_resident, medium=medium,

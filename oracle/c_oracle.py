@@ -39,6 +39,9 @@ def lib():
         _lib.olo_field_columns_hetero_layers.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ctypes.c_int, ip,
                                                          ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                                          ctypes.c_int, dp, dp]
+        _lib.olo_field_columns_hetero_march.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ip, ctypes.c_long,
+                                                        dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_columns_hetero_march.restype = ctypes.c_int
         _lib.olo_hetero_layers.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip]
         _lib.olo_hetero_layers.restype = ctypes.c_int
         _lib.olo_max_threads.restype = ctypes.c_int
@@ -145,6 +148,39 @@ def field_columns_hetero(xs_m, ys_m, zs_m, sig, ab, columns, pos_m, area_m2, del
     lib().olo_field_columns_hetero_layers(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), int(planes_per_layer),
                                           cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(cols), _p(pos), _p(w), _p(phi), len(w),
                                           k, dmin, nthreads, _p(re), _p(im))
+    return re + 1j * im
+
+
+def field_hetero_march(xs_m, ys_m, zs_m, sig, ab, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0, dmin=None, nthreads=0,
+                       columns=None):
+    """The MARCHED heterogeneous definition (oracle/field_oracle.c olo_field_columns_hetero_march: running ray sums carried
+    from one non-trivial plane to the next on the grid, one bilinear look-up per ray) -- what kernel 2m evaluates.
+    columns = None: the whole grid -> complex [nx, ny, nz] (small grids only: every host thread keeps a private volume);
+    columns [ncol, 2] = (i, j) indices -> complex [ncol, nz].  Raises ValueError when an element does not lie strictly
+    below the first non-trivial plane (the model's precondition)."""
+    xs = np.ascontiguousarray(xs_m, dtype=np.float64); ys = np.ascontiguousarray(ys_m, dtype=np.float64)
+    zs = np.ascontiguousarray(zs_m, dtype=np.float64)
+    if dmin is None:
+        dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
+    pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
+    sig = np.ascontiguousarray(sig, dtype=np.float64); ab = np.ascontiguousarray(ab, dtype=np.float64)
+    assert sig.shape == (len(xs), len(ys), len(zs)) == ab.shape
+    ip = ctypes.POINTER(ctypes.c_int)
+    if columns is None:
+        if sig.size > (1 << 21):
+            raise ValueError("whole-grid marched oracle is for small grids; pass columns")
+        cols, cptr, ncol = None, ctypes.cast(None, ip), 0
+        re = np.empty(sig.shape); im = np.empty_like(re)
+    else:
+        cols = np.ascontiguousarray(columns, dtype=np.int32).reshape(-1, 2)
+        cptr, ncol = cols.ctypes.data_as(ip), len(cols)
+        re = np.empty((len(cols), len(zs))); im = np.empty_like(re)
+    rc = lib().olo_field_columns_hetero_march(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(sig), _p(ab), cptr, ncol,
+                                              _p(pos), _p(w), _p(phi), len(w), k, dmin, nthreads, _p(re), _p(im))
+    if rc == -2:
+        raise ValueError("marched model: every element must lie strictly below the first non-trivial plane")
+    if rc:
+        raise RuntimeError(f"olo_field_columns_hetero_march: {rc}")
     return re + 1j * im
 
 

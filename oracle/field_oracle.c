@@ -283,3 +283,102 @@ int olo_field_grid_hetero_layers(const double *xs, int nx, const double *ys, int
     return olo_field_columns_hetero_layers(xs, nx, ys, ny, zs, nz, sig, ab, planes_per_layer, NULL, 0, pos, w, phi, n, k, dmin,
                                            nthreads, re_out, im_out);
 }
+
+/* ---- heterogeneous medium, MARCHED ray integrals: the definition kernel 2m evaluates ----------------
+ * PARITY UNPINNED, like the sampled model above, of which this is the O(1)-per-ray form.  Let m_0 < m_1 < ... be the
+ * non-trivial grid planes (sig or a non-zero somewhere); every element must lie strictly below z_{m_0} (returns -2 otherwise).
+ * Per element e a running ray sum is carried from one non-trivial plane to the next ON THE GRID:
+ *     U_0(i,j)  = (sig, a)(i, j, m_0)
+ *     U_p(i,j)  = B[U_{p-1}](c_{p-1}) + (sig, a)(i, j, m_p),   c_{p-1} = crossing of the ray e -> (x_i, y_j, z_{m_p}) with plane m_{p-1}
+ * B[.] = bilinear interpolation on the plane's grid, border values extended outwards (as in bilinear2 above).  U_p(i,j) is the
+ * sum over the non-trivial planes up to and including m_p along the ray to that grid point; the ONLY approximation against
+ * the sampled model is the re-interpolation of the running sum at every non-trivial plane (the new plane's own term is exact).
+ * A voxel v = (i, j, kv) above the element takes, with p* = the last non-trivial plane strictly below kv,
+ *     (S, A) = B[U_{p*}](crossing of the ray e -> v with plane m_{p*})     (0 when there is none)
+ * and then, exactly as before,  E = l (S + sig(v)/2),  A = l (A + a(v)/2),  l = hz d / |z_v - z_e|,
+ *     p(v) = sum_e w_e / d * exp(-A) * exp(j (k (d + E) + phi_e)).
+ * Voxels level with or below the element see no non-trivial plane on their ray: S = A = 0.
+ * columns[ncol][2] = (i, j) grid columns, NULL = every column.  Outputs [ncol (or nx*ny)][nz]. */
+int olo_field_columns_hetero_march(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
+                                   const double *sig, const double *ab, const int *columns, long ncol,
+                                   const double *pos, const double *w, const double *phi, int n, double k, double dmin,
+                                   int nthreads, double *re_out, double *im_out) {
+    const double hx = nx > 1 ? xs[1] - xs[0] : 1.0, hy = ny > 1 ? ys[1] - ys[0] : 1.0, hz = nz > 1 ? zs[1] - zs[0] : 1.0;
+    const size_t nxy = (size_t)nx * ny;
+    int *mk = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+    int *pstar = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));   /* last non-trivial plane strictly below kv, or -1 */
+    int np = 0;
+    for (int kk = 0; kk < nz; ++kk) {
+        pstar[kk] = np - 1;
+        int any = 0;
+        for (size_t ij = 0; ij < nxy && !any; ++ij)
+            if (sig[ij * nz + kk] != 0.0 || ab[ij * nz + kk] != 0.0) any = 1;
+        if (any) mk[np++] = kk;
+    }
+    if (np > 0)
+        for (int e = 0; e < n; ++e)
+            if (!(pos[3 * e + 2] < zs[mk[0]])) { free(mk); free(pstar); return -2; }
+    const long total = columns ? ncol : (long)nxy;
+    for (size_t q = 0; q < (size_t)total * nz; ++q) { re_out[q] = 0; im_out[q] = 0; }
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        double *ua = (double *)malloc(sizeof(double) * nxy * 2), *ub = (double *)malloc(sizeof(double) * nxy * 2);
+        double *us = (double *)malloc(sizeof(double) * nxy), *uab = (double *)malloc(sizeof(double) * nxy);  /* planar copy for bilinear_map */
+        double *pre = (double *)calloc((size_t)total * nz, sizeof(double)), *pim = (double *)calloc((size_t)total * nz, sizeof(double));
+#pragma omp for schedule(dynamic, 1)
+        for (int e = 0; e < n; ++e) {
+            const double ex = pos[3 * e], ey = pos[3 * e + 1], ez = pos[3 * e + 2];
+            /* voxels of one plane range, given the planar source map (us, uab) at plane zsrc, or no source */
+            for (int p = -1; p < np; ++p) {
+                if (p >= 0) {       /* advance the running sums to plane m_p */
+                    const int m = mk[p];
+                    double *dst = (p & 1) ? ub : ua;
+                    for (int i = 0; i < nx; ++i)
+                        for (int j = 0; j < ny; ++j) {
+                            double s1 = 0, a1 = 0;
+                            if (p > 0) {
+                                const double t = (zs[mk[p - 1]] - ez) / (zs[m] - ez);
+                                bilinear_map(us, uab, nx, ny, (ex + t * (xs[i] - ex) - xs[0]) / hx, (ey + t * (ys[j] - ey) - ys[0]) / hy, &s1, &a1);
+                            }
+                            dst[((size_t)i * ny + j) * 2] = s1 + sig[((size_t)i * ny + j) * nz + m];
+                            dst[((size_t)i * ny + j) * 2 + 1] = a1 + ab[((size_t)i * ny + j) * nz + m];
+                        }
+                    for (size_t ij = 0; ij < nxy; ++ij) { us[ij] = dst[2 * ij]; uab[ij] = dst[2 * ij + 1]; }
+                }
+                /* voxel planes whose p* is p */
+                for (int kv = 0; kv < nz; ++kv) {
+                    if (pstar[kv] != p) continue;
+                    for (long q = 0; q < total; ++q) {
+                        const int i = columns ? columns[2 * q] : (int)(q / ny), j = columns ? columns[2 * q + 1] : (int)(q % ny);
+                        const double dx = xs[i] - ex, dy = ys[j] - ey, dz = zs[kv] - ez;
+                        double d = sqrt(dx * dx + dy * dy + dz * dz);
+                        if (d < dmin) d = dmin;
+                        double E = 0, A = 0;
+                        if (dz != 0) {
+                            const double l = hz * d / fabs(dz);
+                            double s1 = 0, a1 = 0;
+                            if (p >= 0 && dz > 0) {
+                                const double t = (zs[mk[p]] - ez) / dz;
+                                bilinear_map(us, uab, nx, ny, (ex + t * dx - xs[0]) / hx, (ey + t * dy - ys[0]) / hy, &s1, &a1);
+                            }
+                            E = l * (s1 + 0.5 * sig[((size_t)i * ny + j) * nz + kv]);
+                            A = l * (a1 + 0.5 * ab[((size_t)i * ny + j) * nz + kv]);
+                        }
+                        double s, c;
+                        sincos(k * (d + E) + phi[e], &s, &c);
+                        const double amp = w[e] / d * exp(-A);
+                        pre[(size_t)q * nz + kv] += amp * c; pim[(size_t)q * nz + kv] += amp * s;
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        for (size_t q = 0; q < (size_t)total * nz; ++q) { re_out[q] += pre[q]; im_out[q] += pim[q]; }
+        free(ua); free(ub); free(us); free(uab); free(pre); free(pim);
+    }
+    free(mk); free(pstar);
+    return 0;
+}

@@ -341,9 +341,12 @@ def _skull_medium(xs, ys, zs, c_skull=2800.0, a_skull=6.0):
     return cvol, avol, rvol
 
 
-def test_heterogeneous_medium_layered_ray_model(ctx):
+@pytest.mark.parametrize("model", ["sampled", "auto"])
+def test_heterogeneous_medium_layered_ray_model(ctx, model):
     """BASELINE config 5 shape (skull-slab mask, attenuated propagation) at a size the fp64 oracle finishes:
-    kernel 2h vs oracle/field_oracle.c's definition, plus the analytic slab KAT through the C-ABI."""
+    kernel 2h (one sample per plane) and kernel 2m (marched ray sums, what "auto" picks here) each against its own
+    definition in oracle/field_oracle.c, plus the analytic slab KAT through the C-ABI (laterally uniform slab: both
+    models reduce to it exactly)."""
     pos, ori, size = synthetic_array(8, 8, 4.0, jitter=True)
     foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 28e-3]])
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 50.0, 0.0))
@@ -351,14 +354,15 @@ def test_heterogeneous_medium_layered_ray_model(ctx):
     cvol, avol, rvol = _skull_medium(xs, ys, zs)
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 36), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX)
-    ctx.field_set_medium(cvol, avol, rvol)
-    assert "field_hetero_k" in ctx.field_variant(), ctx.field_variant()
+    ctx.field_set_medium(cvol, avol, rvol, model=model)
+    assert ("field_hetero_k" if model == "sampled" else "field_hmarch_k") in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     sig, ab = co.medium_terms(cvol, avol, C, F0)
     homog = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], a[0], F0, C, P0))
+    oracle = co.field_on_grid_hetero if model == "sampled" else co.field_hetero_march
     for f in range(2):
         out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
-        ref = co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0)
+        ref = oracle(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0)
         mx = np.abs(ref).max()
         assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= 2e-5        # bilinear gathers add fp32 rounding
         assert np.abs(out["complex"] - ref).max() / mx <= 6e-5
@@ -374,7 +378,7 @@ def test_heterogeneous_medium_layered_ray_model(ctx):
     a2 = np.zeros_like(c2); a2[:, :, 5:9] = 6.0
     ctx.field_plan((xs2[0], xs2[0], zs2[0]), (1e-3,) * 3, (9, 9, 21), F0, C, RHO, 1.0, flags=nat.OUT_COMPLEX)
     ctx.field_launch(); p0 = ctx.field_fetch(0, want=("complex",))["complex"]
-    ctx.field_set_medium(c2, a2, None); ctx.field_launch(); p1 = ctx.field_fetch(0, want=("complex",))["complex"]
+    ctx.field_set_medium(c2, a2, None, model=model); ctx.field_launch(); p1 = ctx.field_fetch(0, want=("complex",))["complex"]
     E = 4e-3 * (1500 / 2800 - 1); A = 4e-3 * 6.0 * 0.4 ** 0.9 * 100 / 8.685889638
     assert np.isclose(abs(p1[4, 4, 15]) / abs(p0[4, 4, 15]), np.exp(-A), rtol=1e-5)
     assert np.isclose(np.angle(p1[4, 4, 15] / p0[4, 4, 15]), (2 * np.pi * F0 / C * E + np.pi) % (2 * np.pi) - np.pi, atol=1e-4)
@@ -397,7 +401,7 @@ def test_heterogeneous_foci_share_ray_integrals_and_layers(ctx):
     for nfoci, G, expect in ((1, 1, "nf1,noclamp>"), (2, 1, "nf2"), (5, 1, "nf4"), (11, 1, "nf8"), (11, 3, "nf8,noclamp,layers"), (3, 8, "nf2,noclamp,layers")):
         pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci[:nfoci], apod=("maxangle", 55.0, 0.0))
         ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
-        ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G)
+        ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G, model="sampled")
         assert expect in ctx.field_variant(), ctx.field_variant()
         ctx.field_launch()
         whole = np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)])
@@ -408,7 +412,7 @@ def test_heterogeneous_foci_share_ray_integrals_and_layers(ctx):
             parts = []
             for b, cnt in ((0, 9), (9, 8), (17, 8)):
                 ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0, slab=(b, cnt))
-                ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G)
+                ctx.field_set_medium(cvol, avol, rvol, planes_per_layer=G, model="sampled")
                 ctx.field_launch()
                 parts.append(np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)]))
             assert np.array_equal(np.concatenate(parts, axis=1), whole)
@@ -428,7 +432,7 @@ def test_c5_skull_slab_256cubed_sampled(ctx, G):
     vol = skull_slab_volumes(xs, ys, zs)
     hh = (xs[1] - xs[0],) * 3
     ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG)
-    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G)
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G, model="sampled")
     assert ("nf4,noclamp,layers" if G > 1 else "nf4,noclamp>") in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     got = [ctx.field_fetch(f, want=("pmag",))["pmag"] for f in (0, 3)]
@@ -444,7 +448,83 @@ def test_c5_skull_slab_256cubed_sampled(ctx, G):
     homog = np.abs(co.field_at_points(np.column_stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2] % 11]]), pos_m, area, d[0], a[0], F0, C, P0))
     assert np.abs(got[0][idx[:, 0], idx[:, 1], idx[:, 2] % 11] - homog).max() / homog.max() <= TOL_P     # z < 7.75 mm: water only
     ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG, slab=(64, 64))
-    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G)
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"], planes_per_layer=G, model="sampled")
+    ctx.field_launch()
+    assert np.array_equal(ctx.field_fetch(3, want=("pmag",))["pmag"], got[1][64:128])
+
+
+def test_marched_medium_foci_tiles_slabs_and_fallback(ctx):
+    """Kernel 2m: the running ray sums serve up to 8 foci per launch tile (nf1/2/4/8 shapes, last tile partly empty); an
+    x-slab launch marches the WHOLE lateral grid (rays cross slab boundaries) and must reproduce the whole-grid voxels bit for
+    bit; with an element level with or above the first non-trivial plane "auto" falls back to kernel 2h and "marched" is refused."""
+    pos, ori, size = synthetic_array(8, 8, 4.0)
+    foci = np.column_stack([np.linspace(-4, 4, 11), np.linspace(3, -3, 11), np.linspace(24, 32, 11)]) * 1e-3
+    xs = np.linspace(-12e-3, 12e-3, 25); ys = np.linspace(-10e-3, 10e-3, 21); zs = 3e-3 + np.arange(44) * 0.75e-3
+    cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    sig, ab = co.medium_terms(cvol, avol, C, F0)
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    for nfoci, expect in ((1, "nf1,noclamp>"), (2, "nf2"), (5, "nf4"), (11, "nf8")):
+        pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci[:nfoci], apod=("maxangle", 55.0, 0.0))
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
+        ctx.field_set_medium(cvol, avol, rvol)
+        assert "field_hmarch_k" in ctx.field_variant() and expect in ctx.field_variant(), ctx.field_variant()
+        ctx.field_launch()
+        whole = np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)])
+        for f in sorted({0, nfoci // 2, nfoci - 1}):
+            ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0))
+            assert np.abs(whole[f] - ref).max() / ref.max() <= 2e-5, (nfoci, f)
+        if nfoci == 11:
+            parts = []
+            for b, cnt in ((0, 9), (9, 8), (17, 8)):
+                ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0, slab=(b, cnt))
+                ctx.field_set_medium(cvol, avol, rvol, model="marched")
+                ctx.field_launch()
+                parts.append(np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)]))
+            assert np.array_equal(np.concatenate(parts, axis=1), whole)
+            # the two models are different quadratures of the same ray integral: close, not equal
+            ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
+            ctx.field_set_medium(cvol, avol, rvol, model="sampled"); ctx.field_launch()
+            smp = ctx.field_fetch(0)["pmag"]
+            assert 0 < np.abs(smp - whole[0]).max() / whole[0].max() < 0.1
+    # an element inside the medium: no upward-only rays
+    pos2 = pos.copy(); pos2[0, 2] = 12.0            # [mm], above the first skull plane (8 mm)
+    setup_ctx(ctx, pos2, ori, size, foci[:1])
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
+    ctx.field_set_medium(cvol, avol, rvol)
+    assert "field_hetero_k" in ctx.field_variant(), ctx.field_variant()
+    with pytest.raises((ValueError, nat.NativeError)):
+        ctx.field_set_medium(cvol, avol, rvol, model="marched")
+
+
+def test_c5_skull_slab_256cubed_marched(ctx):
+    """BASELINE config 5 at full size with the default (marched) model: 256 el, 256^3 at 0.25 mm, skull-slab phantom, 4 foci
+    in one launch.  Whole z columns (through the slab and the focal region) against the fp64 marched oracle, voxels below the slab
+    equal to the homogeneous field, and one of the four x-slabs of a 4-GPU run equal to the whole-grid result."""
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(8)[[0, 1, 2, 4]]
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    xs, ys, zs = centred_grid(256, 0.25)
+    vol = skull_slab_volumes(xs, ys, zs)
+    hh = (xs[1] - xs[0],) * 3
+    ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG)
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"])
+    assert "field_hmarch_k<nf4,noclamp>" in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    got = [ctx.field_fetch(f, want=("pmag",))["pmag"] for f in (0, 3)]
+    rng = np.random.default_rng(147)
+    cols = np.column_stack([rng.integers(0, 256, 24), rng.integers(0, 256, 24)])
+    cols[:8] = [[127, 127], [128, 140], [100, 128], [160, 90], [127, 200], [40, 60], [0, 0], [255, 255]]
+    idx = np.column_stack([rng.integers(0, 256, 600), rng.integers(0, 256, 600), rng.integers(0, 256, 600)])
+    sig, ab = co.medium_terms(vol["sound_speed"], vol["attenuation"], C, F0)
+    for gi, f in enumerate((0, 3)):
+        ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0, columns=cols))
+        mine = got[gi][cols[:, 0], cols[:, 1], :]
+        assert np.abs(mine - ref).max() / max(ref.max(), mine.max()) <= 3e-5, f
+    homog = np.abs(co.field_at_points(np.column_stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2] % 11]]), pos_m, area, d[0], a[0], F0, C, P0))
+    assert np.abs(got[0][idx[:, 0], idx[:, 1], idx[:, 2] % 11] - homog).max() / homog.max() <= TOL_P     # z < 7.75 mm: water only
+    ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG, slab=(64, 64))
+    ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"])
     ctx.field_launch()
     assert np.array_equal(ctx.field_fetch(3, want=("pmag",))["pmag"], got[1][64:128])
 

@@ -1,6 +1,7 @@
 """Analytic known-answer tests pinning the field oracle (the reference holds no field values:
 parity vs k-Wave is UNPINNED, see oracle/__init__.py), plus NumPy-vs-C oracle agreement."""
 import numpy as np
+import pytest
 
 from oracle import bf_oracle as bo, c_oracle as co, field_oracle as fo
 
@@ -123,3 +124,50 @@ def test_hetero_two_level_quadrature_definition():
     for G in (2, 5, 11, 64):
         lay = co.field_on_grid_hetero(xs, ys, zs, sig_u, ab_u, e0, [4e-6], [0.0], [1.0], 400e3, 1500.0, 1e5, planes_per_layer=G)
         assert np.abs(lay - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_hetero_marched_definition():
+    """The marched heterogeneous definition kernel 2m evaluates (olo_field_columns_hetero_march): on a laterally uniform slab the
+    running sums have nothing to re-interpolate, so it IS the sampled model (and the analytic slab known-answer: amplitude x
+    exp(-alpha L), phase + k L (c0/c - 1)); with ONE non-trivial plane there is no re-interpolation either (U_0 is the plane's
+    own term); on the wavy phantom it differs from the sampled quadrature by a few per cent; column output equals the whole-grid
+    output; an element level with the medium is refused."""
+    from oracle import c_oracle as co
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    rng = np.random.default_rng(147)
+    pos = np.column_stack([rng.uniform(-6e-3, 6e-3, 12), rng.uniform(-6e-3, 6e-3, 12), rng.uniform(-0.3e-3, 0.3e-3, 12)])
+    area = np.full(12, 4e-6); d = rng.uniform(0, 2e-6, 12); a = rng.uniform(0.3, 1.0, 12)
+    xs = np.linspace(-8e-3, 8e-3, 17); ys = np.linspace(-6e-3, 6e-3, 13); zs = 2e-3 + np.arange(30) * 0.5e-3
+    args = (pos, area, d, a, 400e3, 1500.0, 1e5)
+    sig_u = np.zeros((17, 13, 30)); ab_u = np.zeros_like(sig_u)
+    sig_u[:, :, 6:17] = 1500.0 / 2800.0 - 1.0; ab_u[:, :, 6:17] = 30.0
+    ref = co.field_on_grid_hetero(xs, ys, zs, sig_u, ab_u, *args)
+    mar = co.field_hetero_march(xs, ys, zs, sig_u, ab_u, *args)
+    assert np.abs(mar - ref).max() <= 1e-12 * np.abs(ref).max()
+    e0 = np.array([[0.0, 0.0, 0.0]])
+    hom = co.field_on_grid(xs, ys, zs, e0, [4e-6], [0.0], [1.0], 400e3, 1500.0, 1e5)
+    one = co.field_hetero_march(xs, ys, zs, sig_u, ab_u, e0, [4e-6], [0.0], [1.0], 400e3, 1500.0, 1e5)
+    L = 11 * 0.5e-3
+    ratio = one[8, 6, 25] / hom[8, 6, 25]                      # on axis, above the slab: 11 planes of 0.5 mm
+    assert np.isclose(abs(ratio), np.exp(-30.0 * L), rtol=1e-12)
+    assert np.isclose(np.angle(ratio), (2 * np.pi * 400e3 / 1500.0 * L * (1500.0 / 2800.0 - 1.0) + np.pi) % (2 * np.pi) - np.pi, atol=1e-9)
+    # one wavy non-trivial plane: identical to the sampled model
+    vol = skull_slab_volumes(xs * 2.5, ys * 2.5, 6e-3 + (zs - 2e-3) * 1.2)
+    sig, ab = co.medium_terms(vol["sound_speed"], vol["attenuation"], 1500.0, 400e3)
+    nontriv = [k for k in range(30) if sig[:, :, k].any() or ab[:, :, k].any()]
+    k1 = nontriv[-1]
+    s1 = np.zeros_like(sig); a1 = np.zeros_like(ab); s1[:, :, k1] = sig[:, :, k1]; a1[:, :, k1] = ab[:, :, k1]
+    assert s1[:, :, k1].min() != s1[:, :, k1].max()             # really wavy
+    r1 = co.field_on_grid_hetero(xs, ys, zs, s1, a1, *args); m1 = co.field_hetero_march(xs, ys, zs, s1, a1, *args)
+    assert np.abs(m1 - r1).max() <= 1e-12 * np.abs(r1).max()
+    # full phantom: a different quadrature of the same integral
+    smp = co.field_on_grid_hetero(xs, ys, zs, sig, ab, *args); mar = co.field_hetero_march(xs, ys, zs, sig, ab, *args)
+    assert 0 < np.abs(mar - smp).max() <= 0.12 * np.abs(smp).max()
+    below = zs < zs[nontriv[0]] + 1e-9                           # up to and including the first non-trivial plane: nothing to sum yet
+    assert np.abs(mar[:, :, below] - smp[:, :, below]).max() <= 1e-12 * np.abs(smp).max()
+    cols = np.array([[0, 0], [8, 6], [16, 12], [3, 11]])
+    part = co.field_hetero_march(xs, ys, zs, sig, ab, *args, columns=cols)
+    assert np.abs(part - mar[cols[:, 0], cols[:, 1]]).max() <= 1e-12 * np.abs(mar).max()
+    pos_bad = pos.copy(); pos_bad[3, 2] = zs[nontriv[0]]
+    with pytest.raises(ValueError):
+        co.field_hetero_march(xs, ys, zs, sig, ab, pos_bad, *args[1:])
