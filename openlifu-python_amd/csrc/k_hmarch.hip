@@ -18,12 +18,12 @@ namespace olx {
 //
 // The host walks the planes in order and issues one launch per SEGMENT = a run of voxel planes that read the same U_p:
 //   * planes (m_p, m_{p+1}) -- trivial planes, any count -- and the final run above the last non-trivial plane: look-ups
-//     only (ES = 1: the four waves of a block are four consecutive planes of one 8 x 8 lateral tile, so their gathers
+//     only (ES = 1: the four waves of a block are four consecutive planes of one 4 x 16 lateral tile, so their gathers
 //     share cache lines);
 //   * each non-trivial plane m_{p+1} on its own: the look-up value + the plane's own medium term IS U_{p+1}, so the same
 //     launch writes the next running sums (U is double-buffered) -- over the WHOLE lateral grid even in an x-slab launch,
 //     because rays cross slab boundaries (field outputs stay masked to the slab).  One plane is only 1024 tiles, so the
-//     elements are split over the block's four waves (ES = 4) and their partial sums meet in LDS.
+//     elements are split over the 16 waves of a 1024-thread block (ES = 16) and their partial sums meet in LDS.
 // U layout: [element][i][j] float2 {sum sig, sum a'}; a look-up = two 16-byte loads (rows i0, i0 + 1; 8-byte aligned).
 // The ray sums are focus-independent: up to NF = 8 foci of a launch tile share every look-up (only sin, cos and two fma
 // per extra focus).  Table entry as in kernel 2h: { x, y, z, kfirst, klast, 0, 0, 0, (w_f, phi_f) f < NF }.
@@ -37,26 +37,37 @@ struct MarchSeg {
 
 typedef float float4u_t __attribute__((ext_vector_type(4), aligned(8)));
 
+// ES = 1: 4 waves = 4 consecutive planes, every wave walks all elements.  ES = 16: 16 waves = 16 element subsets of ONE plane.
+template <int ES> constexpr int hm_waves() { return ES == 1 ? 4 : ES; }
+constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 voxels -- 16 consecutive y = whole 128-byte lines of a U row
+
 template <int NF, int ES, bool CLAMP>
-__global__ __launch_bounds__(FIELD_THREADS) void field_hmarch_k(
+__global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_of_k,
     const float2* __restrict__ U_src, float2* __restrict__ U_dst, const float* __restrict__ inv2z,
     float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx, const FieldParams P,
     const HeteroParams H, const MarchSeg S) {
     constexpr int STRIDE = HET_TAB_HEAD + 2 * NF;
-    constexpr int PB = 4 / ES;                              // planes per block
+    constexpr int WAVES = hm_waves<ES>(), PB = WAVES / ES;  // planes per block
+    constexpr int EU = 4;                                   // elements in flight per wave: their gathers are issued back to back
+    constexpr int ECH = ES == 1 ? 128 : 64;                 // elements per chunk of the wave's ray table
+    // per-wave ray table: what depends on (element, plane) only -- evaluated once per wave, 64 elements at a time across the
+    // lanes, instead of per lane per element: { tt, cu, cv, lf | dz2, ex, ey, - } with the crossing u = tt i + cu (grid cells),
+    // tt < 0 = no look-up (nothing non-trivial between), lf = hz / |dz|
+    __shared__ float4 s_ray[WAVES][ECH][2];
     __shared__ float s_red[ES > 1 ? (ES - 1) * 2 * NF * 64 : 1];
     const int ftile = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_y = (P.ny + 7) >> 3, zblocks = (S.k_hi - S.k_lo + PB) / PB;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_y = (P.ny + HM_TJ - 1) / HM_TJ, zblocks = (S.k_hi - S.k_lo + PB) / PB;
     const int zb = blockIdx.x % zblocks, tile = blockIdx.x / zblocks;
     const int ti = tile / tiles_y, tj = tile - ti * tiles_y;
-    const int ig = S.i0 + ti * 8 + (lane >> 3), j = tj * 8 + (lane & 7);   // global x index, y index
-    const int k = S.k_lo + zb * PB + wave / ES, es = wave % ES;
+    const int ig = S.i0 + ti * HM_TI + (lane >> 4), j = tj * HM_TJ + (lane & 15);   // global x index, y index
+    const int k = S.k_lo + zb * PB + wave / ES, es = wave % ES;            // wave-uniform (scalar registers)
     const bool in_grid = ig < S.i0 + S.ni && j < P.ny;
-    const bool live_k = k <= S.k_hi;                        // wave-uniform (ES > 1: PB = 1, always true)
+    const bool live_k = k <= S.k_hi;                        // (ES > 1: PB = 1, always true)
     const int ic = min(ig, S.i0 + S.ni - 1), jc = min(j, P.ny - 1), kc = min(k, S.k_hi);
-    const float x = (float)ic * P.hx, y = (float)jc * P.hy, z = (float)kc * P.hz;
+    const float igf = (float)ic, jgf = (float)jc;
+    const float x = igf * P.hx, y = jgf * P.hy, z = (float)kc * P.hz;
     // the voxel's own half layer
     float sv = 0.f, av = 0.f;
     {
@@ -69,49 +80,82 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hmarch_k(
     float re[NF], im[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { re[f] = 0.f; im[f] = 0.f; }
-    const size_t plane_sz = (size_t)H.nxg * H.nyg;
-    const float umax = (float)(H.nxg - 1), vmax = (float)(H.nyg - 1);
-    const int imax = H.nxg - 2, jmax = H.nyg - 2;           // host guarantees nxg, nyg >= 2
+    const unsigned plane_sz = (unsigned)H.nxg * (unsigned)H.nyg;
+    // look-up coordinates are clamped just inside the last cell, so that (i0, i0 + 1) / (j0, j0 + 1) always exist and the
+    // fraction is fract(u): border values extend outwards (the oracle's clamp) to one ulp of the coordinate
+    const float umax = (float)(H.nxg - 1) * (1.f - 0x1p-23f), vmax = (float)(H.nyg - 1) * (1.f - 0x1p-23f);
     const float zsrc = (float)S.k_src * P.hz;
+    const bool have_src = S.k_src >= 0;
     const float* t = tab + (size_t)ftile * P.n_el * STRIDE;
     const bool writer = S.write && ftile == 0 && in_grid;
+    const unsigned own = (unsigned)ig * (unsigned)H.nyg + (unsigned)j;     // this voxel's cell in a U plane
+    const float sv2 = 2.f * sv, av2 = 2.f * av;
     if (live_k) {
-        for (int e = es; e < P.n_el; e += ES) {
-            const float* te = t + (size_t)e * STRIDE;
-            const float ex = te[0], ey = te[1], ez = te[2];
-            const float dx = x - ex, dy = y - ey, dz = z - ez;
-            const float r2 = fmaf(dy, dy, dx * dx);
-            const float idz = dz != 0.f ? __builtin_amdgcn_rcpf(dz) : 0.f;      // wave-uniform
-            float ss = 0.f, as = 0.f;
-            if (S.k_src >= 0 && dz > 0.f) {                 // wave-uniform branch
-                const float tt = (zsrc - ez) * idz;
-                const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
-                const float u = __builtin_amdgcn_fmed3f(fmaf(tt, dx * H.inv_hx, eu), 0.f, umax);   // border values extend outwards
-                const float v = __builtin_amdgcn_fmed3f(fmaf(tt, dy * H.inv_hy, ev), 0.f, vmax);
-                const int i0 = min((int)u, imax), j0 = min((int)v, jmax);
-                const float fu = u - (float)i0, fv = v - (float)j0;
-                const float2* r0 = U_src + (size_t)e * plane_sz + (size_t)i0 * H.nyg + j0;
-                const float4u_t lo = *reinterpret_cast<const float4u_t*>(r0);            // {s00, a00, s01, a01}
-                const float4u_t hi = *reinterpret_cast<const float4u_t*>(r0 + H.nyg);    // {s10, a10, s11, a11}
-                const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
-                const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
-                ss = fmaf(fu, s1 - s0, s0);
-                as = fmaf(fu, a1 - a0, a0);
+        const int n_mine = (P.n_el - es + ES - 1) / ES;     // elements es, es + ES, ...
+        for (int c0 = 0; c0 < n_mine; c0 += ECH) {
+            const int n_ch = min(ECH, n_mine - c0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the previous chunk's reads are done (same wave, in order)
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < n_ch; q += 64) {          // ray table of this chunk: one element per lane
+                const float* te = t + (size_t)(es + ES * (c0 + q)) * STRIDE;
+                const float ex = te[0], ey = te[1], ez = te[2];
+                const float dz = z - ez;
+                const float idz = dz != 0.f ? 1.0f / dz : 0.f;
+                const bool up = have_src && dz > 0.f;
+                const float tt = up ? (zsrc - ez) * idz : -1.f;
+                const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid cells
+                s_ray[wave][q][0] = make_float4(tt, eu - tt * eu, ev - tt * ev, P.hz * fabsf(idz));
+                s_ray[wave][q][1] = make_float4(dz * dz, ex, ey, 0.f);
             }
-            if (writer) U_dst[(size_t)e * plane_sz + (size_t)ig * H.nyg + j] = make_float2(ss + 2.f * sv, as + 2.f * av);
-            float d2 = fmaf(dz, dz, r2);
-            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
-            const float ri = __builtin_amdgcn_rsqf(d2);
-            const float d = d2 * ri;
-            const float l = P.hz * d * fabsf(idz);           // path per layer [wavelengths]; 0 level with the element
-            const float ph0 = fmaf(l, ss + sv, d);
-            const float a0 = ri * __expf(-l * (as + av));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int q0 = 0; q0 < n_ch; q0 += EU) {
+                float4u_t lo[EU], hi[EU];
+                float fu[EU], fv[EU];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {                   // the ray sums above serve every focus of the tile
-                const float ph = ph0 + te[HET_TAB_HEAD + 2 * f + 1];
-                const float a = a0 * te[HET_TAB_HEAD + 2 * f];
-                re[f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[f]);
-                im[f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[f]);
+                for (int s = 0; s < EU; ++s) {               // phase 1: addresses and gathers of EU elements
+                    const int q = min(q0 + s, n_ch - 1);
+                    const float4 r0 = s_ray[wave][q][0];     // same address in every lane: an LDS broadcast
+                    lo[s] = float4u_t{0.f, 0.f, 0.f, 0.f}; hi[s] = lo[s]; fu[s] = 0.f; fv[s] = 0.f;
+                    if (r0.x >= 0.f) {                       // wave-uniform
+                        const float u = __builtin_amdgcn_fmed3f(fmaf(r0.x, igf, r0.y), 0.f, umax);
+                        const float v = __builtin_amdgcn_fmed3f(fmaf(r0.x, jgf, r0.z), 0.f, vmax);
+                        const unsigned i0 = (unsigned)(int)u, j0 = (unsigned)(int)v;
+                        fu[s] = __builtin_amdgcn_fractf(u); fv[s] = __builtin_amdgcn_fractf(v);
+                        // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
+                        const char* Ue = reinterpret_cast<const char*>(U_src + (size_t)(es + ES * (c0 + q)) * plane_sz);
+                        const unsigned off = (__umul24(i0, (unsigned)H.nyg) + j0) << 3;
+                        lo[s] = *reinterpret_cast<const float4u_t*>(Ue + off);                       // {s00, a00, s01, a01}
+                        hi[s] = *reinterpret_cast<const float4u_t*>(Ue + (size_t)H.nyg * 8 + off);   // {s10, a10, s11, a11}
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < EU; ++s) {               // phase 2: interpolate, (write,) accumulate
+                    if (q0 + s >= n_ch) break;               // wave-uniform
+                    const int e = es + ES * (c0 + q0 + s);
+                    const float* te = t + (size_t)e * STRIDE;
+                    const float4 r0 = s_ray[wave][q0 + s][0], r1 = s_ray[wave][q0 + s][1];
+                    const float dx = x - r1.y, dy = y - r1.z;
+                    const float s0 = fmaf(fv[s], lo[s].z - lo[s].x, lo[s].x), a0 = fmaf(fv[s], lo[s].w - lo[s].y, lo[s].y);
+                    const float s1 = fmaf(fv[s], hi[s].z - hi[s].x, hi[s].x), a1 = fmaf(fv[s], hi[s].w - hi[s].y, hi[s].y);
+                    const float ss = fmaf(fu[s], s1 - s0, s0), as = fmaf(fu[s], a1 - a0, a0);
+                    if (writer) (U_dst + (size_t)e * plane_sz)[own] = make_float2(ss + sv2, as + av2);
+                    float d2 = fmaf(dy, dy, fmaf(dx, dx, r1.x));
+                    if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                    const float ri = __builtin_amdgcn_rsqf(d2);
+                    const float d = d2 * ri;
+                    const float l = d * r0.w;                // path per layer [wavelengths]; 0 level with the element
+                    const float ph0 = fmaf(l, ss + sv, d);
+                    const float amp = ri * __expf(-l * (as + av));
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {           // the ray sums above serve every focus of the tile
+                        const float ph = ph0 + te[HET_TAB_HEAD + 2 * f + 1];
+                        const float a = amp * te[HET_TAB_HEAD + 2 * f];
+                        re[f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[f]);
+                        im[f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[f]);
+                    }
+                }
             }
         }
     }
@@ -125,7 +169,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hmarch_k(
         }
         __syncthreads();
         if (es > 0) return;
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < ES - 1; ++q)
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -164,11 +208,11 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
         S.i0 = write ? 0 : c->slab.x_begin; S.ni = write ? c->hp.nxg : P.nx;
         const float2* src = p_src >= 0 ? c->d_U[p_src & 1] : nullptr;
         float2* dst = write ? c->d_U[(p_src + 1) & 1] : nullptr;
-        const long long tiles = (long long)((S.ni + 7) / 8) * ((P.ny + 7) / 8);
-#define OLX_HM(ES_, CL) hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL>), dim3((unsigned)(tiles * ((k_hi - k_lo + 4 / ES_) / (4 / ES_))), ftiles), \
-                                           dim3(FIELD_THREADS), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
+        const long long tiles = (long long)((S.ni + HM_TI - 1) / HM_TI) * ((P.ny + HM_TJ - 1) / HM_TJ);
+#define OLX_HM(ES_, CL) hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL>), dim3((unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)), ftiles), \
+                                           dim3(64 * hm_waves<ES_>()), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
                                            c->d_inten, c->d_cplx, P, c->hp, S)
-        if (write) { if (c->clamp) OLX_HM(4, true); else OLX_HM(4, false); }
+        if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }
         else       { if (c->clamp) OLX_HM(1, true); else OLX_HM(1, false); }
 #undef OLX_HM
     };
