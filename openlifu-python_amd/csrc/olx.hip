@@ -663,7 +663,8 @@ static int configure_variant(olx_ctx* c) {
                      n_img, ntiles);
         }
     } else if (c->mx * c->my * c->nf == 1) {
-        snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+        if (c->force_kind == 5) snprintf(nmbuf, sizeof nmbuf, "field_shfl_k<%s> (elements across lanes, __shfl reduction)", c->clamp ? "clamp" : "noclamp");
+        else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
         std::vector<int> perm((size_t)nm * n);
         for (int m = 0; m < nm; ++m)
@@ -828,8 +829,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
-    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : 0;
-    c->allow_shared = c->force_kind != 1;
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : !strcmp(force, "shfl") ? 5 : 0;
+    c->allow_shared = c->force_kind != 1 && c->force_kind != 5;
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
     {   // worst-case kernel-2a/2b table over every (dx, dy, nf) the steering may select later: tiles = ceil(F / nf)
@@ -885,7 +886,8 @@ int olx_field_launch(olx_ctx* c) {
     else if (c->use_mfma) { if (c->use_lattice) { if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
-    } else olx_launch_accum(c, pm);
+    } else if (c->force_kind == 5) olx_launch_shfl(c, pm);
+    else olx_launch_accum(c, pm);
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
     c->cur = b;

@@ -249,7 +249,7 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
 
 
-@pytest.mark.parametrize("family", ["general", "shared", "mfma", "lattice", "lattice2d"])
+@pytest.mark.parametrize("family", ["general", "shfl", "shared", "mfma", "lattice", "lattice2d"])
 def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     """Kernel 2a (per pair), 2b (shared geometry, VALU), 2c (shared geometry, MFMA fp16 hi/lo split) and 2d
     (lattice: block-Toeplitz geometry tables) are pinned one at a time (OLX_FIELD_VARIANT) on the same
@@ -261,7 +261,7 @@ def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     xs, ys, zs = centred_grid(64, 0.5)
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (64,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
-    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k", "lattice": "field_coset_k", "lattice2d": "field_lattice_k"}[family] in name, name
+    assert {"general": "field_accum_k", "shfl": "field_shfl_k", "shared": "field_shared_k", "mfma": "field_mfma_k", "lattice": "field_coset_k", "lattice2d": "field_lattice_k"}[family] in name, name
     check(ctx, xs, ys, zs, pos_m, area, d, a, complex_out=(family != "lattice"),
           want_variant={"lattice": "field_coset_k", "lattice2d": "field_lattice_k"}.get(family))
 
