@@ -1,0 +1,244 @@
+// kernel 2f (field_toep_k): lattice arrays, ONE steering column -- Toeplitz weights stationary, geometry tables stream
+// gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#include "k_types.hip.h"
+#include "olx_ctx.h"
+#include "olx_launch.h"
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// Kernel 2e contracts G[voxel rows, elements] with W[elements, columns]: with ONE distinct steering vector (an on-axis
+// SinglePoint focus -- the reference's default focal pattern -- on a mirror-symmetric array: all four images share it)
+// 2 of the matrix pipe's 16 output columns carry data.  For a lattice array the same sum is a dilated 2-D convolution
+//     out(kx, ky, k) = sum_{a, b} W(a, b) g(2 kx - a, ky - b, k)           (coset positions, table offsets as in 2e)
+// so the ROLES can be swapped: for one element row b the weights form a Toeplitz matrix over the table's x offsets,
+//     A_b[(kx, o), (ud, c)] = coefficient of g_c(ud) in out_o(kx):  (wr, -wi | wi, wr) of W(2 kx - ud, b), else 0,
+// and the table row wd = ky - b of SIXTEEN PLANES is the other operand, B[(ud, c), plane] = g_c(ud, ky - b, plane):
+//     acc_ky[(kx, o), plane] += A_b . B_{ky - b}          v_mfma_f32_16x16x32_f16, fp16 hi/lo split, 3 products.
+// M = 8 positions x (re, im) = 16/16 rows, N = 16 planes = 16/16 columns, K = 30 offsets x (re, im) -> 64 (47 - 81 % dense,
+// the Toeplitz band): ~2.6 x fewer matrix instructions than 2e's NT = 1 shape on BASELINE's grids.
+//   * Block = (coset, x part <= 8 positions, y part <= 11 positions, 16 planes), 4 waves.  Elements are walked in
+//     super-blocks of 16 (a) x 8 (b); per super-block the block evaluates ONE table of 18 x <= 30 offsets for each of its 16
+//     planes -- shared by all waves, (row, offset) pairs across the threads, the 16 planes in a register loop so that dx^2 +
+//     dy^2 is formed once per pair -- as fp16 (re, im) hi and lo words in LDS.
+//   * B fragment of lane (plane n = lane & 15, k-group g): offsets 16 s + 4 g .. + 3 of the table row = 16 contiguous
+//     bytes: one ds_read_b128 per part and K-step.  Plane stride = 8 (mod 64) words puts the 16 lanes of every b128 lane
+//     group on 16 distinct 16-byte slots (planes {0-3, 12-15} on the even ones, {4-11} one k-group further on the odd ones).
+//   * A fragments (the Toeplitz weights: 4 x 16 bytes per lane and element row) are packed once per steering table by
+//     toep_pack_k in lane order and arrive through L2, one element row ahead.
+//   * Wave w owns the y positions ky = w, w + 4, w + 8 (<= 3 accumulator tiles).  D layout: lane (g, n) holds rows
+//     4 g .. 4 g + 3 = (kx = 2 g, re), (2 g, im), (2 g + 1, re), (2 g + 1, im) of plane n -- |p| and the intensity need
+//     no cross-lane step, and the 16 lanes of a k-group write 64 contiguous bytes of z per (position, target).
+// ------------------------------------------------------------------------------------
+constexpr int TOEP_KXW = 8, TOEP_KYW = 11;         // positions per block along x / y
+constexpr int TOEP_ZB = 16;                        // planes per block (the MFMA N dimension)
+constexpr int TOEP_SA = 16, TOEP_SB = 8;           // element super-block
+constexpr int TOEP_ROWS = TOEP_SB + TOEP_KYW - 1;  // 18 table rows: wd = ky - b in [-7, 10]
+constexpr int TOEP_TW = 32;                        // words per table row: ud' = ud + 15 in [0, 30), padded to two K-steps
+constexpr int TOEP_PSZ = TOEP_ROWS * TOEP_TW + 8;  // 584 = 8 (mod 64): conflict-free ds_read_b128 (see above)
+constexpr int TOEP_WAVES = 4;
+
+struct ToepParams {
+    CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
+    int nsa16;                 // element super-block columns of 16
+    int ay_pad;                // 8 nsb
+    int targets[4];            // store targets of the column: focus * 4 + mirror image, -1 = none
+};
+
+template <int MX, int MY, bool CLAMP>
+__global__ __launch_bounds__(TOEP_WAVES * 64) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
+                                                                 float* __restrict__ inten, const ToepParams T) {
+    const CosetParams& P = T.q;
+    __shared__ __attribute__((aligned(16))) unsigned s_T[2 * TOEP_ZB * TOEP_PSZ];     // [hi | lo][plane][row][ud']
+    unsigned* const s_hi = s_T;
+    unsigned* const s_lo = s_T + TOEP_ZB * TOEP_PSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (x coset, y coset, x part, y part, plane block)
+    unsigned b = blockIdx.x;
+    const int kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks;
+    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
+    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
+    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
+    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
+    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
+    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
+    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
+    if (KX <= 0 || KY <= 0) return;                     // block-uniform
+    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
+    const int k0 = kblock * TOEP_ZB;
+    const int NC = 15 + 2 * (KX - 1) + 1;               // table columns in use: ud' = 0 .. 15 + 2 (KX - 1)
+    // zero the table once: columns past NC are never written, and their Toeplitz weights are zero -- 0 x garbage must stay 0
+    for (int q = tid; q < 2 * TOEP_ZB * TOEP_PSZ / 4; q += TOEP_WAVES * 64) reinterpret_cast<uint4*>(s_T)[q] = make_uint4(0, 0, 0, 0);
+    float dz2[TOEP_ZB];
+#pragma unroll
+    for (int z = 0; z < TOEP_ZB; ++z) {
+        const float dz = (float)(k0 + z) * P.hz - P.flat_ez;
+        dz2[z] = dz * dz;
+    }
+    // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4)
+    const int n16 = lane & 15, g = lane >> 4;
+    const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g);
+    floatx4_t acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    const int n_sb = T.nsa16 * P.nsb;
+    const float inv_nc = 1.0f / (float)NC;
+    for (int sb = 0; sb < n_sb; ++sb) {
+        const int sa = sb / P.nsb, sbb = sb - sa * P.nsb;
+        __syncthreads();                                // table free (zeroed / previous super-block consumed)
+        // ---- G tables of the 16 planes: (row, column) pairs across the threads
+        for (int idx = tid; idx < (KY + TOEP_SB - 1) * NC; idx += TOEP_WAVES * 64) {   // rows wd = -7 .. KY - 1
+            const int row = (int)(((float)idx + 0.5f) * inv_nc), col = idx - row * NC;      // exact for these small integers
+            const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - 15) - TOEP_SA * P.mx * sa);
+            const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
+            const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
+            const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
+            const float r2 = fmaf(dy, dy, dx * dx);
+            const int o = row * TOEP_TW + col;
+#pragma unroll
+            for (int z = 0; z < TOEP_ZB; ++z) {
+                float d2 = r2 + dz2[z];
+                if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                const float ri = __builtin_amdgcn_rsqf(d2);
+                const float ph = d2 * ri;
+                const float rs = ri * P.g_scale;
+                const float gr = rs * __builtin_amdgcn_cosf(ph);
+                const float gi = rs * __builtin_amdgcn_sinf(ph);
+                const half2_t hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                s_hi[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, hi);
+                s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+            }
+        }
+        __syncthreads();
+        // ---- contraction: element rows b of the super-block, this wave's y positions
+        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb) * 4 * 64 + lane;
+        uint4 an[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[q] = ab[q * 64];
+#pragma unroll
+        for (int bl = 0; bl < TOEP_SB; ++bl) {
+            Half8Bits ah[2], al[2];
+            ah[0].u = an[0]; ah[1].u = an[1]; al[0].u = an[2]; al[1].u = an[3];
+            if (bl + 1 < TOEP_SB) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) an[q] = ab[((bl + 1) * 4 + q) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int ky = wave + TOEP_WAVES * t;
+                if (ky >= KY) continue;                 // wave-uniform
+                // table row ky - bl + 7; the (7 - bl) part and the K-step are immediates
+                const unsigned w0 = bbase + (unsigned)(ky * TOEP_TW);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Half8Bits bh, bw;
+                    bh.u = *reinterpret_cast<const uint4*>(s_hi + w0 + (7 - bl) * TOEP_TW + 16 * s);
+                    bw.u = *reinterpret_cast<const uint4*>(s_lo + w0 + (7 - bl) * TOEP_TW + 16 * s);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s].h, bh.h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s].h, bh.h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s].h, bw.h, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: lane (g, n16) holds (kx = 2 g, re | im), (2 g + 1, re | im) of plane k0 + n16 for each of its ky
+    const int kz = k0 + n16;
+    if (kz >= P.nz) return;
+    const float ps = P.out_scale, is = P.out_scale * P.out_scale * P.inten_scale;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int ky = wave + TOEP_WAVES * t;
+        if (ky >= KY) continue;
+        const int j = jbase + P.my * ky;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kx = 2 * g + h;
+            if (kx >= KX) continue;
+            const int i = ibase + 2 * P.mx * kx;
+            const float re = acc[t][2 * h], im = acc[t][2 * h + 1];
+            const float m2 = fmaf(re, re, im * im);
+            const float pv = __builtin_amdgcn_sqrtf(m2) * ps, iv = m2 * is;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int code = T.targets[q];
+                if (code < 0) continue;                 // uniform
+                const int m = code & 3;
+                const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+                const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+                const long long o = (long long)(code >> 2) * P.vox + (long long)(io * P.ny + jo) * P.nz + kz;
+                if (P.flags & 1u) pmag[o] = pv;
+                if (P.flags & 2u) inten[o] = iv;
+            }
+        }
+    }
+}
+
+// Toeplitz weights of kernel 2f in MFMA lane order: afrag[(((tile nsa16 + sa) ay_pad + b) 4 + {hi s0, hi s1, lo s0, lo s1}) 64 + lane].
+// Lane (m = lane & 15 -> kx = m >> 1, o = m & 1; k-group g): k = 32 s + 8 g + jj -> offset ud' = k >> 1, part c = k & 1,
+// element column a = 16 sa + 2 kx - (ud' - 15).  grid (nsa16 * ay_pad, tiles), block 64.
+__global__ void toep_pack_k(const double* __restrict__ area, int n, const double* __restrict__ delays, const double* __restrict__ apod,
+                            const int* __restrict__ perm, double freq, double w_scale, int n_foci,
+                            const int* __restrict__ colinfo /*[tiles][32][2]*/, const int* __restrict__ cell /*[ax][ay] -> element*/,
+                            int ax, int ay, int ay_pad, uint4* __restrict__ afrag) {
+    const int lane = threadIdx.x, tile = blockIdx.y;
+    const int sa = blockIdx.x / ay_pad, b = blockIdx.x - sa * ay_pad;
+    const int m = lane & 15, g = lane >> 4, kx = m >> 1, o = m & 1;
+    const int f = colinfo[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) * 2], mirror = colinfo[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) * 2 + 1];
+    uint4* dst = afrag + ((size_t)(tile * gridDim.x + blockIdx.x)) * 4 * 64;
+    for (int s = 0; s < 2; ++s) {
+        Half8Bits hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = 32 * s + 8 * g + jj, udp = k >> 1, c = k & 1;
+            const int al = 2 * kx - (udp - 15), a = TOEP_SA * sa + al;
+            double val = 0.0;
+            if (al >= 0 && al < TOEP_SA && a < ax && b < ay && f >= 0 && f < n_foci) {
+                const int e = cell[(size_t)a * ay + b];
+                if (e >= 0) {
+                    const int es = perm[mirror * n + e];
+                    const size_t off = (size_t)f * n + es;
+                    const double cyc = freq * delays[off];
+                    const double ph = 6.283185307179586476925286766559 * (cyc - floor(cyc));
+                    const double w = apod[off] * area[es] * w_scale;
+                    const double wr = w * cos(ph), wi = w * sin(ph);
+                    val = o == 0 ? (c == 0 ? wr : -wi) : (c == 0 ? wi : wr);
+                }
+            }
+            const _Float16 h = (_Float16)(float)val;
+            hi.h[jj] = h;
+            lo.h[jj] = (_Float16)(float)(val - (double)(float)h);
+        }
+        dst[s * 64 + lane] = hi.u;
+        dst[(2 + s) * 64 + lane] = lo.u;
+    }
+}
+
+}  // namespace olx
+
+using namespace olx;
+
+void olx_pack_toep(olx_ctx* c) {
+    const olx_ctx::Lattice& A = c->lat;
+    dim3 g(c->toep_nsa16 * 8 * A.nsb, c->mp.n_tiles);
+    hipLaunchKernelGGL(toep_pack_k, g, dim3(64), 0, c->stream, c->d_area, c->n_el, c->d_delays, c->d_apod, c->d_perm, c->freq,
+                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->d_afrag);
+}
+
+template <int MX, int MY>
+static void launch_toep(olx_ctx* c, float* pm) {
+    ToepParams T;
+    T.q = c->cp; T.nsa16 = c->toep_nsa16; T.ay_pad = 8 * c->lat.nsb;
+    for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
+    const CosetParams& Q = T.q;
+    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
+    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);
+    if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, T);
+    else hipLaunchKernelGGL((field_toep_k<MX, MY, false>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, T);
+}
+
+void olx_launch_toep(olx_ctx* c, float* pm) {
+    if (c->mx == 2 && c->my == 2) launch_toep<2, 2>(c, pm);
+    else if (c->mx == 2) launch_toep<2, 1>(c, pm);
+    else if (c->my == 2) launch_toep<1, 2>(c, pm);
+    else launch_toep<1, 1>(c, pm);
+}

@@ -54,7 +54,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1]};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -289,7 +289,7 @@ static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], d
     const double ez = c->h_pos[2 * (size_t)n];
     double min_d2 = 1e300; bool clamp = false;
     const double guard = 2.0 * dmin;
-    for (int a = 0; a < 8 * nsa; ++a)
+    for (int a = 0; a < std::max(8 * nsa, 16 * ((ax + 15) / 16)); ++a)   // (kernel 2f walks the columns in super-blocks of 16)
         for (int b = 0; b < 8 * nsbp; ++b) {          // (kernel 2e's pair table also covers the padding rows)
             const double p[3] = {xs[0] + a * px, ys[0] + b * py, ez};
             double d2 = 0;
@@ -488,13 +488,16 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_coset = false;
+        c->use_coset = false; c->use_toep = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             if (coset_fill(c->nt) > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             const int want = (c->use_coset && c->nt <= 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
             if (want != c->lat.nsbp) build_slot_map(c->lat, want);
+            // kernel 2f: ONE distinct steering vector in the whole launch (an on-axis SinglePoint focus on a mirror-symmetric
+            // array): Toeplitz weights stationary, 16 planes per MFMA tile -- 2e would use 2 of 16 matrix columns
+            c->use_toep = c->use_coset && tiles.size() == 1 && total_cols == 1 && !(fv && !strcmp(fv, "lattice"));
         }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();
@@ -588,7 +591,7 @@ static int configure_variant(olx_ctx* c) {
             // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && cos_fp8(c->nt);
+                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt);
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                     c->foci_version = c->steer_version;
@@ -605,13 +608,13 @@ static int configure_variant(olx_ctx* c) {
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : ok);
+                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : ok);
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 const int kx_max = (P.nx - L.x_lo + 2 * A.mx - 1) / (2 * A.mx), ky_max = (P.ny - L.y_lo + A.my - 1) / A.my;
-                const int kxw = cos_kxw(c->nt);
+                const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
                 Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
                 Q.kblocks = (P.nz + COS_ZB - 1) / COS_ZB;
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
@@ -645,12 +648,46 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
                 }
+                if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
+                    c->toep_nsa16 = (A.ax + 15) / 16;
+                    for (int q = 0; q < 4; ++q) c->toep_targets[q] = tiles[0][0].tgt[q];
+                    if (c->cell_cap < A.cell.size()) {
+                        if (c->d_cell) hipFree(c->d_cell);
+                        c->d_cell = nullptr; c->cell_cap = 0;
+                        HIPCHK(c, hipMalloc((void**)&c->d_cell, sizeof(int) * A.cell.size()));
+                        c->cell_cap = A.cell.size();
+                    }
+                    HIPCHK(c, hipMemcpy(c->d_cell, A.cell.data(), sizeof(int) * A.cell.size(), hipMemcpyHostToDevice));
+                    const size_t need = (size_t)ntiles * c->toep_nsa16 * 8 * A.nsb * 4 * 64;
+                    if (c->afrag_cap < need) {
+                        if (c->d_afrag) hipFree(c->d_afrag);
+                        c->d_afrag = nullptr; c->afrag_cap = 0;
+                        HIPCHK(c, hipMalloc((void**)&c->d_afrag, sizeof(uint4) * need));
+                        c->afrag_cap = need;
+                    }
+                    // matrix instructions: per block and element row, 2 K-steps x 3 products for each of its KY y positions
+                    long long n_mfma = 0;
+                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
+                    for (int rx = 0; rx < 2 * A.mx; ++rx)
+                        for (int ry = 0; ry < A.my; ++ry) {
+                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                            for (int sx = 0; sx < Q.nsx; ++sx)
+                                for (int sy = 0; sy < Q.nsy; ++sy) {
+                                    const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * 6 * c->toep_nsa16 * 8 * A.nsb * Q.kblocks;
+                                }
+                        }
+                    snprintf(nmbuf, sizeof nmbuf, "field_toep_k<mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                             total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
                 const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 snprintf(nmbuf, sizeof nmbuf, "field_coset_k<nt%d,mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          c->fp8corr ? ",fp8corr" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                }
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
                 snprintf(nmbuf, sizeof nmbuf, "field_lattice_k<mt%d,nt%d,mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
@@ -705,6 +742,7 @@ static int pack_if_needed(olx_ctx* c) {
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
                            (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
+        if (c->use_lattice && c->use_toep) olx_pack_toep(c);
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -883,7 +921,7 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) olx_launch_toep(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->force_kind == 5) olx_launch_shfl(c, pm);

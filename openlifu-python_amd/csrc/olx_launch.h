@@ -9,6 +9,8 @@ bool olx_launch_shared(olx_ctx* c, float* pm);       // 2b  field_shared_k (fals
 void olx_launch_mfma(olx_ctx* c, float* pm);         // 2c  field_mfma_k
 void olx_launch_lattice(olx_ctx* c, float* pm);      // 2d  field_lattice_k
 void olx_launch_coset(olx_ctx* c, float* pm);        // 2e  field_coset_k
+void olx_launch_toep(olx_ctx* c, float* pm);         // 2f  field_toep_k (single steering column on a lattice array)
+void olx_pack_toep(olx_ctx* c);                      //     its Toeplitz weight fragments
 void olx_launch_hetero(olx_ctx* c, float* pm);       // 2h  field_hetero_k
 void olx_launch_hmarch(olx_ctx* c, float* pm);       // 2m  field_hmarch_k (marched ray sums: one launch per plane segment)
 void olx_pack_hetero(olx_ctx* c);                    //     its steering table (c->nf foci per launch tile)

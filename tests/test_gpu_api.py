@@ -262,17 +262,20 @@ def test_run_simulation_with_segmented_medium():
     target = ol.Point(position=(0, 0, 30), units="mm")
     delays, apod = proto.beamform(arr, target, params)
     dset, _ = ol.sim.run_simulation(arr, params, delays, apod, freq=400e3, amplitude=1.0)
-    assert "field_hetero_k" in ol.get_engine().ctx.field_variant()
+    assert "field_hmarch_k" in ol.get_engine().ctx.field_variant()      # elements below the medium: marched ray sums (kernel 2m)
     pos_m, _, area, _, _ = arr.element_table()
     xs, ys, zs = (np.asarray(coords[d].data) * 1e-3 for d in "xyz")
     sig, ab = co.medium_terms(params["sound_speed"].data, params["attenuation"].data, 1500.0, 400e3)
-    ref = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, delays, apod, 400e3, 1500.0, 1e5))
+    ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, delays, apod, 400e3, 1500.0, 1e5))
     assert np.abs(dset["p_min"].data - ref).max() / ref.max() <= 2e-5
+    # a laterally uniform slab: the sampled model (kernel 2h) is the same quadrature
+    smp = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, delays, apod, 400e3, 1500.0, 1e5))
+    assert np.abs(smp - ref).max() <= 1e-12 * ref.max()
     iref = 1e-4 * ref ** 2 / (2 * params["density"].data * params["sound_speed"].data)
     assert np.abs(dset["intensity"].data - iref).max() / iref.max() <= 4e-5
     uni = setup.setup_sim_scene(segm)
     ol.sim.run_simulation(arr, uni, delays, apod, freq=400e3, amplitude=1.0)
-    assert "field_hetero_k" not in ol.get_engine().ctx.field_variant()
+    assert "field_h" not in ol.get_engine().ctx.field_variant()
 
 
 def test_offset_grid_matches_reference_literal_and_oracle(golden):
