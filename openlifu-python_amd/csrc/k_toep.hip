@@ -36,7 +36,8 @@ constexpr int TOEP_SA = 16, TOEP_SB = 8;           // element super-block
 constexpr int TOEP_ROWS = TOEP_SB + TOEP_KYW - 1;  // 18 table rows: wd = ky - b in [-7, 10]
 constexpr int TOEP_TW = 32;                        // words per table row: ud' = ud + 15 in [0, 30), padded to two K-steps
 constexpr int TOEP_PSZ = TOEP_ROWS * TOEP_TW + 8;  // 584 = 8 (mod 64): conflict-free ds_read_b128 (see above)
-constexpr int TOEP_WAVES = 4;
+constexpr int TOEP_WAVES = 8;                      // wave = (y-position group w & 3, K-step w >> 2)
+constexpr int TOEP_XS = 20;                        // floats per row of the exchange tiles (16 planes + pad: 16-byte rows, banks spread)
 
 struct ToepParams {
     CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
@@ -46,13 +47,14 @@ struct ToepParams {
 };
 
 template <int MX, int MY, bool CLAMP>
-__global__ __launch_bounds__(TOEP_WAVES * 64) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
-                                                                 float* __restrict__ inten, const ToepParams T) {
+__global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
+                                                                    float* __restrict__ inten, const ToepParams T) {
     const CosetParams& P = T.q;
     __shared__ __attribute__((aligned(16))) unsigned s_T[2 * TOEP_ZB * TOEP_PSZ];     // [hi | lo][plane][row][ud']
     unsigned* const s_hi = s_T;
     unsigned* const s_lo = s_T + TOEP_ZB * TOEP_PSZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kyg = wave & 3, ks = wave >> 2;
     // block -> (x coset, y coset, x part, y part, plane block)
     unsigned b = blockIdx.x;
     const int kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks;
@@ -67,27 +69,36 @@ __global__ __launch_bounds__(TOEP_WAVES * 64) void field_toep_k(const uint4* __r
     const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
     const int k0 = kblock * TOEP_ZB;
     const int NC = 15 + 2 * (KX - 1) + 1;               // table columns in use: ud' = 0 .. 15 + 2 (KX - 1)
-    // zero the table once: columns past NC are never written, and their Toeplitz weights are zero -- 0 x garbage must stay 0
-    for (int q = tid; q < 2 * TOEP_ZB * TOEP_PSZ / 4; q += TOEP_WAVES * 64) reinterpret_cast<uint4*>(s_T)[q] = make_uint4(0, 0, 0, 0);
-    float dz2[TOEP_ZB];
+    const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
+    // columns NC .. 31 of the rows in use are never generated, and their Toeplitz weights are zero -- 0 x garbage must stay 0
+    for (int idx = tid; idx < NR * (TOEP_TW - NC); idx += TOEP_WAVES * 64) {
+        const int row = idx / (TOEP_TW - NC), col = NC + idx - row * (TOEP_TW - NC);
 #pragma unroll
-    for (int z = 0; z < TOEP_ZB; ++z) {
-        const float dz = (float)(k0 + z) * P.hz - P.flat_ez;
-        dz2[z] = dz * dz;
+        for (int z = 0; z < TOEP_ZB; ++z) { s_hi[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; s_lo[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; }
     }
-    // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4)
+    const float dz0 = (float)k0 * P.hz - P.flat_ez;
+    // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4), this wave's K-step
     const int n16 = lane & 15, g = lane >> 4;
-    const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g);
+    const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + 16 * ks);
     floatx4_t acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int n_sb = T.nsa16 * P.nsb;
     const float inv_nc = 1.0f / (float)NC;
+    OLX_STAMP(0);
     for (int sb = 0; sb < n_sb; ++sb) {
         const int sa = sb / P.nsb, sbb = sb - sa * P.nsb;
-        __syncthreads();                                // table free (zeroed / previous super-block consumed)
+        // Toeplitz weights of the super-block's 8 element rows (this wave's K-step: hi + lo = 2 x 16 bytes per lane and row),
+        // requested before the table is generated so that they arrive from L2 behind it
+        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb) * 4 * 64 + ks * 64 + lane;
+        uint4 afr[TOEP_SB][2];
+        __syncthreads();                                // table free (previous super-block consumed)
+        if (sb == 0) OLX_STAMP(1);
+        // (requested behind the barrier: __syncthreads() drains vmcnt, the loads would be waited for right there)
+#pragma unroll
+        for (int bl = 0; bl < TOEP_SB; ++bl) { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
         // ---- G tables of the 16 planes: (row, column) pairs across the threads
-        for (int idx = tid; idx < (KY + TOEP_SB - 1) * NC; idx += TOEP_WAVES * 64) {   // rows wd = -7 .. KY - 1
+        for (int idx = tid; idx < NR * NC; idx += TOEP_WAVES * 64) {
             const int row = (int)(((float)idx + 0.5f) * inv_nc), col = idx - row * NC;      // exact for these small integers
             const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - 15) - TOEP_SA * P.mx * sa);
             const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
@@ -97,7 +108,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64) void field_toep_k(const uint4* __r
             const int o = row * TOEP_TW + col;
 #pragma unroll
             for (int z = 0; z < TOEP_ZB; ++z) {
-                float d2 = r2 + dz2[z];
+                const float dz = fmaf((float)z, P.hz, dz0);
+                float d2 = fmaf(dz, dz, r2);
                 if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                 const float ri = __builtin_amdgcn_rsqf(d2);
                 const float ph = d2 * ri;
@@ -109,68 +121,86 @@ __global__ __launch_bounds__(TOEP_WAVES * 64) void field_toep_k(const uint4* __r
                 s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
             }
         }
+        if (sb == 0) OLX_STAMP(2);
         __syncthreads();
-        // ---- contraction: element rows b of the super-block, this wave's y positions
-        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb) * 4 * 64 + lane;
-        uint4 an[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) an[q] = ab[q * 64];
+        if (sb == 0) OLX_STAMP(3);
+        // ---- contraction: element rows b of the super-block, this wave's y positions and K-step
 #pragma unroll
         for (int bl = 0; bl < TOEP_SB; ++bl) {
-            Half8Bits ah[2], al[2];
-            ah[0].u = an[0]; ah[1].u = an[1]; al[0].u = an[2]; al[1].u = an[3];
-            if (bl + 1 < TOEP_SB) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) an[q] = ab[((bl + 1) * 4 + q) * 64];
-            }
+            Half8Bits ah, al;
+            ah.u = afr[bl][0]; al.u = afr[bl][1];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int ky = wave + TOEP_WAVES * t;
+                const int ky = kyg + 4 * t;
                 if (ky >= KY) continue;                 // wave-uniform
-                // table row ky - bl + 7; the (7 - bl) part and the K-step are immediates
+                // table row ky - bl + 7; the (7 - bl) part is an immediate
                 const unsigned w0 = bbase + (unsigned)(ky * TOEP_TW);
+                Half8Bits bh, bw;
+                bh.u = *reinterpret_cast<const uint4*>(s_hi + w0 + (7 - bl) * TOEP_TW);
+                bw.u = *reinterpret_cast<const uint4*>(s_lo + w0 + (7 - bl) * TOEP_TW);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[t], 0, 0, 0);
+            }
+        }
+        if (sb == 0) OLX_STAMP(4);
+    }
+    OLX_STAMP(5);
+    // ---- the two K-step halves of a y-position group meet in LDS (the table arena is free now); tile = 16 rows (kx, re | im)
+    // x 16 planes.  D layout: lane (g, n16) holds rows 4 g .. 4 g + 3 of plane n16.
+    __syncthreads();
+    float* const s_x = reinterpret_cast<float*>(s_T);
+    {
+        float* xo = s_x + (wave * 3) * 16 * TOEP_XS + n16;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    Half8Bits bh, bw;
-                    bh.u = *reinterpret_cast<const uint4*>(s_hi + w0 + (7 - bl) * TOEP_TW + 16 * s);
-                    bw.u = *reinterpret_cast<const uint4*>(s_lo + w0 + (7 - bl) * TOEP_TW + 16 * s);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s].h, bh.h, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s].h, bh.h, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s].h, bw.h, acc[t], 0, 0, 0);
-                }
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xo[(t * 16 + 4 * g + r) * TOEP_XS] = acc[t][r];
+    }
+    __syncthreads();
+    // read-out: K-step 0 waves finish tiles t = 0, 2, K-step 1 waves tile t = 1.  Lane = (output, kx, plane quad): four
+    // consecutive planes of one position -> one 16-byte store per target (64 contiguous bytes per four lanes)
+    const int out = lane >> 5, kx = (lane >> 2) & 7, pq = lane & 3;
+    const int kz = k0 + 4 * pq;
+    const float sc = out ? P.out_scale * P.out_scale * P.inten_scale : P.out_scale;
+    float* const vol = out ? inten : pmag;
+    const bool want = (P.flags & (out ? 2u : 1u)) != 0 && kx < KX && kz < P.nz;
+    const bool full4 = kz + 3 < P.nz && (P.nz & 3) == 0;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = ks ? 1 : 2 * tt;
+        if (ks && tt) break;
+        const int ky = kyg + 4 * t;
+        if (ky >= KY || !want) continue;
+        const float* xa = s_x + ((kyg * 3 + t) * 16 + 2 * kx) * TOEP_XS + 4 * pq;            // K-step 0 partial
+        const float* xb = xa + 4 * 3 * 16 * TOEP_XS;                                         // K-step 1 partial (wave + 4)
+        const float4 ra = *reinterpret_cast<const float4*>(xa), ia = *reinterpret_cast<const float4*>(xa + TOEP_XS);
+        const float4 rb = *reinterpret_cast<const float4*>(xb), ib = *reinterpret_cast<const float4*>(xb + TOEP_XS);
+        const float re[4] = {ra.x + rb.x, ra.y + rb.y, ra.z + rb.z, ra.w + rb.w};
+        const float im[4] = {ia.x + ib.x, ia.y + ib.y, ia.z + ib.z, ia.w + ib.w};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m2 = fmaf(re[e], re[e], im[e] * im[e]);
+            v[e] = (out ? m2 : __builtin_amdgcn_sqrtf(m2)) * sc;
+        }
+        const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int code = T.targets[q];
+            if (code < 0) continue;                     // uniform
+            const int m = code & 3;
+            const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+            const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+            float* dst = vol + (long long)(code >> 2) * P.vox + (long long)(io * P.ny + jo) * P.nz + kz;
+            if (full4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
             }
         }
     }
-    // ---- epilogue: lane (g, n16) holds (kx = 2 g, re | im), (2 g + 1, re | im) of plane k0 + n16 for each of its ky
-    const int kz = k0 + n16;
-    if (kz >= P.nz) return;
-    const float ps = P.out_scale, is = P.out_scale * P.out_scale * P.inten_scale;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int ky = wave + TOEP_WAVES * t;
-        if (ky >= KY) continue;
-        const int j = jbase + P.my * ky;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kx = 2 * g + h;
-            if (kx >= KX) continue;
-            const int i = ibase + 2 * P.mx * kx;
-            const float re = acc[t][2 * h], im = acc[t][2 * h + 1];
-            const float m2 = fmaf(re, re, im * im);
-            const float pv = __builtin_amdgcn_sqrtf(m2) * ps, iv = m2 * is;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int code = T.targets[q];
-                if (code < 0) continue;                 // uniform
-                const int m = code & 3;
-                const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
-                const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
-                const long long o = (long long)(code >> 2) * P.vox + (long long)(io * P.ny + jo) * P.nz + kz;
-                if (P.flags & 1u) pmag[o] = pv;
-                if (P.flags & 2u) inten[o] = iv;
-            }
-        }
-    }
+    OLX_STAMP(6);
 }
 
 // Toeplitz weights of kernel 2f in MFMA lane order: afrag[(((tile nsa16 + sa) ay_pad + b) 4 + {hi s0, hi s1, lo s0, lo s1}) 64 + lane].
@@ -216,6 +246,13 @@ __global__ void toep_pack_k(const double* __restrict__ area, int n, const double
 }  // namespace olx
 
 using namespace olx;
+
+#ifdef OLX_EXP_STAMPS
+// developer build only (tools/stamps_toep.py): per-wave phase time stamps of this kernel
+extern "C" int olx_exp_read_stamps_toep(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 void olx_pack_toep(olx_ctx* c) {
     const olx_ctx::Lattice& A = c->lat;
