@@ -1,0 +1,334 @@
+// kernel 2g (field_cosetp_k): kernel 2e's NT = 2 shape with the PLANES in the MFMA rows -- no output staging
+// gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#include "k_types.hip.h"
+#include "olx_ctx.h"
+#include "olx_launch.h"
+
+namespace olx {
+
+// ------------------------------------------------------------------------------------
+// Kernel 2e gives a wave a position grid on 2 planes and lists (plane, position) down the MFMA rows; its results then sit
+// in registers with the z neighbours of a voxel in OTHER waves, so every block transposes its whole output through LDS
+// (|p| -> staging -> barrier -> read-out over a job list -> 64-byte runs): 29 % of a wave's lifetime on the headline shard.
+// Here the block's footprint, operands, tables and arithmetic are the same, but the row map is turned:
+//   * MFMA tile = ONE position x the block's 16 planes (row = plane).  Wave w takes the positions w, w + 8, ... of the
+//     block's position grid (<= 5 tiles).  A lane then holds, for its column, rows 4 g .. 4 g + 3 = FOUR CONSECUTIVE PLANES
+//     of one voxel column: |p| / intensity in place, one 16-byte store per store target straight from the accumulators
+//     (the four lanes g = 0 .. 3 of a column write the same 64 contiguous bytes as kernel 2e's read-out).  No staging
+//     arena, no epilogue barriers, no job-list pass.
+//   * The geometry tables of the 16 planes are shared by the block: wave w still evaluates planes 2 w, 2 w + 1 (same
+//     26-row pair tables, same arithmetic), behind the block barriers that the steering-fragment staging needs anyway.
+//   * A fragment of row p (plane), k-group g: table of plane p, row ky - g + ROW0 - 4 kb - 8 sl, entries UW - 8 - 2 kx + 4 ka ..:
+//     a per-lane base (plane, g) + a wave-uniform tile offset.  Plane stride 364 words (182 = 22 (mod 32) 8-byte slots: 16 planes ->
+//     16 distinct even slots) and row stride 14 words (7 slots: the second k-group of a ds_read_b64 lane group -> the odd slots)
+//     put the 32 lanes of a ds_read_b64 group (16 planes x 2 k-groups) on 32 distinct 8-byte slots.
+// NT = 2 (9 - 16 distinct steering columns), KX <= 3: the shape of BASELINE's 8-focus shard; the other shapes stay with 2e.
+// RESULT: correct (fuzz + full-volume parity), but 0 (fp16 corrections) ... 12 % (fp8) SLOWER than kernel 2e on
+// the headline shard: the phase stamps (tools/stamps_cosetp.py) show the same ~17 k cycles between the last K-step and the last
+// store issued as 2e spends on staging + read-out -- the output phase is bound by the write drain of the 1 GB result, which every
+// block reaches at the same time, not by the LDS transposition this kernel removes (first-round start staggers of 6 - 40 k
+// cycles in 2 - 8 groups: +-0).  Kept as the measured counter-example; runs only under OLX_FIELD_VARIANT=cosetp.
+// ------------------------------------------------------------------------------------
+constexpr int CP_TW = 14;                          // words per table row (12 in use): = 2 (mod 4)
+constexpr int CP_TROWS = 26, CP_ROW0 = 15;         // pair table rows; row of offset wd = 0
+constexpr int CP_PSZ = 364;                        // words per plane table = 26 x 14; PSZ / 2 = 22 (mod 32): see above
+constexpr int CP_UW = 12;                          // table columns: ud = 2 kx - a in [-7, 4]
+constexpr int CP_MT = 5;                           // tiles (positions) per wave: ceil(33 / 8)
+
+template <int MX, int MY, bool CLAMP, bool FP8>
+__global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
+    const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
+    const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/, const CosetParams P) {
+    constexpr int NT = 2, THREADS = COS_NW * 64;
+    constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
+    constexpr int B_BYTES = 2 * 4 * NT * 2 * 64 * 16;                           // two super-blocks of steering fragments
+    constexpr int T_WORDS = COS_ZB * CP_PSZ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + 2 * T_WORDS * 4 + 64];
+    typedef uint4 (*BArr)[NT][2][64];
+    BArr s_B = reinterpret_cast<BArr>(smem);
+    unsigned* const s_hi = reinterpret_cast<unsigned*>(smem + B_BYTES);
+    unsigned* const s_lo = s_hi + T_WORDS;
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p16 = lane & 15;
+    // block -> (x coset, y coset, x part, y part, plane block); the two blocks that write the two 64-byte halves of the same
+    // 128-byte lines get ids 8 apart (same XCD under round-robin dispatch), as in kernel 2e
+    unsigned b = blockIdx.x;
+    int kblock;
+    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
+        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
+        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
+    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
+    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
+    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
+    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
+    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
+    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
+    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
+    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
+    const int npos = KX * KY;
+    if (npos <= 0) return;                              // block-uniform
+    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
+    const int k0 = kblock * COS_ZB;
+    const int ntile = (npos - wave + COS_NW - 1) / COS_NW;      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
+    // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl
+    float dz2[COS_P];
+#pragma unroll
+    for (int z = 0; z < COS_P; ++z) {
+        const float dz = (float)(k0 + wave * COS_P + z) * P.hz - P.flat_ez;
+        dz2[z] = dz * dz;
+    }
+    const int wl = lane / CP_UW, ui = lane - CP_UW * wl;
+    const bool gen_lane = wl < RPR;
+    const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
+    const int Wlane = jbase + P.uy0 + P.my * (wl - CP_ROW0);
+    const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + (CP_UW - 1 - ui);   // + z PSZ + RPR r TW
+    // fragment read offset [words] of every tile's row for K-step (0, 0): per-lane (plane, k-group) + the tile's position
+    const float inv_ky = 1.0f / (float)KY;
+    int roffT[CP_MT];
+#pragma unroll
+    for (int t = 0; t < CP_MT; ++t) {
+        const int pos = min(wave + COS_NW * t, npos - 1);
+        const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;   // exact for these small integers
+        roffT[t] = p16 * CP_PSZ + (ky - g + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx);
+    }
+    floatx4_t acc[CP_MT][NT];
+#pragma unroll
+    for (int t = 0; t < CP_MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    const int nsbp = P.nsbp;                    // even: chunks = table pairs never straddle sa
+    const int n_sb = P.nsa * nsbp;
+    constexpr int CHUNK_U4 = 2 * 4 * NT * 128, PRE = CHUNK_U4 / THREADS;
+    static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
+    uint4 pre[PRE];
+    const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * 128);
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int idx = tid + q * THREADS;
+        pre[q] = idx < n_sb * 4 * NT * 128 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
+    }
+    OLX_STAMP(0);
+    for (int sb0 = 0; sb0 < n_sb; sb0 += 2) {
+        const int sa = sb0 / nsbp, sbb0 = sb0 - sa * nsbp;       // the pair (sa, sbb0), (sa, sbb0 + 1)
+        __syncthreads();                                // previous pair consumed: steering stage and tables are free
+        if (sb0 == 0) OLX_STAMP(1);
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
+        {
+            const int nxt = (sb0 + 2) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int idx = nxt + tid + q * THREADS;
+                if (idx < lim) pre[q] = bsrc[idx];
+            }
+        }
+        // ---- G tables of planes 2 wave, 2 wave + 1: 26 rows x 12 offsets, shared by the pair's two super-blocks
+        if (k0 + wave * COS_P < P.nz) {
+            const float U = (float)(Ulane - 8 * P.mx * sa);
+            const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
+            const float dx2 = dx * dx;
+            const int Wsb = Wlane - 8 * P.my * sbb0;
+#pragma unroll 2
+            for (int r = 0; r < NROUND; ++r) {
+                const bool row_ok = gen_lane && RPR * r + wl < CP_TROWS;  // the last round may run past the table
+                const float W = (float)(Wsb + RPR * P.my * r);
+                const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
+                const float r2 = fmaf(dy, dy, dx2);
+#pragma unroll
+                for (int z = 0; z < COS_P; ++z) {
+                    float d2 = r2 + dz2[z];
+                    if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                    const float ri = __builtin_amdgcn_rsqf(d2);
+                    const float ph = d2 * ri;
+                    const float rs = ri * P.g_scale;
+                    const float gr = rs * __builtin_amdgcn_cosf(ph);
+                    const float gi = rs * __builtin_amdgcn_sinf(ph);
+                    half2_t hi;
+                    if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
+                    else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                    unsigned lo_word;
+                    if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
+                        int w = __builtin_amdgcn_cvt_pk_fp8_f32((gr - (float)hi[0]) * COS_F8_LO, (gi - (float)hi[1]) * COS_F8_LO, 0, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(gr * COS_F8_HI, gi * COS_F8_HI, w, true);
+                        lo_word = (unsigned)w;
+                    } else {
+                        lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+                    }
+                    if (row_ok) {
+                        const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
+                        s_hi[o] = __builtin_bit_cast(unsigned, hi);
+                        s_lo[o] = lo_word;
+                    }
+                }
+            }
+        }
+        if (sb0 == 0) OLX_STAMP(2);
+        __syncthreads();
+        if (sb0 == 0) OLX_STAMP(3);
+#pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sbb0 + sl >= P.nsb) break;              // padding super-block of an odd count: zero weights, nothing to do
+            if constexpr (FP8) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {         // K-step pairs (ka = 0, 1): two fp16 hi*hi products + ONE fp8 product
+                    Half8Bits bh[2][NT];
+                    intx8_t b8[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                        for (int ka = 0; ka < 2; ++ka) {
+                            bh[ka][nt].u = s_B[sl * 4 + 2 * kb + ka][nt][0][lane];
+                            const uint4 q = s_B[sl * 4 + 2 * kb + ka][nt][1][lane];
+                            b8[nt][4 * ka + 0] = (int)q.x; b8[nt][4 * ka + 1] = (int)q.y; b8[nt][4 * ka + 2] = (int)q.z; b8[nt][4 * ka + 3] = (int)q.w;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < CP_MT; ++t) {
+                        if (t >= ntile) continue;            // wave-uniform
+                        Half8Bits ah[2];
+                        intx8_t a8;
+#pragma unroll
+                        for (int ka = 0; ka < 2; ++ka) {
+                            const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;   // the pair's second super-block reads 8 table rows lower
+                            const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + roffT[t] + kso);
+                            const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + roffT[t] + kso);
+                            const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            const unsigned long long l1 = __hip_atomic_load(pl2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            ah[ka].w[0] = (unsigned)h0; ah[ka].w[1] = (unsigned)(h0 >> 32); ah[ka].w[2] = (unsigned)h1; ah[ka].w[3] = (unsigned)(h1 >> 32);
+                            a8[4 * ka + 0] = (int)(unsigned)l0; a8[4 * ka + 1] = (int)(unsigned)(l0 >> 32);
+                            a8[4 * ka + 2] = (int)(unsigned)l1; a8[4 * ka + 3] = (int)(unsigned)(l1 >> 32);
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0].h, bh[0][nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1].h, bh[1][nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)      // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
+                            acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {         // unrolled: the K-step's table offset becomes an immediate
+                    const int ka = ks & 1, kb = ks >> 1;
+                    Half8Bits bh[NT], bl[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        bh[nt].u = s_B[sl * 4 + ks][nt][0][lane];
+                        bl[nt].u = s_B[sl * 4 + ks][nt][1][lane];
+                    }
+                    const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
+#pragma unroll
+                    for (int t = 0; t < CP_MT; ++t) {
+                        if (t >= ntile) continue;            // wave-uniform
+                        Half8Bits ah, al;
+                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + roffT[t] + kso);
+                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + roffT[t] + kso);
+                        const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long l1 = __hip_atomic_load(pl2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        ah.w[0] = (unsigned)h0; ah.w[1] = (unsigned)(h0 >> 32); ah.w[2] = (unsigned)h1; ah.w[3] = (unsigned)(h1 >> 32);
+                        al.w[0] = (unsigned)l0; al.w[1] = (unsigned)(l0 >> 32); al.w[2] = (unsigned)l1; al.w[3] = (unsigned)(l1 >> 32);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (sb0 == 0) OLX_STAMP(4);
+    }
+    OLX_STAMP(5);
+    // ---- epilogue, straight from the accumulators.  Lane (g, c16): rows 4 g .. 4 g + 3 = planes k0 + 4 g .. + 3 of the tile's
+    // position, column c16 = (o, re | im).  The |p| lane (part 0) and its partner (part 1, the intensity lane) hold the same
+    // (S re)^2 + (S im)^2 after one quad swap; per pair of rows the |p| lane takes the root of the first and the partner lane of
+    // the second (handed back through the swap): one quarter-rate instruction per two rows.
+    const int c16 = lane & 15, part = c16 & 1;
+    const int kz = k0 + 4 * g;
+    if (kz >= P.nz) return;
+    const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;
+    float* const vol = part ? inten : pmag;
+    const bool want = (P.flags & (part ? 2u : 1u)) != 0;
+    const bool full4 = kz + 3 < P.nz && (P.nz & 3) == 0;
+    // store targets of this lane's column, two 16-bit codes (focus * 4 + mirror image, 0xFFFF = none) per register
+    unsigned tgt[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int4 tq = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (c16 >> 1)) * 4);
+        tgt[nt][0] = want ? (((unsigned)tq.x & 0xFFFFu) | ((unsigned)tq.y << 16)) : 0xFFFFFFFFu;
+        tgt[nt][1] = want ? (((unsigned)tq.z & 0xFFFFu) | ((unsigned)tq.w << 16)) : 0xFFFFFFFFu;
+    }
+    const int xm = P.nx - 1, ym = P.ny - 1;
+#pragma unroll
+    for (int t = 0; t < CP_MT; ++t) {
+        if (t >= ntile) continue;
+        const int pos = wave + COS_NW * t;
+        const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;
+        const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
+                const float sq0 = a0 * a0, sq1 = a1 * a1;
+                const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
+                const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
+                const float ys = quad_swap1(y);
+                v[r] = (part == 0 ? y : m0) * s_lane;
+                v[r + 1] = (part == 0 ? ys : m1) * s_lane;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned code = (tgt[nt][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                if (code == 0xFFFFu) continue;
+                const unsigned m = code & 3u;
+                const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
+                const int io = fx ? xm - i : i, jo = fy ? ym - j : j;
+                float* dst = vol + (long long)(code >> 2) * P.vox + ((long long)(io * P.ny + jo) * P.nz + kz);
+                if (full4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                }
+            }
+        }
+    }
+    OLX_STAMP(6);
+}
+
+}  // namespace olx
+
+using namespace olx;
+
+#ifdef OLX_EXP_STAMPS
+extern "C" int olx_exp_read_stamps_cosetp(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_stamps), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
+
+template <int MX, int MY>
+static void launch_cosetp(olx_ctx* c, float* pm) {
+    const CosetParams& Q = c->cp;
+    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
+    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
+    const bool clamp = c->clamp || c->lat.clamp;
+#define OLX_CP(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, Q)
+    if (c->fp8corr) { if (clamp) OLX_CP(true, true); else OLX_CP(false, true); }
+    else            { if (clamp) OLX_CP(true, false); else OLX_CP(false, false); }
+#undef OLX_CP
+}
+
+void olx_launch_cosetp(olx_ctx* c, float* pm) {
+    if (c->mx == 2 && c->my == 2) launch_cosetp<2, 2>(c, pm);
+    else if (c->mx == 2) launch_cosetp<2, 1>(c, pm);
+    else if (c->my == 2) launch_cosetp<1, 2>(c, pm);
+    else launch_cosetp<1, 1>(c, pm);
+}

@@ -540,7 +540,7 @@ def test_mirror_partner_foci_share_columns(ctx):
     ctx.field_plan((xs[0], ys[0], zs[0]), (xs[1] - xs[0],) * 3, (48,) * 3, F0, C, RHO, P0)
     name = ctx.field_variant()
     # 9 foci x 4 images = 36 vectors; centre 1, axis spokes (0, 90, 180, 270 deg) collapse to 4, diagonals to 4
-    assert ("field_mfma_k" in name or "field_coset_k" in name) and " 9 columns for 9 foci x 4 images" in name, name
+    assert ("field_mfma_k" in name or "field_coset" in name) and " 9 columns for 9 foci x 4 images" in name, name
     check(ctx, xs, ys, zs, pos_m, area, d, a, complex_out=False)
 
 
@@ -550,7 +550,7 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     (+ origin_shift voxels); full-volume parity against the oracle.  Default expectation: kernel 2e, or kernel 2f for the
     default single on-axis focus (one steering column)."""
     if expect is None:
-        expect = "field_toep_k" if (foci is None and tuple(origin_shift) == (0.0, 0.0)) else "field_coset_k"
+        expect = "field_toep_k" if (foci is None and tuple(origin_shift) == (0.0, 0.0)) else "field_coset"
     px, py = pitch_xy
     a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
     pos = np.stack([(a.ravel() - (nax - 1) / 2) * px, (b.ravel() - (nay - 1) / 2) * py, np.zeros(nax * nay)], axis=1)
@@ -566,7 +566,7 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     if slab is None:
         check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect, complex_out=False, fp8=fp8)
-        if expect in ("field_coset_k", "field_toep_k"):      # the same case with complex output: served by kernel 2d
+        if expect in ("field_coset", "field_toep_k"):      # the same case with complex output: served by kernel 2d
             check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant="field_lattice_k")
         return
     ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab,
@@ -599,7 +599,7 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), origin_shift=(3.0, -2.0), foci=[[1e-3, 2e-3, 25e-3]],
                   expect="mx1,my1")
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[1e-3, 2e-3, 25e-3], [0, 0, 30e-3]],
-                  slab=(13, 14), expect="field_coset_k")
+                  slab=(13, 14), expect="field_coset")
 
 
 @pytest.mark.parametrize("case", ["16x16", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
@@ -782,24 +782,28 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
         ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h * 1e-3
         zs = (4.0 + np.arange(n[2]) * h) * 1e-3
         got = {}
-        for fam in ("lattice", "general"):
-            monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
+        for fam in ("lattice", "auto", "cosetp", "general"):      # lattice pins kernel 2e; auto = the planner's choice (2f where it applies);
+            if fam == "auto":                                        # cosetp = kernel 2g (NT = 2 shapes only, else the planner's choice)
+                monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
+            else:
+                monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
             ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, tuple(n), F0, C, RHO, P0)
             ctx.field_launch()
             got[fam] = (ctx.field_variant(), np.stack([ctx.field_fetch(f)["pmag"] for f in range(nf)]),
                         np.stack([ctx.field_fetch(f)["intensity"] for f in range(nf)]))
-        name = got["lattice"][0]
-        seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
         assert "field_accum_k" in got["general"][0]
         ref_p, ref_i = got["general"][1], got["general"][2]
-        tol, scale_p = 4e-6, ref_p.max()
-        if fp8 and "fp8corr" in name:       # error ~ 1 / sqrt(N_eff) of the focal peak, which need not lie in these small volumes
-            w = ap * area[None, :]
-            tol = 1.2e-5 * np.sqrt(256.0 / ((w.sum(axis=1) ** 2) / (w ** 2).sum(axis=1)).min())
-            peaks = [np.abs(co.field_at_points([foci[f]], pos_m, area, d[f], ap[f], F0, C, P0))[0] for f in range(nf)]
-            scale_p = max(scale_p, max(peaks))
-        if fp8 and "field_coset_k" in name:
-            assert ("fp8corr" in name) == ("nt4" not in name), name
-        assert np.abs(got["lattice"][1] - ref_p).max() <= tol * scale_p, (case, name, nax, nay, mxv, myv, n, nf)
-        assert np.abs(got["lattice"][2] - ref_i).max() <= 2 * tol * fo.intensity_wcm2(scale_p, RHO, C), (case, name)
-    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4"} <= seen, seen
+        for fam in ("lattice", "auto", "cosetp"):
+            name = got[fam][0]
+            seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
+            tol, scale_p = 4e-6, ref_p.max()
+            if fp8 and "fp8corr" in name:       # error ~ 1 / sqrt(N_eff) of the focal peak, which need not lie in these small volumes
+                w = ap * area[None, :]
+                tol = 1.2e-5 * np.sqrt(256.0 / ((w.sum(axis=1) ** 2) / (w ** 2).sum(axis=1)).min())
+                peaks = [np.abs(co.field_at_points([foci[f]], pos_m, area, d[f], ap[f], F0, C, P0))[0] for f in range(nf)]
+                scale_p = max(scale_p, max(peaks))
+            if fp8 and "field_coset" in name:
+                assert ("fp8corr" in name) == ("nt4" not in name), name
+            assert np.abs(got[fam][1] - ref_p).max() <= tol * scale_p, (case, name, nax, nay, mxv, myv, n, nf)
+            assert np.abs(got[fam][2] - ref_i).max() <= 2 * tol * fo.intensity_wcm2(scale_p, RHO, C), (case, name)
+    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4", "field_cosetp_k|nt2", "field_toep_k"} <= seen, seen
