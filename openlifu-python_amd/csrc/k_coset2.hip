@@ -23,11 +23,10 @@ namespace olx {
 //     16 distinct even slots) and row stride 14 words (7 slots: the second k-group of a ds_read_b64 lane group -> the odd slots)
 //     put the 32 lanes of a ds_read_b64 group (16 planes x 2 k-groups) on 32 distinct 8-byte slots.
 // NT = 2 (9 - 16 distinct steering columns), KX <= 3: the shape of BASELINE's 8-focus shard; the other shapes stay with 2e.
-// RESULT: correct (fuzz + full-volume parity), but 0 (fp16 corrections) ... 12 % (fp8) SLOWER than kernel 2e on
-// the headline shard: the phase stamps (tools/stamps_cosetp.py) show the same ~17 k cycles between the last K-step and the last
-// store issued as 2e spends on staging + read-out -- the output phase is bound by the write drain of the 1 GB result, which every
-// block reaches at the same time, not by the LDS transposition this kernel removes (first-round start staggers of 6 - 40 k
-// cycles in 2 - 8 groups: +-0).  Kept as the measured counter-example; runs only under OLX_FIELD_VARIANT=cosetp.
+// Measured on the headline shard (8 foci, 256 el x 256^3, alternating runs on one box): 0.404 vs 0.430 ms with fp8 corrections,
+// 0.456 vs 0.499 ms with fp16 corrections (kernel 2e).  A first version was 12 % SLOWER: the read-out loop carried the ragged-nz
+// store form in the same body, which makes the compiler split every 16-byte store into 12 + 4 bytes (twice the store
+// instructions, and the vector memory pipe takes ~16 cycles per wave-instruction whatever its width or exec mask).
 // ------------------------------------------------------------------------------------
 constexpr int CP_TW = 14;                          // words per table row (12 in use): = 2 (mod 4)
 constexpr int CP_TROWS = 26, CP_ROW0 = 15;         // pair table rows; row of offset wd = 0
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;
     float* const vol = part ? inten : pmag;
     const bool want = (P.flags & (part ? 2u : 1u)) != 0;
-    const bool full4 = kz + 3 < P.nz && (P.nz & 3) == 0;
     // store targets of this lane's column, two 16-bit codes (focus * 4 + mirror image, 0xFFFF = none) per register
     unsigned tgt[NT][2];
 #pragma unroll
@@ -266,41 +264,51 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         tgt[nt][1] = want ? (((unsigned)tq.z & 0xFFFFu) | ((unsigned)tq.w << 16)) : 0xFFFFFFFFu;
     }
     const int xm = P.nx - 1, ym = P.ny - 1;
+    // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
+    // splits every 16-byte store into a 12-byte and a 4-byte instruction)
+    auto readout = [&](auto full_c) {
+        constexpr bool FULL4 = decltype(full_c)::value != 0;
 #pragma unroll
-    for (int t = 0; t < CP_MT; ++t) {
-        if (t >= ntile) continue;
-        const int pos = wave + COS_NW * t;
-        const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;
-        const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform
+        for (int t = 0; t < CP_MT; ++t) {
+            if (t >= ntile) continue;
+            const int pos = wave + COS_NW * t;
+            const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;
+            const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float v[4];
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
-                const float sq0 = a0 * a0, sq1 = a1 * a1;
-                const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
-                const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
-                const float ys = quad_swap1(y);
-                v[r] = (part == 0 ? y : m0) * s_lane;
-                v[r + 1] = (part == 0 ? ys : m1) * s_lane;
-            }
+                for (int r = 0; r < 4; r += 2) {
+                    const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
+                    const float sq0 = a0 * a0, sq1 = a1 * a1;
+                    const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
+                    const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
+                    const float ys = quad_swap1(y);
+                    v[r] = (part == 0 ? y : m0) * s_lane;
+                    v[r + 1] = (part == 0 ? ys : m1) * s_lane;
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned code = (tgt[nt][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                if (code == 0xFFFFu) continue;
-                const unsigned m = code & 3u;
-                const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
-                const int io = fx ? xm - i : i, jo = fy ? ym - j : j;
-                float* dst = vol + (long long)(code >> 2) * P.vox + ((long long)(io * P.ny + jo) * P.nz + kz);
-                if (full4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned code = (tgt[nt][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    if (code == 0xFFFFu) continue;
+                    const unsigned m = code & 3u;
+                    const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
+                    const int io = fx ? xm - i : i, jo = fy ? ym - j : j;
+#ifdef OLX_EXP_L2STORE
+                    float* dst = vol + ((unsigned)((io * P.ny + jo) * P.nz + kz) & 0xFFFFFu);   // A/B: stores stay cache resident
+#else
+                    float* dst = vol + (long long)(code >> 2) * P.vox + (unsigned)((io * P.ny + jo) * P.nz + kz);
+#endif
+                    if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                    }
                 }
             }
         }
-    }
+    };
+    if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
     OLX_STAMP(6);
 }
 

@@ -165,41 +165,46 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const float sc = out ? P.out_scale * P.out_scale * P.inten_scale : P.out_scale;
     float* const vol = out ? inten : pmag;
     const bool want = (P.flags & (out ? 2u : 1u)) != 0 && kx < KX && kz < P.nz;
-    const bool full4 = kz + 3 < P.nz && (P.nz & 3) == 0;
+    // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
+    // splits every 16-byte store into a 12-byte and a 4-byte instruction)
+    auto readout = [&](auto full_c) {
+        constexpr bool FULL4 = decltype(full_c)::value != 0;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int t = ks ? 1 : 2 * tt;
-        if (ks && tt) break;
-        const int ky = kyg + 4 * t;
-        if (ky >= KY || !want) continue;
-        const float* xa = s_x + ((kyg * 3 + t) * 16 + 2 * kx) * TOEP_XS + 4 * pq;            // K-step 0 partial
-        const float* xb = xa + 4 * 3 * 16 * TOEP_XS;                                         // K-step 1 partial (wave + 4)
-        const float4 ra = *reinterpret_cast<const float4*>(xa), ia = *reinterpret_cast<const float4*>(xa + TOEP_XS);
-        const float4 rb = *reinterpret_cast<const float4*>(xb), ib = *reinterpret_cast<const float4*>(xb + TOEP_XS);
-        const float re[4] = {ra.x + rb.x, ra.y + rb.y, ra.z + rb.z, ra.w + rb.w};
-        const float im[4] = {ia.x + ib.x, ia.y + ib.y, ia.z + ib.z, ia.w + ib.w};
-        float v[4];
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = ks ? 1 : 2 * tt;
+            if (ks && tt) break;
+            const int ky = kyg + 4 * t;
+            if (ky >= KY || !want) continue;
+            const float* xa = s_x + ((kyg * 3 + t) * 16 + 2 * kx) * TOEP_XS + 4 * pq;            // K-step 0 partial
+            const float* xb = xa + 4 * 3 * 16 * TOEP_XS;                                         // K-step 1 partial (wave + 4)
+            const float4 ra = *reinterpret_cast<const float4*>(xa), ia = *reinterpret_cast<const float4*>(xa + TOEP_XS);
+            const float4 rb = *reinterpret_cast<const float4*>(xb), ib = *reinterpret_cast<const float4*>(xb + TOEP_XS);
+            const float re[4] = {ra.x + rb.x, ra.y + rb.y, ra.z + rb.z, ra.w + rb.w};
+            const float im[4] = {ia.x + ib.x, ia.y + ib.y, ia.z + ib.z, ia.w + ib.w};
+            float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float m2 = fmaf(re[e], re[e], im[e] * im[e]);
-            v[e] = (out ? m2 : __builtin_amdgcn_sqrtf(m2)) * sc;
-        }
-        const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
+            for (int e = 0; e < 4; ++e) {
+                const float m2 = fmaf(re[e], re[e], im[e] * im[e]);
+                v[e] = (out ? m2 : __builtin_amdgcn_sqrtf(m2)) * sc;
+            }
+            const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int code = T.targets[q];
-            if (code < 0) continue;                     // uniform
-            const int m = code & 3;
-            const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
-            const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
-            float* dst = vol + (long long)(code >> 2) * P.vox + (long long)(io * P.ny + jo) * P.nz + kz;
-            if (full4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
+            for (int q = 0; q < 4; ++q) {
+                const int code = T.targets[q];
+                if (code < 0) continue;                     // uniform
+                const int m = code & 3;
+                const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
+                const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
+                float* dst = vol + (long long)(code >> 2) * P.vox + (unsigned)((io * P.ny + jo) * P.nz + kz);   // (uniform base + 32-bit offset)
+                if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                    for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                }
             }
         }
-    }
+    };
+    if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
     OLX_STAMP(6);
 }
 

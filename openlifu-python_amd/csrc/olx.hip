@@ -498,10 +498,17 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2f: ONE distinct steering vector in the whole launch (an on-axis SinglePoint focus on a mirror-symmetric
             // array): Toeplitz weights stationary, 16 planes per MFMA tile -- 2e would use 2 of 16 matrix columns
             c->use_toep = c->use_coset && tiles.size() == 1 && total_cols == 1 && !(fv && !strcmp(fv, "lattice"));
-            // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging).
-            // Measured 0 ... 12 % SLOWER than 2e on the headline shard (the output phase is bound by the
-            // write drain, not by the staging work it removes), so it only runs when pinned: OLX_FIELD_VARIANT=cosetp
-            c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && fv && !strcmp(fv, "cosetp");
+            // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
+            // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
+            c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
+            if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
+                for (auto& t : tiles)   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
+                    for (size_t o = 0; o < t.size() && (int)t.size() < c->nt * MFMA_COLS; ++o)
+                        if (t[o].ntgt > 2) {
+                            Col extra{t[o].f, t[o].m, 0, {-1, -1, -1, -1}};
+                            while (t[o].ntgt > 2) { extra.tgt[extra.ntgt++] = t[o].tgt[--t[o].ntgt]; t[o].tgt[t[o].ntgt] = -1; }
+                            t.push_back(extra);
+                        }
         }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();

@@ -633,9 +633,9 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
     are 3 super-block rows, so the K-slot map is padded with an empty fourth that the kernel skips (and 2d / NT = 1 / NT = 4
     never see).  Off-axis foci so that every column is distinct."""
     foci = np.array([[1e-3, 2e-3, 30e-3], [-3e-3, 1e-3, 26e-3], [2e-3, -4e-3, 22e-3]])      # 3 x 4 mirror images = 12 columns: NT = 2
-    _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci, expect="field_coset_k<nt2")
+    _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci, expect="field_cosetp_k<nt2")
     many = np.column_stack([np.linspace(-4, 4, 9), np.linspace(3, -3, 9), np.linspace(20, 30, 9)]) * 1e-3     # shifted grid: no mirror images
-    _lattice_case(ctx, 9, 23, (2.0, 2.0), (30, 50, 20), (1.0, 1.0, 1.0), origin_shift=(1.0, -2.0), foci=many, expect="field_coset_k<nt2")
+    _lattice_case(ctx, 9, 23, (2.0, 2.0), (30, 50, 20), (1.0, 1.0, 1.0), origin_shift=(1.0, -2.0), foci=many, expect="field_cosetp_k<nt2")
     _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
 
 
@@ -701,7 +701,7 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0,
                    flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
     name = ctx.field_variant()
-    assert "field_coset_k<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name
+    assert "field_cosetp_k<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name
     ctx.field_launch()
     worst = 0.0
     for f in (0, 1, 4):
@@ -782,8 +782,8 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
         ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h * 1e-3
         zs = (4.0 + np.arange(n[2]) * h) * 1e-3
         got = {}
-        for fam in ("lattice", "auto", "cosetp", "general"):      # lattice pins kernel 2e; auto = the planner's choice (2f where it applies);
-            if fam == "auto":                                        # cosetp = kernel 2g (NT = 2 shapes only, else the planner's choice)
+        for fam in ("lattice", "auto", "general"):      # lattice pins kernel 2e; auto = the planner's choice (2f / 2g where they apply)
+            if fam == "auto":
                 monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
             else:
                 monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
@@ -793,7 +793,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                         np.stack([ctx.field_fetch(f)["intensity"] for f in range(nf)]))
         assert "field_accum_k" in got["general"][0]
         ref_p, ref_i = got["general"][1], got["general"][2]
-        for fam in ("lattice", "auto", "cosetp"):
+        for fam in ("lattice", "auto"):
             name = got[fam][0]
             seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
             tol, scale_p = 4e-6, ref_p.max()
