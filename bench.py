@@ -28,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -136,7 +137,6 @@ def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 
 
 def issue_model(name, V, N, F):
     """Issue ceiling of the kernel variant in use: (peak pairs/s, model text)."""
-    import re
     m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
     mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
     ml = re.search(r"field_(?:lattice|coset|cosetp|toep)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
@@ -403,6 +403,23 @@ def main():
                 "value": pairs_per_step * k2 / e2 / 1e6, "roofline_frac": a2 / HBM_PEAK_GBS}
             out["parity"]["fp8" if other_fp8 else "fp16"] = sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])
             out["end_to_end"] = end_to_end(ol, arr, setup, target, sweep, run_idx[:F], args)
+            if off == (0.0, 0.0):   # the same shard size with the sweep's target off the array axis: no focus coincides with a mirror
+                t2 = ol.Point(position=(1.3, 0.7, 40), units="mm")   # image of itself or of a partner, every (focus, image) is a column
+                sw2 = np.array([f.get_position(units="m") for f in pattern.get_targets(t2)])
+                foci2 = sw2[od.plan_foci_orbits(sw2, -(-len(sw2) // fpg), centre_xy=centre)[0]]
+                sf.plan_foci_sweep(arr, foci2, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS, flags=out_flags,
+                                   fp8_correction=False)
+                k3 = min(args.steps, 200)
+                e3, km3 = timed("none", k3, 20)
+                name3 = ctx.field_variant()
+                m3 = re.search(r"(\d+) columns for (\d+) foci x (\d+) images", name3)
+                out["asymmetric"] = {"what": "same shard size, sweep target offset by (1.3, 0.7) mm from the array axis: the mirror folds of the "
+                                             "grid still apply, but no two (focus, image) pairs share a steering column",
+                                     "kernel": name3, "columns_computed": int(m3.group(1)) if m3 else None,
+                                     "focus_image_pairs": int(m3.group(2)) * int(m3.group(3)) if m3 else None,
+                                     "kernel_ms_avg": float(np.mean(km3)), "ms_per_step": e3 / k3 * 1e3, "steps": k3,
+                                     "value": pairs_per_step * k3 / e3 / 1e6,
+                                     "roofline_frac": alg_bytes / (float(np.mean(km3)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if args.cpu_seconds > 0 and world == 1:
             pos_m, _, area, _, _ = arr.element_table()
             out["cpu_baseline"] = cpu_baseline(pos_m, area, coords_m, run_foci[0], args.cpu_seconds)

@@ -65,31 +65,24 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
     const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
     const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
-    const int npos = KX * KY;
+    const int npos = __builtin_amdgcn_readfirstlane(KX * KY);
     if (npos <= 0) return;                              // block-uniform
     const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
     const int k0 = kblock * COS_ZB;
-    const int ntile = (npos - wave + COS_NW - 1) / COS_NW;      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
-    // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl
-    float dz2[COS_P];
-#pragma unroll
-    for (int z = 0; z < COS_P; ++z) {
-        const float dz = (float)(k0 + wave * COS_P + z) * P.hz - P.flat_ez;
-        dz2[z] = dz * dz;
-    }
-    const int wl = lane / CP_UW, ui = lane - CP_UW * wl;
-    const bool gen_lane = wl < RPR;
-    const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
-    const int Wlane = jbase + P.uy0 + P.my * (wl - CP_ROW0);
-    const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + (CP_UW - 1 - ui);   // + z PSZ + RPR r TW
-    // fragment read offset [words] of every tile's row for K-step (0, 0): per-lane (plane, k-group) + the tile's position
+    const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
+    // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl.
+    // (Its per-lane constants are formed inside the pair loop from an opaque copy of the lane index: hoisted, they would be live
+    // across the K-steps, where the fp8 shape has no register to spare -- 5 spilled registers cost 190 MB of scratch traffic.)
+    // fragment read offset [words] of a tile's row for K-step (0, 0) = per-lane part (plane, k-group) + the tile's position
+    // (wave-uniform: kept in scalar registers, added per tile and K-step group -- five registers fewer across the K-steps)
     const float inv_ky = 1.0f / (float)KY;
-    int roffT[CP_MT];
+    const int lane_off = p16 * CP_PSZ - g * CP_TW;
+    int toff[CP_MT];
 #pragma unroll
     for (int t = 0; t < CP_MT; ++t) {
         const int pos = min(wave + COS_NW * t, npos - 1);
         const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;   // exact for these small integers
-        roffT[t] = p16 * CP_PSZ + (ky - g + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx);
+        toff[t] = __builtin_amdgcn_readfirstlane((ky + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx));
     }
     floatx4_t acc[CP_MT][NT];
 #pragma unroll
@@ -110,20 +103,25 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     OLX_STAMP(0);
     for (int sb0 = 0; sb0 < n_sb; sb0 += 2) {
         const int sa = sb0 / nsbp, sbb0 = sb0 - sa * nsbp;       // the pair (sa, sbb0), (sa, sbb0 + 1)
-        __syncthreads();                                // previous pair consumed: steering stage and tables are free
+        // previous pair consumed: steering stage and tables are free.  (Not before the first pair: nothing to protect yet, and
+        // __syncthreads() drains vmcnt -- the wave would wait for its first steering loads before the tables instead of behind them.)
+        if (sb0 > 0) __syncthreads();
         if (sb0 == 0) OLX_STAMP(1);
-#pragma unroll
-        for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
-        {
-            const int nxt = (sb0 + 2) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
-#pragma unroll
-            for (int q = 0; q < PRE; ++q) {
-                const int idx = nxt + tid + q * THREADS;
-                if (idx < lim) pre[q] = bsrc[idx];
-            }
-        }
         // ---- G tables of planes 2 wave, 2 wave + 1: 26 rows x 12 offsets, shared by the pair's two super-blocks
         if (k0 + wave * COS_P < P.nz) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int wl = lane_o / CP_UW, ui = lane_o - CP_UW * wl;
+            const bool gen_lane = wl < RPR;
+            const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
+            const int Wlane = jbase + P.uy0 + P.my * (wl - CP_ROW0);
+            const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + (CP_UW - 1 - ui);   // + z PSZ + RPR r TW
+            float dz2[COS_P];
+#pragma unroll
+            for (int z = 0; z < COS_P; ++z) {
+                const float dz = (float)(k0 + wave * COS_P + z) * P.hz - P.flat_ez;
+                dz2[z] = dz * dz;
+            }
             const float U = (float)(Ulane - 8 * P.mx * sa);
             const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
             const float dx2 = dx * dx;
@@ -162,9 +160,20 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 }
             }
         }
+        // this pair's steering fragments (requested one pair ahead; the first ones arrive behind the table generation above)
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
         if (sb0 == 0) OLX_STAMP(2);
         __syncthreads();
         if (sb0 == 0) OLX_STAMP(3);
+        {   // next pair's fragments: in flight during the K-steps, drained by the next barrier
+            const int nxt = (sb0 + 2) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int idx = nxt + tid + q * THREADS;
+                if (idx < lim) pre[q] = bsrc[idx];
+            }
+        }
 #pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
         for (int sl = 0; sl < 2; ++sl) {
             if (sbb0 + sl >= P.nsb) break;              // padding super-block of an odd count: zero weights, nothing to do
@@ -187,11 +196,14 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         if (t >= ntile) continue;            // wave-uniform
                         Half8Bits ah[2];
                         intx8_t a8;
+                        int lo_t = lane_off;                 // (opaque: formed here, not hoisted into five live registers)
+                        asm volatile("" : "+v"(lo_t));
+                        const int ro = lo_t + toff[t];
 #pragma unroll
                         for (int ka = 0; ka < 2; ++ka) {
                             const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;   // the pair's second super-block reads 8 table rows lower
-                            const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + roffT[t] + kso);
-                            const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + roffT[t] + kso);
+                            const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
+                            const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + ro + kso);
                             const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -224,8 +236,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     for (int t = 0; t < CP_MT; ++t) {
                         if (t >= ntile) continue;            // wave-uniform
                         Half8Bits ah, al;
-                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + roffT[t] + kso);
-                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + roffT[t] + kso);
+                        int lo_t = lane_off;
+                        asm volatile("" : "+v"(lo_t));
+                        const int ro = lo_t + toff[t];
+                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
+                        const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + ro + kso);
                         const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         const unsigned long long l0 = __hip_atomic_load(pl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -694,7 +694,15 @@ static int configure_variant(olx_ctx* c) {
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
-                const long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                if (c->use_cosetp) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
+                    long long npos_all = 0;
+                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
+                    for (int rx = 0; rx < 2 * A.mx; ++rx)
+                        for (int ry = 0; ry < A.my; ++ry)
+                            npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
+                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          c->fp8corr ? ",fp8corr" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);

@@ -279,6 +279,29 @@ def test_solution_persistence_json_blob_and_files(tmp_path):
     assert len(empty.simulation_result) == 0
 
 
+def test_netcdf4_files_read_when_h5py_is_present(tmp_path):
+    """The reference writes Solution volumes as NetCDF-4 / HDF5 (engine='h5netcdf', plan/solution.py:515).  Where h5py is
+    installed this build reads them (dimension scales -> dims / coords); this image has no h5py, so the test is skipped here and
+    the refusal message of the test above is what a user sees."""
+    h5py = pytest.importorskip("h5py")
+    from openlifu_amd.util import netcdf
+    path = tmp_path / "ref_style.nc"
+    x = np.linspace(-1, 1, 5); z = np.linspace(0, 3, 4)
+    vol = np.arange(2 * 5 * 4, dtype=np.float32).reshape(2, 5, 4)
+    with h5py.File(path, "w") as f:
+        for name, vec in (("focal_point_index", np.arange(2)), ("x", x), ("z", z)):
+            d = f.create_dataset(name, data=vec)
+            d.make_scale(name)
+        f["x"].attrs["units"] = "mm"
+        v = f.create_dataset("p_min", data=vol)
+        for i, name in enumerate(("focal_point_index", "x", "z")):
+            v.dims[i].attach_scale(f[name])
+        v.attrs["units"] = "Pa"
+    dset = netcdf.read(path)
+    assert dset["p_min"].dims == ("focal_point_index", "x", "z") and dset["p_min"].attrs["units"] == "Pa"
+    assert np.array_equal(dset["p_min"].data, vol) and np.allclose(dset["p_min"].coords["x"].data, x)
+
+
 def test_parameter_constraints_and_analysis_report():
     """The known answers of the reference's tests/test_param_constraints.py:16-79 and
     tests/test_solution_analysis.py:10-52 (compare table, status ladder, dict / JSON round trips)."""
