@@ -71,7 +71,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int NC = 15 + 2 * (KX - 1) + 1;               // table columns in use: ud' = 0 .. 15 + 2 (KX - 1)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
     // columns NC .. 31 of the rows in use are never generated, and their Toeplitz weights are zero -- 0 x garbage must stay 0
-    for (int idx = tid; idx < NR * (TOEP_TW - NC); idx += TOEP_WAVES * 64) {
+    for (int idx = tid; idx < TOEP_ROWS * (TOEP_TW - NC); idx += TOEP_WAVES * 64) {   // (every physical row: the rows rotate, below)
         const int row = idx / (TOEP_TW - NC), col = NC + idx - row * (TOEP_TW - NC);
 #pragma unroll
         for (int z = 0; z < TOEP_ZB; ++z) { s_hi[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; s_lo[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; }
@@ -98,14 +98,22 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
 #pragma unroll
         for (int bl = 0; bl < TOEP_SB; ++bl) { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
         // ---- G tables of the 16 planes: (row, column) pairs across the threads
-        for (int idx = tid; idx < NR * NC; idx += TOEP_WAVES * 64) {
+        // Sliding rows: logical row r of super-block (sa, sbb) is the offset wd = r - 7 - 8 sbb against element row 0 of the
+        // column of super-blocks, so rows 8 .. NR - 1 of super-block sbb + 1 ARE rows 0 .. NR - 9 of super-block sbb.  The table is a
+        // ring of 18 physical rows, phys(r) = (r - 8 sbb) mod 18: only the 8 new rows are evaluated for sbb >= 1 (they overwrite the
+        // 8 rows the previous super-block no longer needs) -- 18 + 8 (nsb - 1) instead of 18 nsb rows per column of super-blocks.
+        const int n_new = sbb == 0 ? NR : min(NR, TOEP_SB);
+        const int rot = (TOEP_ROWS * 64 - TOEP_SB * sbb) % TOEP_ROWS;         // phys(r) = (r + rot) mod 18
+        for (int idx = tid; idx < n_new * NC; idx += TOEP_WAVES * 64) {
             const int row = (int)(((float)idx + 0.5f) * inv_nc), col = idx - row * NC;      // exact for these small integers
             const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - 15) - TOEP_SA * P.mx * sa);
             const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
             const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
             const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
             const float r2 = fmaf(dy, dy, dx * dx);
-            const int o = row * TOEP_TW + col;
+            int prow = row + rot;
+            prow = prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow;
+            const int o = prow * TOEP_TW + col;
 #pragma unroll
             for (int z = 0; z < TOEP_ZB; ++z) {
                 const float dz = fmaf((float)z, P.hz, dz0);
@@ -133,11 +141,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
             for (int t = 0; t < 3; ++t) {
                 const int ky = kyg + 4 * t;
                 if (ky >= KY) continue;                 // wave-uniform
-                // table row ky - bl + 7; the (7 - bl) part is an immediate
-                const unsigned w0 = bbase + (unsigned)(ky * TOEP_TW);
+                // logical table row ky - bl + 7 -> physical row of the ring (scalar arithmetic: everything here is wave-uniform)
+                int prow = ky + 7 - bl + rot;
+                prow = prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow;
+                const unsigned w0 = bbase + (unsigned)(prow * TOEP_TW);
                 Half8Bits bh, bw;
-                bh.u = *reinterpret_cast<const uint4*>(s_hi + w0 + (7 - bl) * TOEP_TW);
-                bw.u = *reinterpret_cast<const uint4*>(s_lo + w0 + (7 - bl) * TOEP_TW);
+                bh.u = *reinterpret_cast<const uint4*>(s_hi + w0);
+                bw.u = *reinterpret_cast<const uint4*>(s_lo + w0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[t], 0, 0, 0);
