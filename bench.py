@@ -439,10 +439,8 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
     pattern = ol.focal_patterns.SinglePoint(target_pressure=1e6) if len(foci) == 1 else _ListPattern(ol, foci)
     proto = ol.Protocol(pulse=ol.Pulse(frequency=F0, duration=2e-5), sequence=ol.Sequence(pulse_count=len(foci) * 2, pulse_train_interval=0),
                         focal_pattern=pattern, sim_setup=setup)
-    warm = proto.calc_solution(target, arr, simulate=True, scale=True)[0]   # warm (allocations, first-touch ...
-    for k in ("p_min", "intensity"):                                         # ... and the fetch workers' pinned staging buffers)
-        np.asarray(warm.simulation_result[k].data)
-    del warm
+    proto.calc_solution(target, arr, simulate=True, scale=True)   # warm (allocations, first touch ...
+    ol.get_engine().ctx.field_fetch_all()                         # ... and the fetch workers' pinned staging buffers); nothing kept
     t0 = time.perf_counter()
     sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
     t1 = time.perf_counter()
