@@ -139,7 +139,7 @@ def issue_model(name, V, N, F):
     """Issue ceiling of the kernel variant in use: (peak pairs/s, model text)."""
     m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
     mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-    ml = re.search(r"field_(?:lattice|coset|cosetp|toep)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+    ml = re.search(r"field_(?:lattice|coset|cosetp|toep|toepws)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
     if ml:  # lattice kernels: table arithmetic amortised; the matrix pipe is the ceiling (MFMA and VALU issue add up here)
         n_mfma = int(ml.group(5))
         floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
@@ -353,7 +353,7 @@ def main():
         traffic, traffic_src = static_traffic(kernel_name, args.grid)
         ceil_pairs, model = issue_model(kernel_name, vox_launch, N, F)
         fp8_on = "fp8corr" in kernel_name
-        lattice = "field_coset" in kernel_name or "field_lattice_k" in kernel_name or "field_toep_k" in kernel_name or "field_mfma_k" in kernel_name
+        lattice = "field_coset" in kernel_name or "field_lattice_k" in kernel_name or "field_toep" in kernel_name or "field_mfma_k" in kernel_name
         dtype = ("f32-acc/f16x2+e4m3-corr" if fp8_on else ("f32-acc/f16x3" if lattice else "f32"))
         out = {
             "metric": "Mvoxel-elements/s pressure-field accumulate", "value": value, "unit": "Mvoxel-elements/s",

@@ -3,6 +3,7 @@
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
+#include "k_toep.hip.h"
 
 namespace olx {
 
@@ -30,22 +31,6 @@ namespace olx {
 //     4 g .. 4 g + 3 = (kx = 2 g, re), (2 g, im), (2 g + 1, re), (2 g + 1, im) of plane n -- |p| and the intensity need
 //     no cross-lane step, and the 16 lanes of a k-group write 64 contiguous bytes of z per (position, target).
 // ------------------------------------------------------------------------------------
-constexpr int TOEP_KXW = 8, TOEP_KYW = 11;         // positions per block along x / y
-constexpr int TOEP_ZB = 16;                        // planes per block (the MFMA N dimension)
-constexpr int TOEP_SA = 16, TOEP_SB = 8;           // element super-block
-constexpr int TOEP_ROWS = TOEP_SB + TOEP_KYW - 1;  // 18 table rows: wd = ky - b in [-7, 10]
-constexpr int TOEP_TW = 32;                        // words per table row: ud' = ud + 15 in [0, 30), padded to two K-steps
-constexpr int TOEP_PSZ = TOEP_ROWS * TOEP_TW + 8;  // 584 = 8 (mod 64): conflict-free ds_read_b128 (see above)
-constexpr int TOEP_WAVES = 8;                      // wave = (y-position group w & 3, K-step w >> 2)
-constexpr int TOEP_XS = 20;                        // floats per row of the exchange tiles (16 planes + pad: 16-byte rows, banks spread)
-
-struct ToepParams {
-    CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
-    int nsa16;                 // element super-block columns of 16
-    int ay_pad;                // 8 nsb
-    int targets[4];            // store targets of the column: focus * 4 + mirror image, -1 = none
-};
-
 template <int MX, int MY, bool CLAMP>
 __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
                                                                     float* __restrict__ inten, const ToepParams T) {

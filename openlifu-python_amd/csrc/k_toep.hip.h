@@ -1,0 +1,24 @@
+// Shapes and parameters shared by the two forms of kernel 2f (k_toep.hip: one block per work item; k_toepws.hip: persistent,
+// wave-specialised).  No device code here.
+#pragma once
+#include "olx_params.h"
+
+namespace olx {
+
+constexpr int TOEP_KXW = 8, TOEP_KYW = 11;         // positions per block along x / y
+constexpr int TOEP_ZB = 16;                        // planes per block (the MFMA N dimension)
+constexpr int TOEP_SA = 16, TOEP_SB = 8;           // element super-block
+constexpr int TOEP_ROWS = TOEP_SB + TOEP_KYW - 1;  // 18 table rows: wd = ky - b in [-7, 10]
+constexpr int TOEP_TW = 32;                        // words per table row: ud' = ud + 15 in [0, 30), padded to two K-steps
+constexpr int TOEP_PSZ = TOEP_ROWS * TOEP_TW + 8;  // 584 = 8 (mod 64): conflict-free ds_read_b128 (see above)
+constexpr int TOEP_WAVES = 8;                      // wave = (y-position group w & 3, K-step w >> 2)
+constexpr int TOEP_XS = 20;                        // floats per row of the exchange tiles (16 planes + pad: 16-byte rows, banks spread)
+
+struct ToepParams {
+    CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
+    int nsa16;                 // element super-block columns of 16
+    int ay_pad;                // 8 nsb
+    int targets[4];            // store targets of the column: focus * 4 + mirror image, -1 = none
+};
+
+}  // namespace olx

@@ -17,6 +17,14 @@ union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
 
 template <int V> struct IntC { static constexpr int value = V; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. it waits for vmcnt(0):
+// loads requested ahead across the barrier would be waited for right there, and so would the stores of an epilogue.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2]: no LDS traffic)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }

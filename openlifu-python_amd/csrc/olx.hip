@@ -40,6 +40,7 @@ int olx_ctx_create(int device, olx_ctx** out) {
         delete c;
         return OLX_EHIP;
     }
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
     *out = c;
     return OLX_OK;
 }
@@ -498,6 +499,8 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2f: ONE distinct steering vector in the whole launch (an on-axis SinglePoint focus on a mirror-symmetric
             // array): Toeplitz weights stationary, 16 planes per MFMA tile -- 2e would use 2 of 16 matrix columns
             c->use_toep = c->use_coset && tiles.size() == 1 && total_cols == 1 && !(fv && !strcmp(fv, "lattice"));
+            // (the persistent wave-specialised form of kernel 2f, field_toepws_k, measured 13 - 35 % SLOWER -- DESIGN.md 5.4; A/B only)
+            c->toep_block = !(fv && !strcmp(fv, "toepws"));
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
@@ -688,8 +691,8 @@ static int configure_variant(olx_ctx* c) {
                                     if (KX > 0 && KY > 0) n_mfma += (long long)KY * 6 * c->toep_nsa16 * 8 * A.nsb * Q.kblocks;
                                 }
                         }
-                    snprintf(nmbuf, sizeof nmbuf, "field_toep_k<mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                    snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->toep_block ? "" : "ws", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                              total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
@@ -940,7 +943,7 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) olx_launch_toep(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->force_kind == 5) olx_launch_shfl(c, pm);

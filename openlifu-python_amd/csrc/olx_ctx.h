@@ -32,6 +32,7 @@ static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
 
 struct olx_ctx {
     int device = 0;
+    int n_cu = 0;                              // compute units of the device (persistent kernels size their grids by it)
     hipStream_t stream = nullptr;
     std::string err;
     // element table (device fp64 SoA + host copy for variant decisions)
@@ -77,6 +78,7 @@ struct olx_ctx {
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
+    bool toep_block = true;    // kernel 2f as one block per work item (field_toep_k); false (OLX_FIELD_VARIANT=toepws): persistent field_toepws_k
     bool use_toep = false; int toep_nsa16 = 0; int toep_targets[4] = {-1, -1, -1, -1};
     int* d_cell = nullptr; size_t cell_cap = 0; uint4* d_afrag = nullptr; size_t afrag_cap = 0;
     static constexpr int NBUF = 2;

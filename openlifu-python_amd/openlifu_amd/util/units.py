@@ -88,10 +88,25 @@ def getsiscale(unit: str, type: str) -> float:  # noqa: A002 - reference argumen
     return scl
 
 
+_CONV_CACHE = {}
+
+
 def getunitconversion(from_unit, to_unit, unitratio=None, constant=None) -> float:
-    """Multiplicative factor from ``from_unit`` to ``to_unit`` (util/units.py:36-94)."""
+    """Multiplicative factor from ``from_unit`` to ``to_unit`` (util/units.py:36-94).  Plain string pairs are memoised:
+    the host mirror asks for the same few conversions once per element and call (a 256-element calc_solution made ~1000
+    of them, 5 ms); errors are not cached."""
     if not from_unit:
         return 1.0
+    if unitratio is None and constant is None and isinstance(from_unit, str) and isinstance(to_unit, str):
+        key = (from_unit, to_unit)
+        hit = _CONV_CACHE.get(key)
+        if hit is None:
+            hit = _CONV_CACHE[key] = _getunitconversion(from_unit, to_unit)
+        return hit
+    return _getunitconversion(from_unit, to_unit, unitratio, constant)
+
+
+def _getunitconversion(from_unit, to_unit, unitratio=None, constant=None) -> float:
     if unitratio is not None and constant is not None:
         if "/" not in unitratio:
             raise ValueError("Conversion unit ratio must have a '/' symbol")

@@ -550,7 +550,7 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     (+ origin_shift voxels); full-volume parity against the oracle.  Default expectation: kernel 2e, or kernel 2f for the
     default single on-axis focus (one steering column)."""
     if expect is None:
-        expect = "field_toep_k" if (foci is None and tuple(origin_shift) == (0.0, 0.0)) else "field_coset"
+        expect = "field_toep" if (foci is None and tuple(origin_shift) == (0.0, 0.0)) else "field_coset"
     px, py = pitch_xy
     a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
     pos = np.stack([(a.ravel() - (nax - 1) / 2) * px, (b.ravel() - (nay - 1) / 2) * py, np.zeros(nax * nay)], axis=1)
@@ -566,7 +566,7 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     if slab is None:
         check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant=expect, complex_out=False, fp8=fp8)
-        if expect in ("field_coset", "field_toep_k"):      # the same case with complex output: served by kernel 2d
+        if expect in ("field_coset", "field_toep"):      # the same case with complex output: served by kernel 2d
             check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant="field_lattice_k")
         return
     ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab,
@@ -602,22 +602,29 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
                   slab=(13, 14), expect="field_coset")
 
 
+@pytest.mark.parametrize("form", ["block", "toepws"])
 @pytest.mark.parametrize("case", ["16x16", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
-def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
+def test_single_column_toeplitz_kernel(ctx, case, form, monkeypatch):
     """Kernel 2f (one steering column: an on-axis focus on a mirror-symmetric lattice array; Toeplitz weights stationary, 16
     planes per MFMA tile) against the fp64 oracle, full volume: element counts that pad the 16 x 8 super-blocks, arrays of
     several super-blocks in both directions with position grids cut into parts, plane counts that are not multiples of 16, an
-    x-slab launch (only the y mirror folds), angle apodization; OLX_FIELD_VARIANT=lattice pins kernel 2e on the same case."""
+    x-slab launch (only the y mirror folds), angle apodization; OLX_FIELD_VARIANT=lattice pins kernel 2e on the same case.
+    Both forms of the kernel: one block per work item (field_toep_k, default) and the persistent wave-specialised one
+    (field_toepws_k, OLX_FIELD_VARIANT=toepws: slower, kept for A/B)."""
+    if form == "toepws":
+        if case == "apodized_pinned_2e":
+            pytest.skip("2e is pinned by its own value of the variable")
+        monkeypatch.setenv("OLX_FIELD_VARIANT", "toepws")
     if case == "16x16":
-        _lattice_case(ctx, 16, 16, (3.0, 3.0), (64, 64, 48), (0.5, 0.5, 0.5), expect="field_toep_k<mx2,my2,flat,noclamp> 1 columns")
+        _lattice_case(ctx, 16, 16, (3.0, 3.0), (64, 64, 48), (0.5, 0.5, 0.5), expect=("field_toepws_k" if form == "toepws" else "field_toep_k") + "<mx2,my2,flat,noclamp> 1 columns")
     elif case == "padded20x12":
-        _lattice_case(ctx, 20, 12, (2.4, 1.8), (50, 46, 37), (0.6, 0.6, 0.5), expect="field_toep_k")
+        _lattice_case(ctx, 20, 12, (2.4, 1.8), (50, 46, 37), (0.6, 0.6, 0.5), expect="field_toep")
     elif case == "32x32_parts":       # 4 x 4 super-blocks of 8 x 8 -> 2 x 4 of 16 x 8; 11 positions per coset along x, 22 along y: parts
-        _lattice_case(ctx, 32, 32, (1.5, 1.5), (132, 132, 20), (0.25, 0.25, 0.5), foci=[[0, 0, 12e-3]], expect="field_toep_k")
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (132, 132, 20), (0.25, 0.25, 0.5), foci=[[0, 0, 12e-3]], expect="field_toep")
     elif case == "ragged_planes":
-        _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 44, 21), (1.0, 1.0, 1.0), z0=3e-3, expect="field_toep_k")
+        _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 44, 21), (1.0, 1.0, 1.0), z0=3e-3, expect="field_toep")
     elif case == "y_slab_fold_only":
-        _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[0, 0, 30e-3]], slab=(13, 14), expect="field_toep_k<mx1,my2")
+        _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[0, 0, 30e-3]], slab=(13, 14), expect="_k<mx1,my2")
     else:
         monkeypatch.setenv("OLX_FIELD_VARIANT", "lattice")
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (64, 64, 48), (0.5, 0.5, 0.5), apod=("maxangle", 35.0, 0.0), expect="field_coset_k<nt1")
@@ -651,7 +658,7 @@ def test_fp8_correction_products_are_opt_in_and_gated(ctx, monkeypatch):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, solve=True)                 # default: never fp8
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16)                             # nor at the external-delay seam
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[1:], expect=fp8, solve=True, fp8=True)   # NT = 1 (4 columns)
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep_k", solve=True, fp8=True)   # one column: kernel 2f, fp16 products only
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep", solve=True, fp8=True)   # one column: kernel 2f, fp16 products only
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True, fp8=True)       # NT = 2
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, fp8=True)   # external geometric delays: the foci are inferred
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True, fp8=True)   # z = 5 .. 28 mm: foci outside
