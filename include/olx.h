@@ -49,6 +49,9 @@ extern "C" {
 #define OLX_OUT_COMPLEX 4u   /* (re, im) interleaved, float32 */
 /* accuracy / speed option of olx_field_plan (OR-ed into flags; see the accuracy note there) */
 #define OLX_FIELD_FP8_CORRECTION 8u
+/* physics option of olx_field_plan (OR-ed into flags): optional far-field piston directivity, SURVEY.md 8(c) "flagged v1"; needs
+ * olx_set_element_apertures.  Served by the exact per-pair kernel only (kernel 2a-d). */
+#define OLX_FIELD_DIRECTIVITY 16u
 
 typedef struct olx_ctx olx_ctx;
 
@@ -84,6 +87,13 @@ int olx_sync(olx_ctx *ctx);
  * (element.py:181-184).  Order = Transducer.elements order (bit-exact indexing). */
 int olx_set_elements(olx_ctx *ctx, const double *pos_m, const double *normal,
                      const double *area_m2, int n);
+/* Element apertures for OLX_FIELD_DIRECTIVITY (the reference's sources are finite rectangles for k-Wave, kwave_if.py:34-46
+ * add_rect_element; this path's point-source sum can carry their far-field pattern instead):
+ *   D_e(v) = sinc(pi w u_x / lambda) sinc(pi l u_y / lambda),  sinc(t) = sin(t)/t,
+ * u_x, u_y = direction cosines of r_v - r_e along the element's local x axis (xaxis[N*3] = column 0 of Element.get_matrix) and
+ * y axis (normal x xaxis), formed with the clamped distance; size_m[N*2] = (w along x, l along y) = Element.get_size("m").
+ * Call after olx_set_elements (which clears them).  Definition: oracle/field_oracle.py piston_directivity. */
+int olx_set_element_apertures(olx_ctx *ctx, const double *xaxis, const double *size_m);
 
 /* ---- kernel 1: delay / apodization solve --------------------------------------------
  * DelayMethod.calc_delays (bf/delay_methods/direct.py:28-38) and

@@ -105,6 +105,75 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
 }
 
 // ------------------------------------------------------------------------------------
+// kernel 2a-d: kernel 2a with the optional far-field piston directivity (OLX_FIELD_DIRECTIVITY; definition:
+// oracle/field_oracle.py piston_directivity).  Per pair, on top of kernel 2a: the direction cosines along the element's
+// local axes (6 fma + 2 mul with 1/d), two sinc factors -- v_sin on the argument in revolutions, one v_rcp for both
+// denominators, a series value next to the origin -- i.e. 3 more transcendentals and ~16 more plain instructions.  The second
+// table entry { ex, w / (2 lambda) | ey, l / (2 lambda) } arrives through the scalar cache like the first.
+// ------------------------------------------------------------------------------------
+template <int ZPL, bool CLAMP>
+__global__ __launch_bounds__(FIELD_THREADS) void field_accum_dir_k(
+    const float* __restrict__ tab, const float* __restrict__ tab2, float* __restrict__ pmag, float* __restrict__ inten,
+    float* __restrict__ cplx, const FieldParams P) {
+    const int f = blockIdx.y;
+    const int cpr = (P.nz + ZPL - 1) / ZPL;  // chunks per row
+    const long long lane_id = (long long)blockIdx.x * FIELD_THREADS + threadIdx.x;
+    const long long rows = (long long)P.nx * P.ny;
+    const long long row = lane_id / cpr;
+    if (row >= rows) return;
+    const int chunk = (int)(lane_id - row * cpr);
+    const int i = (int)(row / P.ny), j = (int)(row - (long long)i * P.ny);
+    const int k0 = chunk * ZPL;
+    const float x = (float)(i + P.x_begin) * P.hx;
+    const float y = (float)j * P.hy;
+    float z[ZPL], re[ZPL], im[ZPL];
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) { z[q] = (float)(k0 + q) * P.hz; re[q] = 0.f; im[q] = 0.f; }
+    const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
+    constexpr float TWO_PI = 6.283185307179586f;
+    for (int e = 0; e < P.n_el; ++e) {
+        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
+        const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
+        const float phi = t[e * TAB_STRIDE + 4];
+        const float* a = tab2 + (size_t)e * 8;
+        const float dx = x - ex, dy = y - ey;
+        const float r2 = fmaf(dy, dy, dx * dx);
+        const float px = fmaf(dy, a[1], dx * a[0]), py = fmaf(dy, a[5], dx * a[4]);   // lateral part of r . ex, r . ey
+#pragma unroll
+        for (int q = 0; q < ZPL; ++q) {
+            const float dz = z[q] - ez;
+            float d2 = fmaf(dz, dz, r2);
+            if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const float ph = fmaf(d2, ri, phi);  // d [wavelengths] + phi = phase [revolutions]
+            // sinc(pi w u_x / lambda) = sin(2 pi tx) / (2 pi tx), tx = u_x w / (2 lambda) [revolutions]
+            const float tx = fmaf(dz, a[2], px) * ri * a[3], ty = fmaf(dz, a[6], py) * ri * a[7];
+            const float sx = __builtin_amdgcn_sinf(tx), sy = __builtin_amdgcn_sinf(ty);
+            const float ax = TWO_PI * tx, ay = TWO_PI * ty;
+            const float inv = __builtin_amdgcn_rcpf(ax * ay);
+            const bool nx0 = fabsf(ax) < 1e-3f, ny0 = fabsf(ay) < 1e-3f;       // next to the axis: sinc = 1 - t^2 / 6
+            float D;
+            if (!nx0 && !ny0) D = sx * sy * inv;
+            else D = (nx0 ? fmaf(ax * ax, -1.0f / 6.0f, 1.0f) : sx / ax) * (ny0 ? fmaf(ay * ay, -1.0f / 6.0f, 1.0f) : sy / ay);
+            const float s = __builtin_amdgcn_sinf(ph);
+            const float c = __builtin_amdgcn_cosf(ph);
+            const float amp = w * ri * D;
+            re[q] = fmaf(amp, c, re[q]);
+            im[q] = fmaf(amp, s, im[q]);
+        }
+    }
+    const long long base = (long long)f * P.vox + row * P.nz + k0;
+#pragma unroll
+    for (int q = 0; q < ZPL; ++q) {
+        if (k0 + q >= P.nz) continue;
+        const float m2 = fmaf(re[q], re[q], im[q] * im[q]);
+        if (P.flags & 1u) pmag[base + q] = __builtin_sqrtf(m2);
+        if (P.flags & 2u) inten[base + q] = m2 * P.inten_scale;
+        if (P.flags & 4u) { cplx[2 * (base + q)] = re[q]; cplx[2 * (base + q) + 1] = im[q]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // kernel 2b: shared-geometry accumulate.  The geometry term G(v,e) = exp(j k d)/d does not
 // depend on the focus, and for an element set that is mirror-symmetric about the grid's
 // centre plane(s) G(v,e) = G(sigma v, sigma e).  One lane therefore evaluates G once
@@ -281,6 +350,14 @@ static void launch_field(olx_ctx* c, float* pm) {
 }
 
 bool olx_launch_shared(olx_ctx* c, float* pm) { return dispatch_shared(c, pm); }
+
+void olx_launch_accum_dir(olx_ctx* c, float* pm) {
+    const FieldParams& P = c->fp;
+    const long long lanes = (long long)P.nx * P.ny * ((P.nz + 3) / 4);
+    dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci), blk(FIELD_THREADS);
+    if (c->clamp) hipLaunchKernelGGL((field_accum_dir_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_tab2, pm, c->d_inten, c->d_cplx, P);
+    else hipLaunchKernelGGL((field_accum_dir_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_tab2, pm, c->d_inten, c->d_cplx, P);
+}
 
 void olx_launch_accum(olx_ctx* c, float* pm) {
     if (c->flat) { if (c->clamp) launch_field<true, true>(c, pm); else launch_field<true, false>(c, pm); }

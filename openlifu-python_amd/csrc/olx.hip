@@ -55,7 +55,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -96,6 +96,8 @@ int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, cons
     HIPCHK(c, hipMemcpy(c->d_area, area_m2, sizeof(double) * n, hipMemcpyHostToDevice));
     c->h_pos.swap(soa);
     c->h_area.assign(area_m2, area_m2 + n);
+    c->h_nrm.assign(normal, normal + 3 * (size_t)n);
+    c->h_xaxis.clear(); c->h_size.clear();     // apertures belong to an element table
     c->n_el = n;
     c->n_foci = 0;      // steering shape depends on N
     c->planned = false;
@@ -104,6 +106,24 @@ int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, cons
 }
 
 // ---- kernel 1 -----------------------------------------------------------------------------
+int olx_set_element_apertures(olx_ctx* c, const double* xaxis, const double* size_m) {
+    if (!c) return OLX_EINVAL;
+    if (c->n_el <= 0) return fail(c, OLX_ESTATE, "olx_set_element_apertures: call olx_set_elements first");
+    if (!xaxis || !size_m) return fail(c, OLX_EINVAL, "olx_set_element_apertures: null pointer");
+    const int n = c->n_el;
+    for (int e = 0; e < n; ++e) {
+        const double* x = xaxis + 3 * e; const double* nr = c->h_nrm.data() + 3 * e;
+        const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), dot = x[0] * nr[0] + x[1] * nr[1] + x[2] * nr[2];
+        if (!(std::fabs(nx - 1.0) <= 1e-9) || !(std::fabs(dot) <= 1e-9))
+            return fail(c, OLX_EINVAL, "olx_set_element_apertures: element %d: xaxis must be a unit vector orthogonal to the normal", e);
+        if (!(size_m[2 * e] >= 0) || !(size_m[2 * e + 1] >= 0)) return fail(c, OLX_EINVAL, "olx_set_element_apertures: element %d: negative size", e);
+    }
+    c->h_xaxis.assign(xaxis, xaxis + 3 * (size_t)n);
+    c->h_size.assign(size_m, size_m + 2 * (size_t)n);
+    c->planned = false;
+    return OLX_OK;
+}
+
 int olx_bf_solve(olx_ctx* c, const double* foci_m, int n_foci, const double* M, double cs, int apod_kind,
                  double p0, double p1, double* delays_out, double* apod_out) {
     if (!c) return OLX_EINVAL;
@@ -722,7 +742,8 @@ static int configure_variant(olx_ctx* c) {
                      n_img, ntiles);
         }
     } else if (c->mx * c->my * c->nf == 1) {
-        if (c->force_kind == 5) snprintf(nmbuf, sizeof nmbuf, "field_shfl_k<%s> (elements across lanes, __shfl reduction)", c->clamp ? "clamp" : "noclamp");
+        if (c->directivity) snprintf(nmbuf, sizeof nmbuf, "field_accum_dir_k<4,%s> (piston directivity)", c->clamp ? "clamp" : "noclamp");
+        else if (c->force_kind == 5) snprintf(nmbuf, sizeof nmbuf, "field_shfl_k<%s> (elements across lanes, __shfl reduction)", c->clamp ? "clamp" : "noclamp");
         else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
         std::vector<int> perm((size_t)nm * n);
@@ -770,6 +791,25 @@ static int pack_if_needed(olx_ctx* c) {
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
                            c->p0_pa / lambda, c->freq / c->c, nullptr, nullptr, c->d_tab);
+        if (c->directivity) {   // frame table: { ex, pi w / lambda (as revolutions: w / (2 lambda)) | ey = n x ex, l / (2 lambda) } per element
+            const int n = c->n_el;
+            std::vector<float> t2((size_t)n * 8);
+            for (int e = 0; e < n; ++e) {
+                const double* x = &c->h_xaxis[3 * (size_t)e]; const double* nr = &c->h_nrm[3 * (size_t)e];
+                const double y[3] = {nr[1] * x[2] - nr[2] * x[1], nr[2] * x[0] - nr[0] * x[2], nr[0] * x[1] - nr[1] * x[0]};
+                float* t = &t2[(size_t)e * 8];
+                t[0] = (float)x[0]; t[1] = (float)x[1]; t[2] = (float)x[2]; t[3] = (float)(0.5 * c->h_size[2 * (size_t)e] / lambda);
+                t[4] = (float)y[0]; t[5] = (float)y[1]; t[6] = (float)y[2]; t[7] = (float)(0.5 * c->h_size[2 * (size_t)e + 1] / lambda);
+            }
+            if (c->tab2_cap < t2.size()) {
+                if (c->d_tab2) hipFree(c->d_tab2);
+                c->d_tab2 = nullptr; c->tab2_cap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_tab2, sizeof(float) * t2.size()));
+                c->tab2_cap = t2.size();
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_tab2, t2.data(), sizeof(float) * t2.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // t2 lives on this stack frame
+        }
     } else {
         // mirrored axes: table coordinates relative to the grid centre plane
         const double ox = c->mx == 2 ? c->grid.origin[0] + 0.5 * (c->grid.n[0] - 1) * c->grid.spacing[0] : c->grid.origin[0];
@@ -796,7 +836,9 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         if (g->n[a] < 1 || !(g->spacing[a] > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: bad grid axis %d", a);
     if (!(freq > 0) || !(cs > 0) || !(rho > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: freq, c, rho must be > 0");
     if (!(flags & (OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX))) return fail(c, OLX_EINVAL, "olx_field_plan: no outputs selected");
-    if (flags & ~(OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX | OLX_FIELD_FP8_CORRECTION)) return fail(c, OLX_EINVAL, "olx_field_plan: unknown flag bits 0x%x", flags);
+    if (flags & ~(OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX | OLX_FIELD_FP8_CORRECTION | OLX_FIELD_DIRECTIVITY)) return fail(c, OLX_EINVAL, "olx_field_plan: unknown flag bits 0x%x", flags);
+    if ((flags & OLX_FIELD_DIRECTIVITY) && c->h_xaxis.size() != 3 * (size_t)c->n_el)
+        return fail(c, OLX_ESTATE, "olx_field_plan: OLX_FIELD_DIRECTIVITY needs olx_set_element_apertures");
     olx_slab s{0, g->n[0]};
     if (slab) s = *slab;
     if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_plan: slab outside grid");
@@ -836,7 +878,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     const double dmin = 0.5 * std::min({g->spacing[0], g->spacing[1], g->spacing[2]});
     P.dmin2 = (float)(dmin * dmin * rev * rev);
     P.inten_scale = (float)(1e-4 / (2.0 * rho * cs));
-    P.vox = vox; P.flags = flags | OLX_OUT_PMAG;
+    P.vox = vox; P.flags = (flags & 7u) | OLX_OUT_PMAG;
+    c->directivity = (flags & OLX_FIELD_DIRECTIVITY) != 0;
     // variant decisions from host copies (exact, fp64)
     const int n = c->n_el;
     const double* hz = c->h_pos.data() + 2 * (size_t)n;
@@ -890,7 +933,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
     c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : !strcmp(force, "shfl") ? 5 : 0;
-    c->allow_shared = c->force_kind != 1 && c->force_kind != 5;
+    c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && !c->directivity;   // directivity: exact per-pair kernel only (v1)
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
     {   // worst-case kernel-2a/2b table over every (dx, dy, nf) the steering may select later: tiles = ceil(F / nf)
@@ -946,7 +989,8 @@ int olx_field_launch(olx_ctx* c) {
     else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
-    } else if (c->force_kind == 5) olx_launch_shfl(c, pm);
+    } else if (c->directivity) olx_launch_accum_dir(c, pm);
+    else if (c->force_kind == 5) olx_launch_shfl(c, pm);
     else olx_launch_accum(c, pm);
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
@@ -1122,6 +1166,7 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
                          double alpha_power) {
     if (!c) return OLX_EINVAL;
     if (!c->planned || c->uploaded) return fail(c, OLX_ESTATE, "olx_field_set_medium: call olx_field_plan first");
+    if (c->directivity) return fail(c, OLX_EINVAL, "olx_field_set_medium: OLX_FIELD_DIRECTIVITY is not available with a heterogeneous medium");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const olx_grid& g = c->grid;

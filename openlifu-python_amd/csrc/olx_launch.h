@@ -4,6 +4,7 @@
 #pragma once
 struct olx_ctx;
 void olx_launch_accum(olx_ctx* c, float* pm);        // 2a  field_accum_k
+void olx_launch_accum_dir(olx_ctx* c, float* pm);    // 2a-d field_accum_dir_k (piston directivity; needs c->d_tab2)
 void olx_launch_shfl(olx_ctx* c, float* pm);         // 2s  field_shfl_k (elements across lanes + __shfl: evidence variant)
 bool olx_launch_shared(olx_ctx* c, float* pm);       // 2b  field_shared_k (false: no instantiation for the planned shape)
 void olx_launch_mfma(olx_ctx* c, float* pm);         // 2c  field_mfma_k

@@ -20,6 +20,7 @@ OLX_OK, OLX_EINVAL, OLX_ESTATE, OLX_EHIP, OLX_ENOMEM, OLX_ECOMM = 0, -1, -2, -3,
 APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2
 OUT_PMAG, OUT_INTENSITY, OUT_COMPLEX = 1, 2, 4
 MEDIUM_MODELS = {"auto": 0, "sampled": 1, "marched": 2}   # OLX_MEDIUM_*
+FIELD_DIRECTIVITY = 16     # opt-in plan flag: far-field piston directivity (needs set_element_apertures; exact per-pair kernel)
 FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
 UNIQUE_ID_BYTES = 128
 
@@ -31,7 +32,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model",
+    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
 ]
 
 
@@ -103,6 +104,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_fetch_all.argtypes = [vp, fp, fp]
         lib.olx_field_medium_layering.argtypes = [vp, c_int]
         lib.olx_field_medium_model.argtypes = [vp, c_int]
+        lib.olx_set_element_apertures.argtypes = [vp, dp, dp]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -186,6 +188,12 @@ class Context:
         self._chk(self._lib.olx_set_elements(self._h, _dptr(pos_m), _dptr(normal), _dptr(area_m2), n))
         self.n_el = n
         self.n_foci = 0
+
+    def set_element_apertures(self, xaxis, size_m):
+        """Local x axes [N,3] (column 0 of Element.get_matrix) and sizes [N,2] = (w, l) in metres: what the optional piston
+        directivity (FIELD_DIRECTIVITY) needs; call after set_elements."""
+        xaxis = _f64(xaxis, (self.n_el, 3)); size_m = _f64(size_m, (self.n_el, 2))
+        self._chk(self._lib.olx_set_element_apertures(self._h, _dptr(xaxis), _dptr(size_m)))
 
     # -- kernel 1
     def bf_solve(self, foci_m, c, matrix=None, apod_kind=APOD_UNIFORM, p0=1.0, p1=0.0, want_outputs=True):

@@ -172,7 +172,8 @@ class Protocol:
             fields = simulate_foci(transducer, params, delays, apod, self.pulse.frequency,
                                    self.pulse.amplitude * voltage, steering_resident=resident, fp8_correction=fp8,
                                    lazy=not ds.HAVE_XARRAY,
-                                   hetero_planes_per_layer=int(getattr(sim_options, "options", {}).get("hetero_planes_per_layer", 1)))
+                                   hetero_planes_per_layer=int(getattr(sim_options, "options", {}).get("hetero_planes_per_layer", 1)),
+                                   directivity=str(getattr(sim_options, "options", {}).get("directivity", "0")).lower() in ("1", "true", "yes"))
             coords = params.coords
             if not ds.HAVE_XARRAY:
                 stacked = lazy_stack(fields, coords)

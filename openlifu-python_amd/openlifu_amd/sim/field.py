@@ -49,7 +49,7 @@ def _medium(params):
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
                   steering_resident=False, slab=None, fp8_correction=False, lazy=False, hetero_planes_per_layer=1,
-                  hetero_model="auto"):
+                  hetero_model="auto", directivity=False):
     """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz], or with ``lazy`` a
     ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""
     coords = params.coords
@@ -62,7 +62,7 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
                               slab=slab, steering_resident=steering_resident, medium=medium,
-                              fp8_correction=fp8_correction, lazy=lazy)
+                              fp8_correction=fp8_correction, lazy=lazy, directivity=directivity)
 
 
 def lazy_stack(result, coords, dim="focal_point_index"):
@@ -96,14 +96,15 @@ def dataset_from_fields(fields, coords, focus=None):
 def run_simulation(arr, params, delays=None, apod=None, freq: float = 1e6, cycles: float = 20,
                    amplitude: float = 1, dt: float = 0, t_end: float = 0, cfl: float = 0.5,
                    bli_tolerance: float = 0.05, upsampling_rate: int = 5, gpu: bool = True,
-                   ref_values_only: bool = False):
+                   ref_values_only: bool = False, directivity: bool = False):
     n = arr.numelements()
     delays = np.zeros(n) if delays is None else np.asarray(delays, dtype=np.float64)
     apod = np.ones(n) if apod is None else np.asarray(apod, dtype=np.float64)
     if delays.shape != (n,) or apod.shape != (n,):
         raise ValueError(f"delays and apod must have shape ({n},), got {delays.shape} and {apod.shape}")
     logging.info("Running simulation")
-    fields = simulate_foci(arr, params, delays[None, :], apod[None, :], freq, amplitude)
+    # (directivity: this path's extension -- the far-field pattern of the rectangular elements k-Wave models as finite sources)
+    fields = simulate_foci(arr, params, delays[None, :], apod[None, :], freq, amplitude, directivity=directivity)
     logging.info("Simulation Complete")
     dataset = dataset_from_fields(fields, params.coords, focus=0)
     raw = {"p_max": fields["pmag"][0], "p_min": -fields["pmag"][0], "backend": "openlifu_amd/hip-gfx950"}

@@ -76,6 +76,18 @@ class Transducer:
         pin = np.array([el.pin for el in self.elements], dtype=np.int32)
         return pos, np.ascontiguousarray(normal), area, index, pin
 
+    def element_apertures(self):
+        """(xaxis[N,3], size_m[N,2]): column 0 of Element.get_matrix() (xdc/element.py:200-214) and Element.get_size("m")
+        (xdc/element.py:174-179) -- the element frames the optional piston directivity of the field kernels needs."""
+        n = len(self.elements)
+        ori = np.empty((n, 3)); size = np.empty((n, 2))
+        for i, el in enumerate(self.elements):
+            s = getunitconversion(el.units, "m")
+            ori[i] = el.orientation
+            size[i] = (el.size[0] * s, el.size[1] * s)
+        xaxis = rotation_from_angles(ori[:, 0], ori[:, 1], ori[:, 2])[:, :, 0] if n else np.empty((0, 3))
+        return np.ascontiguousarray(xaxis), size
+
     def table_key(self):
         """Cheap fingerprint used by the engine to avoid re-uploading an unchanged table."""
         pos, nrm, area, _, _ = self.element_table()

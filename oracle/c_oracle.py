@@ -29,6 +29,8 @@ def lib():
         _lib.olo_field_grid.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int,
                                         dp, dp, dp, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_grid_dir.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_points.argtypes = [dp, ctypes.c_long, dp, dp, dp, ctypes.c_int,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_grid_hetero.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp,
@@ -61,7 +63,8 @@ def _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa):
 
 
 def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0,
-                  dmin=None, nthreads=0):
+                  dmin=None, nthreads=0, directivity=None):
+    """directivity = (xaxis [N,3], normal [N,3], size_m [N,2]): the optional piston factor (olo_field_grid_dir)."""
     xs = np.ascontiguousarray(xs_m, dtype=np.float64)
     ys = np.ascontiguousarray(ys_m, dtype=np.float64)
     zs = np.ascontiguousarray(zs_m, dtype=np.float64)
@@ -69,6 +72,13 @@ def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c, p0_
         dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
     pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
     re = np.empty((len(xs), len(ys), len(zs))); im = np.empty_like(re)
+    if directivity is not None:
+        ex = np.asarray(directivity[0], dtype=np.float64); nrm = np.asarray(directivity[1], dtype=np.float64)
+        frames = np.ascontiguousarray(np.concatenate([ex, np.cross(nrm, ex)], axis=1))
+        half = np.ascontiguousarray(np.pi * np.asarray(directivity[2], dtype=np.float64) / (c / freq))
+        lib().olo_field_grid_dir(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(pos), _p(w), _p(phi), _p(frames), _p(half),
+                                 len(w), k, dmin, nthreads, _p(re), _p(im))
+        return re + 1j * im
     lib().olo_field_grid(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(pos), _p(w),
                          _p(phi), len(w), k, dmin, nthreads, _p(re), _p(im))
     return re + 1j * im

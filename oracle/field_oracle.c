@@ -72,6 +72,52 @@ int olo_field_points(const double *pts, long npts, const double *pos, const doub
     return 0;
 }
 
+/* ---- optional far-field piston directivity (SURVEY.md 8(c) "flagged v1"; the build's definition, PARITY UNPINNED) --------------
+ * The reference's k-Wave model has finite rectangular sources (kwave_if.py:34-46 add_rect_element); the point-source sum above can
+ * carry the far-field pattern of a w x l rectangular piston instead:
+ *     D_e(v) = sinc(pi w u_x / lambda) sinc(pi l u_y / lambda),   sinc(t) = sin(t) / t,
+ * u_x, u_y = direction cosines of r_v - r_e along the element's local x and y axes (ex = pose column 0, ey = n x ex), formed with the
+ * same clamped distance d as the amplitude.  frames [n][6] = {ex, ey}, half [n][2] = {pi w / lambda, pi l / lambda}. */
+static inline double sinc1(double t) { return fabs(t) < 1e-8 ? 1.0 : sin(t) / t; }
+
+static inline void accumulate_dir(double x, double y, double z, const double *pos, const double *w, const double *phi,
+                                  const double *frames, const double *half, int n, double k, double dmin, double *re, double *im) {
+    double sr = 0.0, si = 0.0;
+    for (int e = 0; e < n; ++e) {
+        double dx = x - pos[3 * e], dy = y - pos[3 * e + 1], dz = z - pos[3 * e + 2];
+        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < dmin) d = dmin;
+        const double *f = frames + 6 * e;
+        const double ux = (dx * f[0] + dy * f[1] + dz * f[2]) / d, uy = (dx * f[3] + dy * f[4] + dz * f[5]) / d;
+        const double D = sinc1(half[2 * e] * ux) * sinc1(half[2 * e + 1] * uy);
+        double s, c;
+        sincos(k * d + phi[e], &s, &c);
+        double a = w[e] * D / d;
+        sr += a * c;
+        si += a * s;
+    }
+    *re = sr;
+    *im = si;
+}
+
+int olo_field_grid_dir(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz, const double *pos,
+                       const double *w, const double *phi, const double *frames, const double *half, int n, double k,
+                       double dmin, int nthreads, double *re_out, double *im_out) {
+    long nxy = (long)nx * ny;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (long ij = 0; ij < nxy; ++ij) {
+        int i = (int)(ij / ny), j = (int)(ij % ny);
+        for (int kz = 0; kz < nz; ++kz) {
+            size_t o = (size_t)ij * nz + kz;
+            accumulate_dir(xs[i], ys[j], zs[kz], pos, w, phi, frames, half, n, k, dmin, &re_out[o], &im_out[o]);
+        }
+    }
+    return 0;
+}
+
 int olo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -35,9 +35,23 @@ def element_weights(area_m2, apod, p0_pa, freq, c):
     return np.asarray(apod, dtype=np.float64) * p0_pa * np.asarray(area_m2, dtype=np.float64) / lam
 
 
+def piston_directivity(v, d, xaxis, normal, size_m, freq, c):
+    """Optional far-field piston factor (SURVEY 8(c) "flagged v1"; the build's definition, parity unpinned):
+    D = sinc(pi w u_x / lambda) sinc(pi l u_y / lambda), sinc(t) = sin(t)/t, with u_x, u_y the direction cosines of
+    v = r_v - r_e [..., N, 3] along the element's local axes ex = xaxis, ey = normal x ex, formed with the (clamped) distance d."""
+    ex = np.asarray(xaxis, dtype=np.float64)
+    ey = np.cross(np.asarray(normal, dtype=np.float64), ex)
+    lam = c / freq
+    size = np.asarray(size_m, dtype=np.float64)
+    ux = (v * ex).sum(axis=-1) / d
+    uy = (v * ey).sum(axis=-1) / d
+    return np.sinc(size[:, 0] * ux / lam) * np.sinc(size[:, 1] * uy / lam)      # np.sinc(x) = sin(pi x) / (pi x)
+
+
 def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0,
-                    dmin=0.0, chunk=8192):
-    """complex128 p at arbitrary points [P,3] for ONE focus (delays[N], apod[N])."""
+                    dmin=0.0, chunk=8192, directivity=None):
+    """complex128 p at arbitrary points [P,3] for ONE focus (delays[N], apod[N]).  directivity = (xaxis [N,3], normal [N,3],
+    size_m [N,2]) switches the optional piston factor on."""
     pts = np.atleast_2d(np.asarray(points_m, dtype=np.float64))
     pos = np.asarray(pos_m, dtype=np.float64)
     w = element_weights(area_m2, apod, p0_pa, freq, c)
@@ -49,7 +63,10 @@ def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0
         d = np.sqrt((v * v).sum(axis=2))
         if dmin > 0:
             d = np.maximum(d, dmin)
-        out[s:s + chunk] = ((w[None, :] / d) * np.exp(1j * (k * d + phi[None, :]))).sum(axis=1)
+        amp = w[None, :] / d
+        if directivity is not None:
+            amp = amp * piston_directivity(v, d, directivity[0], directivity[1], directivity[2], freq, c)
+        out[s:s + chunk] = (amp * np.exp(1j * (k * d + phi[None, :]))).sum(axis=1)
     return out
 
 
@@ -61,12 +78,12 @@ def grid_points(xs_m, ys_m, zs_m):
 
 
 def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c,
-                  p0_pa=1.0, dmin=None):
+                  p0_pa=1.0, dmin=None, directivity=None):
     """complex128 p[nx,ny,nz] for one focus.  dmin defaults to spacing/2."""
     if dmin is None:
         dmin = 0.5 * float(xs_m[1] - xs_m[0]) if len(xs_m) > 1 else 0.0
     p = field_at_points(grid_points(xs_m, ys_m, zs_m), pos_m, area_m2, delays_s, apod,
-                        freq, c, p0_pa, dmin)
+                        freq, c, p0_pa, dmin, directivity=directivity)
     return p.reshape(len(xs_m), len(ys_m), len(zs_m))
 
 

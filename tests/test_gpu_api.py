@@ -278,6 +278,32 @@ def test_run_simulation_with_segmented_medium():
     assert "field_h" not in ol.get_engine().ctx.field_variant()
 
 
+def test_run_simulation_with_piston_directivity():
+    """run_simulation(..., directivity=True) and SimSetup.options["directivity"]: the element frames and sizes of the Transducer reach
+    the kernel (Element.get_matrix column 0, Element.get_size) -- checked against the fp64 oracle fed from the same Transducer."""
+    from oracle import bf_oracle as bo
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    for i, el in enumerate(arr.elements):           # tilt the elements a little so that the frames matter
+        el.orientation = np.array([0.05 * np.sin(i), 0.04 * np.cos(2 * i), 0.3 * np.sin(3 * i)])
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 36))
+    params = setup.setup_sim_scene(ol.seg_methods.UniformWater())
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup)
+    target = ol.Point(position=(0, 0, 30), units="mm")
+    delays, apod = proto.beamform(arr, target, params)
+    dset, _ = ol.sim.run_simulation(arr, params, delays, apod, freq=400e3, amplitude=1.0, directivity=True)
+    assert "field_accum_dir_k" in ol.get_engine().ctx.field_variant()
+    pos_m, nrm, area, _, _ = arr.element_table()
+    xaxis, size_m = arr.element_apertures()
+    ori = np.array([el.orientation for el in arr.elements])
+    assert np.allclose(xaxis, bo.element_rotations(ori)[:, :, 0]) and np.allclose(size_m, 3.6e-3)
+    xs, ys, zs = (np.asarray(setup.get_coords()[d].data) * 1e-3 for d in "xyz")
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, delays, apod, 400e3, 1500.0, 1e5, directivity=(xaxis, nrm, size_m)))
+    assert np.abs(dset["p_min"].data - ref).max() / ref.max() <= 1e-5
+    setup.options["directivity"] = "1"
+    sol, _, _ = proto.calc_solution(target, arr, simulate=True, scale=False)
+    assert np.abs(sol.simulation_result["p_min"].data[0] - ref).max() / ref.max() <= 1e-5
+
+
 def test_offset_grid_matches_reference_literal_and_oracle(golden):
     """get_offset_grid on the device: (i) the reference's own test (tests/test_offset_grid.py:10-58, literal kept as
     golden G7) called the way that test calls it -- a Dataset, focus [0, 0, 1], as_dataset=False; (ii) an oblique

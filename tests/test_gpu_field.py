@@ -529,6 +529,44 @@ def test_c5_skull_slab_256cubed_marched(ctx):
     assert np.array_equal(ctx.field_fetch(3, want=("pmag",))["pmag"], got[1][64:128])
 
 
+def test_piston_directivity_opt_in(ctx):
+    """OLX_FIELD_DIRECTIVITY (optional far-field piston factor, SURVEY 8(c) "flagged v1"): jittered, tilted 8 x 8 array with its real
+    element frames, two foci, full volume against the fp64 oracle of the same definition (incl. voxels next to an element axis and a grid
+    through the element plane: clamp); needs the apertures, is refused with a heterogeneous medium, and leaves the default path alone."""
+    pos, ori, size = synthetic_array(8, 8, 4.0, jitter=True)
+    foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 28e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 50.0, 0.0))
+    R = bo.element_rotations(ori)
+    xaxis, normal, size_m = R[:, :, 0], R[:, :, 2], size * 1e-3
+    flags = nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX
+    for z0, expect in ((5e-3, "field_accum_dir_k<4,noclamp>"), (-2e-3, "field_accum_dir_k<4,clamp>")):
+        xs = np.linspace(-15e-3, 15e-3, 31); ys = np.linspace(-10e-3, 10e-3, 21); zs = z0 + np.arange(30) * 1e-3
+        h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+        with pytest.raises((nat.NativeError, ValueError, RuntimeError)):      # apertures first
+            ctx.set_elements(pos_m, normal, area); ctx.set_steering(d, a)
+            ctx.field_plan((xs[0], ys[0], zs[0]), h, (31, 21, 30), F0, C, RHO, P0, flags=flags | nat.FIELD_DIRECTIVITY)
+        ctx.set_element_apertures(xaxis, size_m)
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, (31, 21, 30), F0, C, RHO, P0, flags=flags | nat.FIELD_DIRECTIVITY)
+        assert expect in ctx.field_variant(), ctx.field_variant()
+        ctx.field_launch()
+        plain = None
+        for f in range(2):
+            out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
+            ref = co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * min(h), directivity=(xaxis, normal, size_m))
+            mx = np.abs(ref).max()
+            assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= TOL_P
+            assert np.abs(out["complex"] - ref).max() / mx <= 3 * TOL_P
+            plain = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * min(h)))
+            assert np.abs(np.abs(ref) - plain).max() / plain.max() > 0.02          # the factor matters
+        cvol = np.full((31, 21, 30), 1500.0); cvol[:, :, 12:15] = 2800.0
+        with pytest.raises((nat.NativeError, ValueError, RuntimeError)):
+            ctx.field_set_medium(cvol, None, None)
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, (31, 21, 30), F0, C, RHO, P0, flags=flags)      # not asked for: kernel 2a as before
+        assert "field_accum_k" in ctx.field_variant() or "field_shared_k" in ctx.field_variant() or "field_mfma_k" in ctx.field_variant()
+        ctx.field_launch()
+        assert np.abs(ctx.field_fetch(1)["pmag"] - plain).max() / plain.max() <= TOL_P
+
+
 def test_mirror_partner_foci_share_columns(ctx):
     """A Wheel's spokes come in mirror orbits: the steering vector of spoke -theta seen through the y-mirror
     equals spoke +theta's, so kernel 2c accumulates one column for both and stores it to both volumes.  The

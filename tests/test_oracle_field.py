@@ -171,3 +171,34 @@ def test_hetero_marched_definition():
     pos_bad = pos.copy(); pos_bad[3, 2] = zs[nontriv[0]]
     with pytest.raises(ValueError):
         co.field_hetero_march(xs, ys, zs, sig, ab, pos_bad, *args[1:])
+
+
+def test_piston_directivity_definition():
+    """Optional far-field piston factor (SURVEY 8(c) "flagged v1"): D = sinc(pi w u_x / lambda) sinc(pi l u_y / lambda).  Known answers:
+    1 on the element's axis; the first null where w u_x = lambda; NumPy == C; a zero-size element is a point source."""
+    e0 = np.array([[0.0, 0.0, 0.0]]); ex = np.array([[1.0, 0.0, 0.0]]); nz = np.array([[0.0, 0.0, 1.0]])
+    w = 2 * LAM
+    size = np.array([[w, 0.5 * LAM]])
+    kw = dict(freq=F0, c=C, p0_pa=1.0)
+    on_axis = np.array([[0.0, 0.0, 30e-3]])
+    p_pt = fo.field_at_points(on_axis, e0, [w * 0.5 * LAM], [0.0], [1.0], **kw)
+    p_d = fo.field_at_points(on_axis, e0, [w * 0.5 * LAM], [0.0], [1.0], directivity=(ex, nz, size), **kw)
+    assert np.isclose(p_d[0], p_pt[0], rtol=1e-14)
+    r = 40e-3                                            # first null in the x-z plane: sin(theta) = lambda / w = 1/2
+    null = np.array([[r * 0.5, 0.0, r * np.sqrt(0.75)]])
+    assert abs(fo.field_at_points(null, e0, [1e-6], [0.0], [1.0], directivity=(ex, nz, size), **kw)[0]) <= 1e-15 * abs(p_pt[0])
+    yz = np.array([[0.0, r * 0.6, r * 0.8]])            # y-z plane: only the l factor, sinc(pi l u_y / lambda) with l u_y / lambda = 0.3
+    ratio = fo.field_at_points(yz, e0, [1e-6], [0.0], [1.0], directivity=(ex, nz, size), **kw)[0] / fo.field_at_points(yz, e0, [1e-6], [0.0], [1.0], **kw)[0]
+    assert np.isclose(ratio, np.sinc(0.3), rtol=1e-13)
+    rng = np.random.default_rng(147)
+    pos = np.column_stack([rng.uniform(-6e-3, 6e-3, 9), rng.uniform(-6e-3, 6e-3, 9), rng.uniform(-0.2e-3, 0.2e-3, 9)])
+    th = rng.uniform(-0.2, 0.2, 9)
+    exs = np.column_stack([np.cos(th), np.zeros(9), -np.sin(th)]); nrm = np.column_stack([np.sin(th), np.zeros(9), np.cos(th)])
+    sizes = np.tile([2.7e-3, 2.2e-3], (9, 1)); area = sizes[:, 0] * sizes[:, 1]
+    d = rng.uniform(0, 2e-6, 9); a = rng.uniform(0.3, 1, 9)
+    xs = np.linspace(-8e-3, 8e-3, 9); ys = np.linspace(-6e-3, 6e-3, 7); zs = 2e-3 + np.arange(10) * 1e-3
+    p1 = fo.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5, directivity=(exs, nrm, sizes))
+    p2 = co.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5, directivity=(exs, nrm, sizes))
+    assert np.abs(p1 - p2).max() <= 1e-12 * np.abs(p1).max()
+    p3 = co.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5, directivity=(exs, nrm, np.zeros_like(sizes)))
+    assert np.abs(p3 - co.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5)).max() <= 1e-12 * np.abs(p3).max()
