@@ -41,8 +41,14 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kyg = wave & 3, ks = wave >> 2;
     // block -> (x coset, y coset, x part, y part, plane block)
+    // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart -- the same XCD, i.e. the same
+    // L2, under round-robin dispatch -- as in kernels 2e / 2g)
     unsigned b = blockIdx.x;
-    const int kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks;
+    int kblock;
+    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
+        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
+        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
+    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
     const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
     const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
     const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
