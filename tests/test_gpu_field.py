@@ -1,6 +1,8 @@
 """Kernel 2 (field_accum_k) through the C-ABI vs the fp64 oracle.
 Gate (north_star / SURVEY 8(d)): max_v | |p_gpu| - |p_oracle| | / max_v |p_oracle| <= 1e-5 on fp32
 pressure magnitude; intensity 2e-5.  Full-size (256^3) checks use size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -809,7 +811,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
     seen = set()
     if fp8:
         monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
-    for case in range(40):
+    for case in range(int(os.environ.get("OLX_FUZZ_CASES", "40"))):      # (more cases: a one-off soak run, OLX_FUZZ_CASES=400)
         nax, nay = int(rng.integers(4, 19)), int(rng.integers(4, 19))
         mxv, myv = int(rng.integers(1, 7)), int(rng.integers(1, 7))
         h = float(rng.choice([0.5, 0.75, 1.0]))
@@ -841,7 +843,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
         for fam in ("lattice", "auto"):
             name = got[fam][0]
             seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
-            tol, scale_p = 4e-6, ref_p.max()
+            tol, scale_p = 5e-6, ref_p.max()      # (the gate is 1e-5; the kernels sit at 1 - 4e-6 of the volume maximum in these corners)
             if fp8 and "fp8corr" in name:       # error ~ 1 / sqrt(N_eff) of the focal peak, which need not lie in these small volumes
                 w = ap * area[None, :]
                 tol = 1.2e-5 * np.sqrt(256.0 / ((w.sum(axis=1) ** 2) / (w ** 2).sum(axis=1)).min())
