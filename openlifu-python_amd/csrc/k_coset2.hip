@@ -108,6 +108,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         if (sb0 > 0) __syncthreads();
         if (sb0 == 0) OLX_STAMP(1);
         // ---- G tables of planes 2 wave, 2 wave + 1: 26 rows x 12 offsets, shared by the pair's two super-blocks
+        // (fp8 shape: table generation at raised priority -- the waves a block's K-steps wait for get the VALU first: -2 ... -4 %;
+        // with fp16 corrections the matrix pipe is the scarcer resource and the same setting costs 1.5 %, priority on the K-steps 2.5 %)
+        if constexpr (FP8) __builtin_amdgcn_s_setprio(1);
         if (k0 + wave * COS_P < P.nz) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 }
             }
         }
+        if constexpr (FP8) __builtin_amdgcn_s_setprio(0);
         // this pair's steering fragments (requested one pair ahead; the first ones arrive behind the table generation above)
 #pragma unroll
         for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
