@@ -37,7 +37,8 @@ constexpr int CP_MT = 5;                           // tiles (positions) per wave
 template <int MX, int MY, bool CLAMP, bool FP8>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
-    const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/, const CosetParams P) {
+    const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
+    const CosetBlock* __restrict__ blocks /*[gridDim.x]*/, const CosetParams P) {
     constexpr int NT = 2, THREADS = COS_NW * 64;
     constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
     constexpr int B_BYTES = 2 * 4 * NT * 2 * 64 * 16;                           // two super-blocks of steering fragments
@@ -50,39 +51,27 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p16 = lane & 15;
-    // block -> (x coset, y coset, x part, y part, plane block); the two blocks that write the two 64-byte halves of the same
-    // 128-byte lines get ids 8 apart (same XCD under round-robin dispatch), as in kernel 2e
-    unsigned b = blockIdx.x;
-    int kblock;
-    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
-        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
-        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
-    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
-    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
-    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
-    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
-    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
-    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
-    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
-    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
-    const int npos = __builtin_amdgcn_readfirstlane(KX * KY);
+    // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip; blockIdx order as in kernel 2e,
+    // the two blocks that write the two 64-byte halves of the same 128-byte lines 8 ids apart = same XCD).  Decoded here it was
+    // ~350 VALU instructions per wave -- a fifth of the wave's vector instructions: integer divisions have no scalar form.
+    const CosetBlock BK = blocks[blockIdx.x];
+    const int npos = BK.npos, KY = BK.KY, ky_magic = BK.ky_magic;
     if (npos <= 0) return;                              // block-uniform
-    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
-    const int k0 = kblock * COS_ZB;
+    const int ibase = BK.ibase, jbase = BK.jbase;
+    const int k0 = BK.k0;
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
     // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl.
     // (Its per-lane constants are formed inside the pair loop from an opaque copy of the lane index: hoisted, they would be live
     // across the K-steps, where the fp8 shape has no register to spare -- 5 spilled registers cost 190 MB of scratch traffic.)
     // fragment read offset [words] of a tile's row for K-step (0, 0) = per-lane part (plane, k-group) + the tile's position
     // (wave-uniform: kept in scalar registers, added per tile and K-step group -- five registers fewer across the K-steps)
-    const float inv_ky = 1.0f / (float)KY;
     const int lane_off = p16 * CP_PSZ - g * CP_TW;
     int toff[CP_MT];
 #pragma unroll
     for (int t = 0; t < CP_MT; ++t) {
         const int pos = min(wave + COS_NW * t, npos - 1);
-        const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;   // exact for these small integers
-        toff[t] = __builtin_amdgcn_readfirstlane((ky + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx));
+        const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;                // scalar: pos / KY, exact for pos <= 40 (host checks)
+        toff[t] = (ky + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx);
     }
     floatx4_t acc[CP_MT][NT];
 #pragma unroll
@@ -147,13 +136,21 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     half2_t hi;
                     if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
                     else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                    // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
+                    float lr, li;
+                    const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
                     unsigned lo_word;
                     if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
-                        int w = __builtin_amdgcn_cvt_pk_fp8_f32((gr - (float)hi[0]) * COS_F8_LO, (gi - (float)hi[1]) * COS_F8_LO, 0, false);
-                        w = __builtin_amdgcn_cvt_pk_fp8_f32(gr * COS_F8_HI, gi * COS_F8_HI, w, true);
-                        lo_word = (unsigned)w;
+                        // (v_cvt_scalef32_pk_fp8_f32 DIVIDES by its power-of-two scale operand -- tools/probe/cvt_scale_probe.hip --
+                        // and rounds / saturates as the unscaled convert: the four operand scalings cost no instruction)
+                        short2_t w;                  // (both halves are written below)
+                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
+                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
+                        lo_word = __builtin_bit_cast(unsigned, w);
                     } else {
-                        lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+                        lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
                     }
                     if (row_ok) {
                         const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
@@ -268,60 +265,77 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     // position, column c16 = (o, re | im).  The |p| lane (part 0) and its partner (part 1, the intensity lane) hold the same
     // (S re)^2 + (S im)^2 after one quad swap; per pair of rows the |p| lane takes the root of the first and the partner lane of
     // the second (handed back through the swap): one quarter-rate instruction per two rows.
+    // Two passes, both counted in vector instructions (the kernel's scarce resource: the VALU port is busy ~2/3 of its time):
+    //   A  |p| / intensity over the accumulators, in place;
+    //   B  per store-target slot of the lane's column (outer) the 64-bit base of its focus volume and its mirror masks once, then
+    //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU) -- 4 vector
+    //      instructions per 16-byte store (the former tile-outer loop formed every address from scratch: 17).
     const int c16 = lane & 15, part = c16 & 1;
     const int kz = k0 + 4 * g;
     if (kz >= P.nz) return;
     const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;
     float* const vol = part ? inten : pmag;
     const bool want = (P.flags & (part ? 2u : 1u)) != 0;
-    // store targets of this lane's column, two 16-bit codes (focus * 4 + mirror image, 0xFFFF = none) per register
-    unsigned tgt[NT][2];
+    int4 tq[NT];                                         // store targets of this lane's column: focus * 4 + mirror image, -1 = none
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int4 tq = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (c16 >> 1)) * 4);
-        tgt[nt][0] = want ? (((unsigned)tq.x & 0xFFFFu) | ((unsigned)tq.y << 16)) : 0xFFFFFFFFu;
-        tgt[nt][1] = want ? (((unsigned)tq.z & 0xFFFFu) | ((unsigned)tq.w << 16)) : 0xFFFFFFFFu;
+    for (int nt = 0; nt < NT; ++nt)
+        tq[nt] = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (c16 >> 1)) * 4);
+#pragma unroll
+    for (int t = 0; t < CP_MT; ++t) {
+        if (t >= ntile) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
+                const float sq0 = a0 * a0, sq1 = a1 * a1;
+                const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
+                const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
+                const float ys = quad_swap1(y);
+                acc[t][nt][r] = (part == 0 ? y : m0) * s_lane;
+                acc[t][nt][r + 1] = (part == 0 ? ys : m1) * s_lane;
+            }
+        }
     }
     const int xm = P.nx - 1, ym = P.ny - 1;
+    const int sxz = P.ny * P.nz;
     // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
     // splits every 16-byte store into a 12-byte and a 4-byte instruction)
     auto readout = [&](auto full_c) {
         constexpr bool FULL4 = decltype(full_c)::value != 0;
 #pragma unroll
-        for (int t = 0; t < CP_MT; ++t) {
-            if (t >= ntile) continue;
-            const int pos = wave + COS_NW * t;
-            const int kx = (int)(((float)pos + 0.5f) * inv_ky), ky = pos - kx * KY;
-            const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
-                    const float sq0 = a0 * a0, sq1 = a1 * a1;
-                    const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
-                    const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
-                    const float ys = quad_swap1(y);
-                    v[r] = (part == 0 ? y : m0) * s_lane;
-                    v[r + 1] = (part == 0 ? ys : m1) * s_lane;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned code = (tgt[nt][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                    if (code == 0xFFFFu) continue;
-                    const unsigned m = code & 3u;
-                    const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
-                    const int io = fx ? xm - i : i, jo = fy ? ym - j : j;
+            for (int q = 0; q < 4; ++q) {
+                const int code = want ? (q == 0 ? tq[nt].x : q == 1 ? tq[nt].y : q == 2 ? tq[nt].z : tq[nt].w) : -1;
+                if (code < 0) continue;
+                const unsigned m = (unsigned)code & 3u;
+                const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
+                unsigned fxm = fx ? 0xFFFFFFFFu : 0u, fym = fy ? 0xFFFFFFFFu : 0u;
+                asm volatile("" : "+v"(fxm), "+v"(fym));      // (opaque: kept as masks -- one v_and per term instead of a move and a select)
 #ifdef OLX_EXP_L2STORE
-                    float* dst = vol + ((unsigned)((io * P.ny + jo) * P.nz + kz) & 0xFFFFFu);   // A/B: stores stay cache resident
+                float* const base = vol;
 #else
-                    float* dst = vol + (long long)(code >> 2) * P.vox + (unsigned)((io * P.ny + jo) * P.nz + kz);
+                float* const base = vol + (long long)(code >> 2) * P.vox + kz;
 #endif
-                    if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int t = 0; t < CP_MT; ++t) {
+                    if (t >= ntile) continue;
+                    const int pos = wave + COS_NW * t;
+                    const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;
+                    const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform (scalar ALU)
+                    const unsigned o00 = (unsigned)(i * sxz + j * P.nz);
+                    const unsigned DX = (unsigned)((xm - 2 * i) * sxz), DY = (unsigned)((ym - 2 * j) * P.nz);
+                    const unsigned off = o00 + (fxm & DX) + (fym & DY);
+#ifdef OLX_EXP_L2STORE
+                    float* dst = base + ((off + (unsigned)kz) & 0xFFFFFu);           // A/B: stores stay cache resident
+#else
+                    float* dst = base + off;
+#endif
+                    if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]);
                     else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
+                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = acc[t][nt][e];
                     }
                 }
             }
@@ -347,7 +361,7 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
     const bool clamp = c->clamp || c->lat.clamp;
-#define OLX_CP(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, Q)
+#define OLX_CP(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q)
     if (c->fp8corr) { if (clamp) OLX_CP(true, true); else OLX_CP(false, true); }
     else            { if (clamp) OLX_CP(true, false); else OLX_CP(false, false); }
 #undef OLX_CP

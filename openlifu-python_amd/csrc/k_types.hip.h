@@ -11,6 +11,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 typedef int intx8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };

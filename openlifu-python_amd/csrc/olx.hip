@@ -55,7 +55,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -681,6 +681,38 @@ static int configure_variant(olx_ctx* c) {
                         c->jobs_cap = jobs.size();
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
+                }
+                if (c->use_cosetp) {   // kernel 2g block records: blockIdx.x -> (coset, part, plane block), in the kernel's former decode order
+                    // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
+                    const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
+                    std::vector<CosetBlock> blk(nblk);
+                    const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
+                    for (unsigned id = 0; id < nblk; ++id) {
+                        unsigned b = id;
+                        int kblock;
+                        if ((Q.kblocks & 1) == 0 && nblk % 16 == 0) {
+                            const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)Q.kblocks / 2;
+                            kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
+                        } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
+                        const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
+                        const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
+                        const int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
+                        const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * Q.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
+                        const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
+                        const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
+                        CosetBlock& B = blk[id];
+                        B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * COS_ZB;
+                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.pad0 = B.pad1 = 0;
+                        if (B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
+                    }
+                    if (c->cpblocks_cap < nblk) {
+                        if (c->d_cpblocks) hipFree(c->d_cpblocks);
+                        c->d_cpblocks = nullptr; c->cpblocks_cap = 0;
+                        HIPCHK(c, hipMalloc((void**)&c->d_cpblocks, sizeof(CosetBlock) * nblk));
+                        c->cpblocks_cap = nblk;
+                    }
+                    HIPCHK(c, hipMemcpy(c->d_cpblocks, blk.data(), sizeof(CosetBlock) * nblk, hipMemcpyHostToDevice));
+                    c->cp_nblocks = nblk;
                 }
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     c->toep_nsa16 = (A.ax + 15) / 16;
