@@ -34,6 +34,15 @@ constexpr int CP_PSZ = 364;                        // words per plane table = 26
 constexpr int CP_UW = 12;                          // table columns: ud = 2 kx - a in [-7, 4]
 constexpr int CP_MT = 5;                           // tiles (positions) per wave: ceil(33 / 8)
 
+#ifdef OLX_EXP_CUTRACE
+// developer build only (tools/cutrace_cosetp.py): per block and wave {HW_ID, XCC_ID, cycle at entry, at the last store issued, at the
+// last store acknowledged} -- the occupancy timeline of a CU (how long a slot idles between two blocks)
+static __device__ unsigned long long g_cutrace[16384][8][5];
+#define OLX_CUTRACE(k, v) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 16384) g_cutrace[blockIdx.x][wave][k] = (v); } while (0)
+#else
+#define OLX_CUTRACE(k, v)
+#endif
+
 template <int MX, int MY, bool CLAMP, bool FP8>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
@@ -51,6 +60,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p16 = lane & 15;
+    OLX_CUTRACE(2, __builtin_readcyclecounter());
+    OLX_CUTRACE(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
+    OLX_CUTRACE(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));     // HW_REG_XCC_ID
     // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip; blockIdx order as in kernel 2e,
     // the two blocks that write the two 64-byte halves of the same 128-byte lines 8 ids apart = same XCD).  Decoded here it was
     // ~350 VALU instructions per wave -- a fifth of the wave's vector instructions: integer divisions have no scalar form.
@@ -343,12 +355,22 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     };
     if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
     OLX_STAMP(6);
+#ifdef OLX_EXP_CUTRACE
+    OLX_CUTRACE(3, __builtin_readcyclecounter());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OLX_CUTRACE(4, __builtin_readcyclecounter());
+#endif
 }
 
 }  // namespace olx
 
 using namespace olx;
 
+#ifdef OLX_EXP_CUTRACE
+extern "C" int olx_exp_read_cutrace_cosetp(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_cutrace), sizeof(unsigned long long) * 16384 * 8 * 5);
+}
+#endif
 #ifdef OLX_EXP_STAMPS
 extern "C" int olx_exp_read_stamps_cosetp(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(olx::g_stamps), sizeof(unsigned long long) * 4096 * 8);

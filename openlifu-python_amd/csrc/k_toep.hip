@@ -33,32 +33,22 @@ namespace olx {
 // ------------------------------------------------------------------------------------
 template <int MX, int MY, bool CLAMP>
 __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
-                                                                    float* __restrict__ inten, const ToepParams T) {
+                                                                    float* __restrict__ inten, const CosetBlock* __restrict__ blocks /*[gridDim.x]*/,
+                                                                    const ToepParams T) {
     const CosetParams& P = T.q;
     __shared__ __attribute__((aligned(16))) unsigned s_T[2 * TOEP_ZB * TOEP_PSZ];     // [hi | lo][plane][row][ud']
     unsigned* const s_hi = s_T;
     unsigned* const s_lo = s_T + TOEP_ZB * TOEP_PSZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kyg = wave & 3, ks = wave >> 2;
-    // block -> (x coset, y coset, x part, y part, plane block)
-    // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart -- the same XCD, i.e. the same
-    // L2, under round-robin dispatch -- as in kernels 2e / 2g)
-    unsigned b = blockIdx.x;
-    int kblock;
-    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
-        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
-        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
-    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
-    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
-    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
-    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
-    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
-    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
-    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
-    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
-    if (KX <= 0 || KY <= 0) return;                     // block-uniform
-    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
-    const int k0 = kblock * TOEP_ZB;
+    // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip, as kernel 2g; the two blocks
+    // that write the two 64-byte halves of the same 128-byte lines have ids 8 apart -- the same XCD, i.e. the same L2, under
+    // round-robin dispatch).  Decoded here, the chain of integer divisions was ~160 vector and ~400 scalar instructions per wave.
+    const CosetBlock BK = blocks[blockIdx.x];
+    const int KX = BK.KX, KY = BK.KY;
+    if (BK.npos <= 0) return;                           // block-uniform
+    const int ibase = BK.ibase, jbase = BK.jbase;
+    const int k0 = BK.k0;
     const int NC = 15 + 2 * (KX - 1) + 1;               // table columns in use: ud' = 0 .. 15 + 2 (KX - 1)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
     // columns NC .. 31 of the rows in use are never generated, and their Toeplitz weights are zero -- 0 x garbage must stay 0
@@ -67,7 +57,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
 #pragma unroll
         for (int z = 0; z < TOEP_ZB; ++z) { s_hi[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; s_lo[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; }
     }
-    const float dz0 = (float)k0 * P.hz - P.flat_ez;
+    // dz^2 of the block's 16 planes: wave-uniform, held in scalar registers (one v_add per evaluation instead of two fmas)
+    float dz2[TOEP_ZB];
+#pragma unroll
+    for (int z = 0; z < TOEP_ZB; ++z) {
+        const float dz = (float)(k0 + z) * P.hz - P.flat_ez;
+        dz2[z] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dz * dz)));
+    }
     // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4), this wave's K-step
     const int n16 = lane & 15, g = lane >> 4;
     const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + 16 * ks);
@@ -107,17 +103,21 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
             const int o = prow * TOEP_TW + col;
 #pragma unroll
             for (int z = 0; z < TOEP_ZB; ++z) {
-                const float dz = fmaf((float)z, P.hz, dz0);
-                float d2 = fmaf(dz, dz, r2);
+                float d2 = r2 + dz2[z];
                 if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                 const float ri = __builtin_amdgcn_rsqf(d2);
                 const float ph = d2 * ri;
                 const float rs = ri * P.g_scale;
-                const float gr = rs * __builtin_amdgcn_cosf(ph);
-                const float gi = rs * __builtin_amdgcn_sinf(ph);
+                const float2_t gv = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * rs;      // (one v_pk_mul_f32)
+                const float gr = gv[0], gi = gv[1];
                 const half2_t hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
                 s_hi[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, hi);
-                s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+                // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
+                float lr, li;
+                const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
+                s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
             }
         }
         if (sb == 0) OLX_STAMP(2);
@@ -166,6 +166,11 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const float sc = out ? P.out_scale * P.out_scale * P.inten_scale : P.out_scale;
     float* const vol = out ? inten : pmag;
     const bool want = (P.flags & (out ? 2u : 1u)) != 0 && kx < KX && kz < P.nz;
+    // store addresses: the targets (focus, mirror image) are block-uniform, so per lane only the two x forms of the voxel
+    // offset are formed once; per (y position, target) the y term is scalar: one add + one 64-bit add per 16-byte store
+    const int i = ibase + 2 * P.mx * kx;
+    const int sxz = P.ny * P.nz;
+    const unsigned ox0 = (unsigned)(i * sxz + kz), ox1 = (unsigned)((P.nx - 1 - i) * sxz + kz);
     // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
     // splits every 16-byte store into a 12-byte and a 4-byte instruction)
     auto readout = [&](auto full_c) {
@@ -188,15 +193,15 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const float m2 = fmaf(re[e], re[e], im[e] * im[e]);
                 v[e] = (out ? m2 : __builtin_amdgcn_sqrtf(m2)) * sc;
             }
-            const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;
+            const int j = jbase + P.my * ky;                 // wave-uniform
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int code = T.targets[q];
                 if (code < 0) continue;                     // uniform
                 const int m = code & 3;
                 const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
-                const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
-                float* dst = vol + (long long)(code >> 2) * P.vox + (unsigned)((io * P.ny + jo) * P.nz + kz);   // (uniform base + 32-bit offset)
+                const unsigned oy = (unsigned)((fy ? (P.ny - 1 - j) : j) * P.nz);                 // scalar
+                float* dst = vol + (long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy);      // (32-bit offset within the focus volume)
                 if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else {
 #pragma unroll
@@ -275,8 +280,8 @@ static void launch_toep(olx_ctx* c, float* pm) {
     const CosetParams& Q = T.q;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);
-    if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, T);
-    else hipLaunchKernelGGL((field_toep_k<MX, MY, false>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, T);
+    if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+    else hipLaunchKernelGGL((field_toep_k<MX, MY, false>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
 }
 
 void olx_launch_toep(olx_ctx* c, float* pm) {

@@ -682,7 +682,7 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
                 }
-                if (c->use_cosetp) {   // kernel 2g block records: blockIdx.x -> (coset, part, plane block), in the kernel's former decode order
+                if (c->use_cosetp || c->use_toep) {   // kernel 2g / 2f block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
                     const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
                     std::vector<CosetBlock> blk(nblk);
@@ -702,8 +702,8 @@ static int configure_variant(olx_ctx* c) {
                         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
                         CosetBlock& B = blk[id];
                         B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * COS_ZB;
-                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.pad0 = B.pad1 = 0;
-                        if (B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
+                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.pad1 = 0;
+                        if (c->use_cosetp && B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
                     }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);

@@ -85,7 +85,7 @@ struct CosetParams {
     unsigned flags;
 };
 
-// kernel 2g: one record per blockIdx.x, written by the host (olx.hip, configure) -- the block's share of the coset decomposition.
+// kernels 2g / 2f: one record per blockIdx.x, written by the host (olx.hip, configure) -- the block's share of the coset decomposition.
 // (Decoded in the kernel these were ~350 VALU instructions per wave: every integer division of a block-uniform value runs
 // on the vector ALU, there is no scalar divide.)  Read with one scalar load.
 struct CosetBlock {
@@ -94,7 +94,8 @@ struct CosetBlock {
     int npos;                  // KX * KY positions (<= 0: nothing to do)
     int KY;                    // positions along y
     int ky_magic;              // floor(65536 / KY) + 1: pos / KY == (pos * ky_magic) >> 16 for pos < 2048 / ... (pos <= 40 here)
-    int pad0, pad1;
+    int KX;                    // positions along x (kernel 2f)
+    int pad1;
 };
 
 constexpr int COS_NW = 8;                  // waves per block
