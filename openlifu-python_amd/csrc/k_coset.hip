@@ -34,7 +34,7 @@ template <int NT, int MX, int MY, bool CLAMP, bool FP8>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
     const int* __restrict__ jobs /*[tiles][MFMA_MAX_NT][COS_JOBS + 1]: dense (column, focus, image) store jobs, [COS_JOBS] = log2 count*/,
-    const CosetParams P) {
+    const CosetBlock* __restrict__ blocks /*[gridDim.x]*/, const CosetParams P) {
     constexpr int THREADS = COS_NW * 64;
     static_assert(!FP8 || cos_fp8(NT), "fp8 correction products need NT <= 2");
     constexpr int COS_KXW = cos_kxw(NT);
@@ -68,26 +68,14 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
-    // block -> (x coset, y coset, x part, y part, plane block)
-    unsigned b = blockIdx.x;
-    // The two blocks that write the two 64-byte halves of the same 128-byte lines get block ids 8 apart (same XCD, i.e.
-    // the same L2, under round-robin dispatch over the 8 XCDs) instead of adjacent ids (measured -1...-2 %).
-    int kblock;
-    if ((P.kblocks & 1) == 0 && gridDim.x % 16 == 0) {
-        const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)P.kblocks / 2;
-        kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
-    } else { kblock = (int)(b % (unsigned)P.kblocks); b /= (unsigned)P.kblocks; }
-    const int sy_part = (int)(b % (unsigned)P.nsy); b /= (unsigned)P.nsy;
-    const int sx_part = (int)(b % (unsigned)P.nsx); b /= (unsigned)P.nsx;
-    const int ry = (int)(b % (unsigned)P.my), rx = (int)(b / (unsigned)P.my);          // rx < 2 mx
-    const int wx = P.nx - P.x_lo, wy = P.ny - P.y_lo;
-    const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * P.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / P.my + 1 : 0;
-    // equal parts: part s of n covers [s K / n, (s+1) K / n)
-    const int kx0 = sx_part * kx_all / P.nsx, KX = (sx_part + 1) * kx_all / P.nsx - kx0;
-    const int ky0 = sy_part * ky_all / P.nsy, KY = (sy_part + 1) * ky_all / P.nsy - ky0;
-    const int npos = KX * KY, nrow = COS_P * npos;
-    const int ibase = P.x_lo + rx + 2 * P.mx * kx0, jbase = P.y_lo + ry + P.my * ky0;
-    const int k0 = (kblock * COS_NW + wave) * COS_P;
+    // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip, as kernels 2g / 2f; the two
+    // blocks that write the two 64-byte halves of the same 128-byte lines have ids 8 apart = same XCD, i.e. the same L2, under
+    // round-robin dispatch: measured -1...-2 %).  Decoded here, the chain of integer divisions was ~350 vector instructions per wave.
+    const CosetBlock BK = blocks[blockIdx.x];
+    const int KX = BK.KX, KY = BK.KY;
+    const int ibase = BK.ibase, jbase = BK.jbase;
+    const int npos = BK.npos, nrow = COS_P * npos;
+    const int k0 = BK.k0 + wave * COS_P;
     const bool active = npos > 0 && k0 < P.nz;
     const int ntile = (nrow + 15) >> 4;              // block-uniform (<= COS_MT)
     const float inv_ky = KY > 0 ? 1.0f / (float)KY : 0.f;
@@ -190,13 +178,21 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         half2_t hi;
                         if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);
                         else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                        // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
+                        float lr, li;
+                        const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
                         unsigned lo_word;
                         if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
-                            int w = __builtin_amdgcn_cvt_pk_fp8_f32((gr - (float)hi[0]) * COS_F8_LO, (gi - (float)hi[1]) * COS_F8_LO, 0, false);
-                            w = __builtin_amdgcn_cvt_pk_fp8_f32(gr * COS_F8_HI, gi * COS_F8_HI, w, true);
-                            lo_word = (unsigned)w;
+                            // (v_cvt_scalef32_pk_fp8_f32 DIVIDES by its power-of-two scale operand -- tools/probe/cvt_scale_probe.hip --
+                            // and rounds / saturates as the unscaled convert: the four operand scalings cost no instruction)
+                            short2_t w;                  // (both halves are written below)
+                            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
+                            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
+                            lo_word = __builtin_bit_cast(unsigned, w);
                         } else {
-                            lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]));
+                            lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
                         }
                         if (row_ok) {                    // spare lanes / rows past the table do not store
                             const int o = z * COS_PSZ + tw_off + RPR * r * COS_TW;
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     // ---- epilogue.  D layout: lane holds rows 4 (lane >> 4) + r of tile t = rows n = 16 t + 4 gy + r -> (plane, position),
     // column lane & 15 = (o, part).  Staging [position][column][plane of the block], two halves of the position grid.
     const int c16 = lane & 15, part = c16 & 1, gy = lane >> 4;
-    const int kb0 = kblock * COS_ZB;
+    const int kb0 = BK.k0;
     const bool fast = (P.nz % COS_ZB) == 0;
     // |p| / intensity in place, then one staged pass per column tile (complex output is served by kernel 2d: the host
     // does not select this kernel when OLX_OUT_COMPLEX is planned)
@@ -436,7 +432,7 @@ static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
     const CosetParams& Q = c->cp;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, Q)
+#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q)
     if constexpr (cos_fp8(NT)) {
         if (c->fp8corr) { if (clamp) OLX_COS(true, true); else OLX_COS(false, true); return; }
     }

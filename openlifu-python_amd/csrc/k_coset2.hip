@@ -1,5 +1,6 @@
 // kernel 2g (field_cosetp_k): kernel 2e's NT = 2 shape with the PLANES in the MFMA rows -- no output staging
 // gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#include <algorithm>
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
@@ -43,11 +44,13 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 #define OLX_CUTRACE(k, v)
 #endif
 
-template <int MX, int MY, bool CLAMP, bool FP8>
+// PERSIST: the grid is two blocks per CU and a block walks the records blockIdx.x, blockIdx.x + gridDim.x, ... (n_items of them);
+// `stagger` [cycles] delays the second block of each CU once, so that the two do not run their phases in lockstep.
+template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
-    const CosetBlock* __restrict__ blocks /*[gridDim.x]*/, const CosetParams P) {
+    const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger) {
     constexpr int NT = 2, THREADS = COS_NW * 64;
     constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
     constexpr int B_BYTES = 2 * 4 * NT * 2 * 64 * 16;                           // two super-blocks of steering fragments
@@ -66,9 +69,20 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip; blockIdx order as in kernel 2e,
     // the two blocks that write the two 64-byte halves of the same 128-byte lines 8 ids apart = same XCD).  Decoded here it was
     // ~350 VALU instructions per wave -- a fifth of the wave's vector instructions: integer divisions have no scalar form.
-    const CosetBlock BK = blocks[blockIdx.x];
+    if constexpr (PERSIST) {
+        if (stagger > 0 && blockIdx.x >= gridDim.x / 2) {       // (dispatch order: the second half of the grid lands on the CUs' second slots)
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    int item = blockIdx.x;
+    do {
+    const CosetBlock BK = blocks[item];
     const int npos = BK.npos, KY = BK.KY, ky_magic = BK.ky_magic;
-    if (npos <= 0) return;                              // block-uniform
+    if (npos <= 0) continue;                            // block-uniform
+    // (persistent form) every wave has left the previous item's K-steps: tables and steering stage are free.  LDS-only barrier:
+    // the previous item's stores drain behind this item's table generation
+    if (PERSIST && item != (int)blockIdx.x) lds_barrier();
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
@@ -96,6 +110,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
     const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * 128);
+    // (the steering fragments do not depend on the item: all items of a launch tile read the same chunks)
 #pragma unroll
     for (int q = 0; q < PRE; ++q) {
         const int idx = tid + q * THREADS;
@@ -282,9 +297,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     //   B  per store-target slot of the lane's column (outer) the 64-bit base of its focus volume and its mirror masks once, then
     //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU) -- 4 vector
     //      instructions per 16-byte store (the former tile-outer loop formed every address from scratch: 17).
-    const int c16 = lane & 15, part = c16 & 1;
-    const int kz = k0 + 4 * g;
-    if (kz >= P.nz) return;
+    int lane_e = lane;                                   // (opaque per item: the persistent form would otherwise keep the epilogue's
+    asm volatile("" : "+v"(lane_e));                     // per-lane constants -- targets, bases, scales -- in registers across the K-steps)
+    const int c16 = lane_e & 15, part = c16 & 1;
+    const int kz = k0 + 4 * (lane_e >> 4);
+    if (kz < P.nz) {
     const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;
     float* const vol = part ? inten : pmag;
     const bool want = (P.flags & (part ? 2u : 1u)) != 0;
@@ -354,12 +371,14 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         }
     };
     if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
+    }
     OLX_STAMP(6);
 #ifdef OLX_EXP_CUTRACE
     OLX_CUTRACE(3, __builtin_readcyclecounter());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     OLX_CUTRACE(4, __builtin_readcyclecounter());
 #endif
+    } while (PERSIST && (item += gridDim.x) < n_items);
 }
 
 }  // namespace olx
@@ -380,12 +399,18 @@ extern "C" int olx_exp_read_stamps_cosetp(unsigned long long* out) {
 template <int MX, int MY>
 static void launch_cosetp(olx_ctx* c, float* pm) {
     const CosetParams& Q = c->cp;
-    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
-    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
+    const int n_items = (int)c->cp_nblocks;
     const bool clamp = c->clamp || c->lat.clamp;
-#define OLX_CP(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q)
-    if (c->fp8corr) { if (clamp) OLX_CP(true, true); else OLX_CP(false, true); }
-    else            { if (clamp) OLX_CP(true, false); else OLX_CP(false, false); }
+    const bool persist = c->cosetp_persist && c->mp.n_tiles == 1;
+    dim3 grid(persist ? (unsigned)std::min(2 * c->n_cu, n_items) : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
+#define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger)
+    if (persist) {
+        if (c->fp8corr) { if (clamp) OLX_CP(true, true, true); else OLX_CP(false, true, true); }
+        else            { if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true); }
+    } else {
+        if (c->fp8corr) { if (clamp) OLX_CP(true, true, false); else OLX_CP(false, true, false); }
+        else            { if (clamp) OLX_CP(true, false, false); else OLX_CP(false, false, false); }
+    }
 #undef OLX_CP
 }
 

@@ -509,7 +509,7 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_coset = false; c->use_toep = false; c->use_cosetp = false;
+        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetq = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
@@ -524,6 +524,10 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
+            // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
+            c->use_cosetq = c->use_cosetp && fv && !strcmp(fv, "cosetq");
+            c->cosetp_persist = c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
+            c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
             if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
                 for (auto& t : tiles)   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
                     for (size_t o = 0; o < t.size() && (int)t.size() < c->nt * MFMA_COLS; ++o)
@@ -650,7 +654,8 @@ static int configure_variant(olx_ctx* c) {
                 const int kx_max = (P.nx - L.x_lo + 2 * A.mx - 1) / (2 * A.mx), ky_max = (P.ny - L.y_lo + A.my - 1) / A.my;
                 const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
                 Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
-                Q.kblocks = (P.nz + COS_ZB - 1) / COS_ZB;
+                const int zb = c->use_cosetq ? 8 : COS_ZB;      // planes per block (kernel 2q: 8)
+                Q.kblocks = (P.nz + zb - 1) / zb;
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
@@ -682,7 +687,7 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
                 }
-                if (c->use_cosetp || c->use_toep) {   // kernel 2g / 2f block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
+                {   // kernel 2e / 2g / 2f / 2q block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
                     const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
                     std::vector<CosetBlock> blk(nblk);
@@ -690,9 +695,10 @@ static int configure_variant(olx_ctx* c) {
                     for (unsigned id = 0; id < nblk; ++id) {
                         unsigned b = id;
                         int kblock;
-                        if ((Q.kblocks & 1) == 0 && nblk % 16 == 0) {
-                            const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % 2, u = (sft / 2) * 8 + xcd, half = (unsigned)Q.kblocks / 2;
-                            kblock = (int)(2 * (u % half) + kb_lo); b = u / half;
+                        const unsigned grp = c->use_cosetq ? 4u : 2u;   // blocks that share 128-byte lines (16 / 8 planes of 4 bytes each)
+                        if ((Q.kblocks % grp) == 0 && nblk % (8 * grp) == 0) {
+                            const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % grp, u = (sft / grp) * 8 + xcd, part = (unsigned)Q.kblocks / grp;
+                            kblock = (int)(grp * (u % part) + kb_lo); b = u / part;
                         } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
                         const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
                         const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
@@ -701,8 +707,13 @@ static int configure_variant(olx_ctx* c) {
                         const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
                         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
                         CosetBlock& B = blk[id];
-                        B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * COS_ZB;
+                        B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
                         B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.pad1 = 0;
+                        if (c->use_cosetq) {   // kernel 2q: tiles are pairs of y-adjacent positions
+                            const int KYP = (B.KY + 1) / 2;
+                            B.npos = (KX > 0 && KY > 0) ? KX * KYP : 0; B.ky_magic = 65536 / KYP + 1;
+                            if (B.npos > 20) return fail(c, OLX_ESTATE, "kernel 2q: a block part holds more than 20 position pairs");
+                        } else
                         if (c->use_cosetp && B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
                     }
                     if (c->cpblocks_cap < nblk) {
@@ -758,9 +769,22 @@ static int configure_variant(olx_ctx* c) {
                             npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
                     n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
-                snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                         c->fp8corr ? ",fp8corr" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                if (c->use_cosetq) {   // kernel 2q: one row tile per PAIR of y-adjacent positions and 8-plane block
+                    long long npair_all = 0;
+                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
+                    for (int rx = 0; rx < 2 * A.mx; ++rx)
+                        for (int ry = 0; ry < A.my; ++ry) {
+                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                            for (int sy = 0; sy < Q.nsy; ++sy) {
+                                const int KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
+                                npair_all += (long long)kxa * ((KY + 1) / 2);
+                            }
+                        }
+                    n_mfma = npair_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                }
+                snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetq ? "q" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         c->fp8corr ? ",fp8corr" : "", (c->cosetp_persist && !c->use_cosetq) ? ",persistent" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 }
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
@@ -1018,7 +1042,7 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetq) olx_launch_cosetq(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->directivity) olx_launch_accum_dir(c, pm);

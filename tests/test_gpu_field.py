@@ -763,6 +763,38 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
     print(f"full-volume 256^3 parity, fp8={fp8}: max error {worst:.2e} of the volume maximum")
 
 
+@pytest.mark.parametrize("fp8", [True, False])
+@pytest.mark.parametrize("grid_n,nz", [(128, 128), (96, 50)])
+def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
+    """Kernel 2g's A/B forms on an 8-focus shard -- the persistent grid (OLX_FIELD_VARIANT=cosetpp[:stagger], two blocks per CU
+    walking the block records) and kernel 2q (cosetq: blocks of 4 waves x 8 planes) -- evaluate the same tables and the same
+    MFMA sequence per voxel as the default launch: bit-identical |p| and intensity.  (Both measured slower than the default,
+    DESIGN.md 5.4; kept selectable as evidence.)  The second shape has a ragged plane count and odd parts."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(8)
+    setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    xs, ys, _ = centred_grid(grid_n, 0.5)
+    zs = (5.0 + 0.5 * np.arange(nz)) * 1e-3
+    h = (xs[1] - xs[0],) * 3
+    flags = nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0)
+    got = {}
+    for fam in (None, "cosetpp:2000", "cosetq"):
+        if fam is None:
+            monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
+        else:
+            monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, (grid_n, grid_n, nz), F0, C, RHO, P0, flags=flags)
+        ctx.field_launch()
+        got[fam] = (ctx.field_variant(), [ctx.field_fetch(f) for f in range(8)])
+    assert "field_cosetp_k<nt2" in got[None][0] and "persistent" not in got[None][0], got[None][0]
+    assert "field_cosetp_k<nt2" in got["cosetpp:2000"][0] and "persistent" in got["cosetpp:2000"][0], got["cosetpp:2000"][0]
+    assert "field_cosetq_k<nt2" in got["cosetq"][0], got["cosetq"][0]
+    for fam in ("cosetpp:2000", "cosetq"):
+        for f in range(8):
+            assert np.array_equal(got[fam][1][f]["pmag"], got[None][1][f]["pmag"]), (fam, f)
+            assert np.array_equal(got[fam][1][f]["intensity"], got[None][1][f]["intensity"]), (fam, f)
+
+
 @pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp> 16 columns"),
                                                  (64, 0, "field_coset_k<nt4,mx2,my2,flat,noclamp>")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, rank, expect):

@@ -67,3 +67,12 @@ gaps = np.array(gaps)
 print(f"per CU: span {np.median(spans):.0f} cycles, blocks {nb / len(np.unique(key)):.1f}, slot occupancy (2 slots) {np.median(busy):.3f}")
 print("  slot freed (last ack of the leaving block) -> next block's first wave in:", q(gaps), f" mean {gaps.mean():.0f}")
 print(f"  sum of gaps per slot {gaps.sum() / (2 * len(np.unique(key))):.0f} cycles = {gaps.sum() / (2 * len(np.unique(key))) / np.median(spans):.3f} of the span")
+if "--dump" in sys.argv[1:]:
+    k = np.unique(key)[3]
+    m = np.where(key == k)[0]
+    order = m[np.argsort(t_in[m])]
+    t0 = t_in[order[0]]
+    print("one CU: block id, first wave in, last wave in, first/last store-issue over waves, first/last ack over waves, npos-ish (lifetime)")
+    for bi in order:
+        w = b[bi]
+        print(f"  {np.where(used)[0][bi]:6d} in {w[:,2].min()-t0:8d} ..{w[:,2].max()-t0:8d}  issue {w[:,3].min()-t0:8d} ..{w[:,3].max()-t0:8d}  ack {w[:,4].min()-t0:8d} ..{w[:,4].max()-t0:8d}   simd/wave-slots {sorted(set(((w[:,0]>>4)&3).tolist()))}")
