@@ -268,7 +268,7 @@ __global__ __launch_bounds__(CQ_NW * 64, 4) void field_cosetq_k(
             for (int r = 0; r < 4; r += 2) {
                 const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
                 const float sq0 = a0 * a0, sq1 = a1 * a1;
-                const float m0 = sq0 + quad_swap1(sq0), m1 = sq1 + quad_swap1(sq1);
+                const float m0 = __builtin_fmaf(a0, a0, quad_swap1(sq0)), m1 = __builtin_fmaf(a1, a1, quad_swap1(sq1));   // (pinned: own square unrounded, partner's rounded)
                 const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
                 const float ys = quad_swap1(y);
                 acc[t][nt][r] = (part == 0 ? y : m0) * s_lane;

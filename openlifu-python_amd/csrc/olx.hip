@@ -55,7 +55,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
+                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -509,7 +509,7 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetq = false;
+        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
@@ -526,6 +526,10 @@ static int configure_variant(olx_ctx* c) {
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
             // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
             c->use_cosetq = c->use_cosetp && fv && !strcmp(fv, "cosetq");
+            // kernel 2r: 2g as one persistent block per CU with the table generation inside the K-steps (OLX_FIELD_VARIANT=cosetr);
+            // steering fragments of at most 4 super-blocks stay resident in LDS, one launch tile
+            c->use_cosetr = c->use_cosetp && fv && !strcmp(fv, "cosetr") && c->lat.nsa * c->lat.nsbp <= 4 && tiles.size() == 1 && (c->fp.nz & 3) == 0 &&
+                            (unsigned long long)F * (unsigned long long)c->fp.vox < (1ull << 32);
             c->cosetp_persist = c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
             c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
             if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
@@ -724,6 +728,21 @@ static int configure_variant(olx_ctx* c) {
                     }
                     HIPCHK(c, hipMemcpy(c->d_cpblocks, blk.data(), sizeof(CosetBlock) * nblk, hipMemcpyHostToDevice));
                     c->cp_nblocks = nblk;
+                    if (c->use_cosetr) {   // kernel 2r walks the non-empty records only
+                        std::vector<CosetBlock> live;
+                        for (const CosetBlock& B : blk) if (B.npos > 0) live.push_back(B);
+                        if (live.empty()) c->use_cosetr = false;
+                        else {
+                            if (c->cprblocks_cap < live.size()) {
+                                if (c->d_cprblocks) hipFree(c->d_cprblocks);
+                                c->d_cprblocks = nullptr; c->cprblocks_cap = 0;
+                                HIPCHK(c, hipMalloc((void**)&c->d_cprblocks, sizeof(CosetBlock) * live.size()));
+                                c->cprblocks_cap = live.size();
+                            }
+                            HIPCHK(c, hipMemcpy(c->d_cprblocks, live.data(), sizeof(CosetBlock) * live.size(), hipMemcpyHostToDevice));
+                            c->cpr_nblocks = (unsigned)live.size();
+                        }
+                    }
                 }
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     c->toep_nsa16 = (A.ax + 15) / 16;
@@ -783,7 +802,7 @@ static int configure_variant(olx_ctx* c) {
                     n_mfma = npair_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetq ? "q" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          c->fp8corr ? ",fp8corr" : "", (c->cosetp_persist && !c->use_cosetq) ? ",persistent" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 }
             } else {
@@ -1042,7 +1061,7 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetq) olx_launch_cosetq(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetr) olx_launch_cosetr(c, pm); else if (c->use_cosetq) olx_launch_cosetq(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->directivity) olx_launch_accum_dir(c, pm);

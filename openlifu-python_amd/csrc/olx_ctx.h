@@ -80,6 +80,7 @@ struct olx_ctx {
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records
+    bool use_cosetr = false; CosetBlock* d_cprblocks = nullptr; size_t cprblocks_cap = 0; unsigned cpr_nblocks = 0;   // kernel 2r: persistent, one block per CU (non-empty records only)
     bool use_cosetq = false;   // kernel 2q: 2g in blocks of 4 waves x 8 planes (four blocks per CU)
     bool cosetp_persist = false; int cosetp_stagger = 0;   // kernel 2g, persistent form (OLX_FIELD_VARIANT=cosetpp[:stagger cycles]; A/B)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)

@@ -767,7 +767,8 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
 @pytest.mark.parametrize("grid_n,nz", [(128, 128), (96, 50)])
 def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
     """Kernel 2g's A/B forms on an 8-focus shard -- the persistent grid (OLX_FIELD_VARIANT=cosetpp[:stagger], two blocks per CU
-    walking the block records) and kernel 2q (cosetq: blocks of 4 waves x 8 planes) -- evaluate the same tables and the same
+    walking the block records), kernel 2q (cosetq: blocks of 4 waves x 8 planes) and kernel 2r (cosetr: one persistent block
+    per CU, next tables generated inside the K-steps) -- evaluate the same tables and the same
     MFMA sequence per voxel as the default launch: bit-identical |p| and intensity.  (Both measured slower than the default,
     DESIGN.md 5.4; kept selectable as evidence.)  The second shape has a ragged plane count and odd parts."""
     pos, ori, size = synthetic_array(16, 16, 3.0)
@@ -778,7 +779,7 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
     h = (xs[1] - xs[0],) * 3
     flags = nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0)
     got = {}
-    for fam in (None, "cosetpp:2000", "cosetq"):
+    for fam in (None, "cosetpp:2000", "cosetq", "cosetr"):
         if fam is None:
             monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
         else:
@@ -789,7 +790,8 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
     assert "field_cosetp_k<nt2" in got[None][0] and "persistent" not in got[None][0], got[None][0]
     assert "field_cosetp_k<nt2" in got["cosetpp:2000"][0] and "persistent" in got["cosetpp:2000"][0], got["cosetpp:2000"][0]
     assert "field_cosetq_k<nt2" in got["cosetq"][0], got["cosetq"][0]
-    for fam in ("cosetpp:2000", "cosetq"):
+    assert ("field_cosetr_k<nt2" if nz % 4 == 0 else "field_cosetp_k<nt2") in got["cosetr"][0], got["cosetr"][0]     # (2r: whole plane quads only)
+    for fam in ("cosetpp:2000", "cosetq", "cosetr"):
         for f in range(8):
             assert np.array_equal(got[fam][1][f]["pmag"], got[None][1][f]["pmag"]), (fam, f)
             assert np.array_equal(got[fam][1][f]["intensity"], got[None][1][f]["intensity"]), (fam, f)

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer tool: phase timeline of kernel 2r (field_cosetr_k) on the headline shard from in-kernel cycle stamps.
+Build:  python openlifu-python_amd/build.py -DOLX_EXP_STAMPS --out lib/libolx_STAMPS.so ; on the GPU box:
+  OLX_LIB_PATH=openlifu-python_amd/lib/libolx_STAMPS.so python tools/stamps_cosetr.py [fp8]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "openlifu-python_amd"))
+import bench  # noqa: E402
+import openlifu_amd as ol  # noqa: E402
+from openlifu_amd import _native as nat, dist as od  # noqa: E402
+from openlifu_amd.engine import grid_from_coords  # noqa: E402
+
+fp8 = "fp8" in sys.argv[1:]
+arr, setup, target, pattern = bench.synthetic_workload(256, 0.25)
+sweep = np.array([f.get_position(units="m") for f in pattern.get_targets(target)])
+shard = od.plan_foci_orbits(sweep, 8, centre_xy=(0.0, 0.0))[0]
+eng = ol.get_engine(0); ctx = eng.ctx; eng.bind(arr)
+ctx.bf_solve(sweep[shard], 1500.0)
+origin, spacing, n = grid_from_coords(setup.get_coords())
+ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+for _ in range(30):
+    ctx.field_launch()
+ctx.sync()
+print(ctx.field_variant())
+lib = nat.load()
+buf = np.zeros((4096, 8), dtype=np.uint64)
+lib.olx_exp_read_stamps_cosetr.argtypes = [ctypes.c_void_p]
+assert lib.olx_exp_read_stamps_cosetr(buf.ctypes.data) == 0
+ok = (buf[:, 0] > 0) & (buf[:, 5] > 0)
+s = buf[ok].astype(np.int64)
+names = ["K-steps + next tables, pair 0", "barrier", "K-steps + next tables, pair 1", "barrier", "|p| + stores issued"]
+d = np.diff(s[:, :6], axis=1)
+print(f"{ok.sum()} waves sampled; shader cycles, median / p10 / p90")
+for k, nm in enumerate(names):
+    print(f"  {nm:45s} {np.median(d[:, k]):10.0f} {np.percentile(d[:, k], 10):10.0f} {np.percentile(d[:, k], 90):10.0f}")
+tot = s[:, 5] - s[:, 0]
+print(f"  {'one record':45s} {np.median(tot):10.0f} {np.percentile(tot, 10):10.0f} {np.percentile(tot, 90):10.0f}")
