@@ -211,11 +211,12 @@ class Protocol:
         # max over foci for pressures, mean for intensity (protocol.py:382-387), on the device
         eng, _, _, _ = solution._bind_device()
         p_agg, i_agg = eng.ctx.field_aggregate(want_intensity=True)
+        p_agg2, _ = eng.ctx.aggregate_fetch(want_intensity=False)     # p_max: its own caller-owned array (a second staged fetch beats a host copy)
         coords = params.coords
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         aggregated = ds.make_dataset({
             "p_min": ds.make_dataarray(p_agg, coords=coords, dims=dims, name="p_min", attrs=_ATTRS["p_min"]),
-            "p_max": ds.make_dataarray(p_agg.copy(), coords=coords, dims=dims, name="p_max", attrs=_ATTRS["p_max"]),
+            "p_max": ds.make_dataarray(p_agg2, coords=coords, dims=dims, name="p_max", attrs=_ATTRS["p_max"]),
             "intensity": ds.make_dataarray(i_agg, coords=coords, dims=dims, name="intensity", attrs=_ATTRS["intensity"])})
         analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints)
         return solution, aggregated, analysis

@@ -126,6 +126,18 @@ class Transducer:
             sig = np.convolve(input_signal, self.interp_impulse_response(dt)[0], mode="full")
         if self.sensitivity is not None:
             sig *= self.sensitivity
+        if n and all(el.impulse_response is None for el in self.elements):
+            # every element hands back the SAME array, scaled in place by its sensitivity (xdc/element.py:144-154): element i
+            # drives a_i * sig * s_1 * ... * s_i and the caller's signal ends up scaled by all of them.  One accumulate over
+            # an [N + 1, T] array reproduces the left-to-right products bit for bit (None -> 1.0, exact) without 2 N Python calls.
+            sens = np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.elements])
+            chain = np.multiply.accumulate(np.vstack([sig[None, :], np.broadcast_to(sens[:, None], (n, sig.shape[0]))]), axis=0)[1:]
+            sig[:] = chain[-1]
+            lead = np.array([int(d / dt) for d in delays], dtype=np.int64)
+            L = sig.shape[0]
+            out = np.zeros((n, int(lead.max()) + L))
+            out[np.arange(n)[:, None], lead[:, None] + np.arange(L)[None, :]] = np.asarray(apod, dtype=float)[:, None] * chain
+            return out
         outs = [np.concatenate([np.zeros(int(d / dt)), a * el.calc_output(sig, dt)])
                 for el, d, a in zip(self.elements, delays, apod)]
         out = np.zeros((n, max(len(o) for o in outs)))
