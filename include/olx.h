@@ -210,6 +210,10 @@ const char *olx_field_variant(const olx_ctx *ctx);
  * p_agg = max_f |p_f|, I_agg = mean_f I_f over the planned volumes, on device;
  * host outputs [slab voxels], either may be NULL. */
 int olx_field_aggregate(olx_ctx *ctx, float *pmag_max_out, float *intensity_mean_out);
+/* The same aggregate left in HBM (nothing copied): olx_aggregate_fetch brings either volume to the host when -- and if --
+ * the caller reads it (Protocol.calc_solution hands the aggregate Dataset out lazily, like the per-focus volumes).
+ * The buffers are reused by the next aggregate and freed by a plan / upload that needs larger volumes. */
+int olx_field_aggregate_device(olx_ctx *ctx, int want_intensity);
 
 /* Per-focus in-place scaling (plan/solution.py:331-337): p_f *= s_f, I_f *= s_f^2. */
 int olx_field_scale(olx_ctx *ctx, const double *scale_per_focus, int n_foci);

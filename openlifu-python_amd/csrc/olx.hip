@@ -1455,26 +1455,40 @@ int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
 
 const char* olx_field_variant(const olx_ctx* c) { return (c && c->planned) ? c->variant.c_str() : ""; }
 
+// max |p| / mean intensity over the planned foci into the aggregate buffers (device only)
+static int aggregate_local(olx_ctx* c, bool with_p, bool with_i) {
+    const size_t vox = (size_t)c->fp.vox;
+    if (with_p && !c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+    if (with_i && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+    hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, with_p ? c->d_pmag[c->cur] : nullptr,
+                       with_i ? c->d_inten : nullptr, c->plan_foci, (long long)vox, 1.0f / (float)c->plan_foci,
+                       with_p ? c->d_agg_p : nullptr, with_i ? c->d_agg_i : nullptr);
+    HIPCHK(c, hipGetLastError());
+    return OLX_OK;
+}
+
 int olx_field_aggregate(olx_ctx* c, float* pmax_out, float* imean_out) {
     if (!c) return OLX_EINVAL;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_aggregate: nothing planned");
     if (imean_out && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_aggregate: intensity not planned");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t vox = (size_t)c->fp.vox;
-    if (pmax_out && !c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
-    if (imean_out && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
-    hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, pmax_out ? c->d_pmag[c->cur] : nullptr,
-                       imean_out ? c->d_inten : nullptr, c->plan_foci, (long long)vox, 1.0f / (float)c->plan_foci,
-                       pmax_out ? c->d_agg_p : nullptr,
-                       imean_out ? c->d_agg_i : nullptr);
-    HIPCHK(c, hipGetLastError());
+    int rc = aggregate_local(c, pmax_out != nullptr, imean_out != nullptr);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the two aggregate volumes go to pageable caller memory through the pipelined staged copy of the per-focus fetches
-    // (a plain hipMemcpy to pageable memory moves ~12 GB/s here, the staged copy 45)
-    int rc = OLX_OK;
+    // (a plain hipMemcpy to pageable memory moves ~12 GB/s here, the staged copy 25 - 45)
     if (pmax_out) rc = fetch_to_host(c, pmax_out, c->d_agg_p, sizeof(float) * vox);
     if (!rc && imean_out) rc = fetch_to_host(c, imean_out, c->d_agg_i, sizeof(float) * vox);
     return rc;
+}
+
+int olx_field_aggregate_device(olx_ctx* c, int want_intensity) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_aggregate_device: nothing planned");
+    if (want_intensity && !(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_aggregate_device: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    return aggregate_local(c, true, want_intensity != 0);
 }
 
 int olx_field_scale(olx_ctx* c, const double* scale, int n_foci) {

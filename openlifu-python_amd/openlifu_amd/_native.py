@@ -32,7 +32,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
+    "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
 ]
 
 
@@ -98,6 +98,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_allreduce_aggregate.argtypes = [vp]
         lib.olx_field_reduce_scatter_aggregate.argtypes = [vp]
         lib.olx_aggregate_fetch.argtypes = [vp, fp, fp]
+        lib.olx_field_aggregate_device.argtypes = [vp, c_int]
         lib.olx_field_aggregate_counts.argtypes = [vp, c_int, c_int]
         lib.olx_rccl_path.argtypes = [vp]; lib.olx_rccl_path.restype = c_char_p
         lib.olx_bf_time.argtypes = [vp, c_int, fp]
@@ -363,6 +364,10 @@ class Context:
         self._chk(self._lib.olx_field_aggregate(self._h, _fptr(pm), _fptr(it)))
         return pm, it
 
+    def field_aggregate_device(self, want_intensity=True):
+        """max |p| / mean intensity over the planned foci, left in HBM (``aggregate_fetch`` reads either volume later)."""
+        self._chk(self._lib.olx_field_aggregate_device(self._h, int(bool(want_intensity))))
+
     def field_scale(self, scale_per_focus):
         s = _f64(scale_per_focus)
         self._chk(self._lib.olx_field_scale(self._h, _dptr(s), int(s.shape[0])))
@@ -439,8 +444,8 @@ class Context:
         """Sharded aggregate: rank r ends up owning voxels [r V/N, (r+1) V/N) of the global max |p| / mean intensity."""
         self._chk(self._lib.olx_field_reduce_scatter_aggregate(self._h))
 
-    def aggregate_fetch(self, want_intensity=True):
-        pm = np.empty(self._shape, dtype=np.float32)
+    def aggregate_fetch(self, want_intensity=True, want_pmag=True):
+        pm = np.empty(self._shape, dtype=np.float32) if want_pmag else None
         it = np.empty(self._shape, dtype=np.float32) if want_intensity else None
         self._chk(self._lib.olx_aggregate_fetch(self._h, _fptr(pm), _fptr(it)))
         return pm, it

@@ -85,6 +85,38 @@ class DeviceResult:
         self.retired = True
 
 
+class AggregateResult:
+    """Handle on the aggregate over foci (max |p|, mean intensity: plan/protocol.py:382-387) that ``Engine.aggregate_lazy``
+    left in HBM.  ``fetch(key)`` returns a fresh [nx, ny, nz] float32 array while the aggregate buffers still hold this
+    result; ``retire()`` (called by the engine before the buffers are reused) reads every lazily handed-out array nobody
+    has read yet, so outstanding ``LazyDataArray``s stay valid -- and an aggregate nobody looks at costs no PCIe traffic."""
+
+    def __init__(self, engine, shape):
+        self.engine, self.shape = engine, tuple(int(v) for v in shape)
+        self._lazies = []
+        self.retired = False
+
+    def fetch(self, key):
+        if self.retired:
+            raise RuntimeError("the device aggregate this array belongs to has been overwritten")
+        pm, it = self.engine.ctx.aggregate_fetch(want_intensity=(key == "intensity"), want_pmag=(key == "pmag"))
+        return pm if key == "pmag" else it
+
+    def lazy_array(self, key, make):
+        da = make(lambda: self.fetch(key))
+        self._lazies.append(weakref.ref(da))
+        return da
+
+    def retire(self):
+        if self.retired:
+            return
+        for ref in self._lazies:
+            da = ref()
+            if da is not None and not da.materialized:
+                _ = da.data
+        self.retired = True
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.ctx = nat.Context(device)
@@ -92,12 +124,24 @@ class Engine:
         self._table_key = None
         self.result_token = 0  # bumped whenever the resident result volumes change
         self._live_result = None
+        self._live_aggregate = None
 
     def retire_results(self):
         """Call before anything overwrites the resident volumes: outstanding lazy arrays are brought to the host."""
+        if self._live_aggregate is not None:      # (a plan / upload that needs larger volumes frees the aggregate buffers too)
+            self._live_aggregate.retire()
+            self._live_aggregate = None
         if self._live_result is not None:
             self._live_result.retire()
             self._live_result = None
+
+    def aggregate_lazy(self, want_intensity=True) -> AggregateResult:
+        """Aggregate the resident focus volumes on the device and return the handle its lazy arrays fetch through."""
+        if self._live_aggregate is not None:
+            self._live_aggregate.retire()
+        self.ctx.field_aggregate_device(want_intensity=want_intensity)
+        self._live_aggregate = AggregateResult(self, self.ctx._shape)
+        return self._live_aggregate
 
     # ---- element table ----------------------------------------------------------------------
     def bind(self, arr):

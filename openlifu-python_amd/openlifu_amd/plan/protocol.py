@@ -210,13 +210,16 @@ class Protocol:
             return solution, None, None
         # max over foci for pressures, mean for intensity (protocol.py:382-387), on the device
         eng, _, _, _ = solution._bind_device()
-        p_agg, i_agg = eng.ctx.field_aggregate(want_intensity=True)
-        p_agg2, _ = eng.ctx.aggregate_fetch(want_intensity=False)     # p_max: its own caller-owned array (a second staged fetch beats a host copy)
+        # ... and left there: the three aggregate volumes reach the host when -- and if -- the caller reads them (each a
+        # fresh, caller-owned array), like the per-focus volumes
+        agg = eng.aggregate_lazy(want_intensity=True)
         coords = params.coords
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
-        aggregated = ds.make_dataset({
-            "p_min": ds.make_dataarray(p_agg, coords=coords, dims=dims, name="p_min", attrs=_ATTRS["p_min"]),
-            "p_max": ds.make_dataarray(p_agg2, coords=coords, dims=dims, name="p_max", attrs=_ATTRS["p_max"]),
-            "intensity": ds.make_dataarray(i_agg, coords=coords, dims=dims, name="intensity", attrs=_ATTRS["intensity"])})
+        shape = agg.shape
+
+        def lazy(name, key):
+            return agg.lazy_array(key, lambda fetch: ds.LazyDataArray(shape, np.float32, fetch, coords=coords, dims=dims, name=name,
+                                                                      attrs=_ATTRS[name]))
+        aggregated = ds.make_dataset({"p_min": lazy("p_min", "pmag"), "p_max": lazy("p_max", "pmag"), "intensity": lazy("intensity", "intensity")})
         analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints)
         return solution, aggregated, analysis

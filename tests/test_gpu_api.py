@@ -96,6 +96,11 @@ def test_calc_solution_wheel_scale_and_aggregate():
     assert np.abs(sol2.simulation_result["intensity"].data - its).max() / its.max() <= 4e-5
     assert np.allclose(an2.mainlobe_pnp_MPa, 1.2, rtol=1e-4)                     # every focus hits the target pressure
     assert np.abs(agg2["p_max"].data - ps.max(axis=0)).max() / ps.max() <= 2e-5   # aggregation sees the scaled volumes
+    # the aggregate Dataset is handed out lazily (device-resident until read); the first call's p_max was never read before the second
+    # call reused the aggregate buffers -- the engine brought it to the host first: still the UNSCALED aggregate, its own writable array
+    assert np.array_equal(agg["p_max"].data, agg["p_min"].data) and agg["p_max"].data is not agg["p_min"].data
+    assert agg["p_max"].data.flags.writeable and agg["p_max"].data.base is None
+    assert not np.array_equal(agg["p_max"].data, agg2["p_max"].data)
 
 
 def test_calc_solution_without_simulation_and_scale_guard():
