@@ -230,6 +230,13 @@ int olx_field_scale(olx_ctx *ctx, const double *scale_per_focus, int n_foci);
 int olx_field_masked_peak(olx_ctx *ctx, int which, const double *A, const double *aspect,
                           double radius_m, int op, int use_zmin, double zmin_m, float *peak_out);
 
+/* The six peaks Solution.analyze takes from |p_f| and intensity_f (plan/solution.py:205-262) in one pass over both volumes:
+ * peaks_out[F*6] = per focus (mainlobe |p|, mainlobe I, sidelobe |p|, sidelobe I, global |p|, global I) with
+ * mainlobe = dist < r_main_m, sidelobe = dist > r_side_m and z > zmin_m, global = z > zmin_m -- the same arithmetic as six
+ * olx_field_masked_peak calls (ops '<', '>' and none), bit-identical results, one sixth of the HBM reads and launches. */
+int olx_field_analysis_peaks(olx_ctx *ctx, const double *A, const double *aspect, double r_main_m, double r_side_m,
+                             double zmin_m, float *peaks_out);
+
 /* Masked first moments per focus (find_centroid, plan/solution_analysis.py:306-317): over voxels with
  * dist < radius_m (same focal-ellipsoid metric as above) and |p_f| > cutoff[f]:
  * moments_out[F*4] = { sum p, sum p x, sum p y, sum p z } (x, y, z = voxel position in metres, fp64). */

@@ -358,6 +358,54 @@ __global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------
+// The six masked peaks Solution.analyze reads off |p_f| and intensity_f (plan/solution.py:205-262) in ONE pass over the two
+// volumes: mainlobe (dist < r_main), sidelobe (dist > r_side, z > zmin) and global (z > zmin) maxima of each.  Same fp64
+// focal-frame arithmetic and comparisons as field_masked_peak_k (ops 0, 2, 4), so the six numbers are bit-identical to six
+// separate scans; out[f][6] = (main p, main I, side p, side I, global p, global I), integer atomicMax of the float bits.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void field_analysis_peaks_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+                                                               const double* __restrict__ A, const PeakParams P /*radius = r_main*/,
+                                                               const double r_side, unsigned* __restrict__ out /*[F][6]*/) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ float s_red[4][6];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float* vp = pmag + (long long)f * P.vox;
+    const float* vi = inten + (long long)f * P.vox;
+    float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long nyz = (long long)P.ny * P.nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
+        const int ix = (int)(i / nyz);
+        const int rem = (int)(i - ix * nyz);
+        const int iy = rem / P.nz, iz = rem - iy * P.nz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+        const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+        const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+        const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+        const bool zok = z > P.zmin;
+        const float p = vp[i], w = vi[i];
+        if (dist < P.radius) { m[0] = fmaxf(m[0], p); m[1] = fmaxf(m[1], w); }
+        if (zok && dist > r_side) { m[2] = fmaxf(m[2], p); m[3] = fmaxf(m[3], w); }
+        if (zok) { m[4] = fmaxf(m[4], p); m[5] = fmaxf(m[5], w); }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const float r = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+        atomicMax(out + f * 6 + k, __float_as_uint(r));
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // masked first moments per focus (find_centroid, plan/solution_analysis.py:306-317): over voxels inside
 // the focal ellipsoid (dist < radius) whose |p| exceeds cutoff_f:  S0 = sum p, S1 = sum p * (x, y, z).
 // fp64 sums, block-reduced, one atomicAdd(double) per block and component.

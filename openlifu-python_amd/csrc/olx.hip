@@ -1546,6 +1546,35 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     return OLX_OK;
 }
 
+int olx_field_analysis_peaks(olx_ctx* c, const double* A, const double* aspect, double r_main_m, double r_side_m, double zmin_m,
+                             float* peaks_out) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_analysis_peaks: nothing planned");
+    if (!A || !aspect || !peaks_out) return fail(c, OLX_EINVAL, "olx_field_analysis_peaks: null argument");
+    if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_analysis_peaks: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->plan_foci;
+    DevScratch scratch;   // [12 F] focal-frame rows (fp64) | [6 F] peaks
+    HIPCHK(c, hipMalloc(&scratch.p, sizeof(double) * 12 * F + sizeof(unsigned) * 6 * F));
+    double* d_A = scratch.at<double>(0);
+    unsigned* d_out = scratch.at<unsigned>(sizeof(double) * 12 * F);
+    HIPCHK(c, hipMemcpyAsync(d_A, A, sizeof(double) * 12 * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(unsigned) * 6 * F, c->stream));
+    PeakParams P;
+    P.nx = c->fp.nx; P.ny = c->fp.ny; P.nz = c->fp.nz;
+    P.ox = c->grid.origin[0] + c->slab.x_begin * c->grid.spacing[0]; P.oy = c->grid.origin[1]; P.oz = c->grid.origin[2];
+    P.hx = c->grid.spacing[0]; P.hy = c->grid.spacing[1]; P.hz = c->grid.spacing[2];
+    P.ia0 = 1.0 / aspect[0]; P.ia1 = 1.0 / aspect[1]; P.ia2 = 1.0 / aspect[2];
+    P.radius = r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = zmin_m; P.vox = c->fp.vox; P.vol_stride = c->fp.vox;
+    const long long want = (P.vox + 255) / 256;
+    dim3 grid((unsigned)std::min<long long>(want, 2048), F);
+    hipLaunchKernelGGL(field_analysis_peaks_k, grid, dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, r_side_m, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(peaks_out, d_out, sizeof(float) * 6 * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
 static void fill_scan_params(const olx_ctx* c, PeakParams& P, const double* aspect) {
     P.nx = c->fp.nx; P.ny = c->fp.ny; P.nz = c->fp.nz;
     P.ox = c->grid.origin[0] + c->slab.x_begin * c->grid.spacing[0]; P.oy = c->grid.origin[1]; P.oz = c->grid.origin[2];

@@ -32,7 +32,7 @@ SYMBOLS = [
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
-    "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
+    "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
 ]
 
 
@@ -99,6 +99,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_reduce_scatter_aggregate.argtypes = [vp]
         lib.olx_aggregate_fetch.argtypes = [vp, fp, fp]
         lib.olx_field_aggregate_device.argtypes = [vp, c_int]
+        lib.olx_field_analysis_peaks.argtypes = [vp, dp, dp, c_double, c_double, c_double, fp]
         lib.olx_field_aggregate_counts.argtypes = [vp, c_int, c_int]
         lib.olx_rccl_path.argtypes = [vp]; lib.olx_rccl_path.restype = c_char_p
         lib.olx_bf_time.argtypes = [vp, c_int, fp]
@@ -384,6 +385,15 @@ class Context:
         self._chk(self._lib.olx_field_masked_peak(self._h, {"pmag": 0, "intensity": 1, "weighted_intensity": 2}[which], _dptr(A), _dptr(aspect),
                                                   float(radius_m), ops[op], int(zmin_m is not None),
                                                   float(zmin_m or 0.0), _fptr(out)))
+        return out
+
+    def field_analysis_peaks(self, A, aspect, r_main_m, r_side_m, zmin_m):
+        """[F, 6] = per focus (mainlobe |p|, mainlobe I, sidelobe |p|, sidelobe I, global |p|, global I): the six masked peaks
+        of ``Solution.analyze`` in one pass (bit-identical to six ``field_masked_peak`` calls)."""
+        F = self._plan_foci
+        A = _f64(A, (F, 12)); aspect = _f64(aspect, (3,))
+        out = np.empty((F, 6), dtype=np.float32)
+        self._chk(self._lib.olx_field_analysis_peaks(self._h, _dptr(A), _dptr(aspect), float(r_main_m), float(r_side_m), float(zmin_m), _fptr(out)))
         return out
 
     def field_masked_moments(self, A, aspect, radius_m, cutoff):

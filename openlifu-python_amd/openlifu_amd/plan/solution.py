@@ -151,13 +151,10 @@ class Solution:
             an.target_position_ax_mm.append(f_mm[2])
         aspect = options.mainlobe_aspect_ratio
         ctx = eng.ctx
-        main_p = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "pmag")
-        main_i = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "intensity")
         zmin = options.sidelobe_zmin * to_m
-        side_p = ctx.field_masked_peak(A, aspect, options.sidelobe_radius * to_m, ">", "pmag", zmin_m=zmin)
-        side_i = ctx.field_masked_peak(A, aspect, options.sidelobe_radius * to_m, ">", "intensity", zmin_m=zmin)
-        glob_p = ctx.field_masked_peak(None, aspect, 0.0, None, "pmag", zmin_m=zmin)
-        glob_i = ctx.field_masked_peak(None, aspect, 0.0, None, "intensity", zmin_m=zmin)
+        # mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin) peaks of |p| and intensity: one pass over both volumes
+        pk = ctx.field_analysis_peaks(A, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin)
+        main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
         # -3 dB centroid of the mainlobe (find_centroid) and time-average intensity volume (get_ita)
         mom = ctx.field_masked_moments(A, aspect, options.mainlobe_radius * to_m, main_p * 10 ** (-3 / 20))
         pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % self.num_foci() + 1

@@ -169,6 +169,12 @@ def test_aggregate_scale_masked_peak_and_upload(ctx):
             assert got[f] == vols[f][mask].max()
     got = ctx.field_masked_peak(None, aspect, 0.0, None, zmin_m=10e-3)
     assert np.array_equal(got, [v[Z > 10e-3].max() for v in vols])
+    # the six peaks of Solution.analyze in one pass == six separate scans, bit for bit
+    six = ctx.field_analysis_peaks(A, aspect, 2.5e-3, 4e-3, 12e-3)
+    sep = [ctx.field_masked_peak(A, aspect, 2.5e-3, "<", "pmag"), ctx.field_masked_peak(A, aspect, 2.5e-3, "<", "intensity"),
+           ctx.field_masked_peak(A, aspect, 4e-3, ">", "pmag", zmin_m=12e-3), ctx.field_masked_peak(A, aspect, 4e-3, ">", "intensity", zmin_m=12e-3),
+           ctx.field_masked_peak(None, aspect, 0.0, None, "pmag", zmin_m=12e-3), ctx.field_masked_peak(None, aspect, 0.0, None, "intensity", zmin_m=12e-3)]
+    assert six.shape == (3, 6) and all(np.array_equal(six[:, k], sep[k]) for k in range(6))
     ctx.field_scale([2.0, 0.5, 1.0])
     assert np.allclose(ctx.field_fetch(0)["pmag"], vols[0] * 2) and np.allclose(ctx.field_fetch(1)["intensity"], ints[1] * 0.25)
     fresh = nat.Context(0)
