@@ -1,6 +1,7 @@
 // kernel 2g (field_cosetp_k): kernel 2e's NT = 2 shape with the PLANES in the MFMA rows -- no output staging
 // gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
 #include <algorithm>
+#include <cstdlib>
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
@@ -80,9 +81,6 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const CosetBlock BK = blocks[item];
     const int npos = BK.npos, KY = BK.KY, ky_magic = BK.ky_magic;
     if (npos <= 0) continue;                            // block-uniform
-    // (persistent form) every wave has left the previous item's K-steps: tables and steering stage are free.  LDS-only barrier:
-    // the previous item's stores drain behind this item's table generation
-    if (PERSIST && item != (int)blockIdx.x) lds_barrier();
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
@@ -288,6 +286,9 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         if (sb0 == 0) OLX_STAMP(4);
     }
     OLX_STAMP(5);
+    // (persistent form) every wave has left this record's K-steps: tables and steering stage are free for the next record.  LDS-only,
+    // and BEFORE the epilogue: no wave waits for another wave's stores
+    if constexpr (PERSIST) lds_barrier();
     // ---- epilogue, straight from the accumulators.  Lane (g, c16): rows 4 g .. 4 g + 3 = planes k0 + 4 g .. + 3 of the tile's
     // position, column c16 = (o, re | im).  The |p| lane (part 0) and its partner (part 1, the intensity lane) hold the same
     // (S re)^2 + (S im)^2 after one quad swap; per pair of rows the |p| lane takes the root of the first and the partner lane of
@@ -402,7 +403,9 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     const int n_items = (int)c->cp_nblocks;
     const bool clamp = c->clamp || c->lat.clamp;
     const bool persist = c->cosetp_persist && c->mp.n_tiles == 1;
-    dim3 grid(persist ? (unsigned)std::min(2 * c->n_cu, n_items) : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
+    int pgrid = std::min(2 * c->n_cu, n_items);
+    if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
+    dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
 #define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger)
     if (persist) {
         if (c->fp8corr) { if (clamp) OLX_CP(true, true, true); else OLX_CP(false, true, true); }
