@@ -190,7 +190,8 @@ int olx_field_medium_model(olx_ctx *ctx, int model);
 /* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
  * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]
  * floats each; intensity may be NULL.  Needs no element or steering table; olx_field_launch is
- * refused afterwards until the next olx_field_plan. */
+ * refused afterwards until the next olx_field_plan.  Like a plan it resets olx_field_aggregate_counts
+ * (aggregates cover all n_foci uploaded volumes) and drops any heterogeneous-medium state. */
 int olx_field_upload(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab, int n_foci,
                      const float *pmag, const float *intensity);
 
@@ -294,7 +295,7 @@ int olx_field_allreduce_aggregate(olx_ctx *ctx);
 int olx_field_reduce_scatter_aggregate(olx_ctx *ctx);
 /* Shards padded to equal size (RCCL all-gather needs equal counts; dist.plan_foci_orbits repeats a rank's last focus):
  * only the first local_valid planned foci of this rank enter its local max / sum, and the intensity mean divides by
- * global_total (the number of genuine foci over all ranks).  Valid until the next olx_field_plan. */
+ * global_total (the number of genuine foci over all ranks).  Valid until the next olx_field_plan / olx_field_upload. */
 int olx_field_aggregate_counts(olx_ctx *ctx, int local_valid, int global_total);
 /* File the RCCL entry points were bound from ("" before the first olx_comm_* call). */
 const char *olx_rccl_path(const olx_ctx *ctx);

@@ -407,10 +407,13 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
     dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
 #define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger)
+#ifdef OLX_AB_VARIANTS   // the persistent grid (OLX_FIELD_VARIANT=cosetpp): measured slower, developer library only
     if (persist) {
         if (c->fp8corr) { if (clamp) OLX_CP(true, true, true); else OLX_CP(false, true, true); }
         else            { if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true); }
-    } else {
+    } else
+#endif
+    {
         if (c->fp8corr) { if (clamp) OLX_CP(true, true, false); else OLX_CP(false, true, false); }
         else            { if (clamp) OLX_CP(true, false, false); else OLX_CP(false, false, false); }
     }

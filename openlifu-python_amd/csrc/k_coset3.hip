@@ -1,5 +1,6 @@
 // kernel 2q (field_cosetq_k): kernel 2g cut into blocks of FOUR waves x EIGHT planes -- four blocks per CU instead of two
 // gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#ifdef OLX_AB_VARIANTS   // measured-slower A/B form: compiled only into the developer library (build.py -DOLX_AB_VARIANTS), never into libolx.so
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
@@ -342,3 +343,4 @@ void olx_launch_cosetq(olx_ctx* c, float* pm) {
     else if (c->my == 2) launch_cosetq<1, 2>(c, pm);
     else launch_cosetq<1, 1>(c, pm);
 }
+#endif  // OLX_AB_VARIANTS

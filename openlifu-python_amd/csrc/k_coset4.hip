@@ -1,5 +1,6 @@
 // kernel 2r (field_cosetr_k): kernel 2g as ONE persistent block per CU -- the next tables are generated INSIDE the K-steps
 // gfx950 (CDNA4, wave64) only.  Data layout in HBM: DESIGN.md section 4; launchers declared in olx_launch.h.
+#ifdef OLX_AB_VARIANTS   // measured-slower A/B form: compiled only into the developer library (build.py -DOLX_AB_VARIANTS), never into libolx.so
 #include <algorithm>
 #include "k_types.hip.h"
 #include "olx_ctx.h"
@@ -360,3 +361,4 @@ void olx_launch_cosetr(olx_ctx* c, float* pm) {
     else if (c->my == 2) launch_cosetr<1, 2>(c, pm);
     else launch_cosetr<1, 1>(c, pm);
 }
+#endif  // OLX_AB_VARIANTS

@@ -2,6 +2,7 @@
 // design for the accumulate, built to evidence the choice against the one-voxel-per-lane kernel 2a with rocprof
 // (profiles/r02_shfl_vs_accum.*; OLX_FIELD_VARIANT=shfl selects it, the planner never does).
 // gfx950 (CDNA4, wave64) only.
+#ifdef OLX_AB_VARIANTS   // measured-slower A/B form: compiled only into the developer library (build.py -DOLX_AB_VARIANTS), never into libolx.so
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
@@ -86,3 +87,4 @@ void olx_launch_shfl(olx_ctx* c, float* pm) {
     if (c->clamp) hipLaunchKernelGGL((field_shfl_k<true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, P);
     else hipLaunchKernelGGL((field_shfl_k<false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, P);
 }
+#endif  // OLX_AB_VARIANTS

@@ -1,6 +1,7 @@
 // kernel 2f, wave-specialised form (field_toepws_k): one steering column on a lattice array -- persistent blocks, one team of
 // waves evaluates the NEXT geometry tables while the other contracts the CURRENT ones on the matrix pipe
 // gfx950 (CDNA4, wave64) only.  Mathematics, operands and table layout: k_toep.hip (kernel 2f).
+#ifdef OLX_AB_VARIANTS   // measured-slower A/B form: compiled only into the developer library (build.py -DOLX_AB_VARIANTS), never into libolx.so
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
@@ -299,3 +300,4 @@ void olx_launch_toepws(olx_ctx* c, float* pm) {
     else if (c->my == 2) launch_toepws<1, 2>(c, pm);
     else launch_toepws<1, 1>(c, pm);
 }
+#endif  // OLX_AB_VARIANTS

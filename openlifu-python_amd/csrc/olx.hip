@@ -14,6 +14,15 @@
 #include "k_small.hip.h"
 #include "olx_launch.h"
 
+// The measured-slower A/B forms of the accumulate (kernels 2q, 2r, 2s, persistent 2g, wave-specialised 2f: DESIGN.md 5.4) are
+// compiled only into the developer library (build.py -DOLX_AB_VARIANTS --out lib/libolx_ab.so); the product library carries the
+// kernels its planner can select, and ignores their OLX_FIELD_VARIANT names.
+#ifdef OLX_AB_VARIANTS
+static constexpr bool kAbVariants = true;
+#else
+static constexpr bool kAbVariants = false;
+#endif
+
 extern "C" {
 
 int olx_abi_version(void) { return OLX_ABI_VERSION; }
@@ -46,12 +55,16 @@ int olx_ctx_create(int device, olx_ctx** out) {
 }
 
 int olx_comm_destroy(olx_ctx* c);
+}
+static void free_fetch_lanes(olx_ctx* c);
+extern "C" {
 
 int olx_ctx_destroy(olx_ctx* c) {
     if (!c) return OLX_EINVAL;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     olx_comm_destroy(c);
+    free_fetch_lanes(c);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
@@ -520,17 +533,17 @@ static int configure_variant(olx_ctx* c) {
             // array): Toeplitz weights stationary, 16 planes per MFMA tile -- 2e would use 2 of 16 matrix columns
             c->use_toep = c->use_coset && tiles.size() == 1 && total_cols == 1 && !(fv && !strcmp(fv, "lattice"));
             // (the persistent wave-specialised form of kernel 2f, field_toepws_k, measured 13 - 35 % SLOWER -- DESIGN.md 5.4; A/B only)
-            c->toep_block = !(fv && !strcmp(fv, "toepws"));
+            c->toep_block = !(kAbVariants && fv && !strcmp(fv, "toepws"));
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
             // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
-            c->use_cosetq = c->use_cosetp && fv && !strcmp(fv, "cosetq");
+            c->use_cosetq = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetq");
             // kernel 2r: 2g as one persistent block per CU with the table generation inside the K-steps (OLX_FIELD_VARIANT=cosetr);
             // steering fragments of at most 4 super-blocks stay resident in LDS, one launch tile
-            c->use_cosetr = c->use_cosetp && fv && !strcmp(fv, "cosetr") && c->lat.nsa * c->lat.nsbp <= 4 && tiles.size() == 1 && (c->fp.nz & 3) == 0 &&
+            c->use_cosetr = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetr") && c->lat.nsa * c->lat.nsbp <= 4 && tiles.size() == 1 && (c->fp.nz & 3) == 0 &&
                             (unsigned long long)F * (unsigned long long)c->fp.vox < (1ull << 32);
-            c->cosetp_persist = c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
+            c->cosetp_persist = kAbVariants && c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
             c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
             if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
                 for (auto& t : tiles)   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
@@ -1007,7 +1020,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
-    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : !strcmp(force, "shfl") ? 5 : 0;
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : (kAbVariants && !strcmp(force, "shfl")) ? 5 : 0;
     c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && !c->directivity;   // directivity: exact per-pair kernel only (v1)
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
@@ -1061,11 +1074,22 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-    else if (c->use_mfma) { if (c->use_lattice) { if (c->use_toep) { if (c->toep_block) olx_launch_toep(c, pm); else olx_launch_toepws(c, pm); } else if (c->use_cosetr) olx_launch_cosetr(c, pm); else if (c->use_cosetq) olx_launch_cosetq(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else if (c->use_coset) olx_launch_coset(c, pm); else olx_launch_lattice(c, pm); } else olx_launch_mfma(c, pm); }
+#ifdef OLX_AB_VARIANTS
+    else if (c->use_mfma && c->use_lattice && c->use_toep && !c->toep_block) olx_launch_toepws(c, pm);
+    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetr) olx_launch_cosetr(c, pm);
+    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetq) olx_launch_cosetq(c, pm);
+    else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->directivity && c->force_kind == 5) olx_launch_shfl(c, pm);
+#endif
+    else if (c->use_mfma) {
+        if (!c->use_lattice) olx_launch_mfma(c, pm);
+        else if (c->use_toep) olx_launch_toep(c, pm);
+        else if (c->use_cosetp) olx_launch_cosetp(c, pm);
+        else if (c->use_coset) olx_launch_coset(c, pm);
+        else olx_launch_lattice(c, pm);
+    }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
     } else if (c->directivity) olx_launch_accum_dir(c, pm);
-    else if (c->force_kind == 5) olx_launch_shfl(c, pm);
     else olx_launch_accum(c, pm);
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
@@ -1113,18 +1137,40 @@ struct FetchLane {                 // one per worker thread: its own stream and 
     hipStream_t stream = nullptr;
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
-    bool init() {
-        if (stream) return true;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+    bool ok = false;
+    void release() {
         for (int i = 0; i < 2; ++i) {
-            if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+            if (ev[i]) hipEventDestroy(ev[i]);
+            if (buf[i]) hipHostFree(buf[i]);
+            ev[i] = nullptr; buf[i] = nullptr;
         }
-        return true;
+        if (stream) hipStreamDestroy(stream);
+        stream = nullptr; ok = false;
+    }
+    bool init() {                  // complete or not at all: a partial failure leaves nothing behind and is retried next time
+        if (ok) return true;
+        release();
+        bool good = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; good && i < 2; ++i)
+            good = hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) == hipSuccess &&
+                   hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); release(); return false; }
+        return ok = true;
     }
 };
 static constexpr int FETCH_MAX_THREADS = 32;
-static FetchLane g_lanes[16][FETCH_MAX_THREADS];   // [device ordinal][worker]; one caller thread per context
+// The lanes belong to the CONTEXT (olx_ctx::fetch_lanes, freed by olx_ctx_destroy): two contexts on one device fetching from two
+// threads never share pinned chunks (ctypes releases the GIL; the contract is one caller thread per context).
+static FetchLane* ctx_fetch_lanes(olx_ctx* c) {
+    if (!c->fetch_lanes) c->fetch_lanes = new FetchLane[FETCH_MAX_THREADS];
+    return c->fetch_lanes;
+}
+static void free_fetch_lanes(olx_ctx* c) {
+    if (!c->fetch_lanes) return;
+    for (int t = 0; t < FETCH_MAX_THREADS; ++t) c->fetch_lanes[t].release();
+    delete[] c->fetch_lanes;
+    c->fetch_lanes = nullptr;
+}
 
 // Worker t moves bytes [lo, hi) of the transfer: DMA of chunk i+1 into its second pinned buffer is in flight while it
 // copies chunk i into the destination (first touch of those destination pages happens on this thread).
@@ -1166,7 +1212,7 @@ static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
         if (const char* t = getenv("OLX_FETCH_THREADS")) nthr = atoi(t);
         const int hw = (int)std::thread::hardware_concurrency();
         nthr = std::max(1, std::min({nthr, FETCH_MAX_THREADS, hw > 0 ? hw : 1, (int)(bytes / (2 * FetchLane::CHUNK))}));
-        FetchLane* lanes = g_lanes[c->device & 15];
+        FetchLane* lanes = ctx_fetch_lanes(c);
         bool ready = true;
         for (int t = 0; t < nthr; ++t) ready = ready && lanes[t].init();
         if (ready) {
@@ -1419,6 +1465,8 @@ int olx_field_upload(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_
     HIPCHK(c, hipMemcpy(c->d_pmag[0], pmag, sizeof(float) * total, hipMemcpyHostToDevice));
     if (intensity) HIPCHK(c, hipMemcpy(c->d_inten, intensity, sizeof(float) * total, hipMemcpyHostToDevice));
     c->grid = *g; c->slab = s; c->plan_foci = n_foci;
+    c->agg_local = -1; c->agg_total = 0;   // like olx_field_plan: the counts of a former padded sweep do not describe these volumes
+    c->hetero = false; c->marched = false;
     c->fp.nx = s.x_count; c->fp.ny = g->n[1]; c->fp.nz = g->n[2]; c->fp.vox = vox;
     c->flags = OLX_OUT_PMAG | (intensity ? OLX_OUT_INTENSITY : 0u);
     c->cur = 0; c->nbuf = 1;

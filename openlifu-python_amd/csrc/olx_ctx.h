@@ -30,8 +30,11 @@ struct RcclApi {
 static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
 static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
 
+struct FetchLane;   // olx.hip: pinned staging of the device -> host fetches
+
 struct olx_ctx {
     int device = 0;
+    FetchLane* fetch_lanes = nullptr;          // per context, created on the first staged fetch
     int n_cu = 0;                              // compute units of the device (persistent kernels size their grids by it)
     hipStream_t stream = nullptr;
     std::string err;

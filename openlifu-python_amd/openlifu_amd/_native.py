@@ -359,7 +359,15 @@ class Context:
         v = self._lib.olx_field_variant(self._h)
         return v.decode() if v else ""
 
+    def _aggregate_overwrite(self):
+        """The aggregate buffers are about to be rewritten: whoever handed out lazy arrays on them (Engine.aggregate_lazy)
+        reads those to the host first (``before_aggregate`` hook; None when nobody did)."""
+        hook = getattr(self, "before_aggregate", None)
+        if hook is not None:
+            hook()
+
     def field_aggregate(self, want_intensity=True):
+        self._aggregate_overwrite()
         pm = np.empty(self._shape, dtype=np.float32)
         it = np.empty(self._shape, dtype=np.float32) if want_intensity else None
         self._chk(self._lib.olx_field_aggregate(self._h, _fptr(pm), _fptr(it)))
@@ -367,6 +375,7 @@ class Context:
 
     def field_aggregate_device(self, want_intensity=True):
         """max |p| / mean intensity over the planned foci, left in HBM (``aggregate_fetch`` reads either volume later)."""
+        self._aggregate_overwrite()
         self._chk(self._lib.olx_field_aggregate_device(self._h, int(bool(want_intensity))))
 
     def field_scale(self, scale_per_focus):
@@ -448,10 +457,12 @@ class Context:
         self._chk(self._lib.olx_field_allgather(self._h))
 
     def field_allreduce_aggregate(self):
+        self._aggregate_overwrite()
         self._chk(self._lib.olx_field_allreduce_aggregate(self._h))
 
     def field_reduce_scatter_aggregate(self):
         """Sharded aggregate: rank r ends up owning voxels [r V/N, (r+1) V/N) of the global max |p| / mean intensity."""
+        self._aggregate_overwrite()
         self._chk(self._lib.olx_field_reduce_scatter_aggregate(self._h))
 
     def aggregate_fetch(self, want_intensity=True, want_pmag=True):

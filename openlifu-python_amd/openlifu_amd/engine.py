@@ -125,6 +125,14 @@ class Engine:
         self.result_token = 0  # bumped whenever the resident result volumes change
         self._live_result = None
         self._live_aggregate = None
+        # every path that rewrites the aggregate buffers -- ctx.field_aggregate, the cross-rank all-reduce / reduce-scatter of
+        # dist.ShardedField, another aggregate_lazy -- first brings a lazily handed-out aggregate Dataset to the host
+        self.ctx.before_aggregate = self._retire_aggregate
+
+    def _retire_aggregate(self):
+        if self._live_aggregate is not None:
+            live, self._live_aggregate = self._live_aggregate, None
+            live.retire()
 
     def retire_results(self):
         """Call before anything overwrites the resident volumes: outstanding lazy arrays are brought to the host."""
@@ -137,9 +145,7 @@ class Engine:
 
     def aggregate_lazy(self, want_intensity=True) -> AggregateResult:
         """Aggregate the resident focus volumes on the device and return the handle its lazy arrays fetch through."""
-        if self._live_aggregate is not None:
-            self._live_aggregate.retire()
-        self.ctx.field_aggregate_device(want_intensity=want_intensity)
+        self.ctx.field_aggregate_device(want_intensity=want_intensity)      # (retires a live aggregate through the hook)
         self._live_aggregate = AggregateResult(self, self.ctx._shape)
         return self._live_aggregate
 

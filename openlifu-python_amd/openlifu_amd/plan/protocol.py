@@ -35,6 +35,15 @@ from .target_constraints import TargetConstraints
 
 OnPulseMismatchAction = Enum("OnPulseMismatchAction", ["ERROR", "ROUND", "ROUNDUP", "ROUNDDOWN"])
 
+def aggregate_dataset_eager(agg, coords, dims):
+    """Dataset{p_min, p_max, intensity} of an ``AggregateResult`` read to the host NOW (three fresh arrays), built through
+    ``ds.make_dataarray`` -- the form that also works when ``ds`` hands out real xarray objects."""
+    pm, it = agg.fetch("pmag"), agg.fetch("intensity")
+    return ds.make_dataset({"p_min": ds.make_dataarray(pm, coords=coords, dims=dims, name="p_min", attrs=_ATTRS["p_min"]),
+                            "p_max": ds.make_dataarray(pm.copy(), coords=coords, dims=dims, name="p_max", attrs=_ATTRS["p_max"]),
+                            "intensity": ds.make_dataarray(it, coords=coords, dims=dims, name="intensity", attrs=_ATTRS["intensity"])})
+
+
 # module-level seam, as in the reference (plan/protocol.py:24; its tests patch this name)
 run_simulation = sim.run_simulation
 
@@ -217,9 +226,14 @@ class Protocol:
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         shape = agg.shape
 
-        def lazy(name, key):
-            return agg.lazy_array(key, lambda fetch: ds.LazyDataArray(shape, np.float32, fetch, coords=coords, dims=dims, name=name,
-                                                                      attrs=_ATTRS[name]))
-        aggregated = ds.make_dataset({"p_min": lazy("p_min", "pmag"), "p_max": lazy("p_max", "pmag"), "intensity": lazy("intensity", "intensity")})
-        analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints)
+        if ds.HAVE_XARRAY:
+            # real xarray objects cannot defer (xa.Dataset would turn a LazyDataArray into an unnamed-dims ndarray and raise
+            # MissingDimensionsError): fetch now, like the per-focus volumes above
+            aggregated = aggregate_dataset_eager(agg, coords, dims)
+        else:
+            def lazy(name, key):
+                return agg.lazy_array(key, lambda fetch: ds.LazyDataArray(shape, np.float32, fetch, coords=coords, dims=dims, name=name,
+                                                                          attrs=_ATTRS[name]))
+            aggregated = ds.make_dataset({"p_min": lazy("p_min", "pmag"), "p_max": lazy("p_max", "pmag"), "intensity": lazy("intensity", "intensity")})
+        analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints, _host_unchanged=True)
         return solution, aggregated, analysis

@@ -107,17 +107,24 @@ class Solution:
         res = self.simulation_result
         return all(isinstance(res[k], ds.LazyDataArray) and not res[k].materialized for k in ("p_min", "intensity"))
 
-    def _bind_device(self):
-        """Make sure the GPU holds this solution's CURRENT volumes; returns (engine, origin, spacing, n)."""
+    def _bind_device(self, assume_host_unchanged: bool = False):
+        """Make sure the GPU holds this solution's CURRENT volumes; returns (engine, origin, spacing, n).  Host-resident volumes
+        may have been edited in place at any time, so they are uploaded on every call -- unless the caller vouches that nothing
+        touched them since this solution's last upload (``calc_solution`` between its own consecutive steps) and the engine
+        still holds that upload."""
         res = self.simulation_result
         origin, spacing, n = grid_from_coords({d: res.coords[d] for d in res["p_min"].dims if d != "focal_point_index"})
         eng = get_engine()
+        up = getattr(self, "_uploaded", None)
+        if assume_host_unchanged and up is not None and up[0] is eng and up[1] == eng.result_token:
+            return eng, origin, spacing, n
         if not self._device_is_current():
             pm, it = np.asarray(res["p_min"].data), np.asarray(res["intensity"].data)   # (reads any still-lazy volume first)
             if "p_max" in res:
                 _ = res["p_max"].data
             eng.upload_result(origin, spacing, n, pm, it)
             self._resident = (eng, eng.result_token)
+            self._uploaded = (eng, eng.result_token)
         return eng, origin, spacing, n
 
     def _focus_frames(self):
@@ -138,11 +145,12 @@ class Solution:
         an.mainlobe_pnp_MPa = [float(v) * 1e-6 for v in peaks]
         return an
 
-    def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None) -> SolutionAnalysis:
+    def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None,
+                _host_unchanged: bool = False) -> SolutionAnalysis:
         """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
         options = SolutionAnalysisOptions() if options is None else options
         an = SolutionAnalysis()
-        eng, _, _, _ = self._bind_device()
+        eng, _, _, _ = self._bind_device(assume_host_unchanged=_host_unchanged)
         to_m = getunitconversion(options.distance_units, "m")
         A = self._focus_frames()
         for i, focus in enumerate(self.foci):
@@ -238,6 +246,7 @@ class Solution:
                 continue                      # still in HBM only: scaled there below, read (scaled) whenever the caller asks
             for i in range(self.num_foci()):
                 da[i].data *= factors[i] ** power
+            self._uploaded = None             # host copy edited: whatever the device holds of it is stale
         for i in range(self.num_foci()):
             self.apodizations[i] = self.apodizations[i] * apod_factors[i]
         if on_device:

@@ -198,9 +198,34 @@ class LazyDataArray(DataArray):
     def dtype(self):
         return self._dtype
 
+    # copies and pickles must not share the fetch closure: the device result behind it is retired (and unreadable) after the
+    # next launch or upload, and only arrays registered with it are rescued to the host first.  A copy therefore takes the
+    # values NOW (one device read, which also materialises this array); declared-constant volumes stay lazy.
+    def _detached(self, memo=None):
+        import copy as _copy
+        kw = dict(coords=_copy.deepcopy(self.coords, memo), dims=self.dims, name=self.name, attrs=_copy.deepcopy(self.attrs, memo))
+        if self._host is None and self._uniform is not None:
+            return LazyDataArray.uniform(self._shape, self._uniform, dtype=self._dtype, **kw)
+        return DataArray(np.array(self.data, copy=True), **kw)
+
+    def __deepcopy__(self, memo):
+        return self._detached(memo)
+
+    def __copy__(self):
+        return self._detached()
+
+    def __reduce__(self):
+        if self._host is None and self._uniform is not None:
+            return (_rebuild_uniform, (self._shape, self._uniform, self._dtype.str, dict(self.coords), self.dims, self.name, self.attrs))
+        return (DataArray, (np.array(self.data, copy=True), dict(self.coords), self.dims, self.name, self.attrs))
+
     def __repr__(self):
         where = "host" if self.materialized else "device"
         return f"<openlifu_amd.LazyDataArray {self.name!r} dims={self.dims} shape={self.shape} on {where}>"
+
+
+def _rebuild_uniform(shape, value, dtype, coords, dims, name, attrs):
+    return LazyDataArray.uniform(shape, value, coords=coords, dims=dims, name=name, attrs=attrs, dtype=np.dtype(dtype))
 
 
 class Coordinates(OrderedDict):

@@ -12,6 +12,11 @@ from conftest import centred_grid, synthetic_array
 
 pytestmark = pytest.mark.gpu
 F0, C, RHO, P0 = 400e3, 1500.0, 1000.0, 1e5
+# The measured-slower A/B forms (kernels 2q, 2r, 2s, persistent 2g, wave-specialised 2f) exist only in the developer library
+# (build.py -DOLX_AB_VARIANTS -> lib/libolx_ab.so); tests/test_gpu_ab_variants.py re-runs the cases below that name them in a child
+# process bound to that library (OLX_LIB_PATH).
+AB = "libolx_ab" in os.path.basename(nat.LIB_PATH)
+FAMILIES = ["general", "shared", "mfma", "lattice", "lattice2d"] + (["shfl"] if AB else [])
 TOL_P, TOL_I = 1e-5, 2e-5
 
 
@@ -257,7 +262,7 @@ def test_rccl_allgather_single_rank_and_sharded_driver(ctx):
     assert np.array_equal(pf, ps) and np.abs(pf[1] - ref).max() / ref.max() <= TOL_P
 
 
-@pytest.mark.parametrize("family", ["general", "shfl", "shared", "mfma", "lattice", "lattice2d"])
+@pytest.mark.parametrize("family", FAMILIES)
 def test_kernel_families_agree_with_oracle(ctx, family, monkeypatch):
     """Kernel 2a (per pair), 2b (shared geometry, VALU), 2c (shared geometry, MFMA fp16 hi/lo split) and 2d
     (lattice: block-Toeplitz geometry tables) are pinned one at a time (OLX_FIELD_VARIANT) on the same
@@ -648,7 +653,7 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
                   slab=(13, 14), expect="field_coset")
 
 
-@pytest.mark.parametrize("form", ["block", "toepws"])
+@pytest.mark.parametrize("form", ["block"] + (["toepws"] if AB else []))
 @pytest.mark.parametrize("case", ["16x16", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
 def test_single_column_toeplitz_kernel(ctx, case, form, monkeypatch):
     """Kernel 2f (one steering column: an on-axis focus on a mirror-symmetric lattice array; Toeplitz weights stationary, 16
@@ -769,6 +774,7 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
     print(f"full-volume 256^3 parity, fp8={fp8}: max error {worst:.2e} of the volume maximum")
 
 
+@pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
 @pytest.mark.parametrize("fp8", [True, False])
 @pytest.mark.parametrize("grid_n,nz", [(128, 128), (96, 50)])
 def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):

@@ -502,3 +502,56 @@ def test_threshold_segmentation_labels_and_params():
     mask = (zs[None, None, :] >= 8e-3) & (zs[None, None, :] < zsurf[:, :, None])
     assert np.array_equal(v["sound_speed"], np.where(mask, 2800.0, 1500.0).astype(np.float32))
     assert np.array_equal(v["attenuation"], np.where(mask, 6.0, 0.0).astype(np.float32)) and v["density"].max() == 1900.0
+
+
+def test_lazy_arrays_detach_on_copy_and_pickle():
+    """A LazyDataArray fetches through a closure on the device result that produced it; copies and pickles must not share that
+    closure (the result is retired -- unreadable -- after the next launch): they take the values at copy time.  Declared-constant
+    volumes (uniform media) stay lazy in the copy."""
+    import copy
+    import pickle
+    from openlifu_amd.util import dataset as ds
+    calls = []
+
+    def fetch():
+        calls.append(1)
+        return np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    coords = ds.make_coords({"x": [0.0, 1.0], "y": [0.0, 1.0, 2.0], "z": [0.0, 1.0, 2.0, 3.0]}, {"x": {"units": "mm"}})
+    lz = ds.LazyDataArray((2, 3, 4), np.float32, fetch, coords=coords, dims=("x", "y", "z"), name="p_min", attrs={"units": "Pa"})
+    dset = ds.make_dataset({"p_min": lz})
+    c1 = copy.deepcopy(dset)
+    assert calls == [1] and lz.materialized                     # one device read serves the original and the copy
+    assert not isinstance(c1["p_min"], ds.LazyDataArray) and np.array_equal(c1["p_min"].data, lz.data)
+    c1["p_min"].data[0, 0, 0] = -1.0
+    assert lz.data[0, 0, 0] == 0.0 and c1["p_min"].attrs == {"units": "Pa"} and c1["p_min"].dims == ("x", "y", "z")
+    lz2 = ds.LazyDataArray((2, 3, 4), np.float32, fetch, coords=coords, dims=("x", "y", "z"), name="p_min")
+    back = pickle.loads(pickle.dumps(lz2))
+    assert np.array_equal(back.data, lz.data) and back.dims == ("x", "y", "z") and list(back.coords) == ["x", "y", "z"]
+    uni = ds.LazyDataArray.uniform((2, 3, 4), 1500.0, coords=coords, dims=("x", "y", "z"), name="sound_speed", attrs={"ref_value": 1500.0})
+    for dup in (copy.deepcopy(uni), copy.copy(uni), pickle.loads(pickle.dumps(uni))):
+        assert isinstance(dup, ds.LazyDataArray) and dup.uniform_value == 1500.0 and not dup.materialized and not uni.materialized
+        assert dup.data.shape == (2, 3, 4) and float(dup.data.max()) == 1500.0
+
+
+def test_load_transducer_from_file_on_the_reference_fixtures():
+    """xdc/util.py:10-30 on the reference's own example_db files: a Transducer file, two TransducerArray files (flattened unless
+    convert_array=False), and the example protocol through Protocol.from_file."""
+    import os
+    import openlifu_amd as ol
+    from openlifu_amd.xdc import Transducer, TransducerArray, load_transducer_from_file
+    db = os.path.join(os.path.dirname(__file__), "golden", "example_db")
+    t = load_transducer_from_file(os.path.join(db, "example_transducer.json"))
+    assert isinstance(t, Transducer) and t.numelements() == 64 and t.id == "example_transducer"
+    assert [el.pin for el in t.elements] == list(range(1, 65)) and t.frequency == 400.6e3
+    for name in ("example_transducer_array.json", "example_transducer_array2.json"):
+        flat = load_transducer_from_file(os.path.join(db, name))
+        arr = load_transducer_from_file(os.path.join(db, name), convert_array=False)
+        assert isinstance(flat, Transducer) and isinstance(arr, TransducerArray)
+        assert flat.numelements() == sum(m.numelements() for m in arr.modules)
+        ref = arr.to_transducer()
+        assert np.array_equal(flat.get_positions(), ref.get_positions()) and [e.pin for e in flat.elements] == [e.pin for e in ref.elements]
+    with pytest.raises(FileNotFoundError):
+        load_transducer_from_file(os.path.join(db, "no_such_transducer.json"))
+    proto = ol.Protocol.from_file(os.path.join(db, "example_protocol.json"))
+    assert proto.pulse.frequency == 500000 and proto.delay_method.c0 == 1540 and type(proto.focal_pattern).__name__ == "SinglePoint"
+    assert proto.seg_method.materials["water"].sound_speed == 1500 and proto.sim_setup.z_extent == (-4, 70)
