@@ -270,6 +270,38 @@ int olx_tof_spread(olx_ctx *ctx, const double *xs, int nx, const double *ys, int
  * volume with every focus' mask. */
 int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci);
 
+/* ---- one-call analysis (Solution.analyze, plan/solution.py:135-281) ---------------------
+ * Everything analyze() reads off the resident volumes in ONE crossing: the six masked peaks of olx_field_analysis_peaks,
+ * the -3 dB centroid moments (olx_field_masked_moments with cut-off = mainlobe |p| peak * centroid_factor, fp32 product),
+ * the time-average volume of olx_field_weighted_intensity with its per-focus mainlobe peaks and its global peak above
+ * zmin (*ita_global), and the beam-width crossings of get_beam_bounds (solution_analysis.py:488-535) along the three focal
+ * axes.  Same kernels and arithmetic as the separate entry points (results identical); no intermediate leaves the device.
+ *   A[F*12]            focal frames as for olx_field_masked_peak
+ *   ita_weights[F]     per-focus weights of the time-average intensity
+ *   line_pts           [F][n_line[0] + n_line[1] + n_line[2]][3] sample positions [m] of each focus' lateral, elevation and
+ *                      axial line (the caller forms them: offsets linspace(-r, r, n) mapped through its focus matrix);
+ *                      may be NULL when all n_line are 0 (no beam widths; bounds = -1)
+ *   n_le[a] / i_ge[a]  number of leading samples of line a whose offset is <= 0 / index of its first sample with offset >= 0
+ *   beam_factor[2]     cut-off of level l = (float)(mainlobe |p| peak * beam_factor[l])  (10^(-3/20), 10^(-6/20))
+ * bounds[a][l][0] = index within line a of the LAST sample at an offset <= 0 below the cut-off, [1] = the FIRST at an offset
+ * >= 0; -1 = none (NaN samples -- outside the grid -- never qualify). */
+typedef struct olx_analysis_opts {
+    double aspect[3];
+    double r_main_m, r_side_m, zmin_m;
+    double beam_factor[2];
+    float centroid_factor;
+    int32_t n_line[3], n_le[3], i_ge[3];
+} olx_analysis_opts;
+typedef struct olx_focus_report {
+    float peaks[6];          /* mainlobe |p|, mainlobe I, sidelobe |p|, sidelobe I, global |p|, global I */
+    float ita_main;          /* mainlobe peak of the time-average intensity volume */
+    float reserved;
+    double moments[4];       /* S0 = sum |p|, S1 = sum |p| (x, y, z) [m] over the -3 dB mainlobe voxels */
+    int32_t bounds[3][2][2];
+} olx_focus_report;
+int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weights, const double *line_pts,
+                         const olx_analysis_opts *opts, olx_focus_report *reports, float *ita_global);
+
 /* ---- multi-GPU reassembly (RCCL over xGMI) -------------------------------------------
  * One context per rank.  id_bytes = the 128-byte ncclUniqueId made by rank 0
  * (olx_comm_unique_id) and distributed by the host launcher.  olx_field_allgather

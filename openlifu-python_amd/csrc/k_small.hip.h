@@ -565,4 +565,79 @@ __global__ void field_weighted_sum_k(const float* __restrict__ vol, const float*
 }
 
 
+// ------------------------------------------------------------------------------------
+// Pieces of the one-call analysis (olx_solution_analyze): everything Solution.analyze reads off the resident volumes is
+// enqueued back to back on the context's stream, the intermediate numbers (mainlobe peaks -> -3 dB centroid cut-offs and beam
+// width cut-offs) never leave the device, and ONE copy brings the per-focus reports to the host.
+// ------------------------------------------------------------------------------------
+// cut[f] = mainlobe |p| peak * factor, in fp32 (what NumPy's float32 array * Python float does on the host path)
+__global__ void analysis_cutoffs_k(const unsigned* __restrict__ peaks /*[F][6]*/, int n_foci, float factor, float* __restrict__ cut) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_foci) cut[f] = __fmul_rn(__uint_as_float(peaks[6 * f]), factor);
+}
+
+// trilinear samples of every focus' |p| volume along its three focal-axis lines: pts [F][npts][3] (fp64, formed on the host with the
+// expression Solution.analyze always used), out [F][npts]; same arithmetic as field_sample_k
+__global__ __launch_bounds__(128) void field_sample_lines_k(const float* __restrict__ vol, const double* __restrict__ pts, int npts,
+                                                            const PeakParams P, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (i >= npts) return;
+    const double* q = pts + ((size_t)f * npts + i) * 3;
+    const float* v = vol + (long long)f * P.vol_stride;
+    const double c[3] = {(q[0] - P.ox) / P.hx, (q[1] - P.oy) / P.hy, (q[2] - P.oz) / P.hz};
+    const int n[3] = {P.nx, P.ny, P.nz};
+    int i0[3]; double w[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double tol = 1e-9 * (n[a] > 1 ? n[a] - 1 : 1);
+        if (!(c[a] >= -tol && c[a] <= n[a] - 1 + tol)) inside = false;
+        double cc = fmin(fmax(c[a], 0.0), (double)(n[a] - 1));
+        i0[a] = (int)fmin(floor(cc), (double)max(n[a] - 2, 0));
+        w[a] = cc - i0[a];
+    }
+    float* o = out + (size_t)f * npts + i;
+    if (!inside) { *o = __builtin_nanf(""); return; }
+    double acc = 0;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const int ix = min(i0[0] + dx, P.nx - 1), iy = min(i0[1] + dy, P.ny - 1), iz = min(i0[2] + dz, P.nz - 1);
+                const double ww = (dx ? w[0] : 1 - w[0]) * (dy ? w[1] : 1 - w[1]) * (dz ? w[2] : 1 - w[2]);
+                acc += ww * v[((long long)ix * P.ny + iy) * P.nz + iz];
+            }
+    *o = (float)acc;
+}
+
+// get_beam_bounds on the sampled lines (plan/solution_analysis.py:488-535): per (focus, axis, level) the LAST sample at an
+// offset <= 0 and the FIRST at an offset >= 0 whose value lies below the level's cut-off (NaN never does); indices into the
+// axis line, -1 = none.  One 64-lane block per (axis, focus); cut-off = (float)(main peak * factor) as on the host path.
+struct BeamLines { int start[3], n[3], n_le[3], i_ge[3]; double factor[2]; };
+__global__ __launch_bounds__(64) void beam_bounds_k(const float* __restrict__ samples /*[F][npts]*/, int npts, const unsigned* __restrict__ peaks,
+                                                    const BeamLines L, int* __restrict__ bounds /*[F][3][2][2]*/) {
+    const int a = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const float* v = samples + (size_t)f * npts + L.start[a];
+    const double mp = (double)__uint_as_float(peaks[6 * f]);
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv) {
+        const float cut = (float)(mp * L.factor[lv]);
+        int neg = -1, pos = 0x7fffffff;
+        for (int i = lane; i < L.n[a]; i += 64) {
+            const bool below = v[i] < cut;
+            if (below && i < L.n_le[a]) neg = max(neg, i);
+            if (below && i >= L.i_ge[a]) pos = min(pos, i);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { neg = max(neg, __shfl_xor(neg, off, 64)); pos = min(pos, __shfl_xor(pos, off, 64)); }
+        if (lane == 0) {
+            int* b = bounds + ((f * 3 + a) * 2 + lv) * 2;
+            b[0] = neg; b[1] = pos == 0x7fffffff ? -1 : pos;
+        }
+    }
+}
+
+
 }  // namespace olx

@@ -65,10 +65,11 @@ int olx_ctx_destroy(olx_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     olx_comm_destroy(c);
     free_fetch_lanes(c);
+    if (c->h_an) hipHostFree(c->h_an);
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks};
+                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1755,6 +1756,116 @@ int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) 
     hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, c->d_scale, n_foci, c->fp.vox, c->d_wint);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+// ---- one-call analysis ------------------------------------------------------------------------------------------
+// Solution.analyze used to cross the C-ABI ~40 times per 8-focus solution (6-peak scan, moments, weighted intensity, two masked
+// peaks, 24 line samplings), every crossing with its own scratch hipMalloc / hipFree, pageable copies and a stream
+// synchronisation: 7.6 of calc_solution's 11 ms.  Here the same kernels are enqueued back to back; the numbers that feed later
+// steps (mainlobe peak -> -3 dB centroid cut-off, beam-width cut-offs) stay on the device; one pinned block goes in, one
+// comes out, one synchronisation.  Scratch is owned by the context and reused.
+static int analysis_scratch(olx_ctx* c, size_t dev_bytes, size_t host_bytes) {
+    if (c->an_dev_cap < dev_bytes) {
+        if (c->d_an) hipFree(c->d_an);
+        c->d_an = nullptr; c->an_dev_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_an, dev_bytes));
+        c->an_dev_cap = dev_bytes;
+    }
+    if (c->an_host_cap < host_bytes) {
+        if (c->h_an) hipHostFree(c->h_an);
+        c->h_an = nullptr; c->an_host_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_an, host_bytes, hipHostMallocDefault));
+        c->an_host_cap = host_bytes;
+    }
+    return OLX_OK;
+}
+
+int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
+                         const olx_analysis_opts* o, olx_focus_report* reports, float* ita_global) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_solution_analyze: nothing planned");
+    if (!A || !ita_weights || !o || !reports || !ita_global) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
+    if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_solution_analyze: intensity not planned");
+    const int F = c->plan_foci;
+    if (F > 4096) return fail(c, OLX_EINVAL, "olx_solution_analyze: too many foci");
+    int npts = 0;
+    BeamLines L{};
+    for (int a = 0; a < 3; ++a) {
+        if (o->n_line[a] < 0 || o->n_le[a] < 0 || o->n_le[a] > o->n_line[a] || o->i_ge[a] < 0 || o->i_ge[a] > o->n_line[a])
+            return fail(c, OLX_EINVAL, "olx_solution_analyze: bad line description for axis %d", a);
+        L.start[a] = npts; L.n[a] = o->n_line[a]; L.n_le[a] = o->n_le[a]; L.i_ge[a] = o->i_ge[a];
+        npts += o->n_line[a];
+    }
+    L.factor[0] = o->beam_factor[0]; L.factor[1] = o->beam_factor[1];
+    if (npts > 0 && !line_pts) return fail(c, OLX_EINVAL, "olx_solution_analyze: line points missing");
+    for (int a = 0; a < 3; ++a) if (!(o->aspect[a] != 0.0)) return fail(c, OLX_EINVAL, "olx_solution_analyze: zero aspect ratio");
+    HIPCHK(c, hipSetDevice(c->device));
+    // device / pinned layout.  in: [A 12 F f64][pts 3 npts F f64][weights F f32]   out: [peaks 6 F u32][ita F + 1 u32][bounds 12 F i32][moments 4 F f64]
+    // work (device only): [cut F f32][samples npts F f32]
+    auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    const size_t in_A = 0, in_pts = in_A + sizeof(double) * 12 * F, in_w = in_pts + sizeof(double) * 3 * (size_t)npts * F;
+    const size_t in_bytes = up8(in_w + sizeof(float) * F);
+    const size_t out_pk = in_bytes, out_ita = out_pk + sizeof(unsigned) * 6 * F, out_bd = out_ita + sizeof(unsigned) * (F + 1);
+    const size_t out_mom = up8(out_bd + sizeof(int) * 12 * F), out_end = out_mom + sizeof(double) * 4 * F;
+    const size_t wk_cut = out_end, wk_smp = up8(wk_cut + sizeof(float) * F), dev_bytes = wk_smp + sizeof(float) * (size_t)npts * F + 8;
+    { int rc = analysis_scratch(c, dev_bytes, out_end); if (rc) return rc; }
+    if (!c->d_wint || c->wint_cap < (size_t)c->fp.vox) {
+        if (c->d_wint) hipFree(c->d_wint);
+        c->d_wint = nullptr; c->wint_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_wint, sizeof(float) * c->fp.vox));
+        c->wint_cap = (size_t)c->fp.vox;
+    }
+    unsigned char* h = static_cast<unsigned char*>(c->h_an);
+    unsigned char* d = static_cast<unsigned char*>(c->d_an);
+    memcpy(h + in_A, A, sizeof(double) * 12 * F);
+    if (npts) memcpy(h + in_pts, line_pts, sizeof(double) * 3 * (size_t)npts * F);
+    for (int f = 0; f < F; ++f) reinterpret_cast<float*>(h + in_w)[f] = (float)ita_weights[f];
+    HIPCHK(c, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d + out_pk, 0, out_end - out_pk, c->stream));
+    const double* d_A = reinterpret_cast<const double*>(d + in_A);
+    unsigned* d_pk = reinterpret_cast<unsigned*>(d + out_pk);
+    unsigned* d_ita = reinterpret_cast<unsigned*>(d + out_ita);
+    float* d_cut = reinterpret_cast<float*>(d + wk_cut);
+    float* d_smp = reinterpret_cast<float*>(d + wk_smp);
+    const float* pm = c->d_pmag[c->cur];
+    PeakParams P; fill_scan_params(c, P, o->aspect);
+    // (1) the six masked peaks of |p| and intensity, one pass
+    P.radius = o->r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = o->zmin_m;
+    const long long want = (P.vox + 255) / 256;
+    hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
+    // (2) -3 dB centroid of the mainlobe: cut-off from the peak just found
+    hipLaunchKernelGGL(analysis_cutoffs_k, dim3((F + 63) / 64), dim3(64), 0, c->stream, d_pk, F, o->centroid_factor, d_cut);
+    P.use_zmin = 0; P.zmin = 0;
+    hipLaunchKernelGGL(field_masked_moments_k, dim3((unsigned)std::min<long long>(want, 1024), F), dim3(256), 0, c->stream, pm, d_A, d_cut, P,
+                       reinterpret_cast<double*>(d + out_mom));
+    // (3) time-average intensity volume, its mainlobe peaks (F masks over the ONE volume) and its global peak above zmin
+    hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, reinterpret_cast<const float*>(d + in_w), F, c->fp.vox, c->d_wint);
+    P.vol_stride = 0;
+    hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_ita);
+    P.op = 4; P.use_zmin = 1; P.zmin = o->zmin_m;
+    hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), 1), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_ita + F);
+    // (4) beam widths: |p| along the three focal axes of every focus, then the cut-off crossings
+    if (npts) {
+        P.vol_stride = c->fp.vox;
+        hipLaunchKernelGGL(field_sample_lines_k, dim3((npts + 127) / 128, F), dim3(128), 0, c->stream, pm, reinterpret_cast<const double*>(d + in_pts), npts, P, d_smp);
+        hipLaunchKernelGGL(beam_bounds_k, dim3(3, F), dim3(64), 0, c->stream, d_smp, npts, d_pk, L, reinterpret_cast<int*>(d + out_bd));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h + out_pk, d + out_pk, out_end - out_pk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const float* pk = reinterpret_cast<const float*>(h + out_pk);
+    const float* ita = reinterpret_cast<const float*>(h + out_ita);
+    const int* bd = reinterpret_cast<const int*>(h + out_bd);
+    const double* mom = reinterpret_cast<const double*>(h + out_mom);
+    for (int f = 0; f < F; ++f) {
+        olx_focus_report& R = reports[f];
+        for (int k = 0; k < 6; ++k) R.peaks[k] = pk[6 * f + k];
+        R.ita_main = ita[f]; R.reserved = 0.f;
+        for (int k = 0; k < 4; ++k) R.moments[k] = mom[4 * f + k];
+        for (int k = 0; k < 12; ++k) (&R.bounds[0][0][0])[k] = npts ? bd[12 * f + k] : -1;
+    }
+    *ita_global = ita[F];
     return OLX_OK;
 }
 

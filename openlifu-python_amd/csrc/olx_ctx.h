@@ -96,6 +96,7 @@ struct olx_ctx {
     float* d_agg_p = nullptr; float* d_agg_i = nullptr; float* d_scale = nullptr;
     double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
     float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
+    void* d_an = nullptr; void* h_an = nullptr; size_t an_dev_cap = 0, an_host_cap = 0;   // olx_solution_analyze: device scratch, pinned staging
     // heterogeneous medium (kernel 2h)
     bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
     float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;

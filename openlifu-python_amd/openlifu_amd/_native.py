@@ -33,6 +33,7 @@ SYMBOLS = [
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
+    "olx_solution_analyze",
 ]
 
 
@@ -46,6 +47,17 @@ class OlxGrid(ctypes.Structure):
 
 class OlxSlab(ctypes.Structure):
     _fields_ = [("x_begin", c_int32), ("x_count", c_int32)]
+
+
+class OlxAnalysisOpts(ctypes.Structure):
+    _fields_ = [("aspect", c_double * 3), ("r_main_m", c_double), ("r_side_m", c_double), ("zmin_m", c_double),
+                ("beam_factor", c_double * 2), ("centroid_factor", c_float), ("n_line", c_int32 * 3), ("n_le", c_int32 * 3),
+                ("i_ge", c_int32 * 3)]
+
+
+class OlxFocusReport(ctypes.Structure):
+    _fields_ = [("peaks", c_float * 6), ("ita_main", c_float), ("reserved", c_float), ("moments", c_double * 4),
+                ("bounds", c_int32 * 12)]
 
 
 _lib = None
@@ -107,6 +119,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_medium_layering.argtypes = [vp, c_int]
         lib.olx_field_medium_model.argtypes = [vp, c_int]
         lib.olx_set_element_apertures.argtypes = [vp, dp, dp]
+        lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), POINTER(OlxFocusReport), fp]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -404,6 +417,38 @@ class Context:
         out = np.empty((F, 6), dtype=np.float32)
         self._chk(self._lib.olx_field_analysis_peaks(self._h, _dptr(A), _dptr(aspect), float(r_main_m), float(r_side_m), float(zmin_m), _fptr(out)))
         return out
+
+    def solution_analyze(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
+                         beam_db=(3, 6)):
+        """Everything ``Solution.analyze`` reads off the resident volumes in one crossing (``olx_solution_analyze``).
+        ``line_offsets`` = the three offset vectors [m] of the focal-axis lines, ``line_pts`` [F, n0 + n1 + n2, 3] their
+        positions.  Returns a dict of arrays: peaks [F, 6], ita_main [F], moments [F, 4], bounds [F, 3, 2, 2] (indices into
+        the axis lines, -1 = none) and the scalar ita_global."""
+        F = self._plan_foci
+        A = _f64(A, (F, 12))
+        w = _f64(ita_weights, (F,))
+        o = OlxAnalysisOpts()
+        o.aspect[:] = [float(v) for v in aspect]
+        o.r_main_m, o.r_side_m, o.zmin_m = float(r_main_m), float(r_side_m), float(zmin_m)
+        o.beam_factor[:] = [10 ** (-db / 20) for db in beam_db]
+        o.centroid_factor = float(np.float32(10 ** (-3 / 20)))
+        pts = None
+        if line_offsets is not None:
+            for a, off in enumerate(line_offsets):
+                o.n_line[a] = len(off)
+                o.n_le[a] = int(np.count_nonzero(off <= 0))
+                ge = np.nonzero(off >= 0)[0]
+                o.i_ge[a] = int(ge[0]) if ge.size else len(off)
+                if o.n_le[a] and not np.all(off[:o.n_le[a]] <= 0):
+                    raise ValueError("line offsets must ascend")
+            pts = _f64(line_pts, (F, sum(len(v) for v in line_offsets), 3))
+        rep = (OlxFocusReport * F)()
+        glob = c_float(0)
+        self._chk(self._lib.olx_solution_analyze(self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), rep, ctypes.byref(glob)))
+        raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
+                                                 ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
+        return {"peaks": raw["peaks"].copy(), "ita_main": raw["ita_main"].copy(), "moments": raw["moments"].copy(),
+                "bounds": raw["bounds"].copy(), "ita_global": float(glob.value)}
 
     def field_masked_moments(self, A, aspect, radius_m, cutoff):
         """[F,4] = (sum p, sum p x, sum p y, sum p z) over the mainlobe mask where |p| > cutoff[f]."""

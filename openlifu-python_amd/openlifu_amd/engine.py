@@ -183,8 +183,8 @@ class Engine:
         (OLX_FIELD_DIRECTIVITY; exact per-pair kernel, homogeneous media).  ``lazy=True`` returns a ``DeviceResult`` instead: the volumes
         stay in HBM until somebody reads them."""
         self.retire_results()
-        self.bind(arr)
-        if not steering_resident:
+        if not steering_resident:        # (resident steering came from beamform(arr, ...) an instant ago: same table, bound there)
+            self.bind(arr)
             self.ctx.set_steering(delays, apod)
         flags = nat.OUT_PMAG
         if "intensity" in want:

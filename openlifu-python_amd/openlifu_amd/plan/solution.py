@@ -160,36 +160,48 @@ class Solution:
         aspect = options.mainlobe_aspect_ratio
         ctx = eng.ctx
         zmin = options.sidelobe_zmin * to_m
-        # mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin) peaks of |p| and intensity: one pass over both volumes
-        pk = ctx.field_analysis_peaks(A, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin)
-        main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
-        # -3 dB centroid of the mainlobe (find_centroid) and time-average intensity volume (get_ita)
-        mom = ctx.field_masked_moments(A, aspect, options.mainlobe_radius * to_m, main_p * 10 ** (-3 / 20))
-        pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % self.num_foci() + 1
-        counts = np.array([np.sum(pulse_seq == (i + 1)) for i in range(self.num_foci())], dtype=float)
+        F = self.num_foci()
+        pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % F + 1
+        counts = np.array([np.sum(pulse_seq == (i + 1)) for i in range(F)], dtype=float)
         ita_w = 1e3 * counts / counts.sum() * self.get_pulsetrain_dutycycle() * self.get_sequence_dutycycle()  # W -> mW
-        ctx.field_weighted_intensity(ita_w)
-        ita_main = ctx.field_masked_peak(A, aspect, options.mainlobe_radius * to_m, "<", "weighted_intensity")
-        ita_glob = ctx.field_masked_peak(None, aspect, 0.0, None, "weighted_intensity", zmin_m=zmin)
         sizes = ctx._shape
+        # beam-width lines: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
+        offsets = [np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, int(sizes[a]) * 2)
+                   for a, scale in enumerate(aspect)]
+        pts = np.empty((F, sum(len(o) for o in offsets), 3))
+        for i in range(F):
+            M = np.linalg.inv(np.vstack([A[i].reshape(3, 4), [0, 0, 0, 1]]))
+            k = 0
+            for a, off in enumerate(offsets):
+                local = np.zeros((len(off), 4)); local[:, a] = off; local[:, 3] = 1.0
+                pts[i, k:k + len(off)] = (local @ M.T)[:, :3]
+                k += len(off)
+        # ONE crossing of the C-ABI (olx_solution_analyze): mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin)
+        # peaks of |p| and intensity, -3 dB centroid moments (find_centroid), time-average intensity volume (get_ita) with its
+        # mainlobe / global peaks, and the -3 / -6 dB crossings along the three focal axes of every focus
+        rep = ctx.solution_analyze(A, ita_w, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin,
+                                   line_pts=pts, line_offsets=offsets)
+        pk, mom, ita_main = rep["peaks"], rep["moments"], rep["ita_main"]
+        main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
         # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
         # drive signal is created once and handed to calc_output for every focus (which scales it in place by the
-        # transducer sensitivity, xdc/transducer.py:100-106).
+        # transducer sensitivity, xdc/transducer.py:100-106); only the per-element maximum of that [N, T] matrix is used.
         dt = 1 / (self.pulse.frequency * 20)
         input_signal_V = self.pulse.calc_pulse(self.pulse.calc_time(dt)) * self.voltage
         standoff_Z = options.standoff_density * 1500
         c_tic = 40e-3  # W cm-1
-        d_eq_cm = np.sqrt(4 * self.transducer.get_area("cm") / np.pi)
-        ele_sizes_cm2 = np.array([el.get_area("cm") for el in self.transducer.elements])
-        power_W = np.zeros(self.num_foci()); tic = np.zeros(self.num_foci())
-        for i in range(self.num_foci()):
-            p0_Pa = np.max(self.transducer.calc_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :]), axis=1)
+        ele_sizes_cm2 = self.transducer.element_areas("cm")
+        d_eq_cm = np.sqrt(4 * sum(ele_sizes_cm2.tolist()) / np.pi)       # Transducer.get_area: the same left-to-right sum
+        power_W = np.zeros(F); tic = np.zeros(F)
+        for i in range(F):
+            p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :])
             i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()
             power_W[i] = np.mean(np.sum(i0ta_Wcm2 * ele_sizes_cm2 * self.apodizations[i, :]))
             tic[i] = power_W[i] / (d_eq_cm * c_tic)
             an.p0_MPa.append(float(1e-6 * np.max(p0_Pa)))
         an.TIC = float(np.mean(tic)); an.power_W = float(np.mean(power_W))
-        for i in range(self.num_foci()):
+        bounds = rep["bounds"]
+        for i in range(F):
             mp, mi, sp, si = float(main_p[i]) * 1e-6, float(main_i[i]), float(side_p[i]) * 1e-6, float(side_i[i])
             an.mainlobe_pnp_MPa.append(mp); an.mainlobe_isppa_Wcm2.append(mi)
             an.sidelobe_pnp_MPa.append(sp); an.sidelobe_isppa_Wcm2.append(si)
@@ -201,17 +213,13 @@ class Solution:
                 cen = mom[i, 1:] / mom[i, 0] * 1e3
             an.focal_centroid_lat_mm.append(float(cen[0])); an.focal_centroid_ele_mm.append(float(cen[1]))
             an.focal_centroid_ax_mm.append(float(cen[2]))
-            # beam widths: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
-            M = np.linalg.inv(np.vstack([A[i].reshape(3, 4), [0, 0, 0, 1]]))
-            for a, (named, scale) in enumerate(zip(("lat", "ele", "ax"), aspect)):
-                n = int(sizes[a]) * 2
-                off = np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, n)
-                local = np.zeros((n, 4)); local[:, a] = off; local[:, 3] = 1.0
-                vals = ctx.field_sample(i, (local @ M.T)[:, :3], "pmag")
-                for db in (3, 6):
-                    neg, pos = beam_bounds_from_samples(off, vals, float(main_p[i]) * 10 ** (-db / 20))
+            for a, named in enumerate(("lat", "ele", "ax")):
+                for lv, db in enumerate((3, 6)):
+                    ineg, ipos = int(bounds[i, a, lv, 0]), int(bounds[i, a, lv, 1])
+                    neg = float(offsets[a][ineg]) if ineg >= 0 else np.nan
+                    pos = float(offsets[a][ipos]) if ipos >= 0 else np.nan
                     getattr(an, f"beamwidth_{named}_{db}dB_mm").append((pos - neg) * 1e3)
-        an.global_ispta_mWcm2 = float(ita_glob[-1])
+        an.global_ispta_mWcm2 = float(rep["ita_global"])
         an.MI = float(np.max(an.mainlobe_pnp_MPa) / np.sqrt(self.pulse.frequency * 1e-6))
         an.voltage_V = self.voltage
         an.duty_cycle_pulse_train_pct = self.get_pulsetrain_dutycycle() * 100
