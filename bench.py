@@ -16,10 +16,13 @@ RCCL/xGMI on a side stream, overlapped with the next step's compute; the same ru
 (reduce-scatter of max |p| / mean intensity, plan/protocol.py:382-387) and the compute without any exchange beside it.
 torch is used only for the rendezvous / barrier (gloo); the product path is ctypes -> HIP.
 
-Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `--corrections fp8` (bench default, an explicit
-opt-in through the plan flag OLX_FIELD_FP8_CORRECTION) computes the two hi x lo correction products in e4m3
-(<= 6e-6 of the focal peak); `--corrections fp16` is the library default (<= 2e-6).  At N = 1 the line carries BOTH
-timings (`precision_safe` = the fp16 one) and a `parity` block measured in this run against the fp64 C oracle.
+Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `value` is measured in the LIBRARY DEFAULT mode --
+`--corrections fp16`, three fp16 products, <= 2e-6 of the focal peak: what Protocol.calc_solution runs unless told otherwise.
+`--corrections fp8` times the opt-in mode (plan flag OLX_FIELD_FP8_CORRECTION / SimSetup.options["fp8_correction"]: the two
+hi x lo correction products in e4m3, <= 6e-6 of the focal peak) as the headline instead.  At N = 1 the line carries the other mode
+beside it (`fp8_optin` / `precision_safe`), a `parity` block measured in this run against the fp64 C oracle, and the other
+shapes of the path (`legs`: single focus on / off axis, off-axis shard, 64-focus sweep), each planned, clock-ramped and timed
+over its own >= 200 steps; `scans` = GB/s of the HBM-bound streaming kernels; `kernel1` with its CPU baselines.
 
 Prints ONE JSON line (rank 0).  `value` = V * N_el * F_total / time [Mvoxel-elements/s].
 """
@@ -112,6 +115,29 @@ def cpu_baseline_c(pos_m, area, coords, focus_m, budget_s: float):
             "sample": f"fp64 C/OpenMP oracle, centred {n2}^3 sub-cube x {len(pos_m)} elements, {dt:.1f} s"}
 
 
+def kernel1_cpu(arr, foci_m):
+    """CPU legs of kernel 1 on this box: the vectorised fp64 restatement and the per-element Python loop that
+    mirrors the reference's cost model (bf/delay_methods/direct.py:35), one thread, same F x N solve."""
+    from oracle import bf_oracle as bo
+    pos_m, _, _, _, _ = arr.element_table()
+    ori = np.array([el.orientation for el in arr.elements], dtype=np.float64)
+    pos_u = np.array([el.position for el in arr.elements], dtype=np.float64)
+    units = arr.elements[0].units
+
+    def best(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return min(ts) * 1e6
+    vec = best(lambda: [bo.beamform(pos_m, ori, f, C0) for f in foci_m], 5)
+    loop = best(lambda: [bo.beamform_per_element(pos_u, ori, f, C0, units=units) for f in foci_m], 2)
+    return {"cpu_vectorised_us_per_solve": vec, "cpu_per_element_loop_us_per_solve": loop, "cpu_cores": 1, "cpu_model": cpu_model(),
+            "cpu_what": "oracle/bf_oracle.py beamform (vectorised fp64 NumPy) and beamform_per_element (one Python call per element, "
+                        "the cost model of bf/delay_methods/direct.py:35), Direct delays + Uniform apodization, best of 5 / 2"}
+
+
 def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), medium=None):
     """Post-timing parity of the resident result against the fp64 C oracle: `n_samples` random voxels of up to three
     focus volumes, error normalised by each focus' own peak (the volume maximum for a focus inside the grid)."""
@@ -186,9 +212,9 @@ def main():
     ap.add_argument("--foci-per-gpu", type=int, default=8)
     ap.add_argument("--reassemble", choices=["allgather", "aggregate", "none"], default=None,
                     help="default: allgather for N > 1 (north_star), none for N = 1")
-    ap.add_argument("--corrections", choices=["fp8", "fp16"], default="fp8",
-                    help="hi x lo correction products of the fp16 operand split: fp8 = opt-in e4m3 products (<= 6e-6 of the "
-                         "focal peak), fp16 = the library default (<= 2e-6); the other one is timed beside it at N = 1")
+    ap.add_argument("--corrections", choices=["fp8", "fp16"], default="fp16",
+                    help="hi x lo correction products of the fp16 operand split: fp16 = the library default (<= 2e-6 of the focal "
+                         "peak; the default here too), fp8 = opt-in e4m3 products (<= 6e-6); the other one is timed beside it at N = 1")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--spacing-mm", type=float, default=0.25)
     ap.add_argument("--elements", type=str, default="16x16")
@@ -320,12 +346,17 @@ def main():
             elapsed = float(t[0])
         return elapsed, kern
 
+    def ramp():
+        """Before EVERY timed leg: the planned launch, discarded, until the shader clock has left the idle state (the GPU idles
+        for seconds during planning, parity checks and CPU legs; the first ~20 launches after idle run 15-20 % slower)."""
+        if args.clock_ramp_ms > 0:
+            t_ramp = time.perf_counter()
+            while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
+                ctx.field_launch()
+                ctx.sync()
+
     F = plan(args.corrections == "fp8")
-    if args.clock_ramp_ms > 0:  # not steps: the same launches, discarded, until the shader clock has ramped up
-        t_ramp = time.perf_counter()
-        while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
-            ctx.field_launch()
-            ctx.sync()
+    ramp()
     mode = reassemble if gather else "none"
     elapsed, kern_ms = timed(mode, args.steps, args.warmup)
     kernel_name = ctx.field_variant()
@@ -339,8 +370,10 @@ def main():
         k2 = min(args.steps, 200)
         other = "aggregate" if mode == "allgather" else "allgather"
         if skull is None:
+            ramp()
             e2, _ = timed(other, k2, 10)
             beside[f"with_{other}"] = {"steps": k2, "ms_per_step": e2 / k2 * 1e3, "value": pairs_per_step * k2 / e2 / 1e6}
+        ramp()
         e3, _ = timed("none", k2, 10)
         beside["without_exchange"] = {"steps": k2, "ms_per_step": e3 / k2 * 1e3, "value": pairs_per_step * k2 / e3 / 1e6}
 
@@ -387,39 +420,58 @@ def main():
         if world == 1 and not args.no_extras and skull is None:
             pos_m, _, area, _, _ = arr.element_table()
             out["parity"] = {args.corrections: sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])}
-            # kernel 1: microseconds per F x N solve, HIP events around 50 repeats
-            us = ctx.bf_time(50)
-            out["kernel1"] = {"us_per_solve": float(np.median(us)), "foci": F, "elements": N, "dtype": "f64"}
-            # the other correction mode on the same workload, same box, right after
+            k2 = max(200, min(args.steps, 500))     # secondary legs: their own floor, whatever --steps says
+
+            def leg(foci_m, fp8, what):
+                """plan -> clock ramp -> 20 warm-up + k2 timed steps of one more shape of the path."""
+                foci_m = np.atleast_2d(foci_m)
+                sf.plan_foci_sweep(arr, foci_m, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS, flags=out_flags,
+                                   fp8_correction=fp8)
+                ramp()
+                e, km = timed("none", k2, 20)
+                name = ctx.field_variant()
+                nf = foci_m.shape[0]
+                bytes_l = 8.0 * V * nf + 32.0 * N * nf
+                m = re.search(r"(\d+) columns for (\d+) foci x (\d+) images", name)
+                return {"what": what, "kernel": name, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else "f32-acc/f16x3",
+                        "foci": nf, "columns_computed": int(m.group(1)) if m else None,
+                        "kernel_ms_avg": float(np.mean(km)), "kernel_launches_timed": int(len(km)), "ms_per_step": e / k2 * 1e3, "steps": k2,
+                        "value": float(V) * N * nf * k2 / e / 1e6, "roofline_frac": bytes_l / (float(np.mean(km)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+            # the other correction mode on the same workload, same box
             other_fp8 = args.corrections != "fp8"
-            plan(other_fp8)
-            k2 = min(args.steps, 300)
-            e2, km2 = timed("none", k2, 20)
-            name2 = ctx.field_variant()
-            a2 = alg_bytes / (float(np.mean(km2)) * 1e-3) / 1e9
-            out["fp8_optin" if other_fp8 else "precision_safe"] = {
-                "kernel": name2, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name2 else "f32-acc/f16x3",
-                "kernel_ms_avg": float(np.mean(km2)), "ms_per_step": e2 / k2 * 1e3, "steps": k2,
-                "value": pairs_per_step * k2 / e2 / 1e6, "roofline_frac": a2 / HBM_PEAK_GBS}
+            o = leg(run_foci[:F], other_fp8, "the headline shard in the other correction mode")
+            out["fp8_optin" if other_fp8 else "precision_safe"] = o
             out["parity"]["fp8" if other_fp8 else "fp16"] = sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])
-            out["end_to_end"] = end_to_end(ol, arr, setup, target, sweep, run_idx[:F], args)
-            if off == (0.0, 0.0):   # the same shard size with the sweep's target off the array axis: no focus coincides with a mirror
-                t2 = ol.Point(position=(1.3, 0.7, 40), units="mm")   # image of itself or of a partner, every (focus, image) is a column
+            legs = {}
+            if off == (0.0, 0.0):
+                on_axis = sweep_m[0]                                          # the Wheel's centre = the target itself
+                t2 = ol.Point(position=(1.3, 0.7, 40), units="mm")           # off the array axis: no (focus, image) pair shares a column
                 sw2 = np.array([f.get_position(units="m") for f in pattern.get_targets(t2)])
-                foci2 = sw2[od.plan_foci_orbits(sw2, -(-len(sw2) // fpg), centre_xy=centre)[0]]
-                sf.plan_foci_sweep(arr, foci2, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS, flags=out_flags,
-                                   fp8_correction=False)
-                k3 = min(args.steps, 200)
-                e3, km3 = timed("none", k3, 20)
-                name3 = ctx.field_variant()
-                m3 = re.search(r"(\d+) columns for (\d+) foci x (\d+) images", name3)
-                out["asymmetric"] = {"what": "same shard size, sweep target offset by (1.3, 0.7) mm from the array axis: the mirror folds of the "
-                                             "grid still apply, but no two (focus, image) pairs share a steering column",
-                                     "kernel": name3, "columns_computed": int(m3.group(1)) if m3 else None,
-                                     "focus_image_pairs": int(m3.group(2)) * int(m3.group(3)) if m3 else None,
-                                     "kernel_ms_avg": float(np.mean(km3)), "ms_per_step": e3 / k3 * 1e3, "steps": k3,
-                                     "value": pairs_per_step * k3 / e3 / 1e6,
-                                     "roofline_frac": alg_bytes / (float(np.mean(km3)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                legs["single_focus_on_axis"] = leg(on_axis, False, "one focus on the array axis (SinglePoint, the reference's default pattern)")
+                legs["single_focus_off_axis"] = leg(sw2[0], False, "one focus 1.3 / 0.7 mm off the array axis (an arbitrary target: 4 mirror images = 4 columns)")
+                legs["asymmetric"] = leg(sw2[od.plan_foci_orbits(sw2, -(-len(sw2) // fpg), centre_xy=centre)[0]], False,
+                                         "same shard size, sweep target offset by (1.3, 0.7) mm from the array axis: the mirror folds of the grid "
+                                         "still apply, but no two (focus, image) pairs share a steering column")
+                legs["sweep64"] = leg(sweep_m, False, "the whole 64-focus Wheel sweep of configs[2] on one GPU")
+            out["legs"] = legs
+            # HBM-bound streaming scans over the resident result of the headline shard (SURVEY 8(f)2)
+            plan(args.corrections == "fp8")
+            ctx.field_launch(); ctx.sync()
+            scans = {}
+            for kname in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid"):
+                ctx.scan_time(kname, 5)                                       # warm
+                ms, nbytes = ctx.scan_time(kname, 30)
+                t_ms = float(np.mean(ms))
+                scans[kname] = {"ms": t_ms, "algorithmic_bytes": nbytes, "GBps": nbytes / (t_ms * 1e-3) / 1e9,
+                                "roofline_frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["scans"] = {"what": f"streaming kernels over the {F} resident focus volumes of the headline shard (offset_grid: one fp64 grid), "
+                                    "30 launches each, HIP events (olx_scan_time)", **scans}
+            # kernel 1 (SURVEY 8(d)): microseconds per F x N solve, HIP events around 50 repeats, with its CPU restatements beside it
+            plan(args.corrections == "fp8")
+            us = ctx.bf_time(50)
+            out["kernel1"] = {"us_per_solve": float(np.median(us)), "foci": F, "elements": N, "dtype": "f64", **kernel1_cpu(arr, run_foci[:F])}
+            out["end_to_end"] = end_to_end(ol, arr, setup, target, sweep, run_idx[:F], args)
         if args.cpu_seconds > 0 and world == 1:
             pos_m, _, area, _, _ = arr.element_table()
             out["cpu_baseline"] = cpu_baseline(pos_m, area, coords_m, run_foci[0], args.cpu_seconds)
@@ -441,16 +493,19 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
                         focal_pattern=pattern, sim_setup=setup)
     proto.calc_solution(target, arr, simulate=True, scale=True)   # warm (allocations, first touch ...
     ol.get_engine().ctx.field_fetch_all()                         # ... and the fetch workers' pinned staging buffers); nothing kept
-    t0 = time.perf_counter()
-    sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
-    t1 = time.perf_counter()
+    walls = []
+    for _ in range(7):      # the call is ~10 launches of 0.1 - 0.5 ms each: the first ones after an idle gap run at the idle clock
+        t0 = time.perf_counter()
+        sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
+        t1 = time.perf_counter()
+        walls.append((t1 - t0) * 1e3)
     abytes = sum(np.asarray(agg[k].data).nbytes for k in ("p_min", "p_max", "intensity"))
     ta = time.perf_counter()
     nbytes = 0
     for k in ("p_min", "intensity"):
         nbytes += np.asarray(sol.simulation_result[k].data).nbytes
     t2 = time.perf_counter()
-    return {"calc_solution_ms": (t1 - t0) * 1e3, "foci": len(foci), "what": "Protocol.calc_solution(simulate=True, scale=True): "
+    return {"calc_solution_ms": float(np.median(walls)), "calc_solution_ms_all": [round(w, 3) for w in walls], "foci": len(foci), "what": "Protocol.calc_solution(simulate=True, scale=True): "
             "kernel 1 + kernel 2 + device-side scale / aggregate / analyze; aggregate and per-focus volumes left in HBM until read",
             "aggregate_fetch_ms": (ta - t1) * 1e3, "aggregate_fetch_bytes": int(abytes),
             "aggregate_fetch_what": "first .data access of the aggregate Dataset's p_min, p_max and intensity (three fresh NumPy arrays)",

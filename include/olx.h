@@ -204,6 +204,19 @@ int olx_field_time(olx_ctx *ctx, int iters, float *ms_each);
 int olx_profile_begin(olx_ctx *ctx, int max_launches);
 int olx_profile_end(olx_ctx *ctx, float *ms_each, int capacity, int *n_recorded);
 
+/* Times one of the HBM-bound streaming scans over the resident result (bench.py: GB/s against the roofline): `iters`
+ * back-to-back launches on the context's stream, HIP events between them; *bytes_per_launch = algorithmic bytes of one launch
+ * (F = planned foci, V = slab voxels): aggregate V (8 F + 8), scale 16 F V (by 1.0: the result is unchanged), the six-peak
+ * analysis scan 8 F V, one masked |p| peak 4 F V, the fp64 offset grid 32 V (coords + distance, written to scratch), the
+ * weighted intensity sum V (4 F + 4).  Needs a plan with intensity output. */
+#define OLX_SCAN_AGGREGATE 0
+#define OLX_SCAN_SCALE 1
+#define OLX_SCAN_ANALYSIS_PEAKS 2
+#define OLX_SCAN_MASKED_PEAK 3
+#define OLX_SCAN_OFFSET_GRID 4
+#define OLX_SCAN_WEIGHTED_SUM 5
+int olx_scan_time(olx_ctx *ctx, int kernel, int iters, float *ms_each, double *bytes_per_launch);
+
 /* Name of the field kernel variant the current plan dispatches to (for profiles). */
 const char *olx_field_variant(const olx_ctx *ctx);
 
@@ -310,6 +323,18 @@ int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weight
  * side stream ordered after the last olx_field_launch; olx_allgather_fetch copies
  * rank r's block to the host. */
 #define OLX_UNIQUE_ID_BYTES 128
+/* Transport (environment OLX_GATHER, read by rank 0 in olx_comm_unique_id; the id tells the other ranks):
+ *   rccl (default)  ncclAllGather / all-reduce / reduce-scatter over RCCL;
+ *   p2p             direct all-gather without RCCL: every rank PULLS each peer's block over its own xGMI link, all links at
+ *                   once, out of output buffers mapped with HIP IPC (works for ranks that share one device too).  The output
+ *                   blocks are reallocated by olx_field_plan, so after EVERY plan each rank calls olx_comm_export
+ *                   (OLX_P2P_BLOB_BYTES), the launcher all-gathers the blobs in rank order and each rank calls olx_comm_import
+ *                   with all of them.  All-gather only: the aggregate exchanges return OLX_ECOMM.
+ * olx_comm_transport names what this context uses ("rccl", "p2p", "" before olx_comm_init). */
+#define OLX_P2P_BLOB_BYTES 192
+int olx_comm_export(olx_ctx *ctx, void *blob_out);
+int olx_comm_import(olx_ctx *ctx, const void *blobs);
+const char *olx_comm_transport(const olx_ctx *ctx);
 int olx_comm_unique_id(olx_ctx *ctx, void *id_bytes);
 int olx_comm_init(olx_ctx *ctx, const void *id_bytes, int nranks, int rank);
 int olx_comm_destroy(olx_ctx *ctx);

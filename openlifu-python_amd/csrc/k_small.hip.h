@@ -566,6 +566,157 @@ __global__ void field_weighted_sum_k(const float* __restrict__ vol, const float*
 
 
 // ------------------------------------------------------------------------------------
+// The same six peaks with 16-byte loads: a thread owns FOUR consecutive z voxels (nz % 4 == 0), so the index decode (32-bit
+// divisions: there is no hardware integer divide) is paid once per 32 bytes of traffic instead of once per 8.  The fp64 focal-frame
+// expression and the comparisons per voxel are the ones of field_analysis_peaks_k, so the peaks are bit-identical.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void field_analysis_peaks4_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+                                                                const double* __restrict__ A, const PeakParams P /*radius = r_main*/,
+                                                                const double r_side, unsigned* __restrict__ out /*[F][6]*/) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ float s_red[4][6];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const float4* vp = reinterpret_cast<const float4*>(pmag + (long long)f * P.vox);
+    const float4* vi = reinterpret_cast<const float4*>(inten + (long long)f * P.vox);
+    float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = (int)(P.vox >> 2);
+    const int stride = gridDim.x * blockDim.x;
+    for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
+        const int ix = iq / nyzq;
+        const int rem = iq - ix * nyzq;
+        const int iy = rem / nzq, iz0 = (rem - iy * nzq) << 2;
+        const float4 p4 = vp[iq], w4 = vi[iq];
+        const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int iz = iz0 + e;
+            const double z = P.oz + iz * P.hz;
+            const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+            const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+            const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+            const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+            const bool zok = z > P.zmin;
+            const float p = pv[e], w = wv[e];
+            if (dist < P.radius) { m[0] = fmaxf(m[0], p); m[1] = fmaxf(m[1], w); }
+            if (zok && dist > r_side) { m[2] = fmaxf(m[2], p); m[3] = fmaxf(m[3], w); }
+            if (zok) { m[4] = fmaxf(m[4], p); m[5] = fmaxf(m[5], w); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const float r = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+        atomicMax(out + f * 6 + k, __float_as_uint(r));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Mainlobe masks are small: a 2.5 mm x 2.5 mm x 12.5 mm ellipsoid holds ~0.3 % of a 64 mm cube.  The host hands every focus
+// the index box that encloses its ellipsoid (one voxel of margin); these two kernels evaluate the SAME per-voxel expressions as
+// field_masked_peak_k / field_masked_moments_k (ops '<' and '<=') on the box only -- voxels outside it cannot be selected, so the
+// peak is bit-identical and the moments sum the same terms.  box[f] = {x0, x1, y0, y1, z0, z1} (half-open, slab indices).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void field_masked_peak_box_k(const float* __restrict__ vol, const double* __restrict__ A, const PeakParams P,
+                                                                const int* __restrict__ boxes, unsigned* __restrict__ out) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ float s_red[4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const int* b = boxes + 6 * f;
+    const int bx = b[1] - b[0], by = b[3] - b[2], bz = b[5] - b[4];
+    const float* v = vol + (long long)f * P.vol_stride;
+    float m = 0.f;
+    const int total = (bx > 0 && by > 0 && bz > 0) ? bx * by * bz : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lx = i / (by * bz), rem = i - lx * (by * bz), ly = rem / bz, lz = rem - ly * bz;
+        const int ix = b[0] + lx, iy = b[2] + ly, iz = b[4] + lz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+        const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+        const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+        const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+        bool sel = (P.op == 0) ? (dist < P.radius) : (dist <= P.radius);
+        if (P.use_zmin) sel = sel && (z > P.zmin);
+        if (sel) m = fmaxf(m, v[((long long)ix * P.ny + iy) * P.nz + iz]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + f, __float_as_uint(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
+}
+
+__global__ __launch_bounds__(256) void field_masked_moments_box_k(const float* __restrict__ vol, const double* __restrict__ A,
+                                                                   const float* __restrict__ cutoff, const PeakParams P,
+                                                                   const int* __restrict__ boxes, double* __restrict__ out /*[F][4]*/) {
+    const int f = blockIdx.y;
+    __shared__ double sA[12];
+    __shared__ double s_red[4][4];
+    if (threadIdx.x < 12) sA[threadIdx.x] = A[f * 12 + threadIdx.x];
+    __syncthreads();
+    const int* b = boxes + 6 * f;
+    const int bx = b[1] - b[0], by = b[3] - b[2], bz = b[5] - b[4];
+    const float* v = vol + (long long)f * P.vol_stride;
+    const float cut = cutoff[f];
+    double s0 = 0, sx = 0, sy = 0, sz = 0;
+    const int total = (bx > 0 && by > 0 && bz > 0) ? bx * by * bz : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lx = i / (by * bz), rem = i - lx * (by * bz), ly = rem / bz, lz = rem - ly * bz;
+        const int ix = b[0] + lx, iy = b[2] + ly, iz = b[4] + lz;
+        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy, z = P.oz + iz * P.hz;
+        const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+        const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+        const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+        const float p = v[((long long)ix * P.ny + iy) * P.nz + iz];
+        if (sqrt(q0 * q0 + q1 * q1 + q2 * q2) < P.radius && p > cut) {
+            s0 += p; sx += p * x; sy += p * y; sz += p * z;
+        }
+    }
+    double comp[4] = {s0, sx, sy, sz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) comp[k] += __shfl_xor(comp[k], off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = comp[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(out + 4 * f + threadIdx.x, s_red[0][threadIdx.x] + s_red[1][threadIdx.x] +
+                                                                s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// out[v] = sum_f w_f I_f[v] (field_weighted_sum_k) and, in the same pass, the maximum of out over the voxels with z > zmin
+// (field_masked_peak_k with op 4 on that volume): the global time-average intensity peak costs no second scan.
+__global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
+                                                                  const PeakParams P, float* __restrict__ out, unsigned* __restrict__ peak) {
+    __shared__ float s_red[4];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float m = 0.f;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P.vox; v += stride) {
+        float s = 0.f;
+        for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * P.vox + v];
+        out[v] = s;
+        const int iz = P.vox < (1ll << 31) ? (int)((unsigned)v % (unsigned)P.nz) : (int)(v % P.nz);
+        const double z = P.oz + iz * P.hz;
+        if (z > P.zmin) m = fmaxf(m, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(peak, __float_as_uint(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
+}
+
+// ------------------------------------------------------------------------------------
 // Pieces of the one-call analysis (olx_solution_analyze): everything Solution.analyze reads off the resident volumes is
 // enqueued back to back on the context's stream, the intermediate numbers (mainlobe peaks -> -3 dB centroid cut-offs and beam
 // width cut-offs) never leave the device, and ONE copy brings the per-focus reports to the host.

@@ -83,6 +83,7 @@ int olx_sync(olx_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->p2p) return olx_p2p_drain(c);     // peer-to-peer gathers run on the transport's worker thread
     return OLX_OK;
 }
 
@@ -938,7 +939,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags;
     const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
     const size_t total = (size_t)vox * n_foci;
-    c->nbuf = c->comm ? olx_ctx::NBUF : 1;
+    c->nbuf = c->comm_active() ? olx_ctx::NBUF : 1;
     // outputs
     if (c->out_cap < total || (c->nbuf == 2 && !c->d_pmag[1])) {
         for (float** p : {&c->d_pmag[0], &c->d_pmag[1], &c->d_inten, &c->d_cplx, &c->d_agg_p, &c->d_agg_i}) { if (*p) hipFree(*p); *p = nullptr; }
@@ -1068,7 +1069,8 @@ int olx_field_launch(olx_ctx* c) {
     if (rc) return rc;
     const int b = (c->nbuf == 2) ? (c->cur ^ 1) : 0;
     if (c->gather_pending[b]) {  // the gather that read this buffer must be done before we overwrite it
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[b], 0));
+        if (c->p2p) { rc = olx_p2p_before_overwrite(c, b); if (rc) return rc; }   // ... on EVERY rank that pulls from it
+        else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[b], 0));
         c->gather_pending[b] = false;
     }
     float* pm = c->d_pmag[b];
@@ -1502,6 +1504,103 @@ int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
     return rc;
 }
 
+static int aggregate_local(olx_ctx* c, bool with_p, bool with_i);
+}
+static void fill_scan_params(const olx_ctx* c, PeakParams& P, const double* aspect);
+extern "C" {
+
+// Streaming scans over the resident result, timed like olx_field_time: `iters` back-to-back launches of ONE scan kernel on the
+// context's stream, a HIP event between each.  These are the HBM-bound kernels of the path; *bytes_per_launch
+// receives the algorithmic traffic of one launch so that the caller can quote GB/s against the roofline.
+int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* bytes_per_launch) {
+    if (!c) return OLX_EINVAL;
+    if (iters < 1 || !ms_each || !bytes_per_launch) return fail(c, OLX_EINVAL, "olx_scan_time: iters < 1 or null output");
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_scan_time: nothing planned");
+    if (kernel < 0 || kernel > OLX_SCAN_WEIGHTED_SUM) return fail(c, OLX_EINVAL, "olx_scan_time: unknown kernel %d", kernel);
+    if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_scan_time: intensity not planned");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->plan_foci;
+    const double vox = (double)c->fp.vox;
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (auto e : ev) if (e) hipEventDestroy(e); }
+    } T;
+    T.ev.assign(iters + 1, nullptr);
+    for (auto& e : T.ev) HIPCHK(c, hipEventCreate(&e));
+    // a focal frame per focus: axes = grid axes, origin = the grid centre (a mainlobe-sized mask in the middle of the volume)
+    DevScratch scratch;
+    const size_t n_ax = (size_t)c->fp.nx + c->fp.ny + c->fp.nz;
+    const size_t og_bytes = kernel == OLX_SCAN_OFFSET_GRID ? sizeof(double) * 4 * (size_t)c->fp.vox : 0;
+    HIPCHK(c, hipMalloc(&scratch.p, sizeof(double) * (12 * (size_t)F + n_ax) + sizeof(unsigned) * 6 * F + sizeof(float) * F + og_bytes + 64));
+    double* d_A = scratch.at<double>(0);
+    double* d_ax = d_A + 12 * (size_t)F;
+    unsigned* d_pk = reinterpret_cast<unsigned*>(d_ax + n_ax);
+    float* d_w = reinterpret_cast<float*>(d_pk + 6 * (size_t)F);
+    double* d_og = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_w + F) + 63) & ~(uintptr_t)63);
+    {
+        std::vector<double> hA(12 * (size_t)F, 0.0), hax(n_ax);
+        const double ctr[3] = {c->grid.origin[0] + (c->slab.x_begin + 0.5 * (c->fp.nx - 1)) * c->grid.spacing[0],
+                               c->grid.origin[1] + 0.5 * (c->fp.ny - 1) * c->grid.spacing[1], c->grid.origin[2] + 0.5 * (c->fp.nz - 1) * c->grid.spacing[2]};
+        for (int f = 0; f < F; ++f) for (int a = 0; a < 3; ++a) { hA[12 * (size_t)f + 4 * a + a] = 1.0; hA[12 * (size_t)f + 4 * a + 3] = -ctr[a]; }
+        size_t k = 0;
+        for (int i = 0; i < c->fp.nx; ++i) hax[k++] = c->grid.origin[0] + (c->slab.x_begin + i) * c->grid.spacing[0];
+        for (int i = 0; i < c->fp.ny; ++i) hax[k++] = c->grid.origin[1] + i * c->grid.spacing[1];
+        for (int i = 0; i < c->fp.nz; ++i) hax[k++] = c->grid.origin[2] + i * c->grid.spacing[2];
+        std::vector<float> hw(F, 1.0f / (float)F);
+        HIPCHK(c, hipMemcpy(d_A, hA.data(), sizeof(double) * hA.size(), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_ax, hax.data(), sizeof(double) * hax.size(), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_w, hw.data(), sizeof(float) * F, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemset(d_pk, 0, sizeof(unsigned) * 6 * F));
+    }
+    if (kernel == OLX_SCAN_WEIGHTED_SUM && (!c->d_wint || c->wint_cap < (size_t)c->fp.vox)) {
+        if (c->d_wint) hipFree(c->d_wint);
+        c->d_wint = nullptr; c->wint_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_wint, sizeof(float) * c->fp.vox));
+        c->wint_cap = (size_t)c->fp.vox;
+    }
+    if (kernel == OLX_SCAN_SCALE) {
+        if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+        if (F > 4096) return fail(c, OLX_EINVAL, "olx_scan_time: too many foci");
+        std::vector<float> one(F, 1.0f);        // x 1.0f is exact: the resident result is unchanged
+        HIPCHK(c, hipMemcpy(c->d_scale, one.data(), sizeof(float) * F, hipMemcpyHostToDevice));
+    }
+    const double asp[3] = {1.0, 1.0, 5.0};
+    PeakParams P; fill_scan_params(c, P, asp);
+    P.radius = 2.5e-3; P.op = 0; P.use_zmin = 1; P.zmin = c->grid.origin[2] + c->grid.spacing[2];
+    const long long want = (P.vox + 255) / 256;
+    HIPCHK(c, hipEventRecord(T.ev[0], c->stream));
+    for (int i = 0; i < iters; ++i) {
+        switch (kernel) {
+        case OLX_SCAN_AGGREGATE: { int rc = aggregate_local(c, true, true); if (rc) return rc; *bytes_per_launch = vox * (8.0 * F + 8.0); break; }
+        case OLX_SCAN_SCALE:
+            hipLaunchKernelGGL(field_scale_k, dim3(1024, F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, (float*)nullptr, c->d_scale, c->fp.vox);
+            *bytes_per_launch = vox * 16.0 * F; break;
+        case OLX_SCAN_ANALYSIS_PEAKS:      // (the form olx_solution_analyze launches)
+            if ((c->fp.nz & 3) == 0 && c->fp.vox < (1ll << 33))
+                hipLaunchKernelGGL(field_analysis_peaks4_k, dim3((unsigned)std::min<long long>((want + 3) / 4, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, 5e-3, d_pk);
+            else
+                hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, 5e-3, d_pk);
+            *bytes_per_launch = vox * 8.0 * F; break;
+        case OLX_SCAN_MASKED_PEAK:         // an OUTSIDE mask ('>': every voxel is visited; inside masks only visit their index box)
+            P.op = 2;
+            hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], d_A, P, d_pk);
+            *bytes_per_launch = vox * 4.0 * F; break;
+        case OLX_SCAN_OFFSET_GRID:
+            hipLaunchKernelGGL(offset_grid_k, dim3((unsigned)std::min<long long>(want, 4096)), dim3(256), 0, c->stream, d_ax, d_ax + c->fp.nx, d_ax + c->fp.nx + c->fp.ny,
+                               c->fp.nx, c->fp.ny, c->fp.nz, d_A, 1.0, 1.0, 0.2, d_og, d_og + 3 * (size_t)c->fp.vox);
+            *bytes_per_launch = vox * 32.0; break;
+        default:
+            hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, d_w, F, c->fp.vox, c->d_wint);
+            *bytes_per_launch = vox * (4.0 * F + 4.0); break;
+        }
+        HIPCHK(c, hipEventRecord(T.ev[i + 1], c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(c, hipEventElapsedTime(&ms_each[i], T.ev[i], T.ev[i + 1]));
+    return OLX_OK;
+}
+
 const char* olx_field_variant(const olx_ctx* c) { return (c && c->planned) ? c->variant.c_str() : ""; }
 
 // max |p| / mean intensity over the planned foci into the aggregate buffers (device only)
@@ -1558,6 +1657,57 @@ int olx_field_scale(olx_ctx* c, const double* scale, int n_foci) {
     return OLX_OK;
 }
 
+// Index box [x0, x1) x [y0, y1) x [z0, z1) (slab indices) that encloses the focal ellipsoid |diag(1 / aspect) . A_f . [r, 1]| <= radius
+// of every focus, with one voxel of margin: half-extent along axis i = radius * sqrt((M^-1)_ii), M = B^T B, B = diag(1 / aspect) . A_3x3.
+// A degenerate frame (singular B) gets the whole slab.
+static void focus_boxes(const olx_ctx* c, const double* A, const double* aspect, double radius, int F, int* boxes) {
+    const int n[3] = {c->fp.nx, c->fp.ny, c->fp.nz};
+    const double o[3] = {c->grid.origin[0] + c->slab.x_begin * c->grid.spacing[0], c->grid.origin[1], c->grid.origin[2]};
+    for (int f = 0; f < F; ++f) {
+        const double* a = A + 12 * (size_t)f;
+        double B[3][3], t[3];
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) B[r][k] = a[4 * r + k] / aspect[r]; t[r] = a[4 * r + 3] / aspect[r]; }
+        double M[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i][j] = B[0][i] * B[0][j] + B[1][i] * B[1][j] + B[2][i] * B[2][j];
+        const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+        int* b = boxes + 6 * (size_t)f;
+        if (!(std::fabs(det) > 1e-300) || !(radius >= 0)) { for (int i = 0; i < 3; ++i) { b[2 * i] = 0; b[2 * i + 1] = n[i]; } continue; }
+        const double inv_diag[3] = {(M[1][1] * M[2][2] - M[1][2] * M[2][1]) / det, (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det,
+                                    (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det};
+        // centre: B c + t = 0  ->  c = -M^-1 B^T t (solved through the adjugate of M)
+        const double bt[3] = {B[0][0] * t[0] + B[1][0] * t[1] + B[2][0] * t[2], B[0][1] * t[0] + B[1][1] * t[1] + B[2][1] * t[2],
+                              B[0][2] * t[0] + B[1][2] * t[1] + B[2][2] * t[2]};
+        const double adj[3][3] = {{M[1][1] * M[2][2] - M[1][2] * M[2][1], M[0][2] * M[2][1] - M[0][1] * M[2][2], M[0][1] * M[1][2] - M[0][2] * M[1][1]},
+                                  {M[1][2] * M[2][0] - M[1][0] * M[2][2], M[0][0] * M[2][2] - M[0][2] * M[2][0], M[0][2] * M[1][0] - M[0][0] * M[1][2]},
+                                  {M[1][0] * M[2][1] - M[1][1] * M[2][0], M[0][1] * M[2][0] - M[0][0] * M[2][1], M[0][0] * M[1][1] - M[0][1] * M[1][0]}};
+        for (int i = 0; i < 3; ++i) {
+            const double ctr = -(adj[i][0] * bt[0] + adj[i][1] * bt[1] + adj[i][2] * bt[2]) / det;
+            const double half = radius * std::sqrt(std::max(inv_diag[i], 0.0)) * (1.0 + 1e-9);
+            const double h = i == 0 ? c->grid.spacing[0] : c->grid.spacing[i];
+            const double lo = std::floor((ctr - half - o[i]) / h) - 1.0, hi = std::ceil((ctr + half - o[i]) / h) + 2.0;
+            b[2 * i] = (int)std::min(std::max(lo, 0.0), (double)n[i]);
+            b[2 * i + 1] = (int)std::min(std::max(hi, 0.0), (double)n[i]);
+        }
+    }
+}
+
+static int analysis_scratch(olx_ctx* c, size_t dev_bytes, size_t host_bytes) {
+    if (c->an_dev_cap < dev_bytes) {
+        if (c->d_an) hipFree(c->d_an);
+        c->d_an = nullptr; c->an_dev_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_an, dev_bytes));
+        c->an_dev_cap = dev_bytes;
+    }
+    if (c->an_host_cap < host_bytes) {
+        if (c->h_an) hipHostFree(c->h_an);
+        c->h_an = nullptr; c->an_host_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_an, host_bytes, hipHostMallocDefault));
+        c->an_host_cap = host_bytes;
+    }
+    return OLX_OK;
+}
+
 int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* aspect, double radius_m, int op,
                           int use_zmin, double zmin_m, float* peak_out) {
     if (!c) return OLX_EINVAL;
@@ -1587,8 +1737,16 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     P.vol_stride = which == 2 ? 0 : c->fp.vox;
     const long long want = (P.vox + 255) / 256;
     dim3 grid((unsigned)std::min<long long>(want, 2048), F);
-    hipLaunchKernelGGL(field_masked_peak_k, grid, dim3(256), 0, c->stream,
-                       which == 0 ? c->d_pmag[c->cur] : (which == 1 ? c->d_inten : c->d_wint), c->d_peakA, P, c->d_peak);
+    const float* vol = which == 0 ? c->d_pmag[c->cur] : (which == 1 ? c->d_inten : c->d_wint);
+    if (op <= 1) {   // inside-the-ellipsoid masks: only the index box around each focus' ellipsoid is visited (same per-voxel test)
+        std::vector<int> boxes(6 * (size_t)F);
+        focus_boxes(c, A, aspect, radius_m, F, boxes.data());
+        { int rc = analysis_scratch(c, sizeof(int) * 6 * F, 0); if (rc) return rc; }
+        HIPCHK(c, hipMemcpyAsync(c->d_an, boxes.data(), sizeof(int) * 6 * F, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(field_masked_peak_box_k, dim3(32, F), dim3(256), 0, c->stream, vol, c->d_peakA, P, static_cast<const int*>(c->d_an), c->d_peak);
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // (boxes lives on this frame)
+    } else
+    hipLaunchKernelGGL(field_masked_peak_k, grid, dim3(256), 0, c->stream, vol, c->d_peakA, P, c->d_peak);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(peak_out, c->d_peak, sizeof(float) * F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1765,22 +1923,6 @@ int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) 
 // synchronisation: 7.6 of calc_solution's 11 ms.  Here the same kernels are enqueued back to back; the numbers that feed later
 // steps (mainlobe peak -> -3 dB centroid cut-off, beam-width cut-offs) stay on the device; one pinned block goes in, one
 // comes out, one synchronisation.  Scratch is owned by the context and reused.
-static int analysis_scratch(olx_ctx* c, size_t dev_bytes, size_t host_bytes) {
-    if (c->an_dev_cap < dev_bytes) {
-        if (c->d_an) hipFree(c->d_an);
-        c->d_an = nullptr; c->an_dev_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_an, dev_bytes));
-        c->an_dev_cap = dev_bytes;
-    }
-    if (c->an_host_cap < host_bytes) {
-        if (c->h_an) hipHostFree(c->h_an);
-        c->h_an = nullptr; c->an_host_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_an, host_bytes, hipHostMallocDefault));
-        c->an_host_cap = host_bytes;
-    }
-    return OLX_OK;
-}
-
 int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
                          const olx_analysis_opts* o, olx_focus_report* reports, float* ita_global) {
     if (!c) return OLX_EINVAL;
@@ -1805,7 +1947,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     // work (device only): [cut F f32][samples npts F f32]
     auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
     const size_t in_A = 0, in_pts = in_A + sizeof(double) * 12 * F, in_w = in_pts + sizeof(double) * 3 * (size_t)npts * F;
-    const size_t in_bytes = up8(in_w + sizeof(float) * F);
+    const size_t in_box = in_w + sizeof(float) * F, in_bytes = up8(in_box + sizeof(int) * 6 * F);
     const size_t out_pk = in_bytes, out_ita = out_pk + sizeof(unsigned) * 6 * F, out_bd = out_ita + sizeof(unsigned) * (F + 1);
     const size_t out_mom = up8(out_bd + sizeof(int) * 12 * F), out_end = out_mom + sizeof(double) * 4 * F;
     const size_t wk_cut = out_end, wk_smp = up8(wk_cut + sizeof(float) * F), dev_bytes = wk_smp + sizeof(float) * (size_t)npts * F + 8;
@@ -1821,6 +1963,9 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     memcpy(h + in_A, A, sizeof(double) * 12 * F);
     if (npts) memcpy(h + in_pts, line_pts, sizeof(double) * 3 * (size_t)npts * F);
     for (int f = 0; f < F; ++f) reinterpret_cast<float*>(h + in_w)[f] = (float)ita_weights[f];
+    focus_boxes(c, A, o->aspect, o->r_main_m, F, reinterpret_cast<int*>(h + in_box));     // the mainlobe ellipsoids' index boxes
+    const int* d_box = reinterpret_cast<const int*>(d + in_box);
+    const bool quad = (c->fp.nz & 3) == 0 && c->fp.vox < (1ll << 33);
     HIPCHK(c, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d + out_pk, 0, out_end - out_pk, c->stream));
     const double* d_A = reinterpret_cast<const double*>(d + in_A);
@@ -1833,18 +1978,17 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     // (1) the six masked peaks of |p| and intensity, one pass
     P.radius = o->r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = o->zmin_m;
     const long long want = (P.vox + 255) / 256;
-    hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
+    if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3((unsigned)std::min<long long>((want + 3) / 4, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
+    else hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     // (2) -3 dB centroid of the mainlobe: cut-off from the peak just found
     hipLaunchKernelGGL(analysis_cutoffs_k, dim3((F + 63) / 64), dim3(64), 0, c->stream, d_pk, F, o->centroid_factor, d_cut);
     P.use_zmin = 0; P.zmin = 0;
-    hipLaunchKernelGGL(field_masked_moments_k, dim3((unsigned)std::min<long long>(want, 1024), F), dim3(256), 0, c->stream, pm, d_A, d_cut, P,
-                       reinterpret_cast<double*>(d + out_mom));
+    hipLaunchKernelGGL(field_masked_moments_box_k, dim3(32, F), dim3(256), 0, c->stream, pm, d_A, d_cut, P, d_box, reinterpret_cast<double*>(d + out_mom));
     // (3) time-average intensity volume, its mainlobe peaks (F masks over the ONE volume) and its global peak above zmin
-    hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, reinterpret_cast<const float*>(d + in_w), F, c->fp.vox, c->d_wint);
-    P.vol_stride = 0;
-    hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_ita);
-    P.op = 4; P.use_zmin = 1; P.zmin = o->zmin_m;
-    hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), 1), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_ita + F);
+    P.zmin = o->zmin_m;        // (the global peak above zmin comes out of the same pass that writes the volume)
+    hipLaunchKernelGGL(field_weighted_sum_peak_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, reinterpret_cast<const float*>(d + in_w), F, P, c->d_wint, d_ita + F);
+    P.vol_stride = 0; P.zmin = 0;
+    hipLaunchKernelGGL(field_masked_peak_box_k, dim3(32, F), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_box, d_ita);
     // (4) beam widths: |p| along the three focal axes of every focus, then the cut-off crossings
     if (npts) {
         P.vol_stride = c->fp.vox;
@@ -1911,6 +2055,7 @@ const char* olx_rccl_path(const olx_ctx* c) { return c ? c->rccl_path.c_str() : 
 
 int olx_comm_unique_id(olx_ctx* c, void* id_bytes) {
     if (!c || !id_bytes) return OLX_EINVAL;
+    if (olx_p2p_requested()) return olx_p2p_unique_id(c, id_bytes);     // OLX_GATHER=p2p: the id names the transport's control block
     int rc = load_rccl(c);
     if (rc) return rc;
     olx_nccl_id id;
@@ -1923,10 +2068,22 @@ int olx_comm_unique_id(olx_ctx* c, void* id_bytes) {
 int olx_comm_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
     if (!c || !id_bytes) return OLX_EINVAL;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, OLX_EINVAL, "olx_comm_init: bad rank %d / %d", rank, nranks);
-    if (c->comm) return fail(c, OLX_ESTATE, "olx_comm_init: communicator already initialised");
+    if (c->comm || (c->p2p && c->comm_stream)) return fail(c, OLX_ESTATE, "olx_comm_init: communicator already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (olx_p2p_is_id(id_bytes)) {      // rank 0 chose the peer-to-peer transport: no RCCL at all
+        int rc = olx_p2p_init(c, id_bytes, nranks, rank);
+        if (rc) return rc;
+        c->nranks = nranks; c->rank = rank;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        for (int b = 0; b < olx_ctx::NBUF; ++b) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_field[b], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather[b], hipEventDisableTiming));
+        }
+        c->planned = false;
+        return OLX_OK;
+    }
     int rc = load_rccl(c);
     if (rc) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
     olx_nccl_id id;
     memcpy(&id, id_bytes, sizeof id);
     {
@@ -1945,6 +2102,7 @@ int olx_comm_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
 
 int olx_comm_destroy(olx_ctx* c) {
     if (!c) return OLX_EINVAL;
+    if (c->p2p) { hipSetDevice(c->device); olx_p2p_destroy(c); }
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
     if (c->comm) { c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
     for (int b = 0; b < olx_ctx::NBUF; ++b) {
@@ -1959,11 +2117,26 @@ int olx_comm_destroy(olx_ctx* c) {
     return OLX_OK;
 }
 
+// p2p transport only: after EVERY olx_field_plan each rank exports the IPC handles of its output blocks, the launcher
+// all-gathers the blobs (rank order) and every rank imports them
+int olx_comm_export(olx_ctx* c, void* blob_out) {
+    if (!c || !blob_out) return OLX_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return olx_p2p_export(c, blob_out);
+}
+int olx_comm_import(olx_ctx* c, const void* blobs) {
+    if (!c || !blobs) return OLX_EINVAL;
+    return olx_p2p_import(c, blobs);
+}
+const char* olx_comm_transport(const olx_ctx* c) { return !c ? "" : c->p2p ? "p2p" : c->comm ? "rccl" : ""; }
+
 int olx_field_allgather(olx_ctx* c) {
     if (!c) return OLX_EINVAL;
-    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allgather: call olx_comm_init first");
+    if (!c->comm_active()) return fail(c, OLX_ESTATE, "olx_field_allgather: call olx_comm_init first");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allgather: nothing planned");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->p2p) return olx_p2p_allgather(c);
     const size_t count = (size_t)c->fp.vox * c->plan_foci;
     const size_t need = count * c->nranks;
     if (c->gather_cap < need) {
@@ -1987,6 +2160,7 @@ int olx_field_allgather(olx_ctx* c) {
 // intensity mean) of ONE volume each on the side stream -- the exchange step the sharded path really has.
 static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
     if (!c) return OLX_EINVAL;
+    if (c->p2p) return fail(c, OLX_ECOMM, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate need the RCCL transport (this communicator is OLX_GATHER=p2p: all-gather only)");
     if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate: call olx_comm_init first");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: nothing planned");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2060,6 +2234,7 @@ int olx_allgather_fetch(olx_ctx* c, int rank, float* out) {
     if (rank < 0 || rank >= c->nranks) return fail(c, OLX_EINVAL, "olx_allgather_fetch: rank out of range");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->p2p) { int rc = olx_p2p_drain(c); if (rc) return rc; }
     const size_t count = (size_t)c->fp.vox * c->plan_foci;
     HIPCHK(c, hipMemcpy(out, c->d_gather + count * rank, sizeof(float) * count, hipMemcpyDeviceToHost));
     return OLX_OK;

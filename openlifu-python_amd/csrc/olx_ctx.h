@@ -31,6 +31,7 @@ static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_
 static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
 
 struct FetchLane;   // olx.hip: pinned staging of the device -> host fetches
+struct P2PState;    // olx_p2p.hip: direct peer-to-peer reassembly (OLX_GATHER=p2p)
 
 struct olx_ctx {
     int device = 0;
@@ -108,7 +109,9 @@ struct olx_ctx {
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
     std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;
-    // comm
+    // comm: RCCL communicator, or the direct peer-to-peer transport (exactly one of comm / p2p is set once initialised)
+    P2PState* p2p = nullptr;
+    bool comm_active() const { return comm != nullptr || p2p != nullptr; }
     RcclApi rccl; olx_nccl_comm comm = nullptr; int nranks = 1, rank = 0;
     hipStream_t comm_stream = nullptr; hipEvent_t ev_field[NBUF] = {nullptr, nullptr};
     hipEvent_t ev_gather[NBUF] = {nullptr, nullptr}; bool gather_pending[NBUF] = {false, false};
@@ -119,6 +122,18 @@ struct olx_ctx {
     // parameters of the last olx_bf_solve (olx_bf_time repeats it)
     bool bf_valid = false; double bf_c = 0, bf_scale = 1, bf_p0 = 0, bf_p1 = 0; int bf_kind = 0;
 };
+
+// olx_p2p.hip
+bool olx_p2p_requested();                                  // OLX_GATHER=p2p
+bool olx_p2p_is_id(const void* id_bytes);
+int olx_p2p_unique_id(olx_ctx* c, void* id_bytes);
+int olx_p2p_init(olx_ctx* c, const void* id_bytes, int nranks, int rank);
+int olx_p2p_destroy(olx_ctx* c);
+int olx_p2p_export(olx_ctx* c, void* blob_out);
+int olx_p2p_import(olx_ctx* c, const void* blobs);
+int olx_p2p_allgather(olx_ctx* c);
+int olx_p2p_before_overwrite(olx_ctx* c, int b);
+int olx_p2p_drain(olx_ctx* c);
 
 static inline int fail(olx_ctx* c, int code, const char* fmt, ...) {
     char buf[512];

@@ -23,6 +23,7 @@ MEDIUM_MODELS = {"auto": 0, "sampled": 1, "marched": 2}   # OLX_MEDIUM_*
 FIELD_DIRECTIVITY = 16     # opt-in plan flag: far-field piston directivity (needs set_element_apertures; exact per-pair kernel)
 FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
 UNIQUE_ID_BYTES = 128
+P2P_BLOB_BYTES = 192
 
 # every symbol include/olx.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
@@ -33,7 +34,7 @@ SYMBOLS = [
     "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
-    "olx_solution_analyze",
+    "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
 ]
 
 
@@ -119,6 +120,10 @@ def load(require_gpu: bool = True):
         lib.olx_field_medium_layering.argtypes = [vp, c_int]
         lib.olx_field_medium_model.argtypes = [vp, c_int]
         lib.olx_set_element_apertures.argtypes = [vp, dp, dp]
+        lib.olx_comm_export.argtypes = [vp, vp]
+        lib.olx_comm_import.argtypes = [vp, vp]
+        lib.olx_comm_transport.argtypes = [vp]; lib.olx_comm_transport.restype = c_char_p
+        lib.olx_scan_time.argtypes = [vp, c_int, c_int, fp, dp]
         lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), POINTER(OlxFocusReport), fp]
         _lib = lib
     if require_gpu and device_count() < 1:
@@ -358,6 +363,15 @@ class Context:
         self._chk(self._lib.olx_field_time(self._h, int(iters), _fptr(ms)))
         return ms
 
+    SCANS = {"aggregate": 0, "scale": 1, "analysis_peaks": 2, "masked_peak": 3, "offset_grid": 4, "weighted_sum": 5}
+
+    def scan_time(self, kernel: str, iters: int = 20):
+        """(ms per launch [iters], algorithmic bytes per launch) of one streaming scan over the resident result."""
+        ms = np.empty(int(iters), dtype=np.float32)
+        nbytes = c_double(0)
+        self._chk(self._lib.olx_scan_time(self._h, self.SCANS[kernel], int(iters), _fptr(ms), ctypes.byref(nbytes)))
+        return ms, float(nbytes.value)
+
     def profile_begin(self, max_launches: int):
         self._prof_cap = int(max_launches)
         self._chk(self._lib.olx_profile_begin(self._h, int(max_launches)))
@@ -497,6 +511,24 @@ class Context:
     def comm_destroy(self):
         self._chk(self._lib.olx_comm_destroy(self._h))
         self.nranks = 1
+
+    def comm_transport(self) -> str:
+        v = self._lib.olx_comm_transport(self._h)
+        return v.decode() if v else ""
+
+    def comm_export(self) -> bytes:
+        """p2p transport: IPC handles of this rank's output blocks (after every field_plan)."""
+        buf = ctypes.create_string_buffer(P2P_BLOB_BYTES)
+        self._chk(self._lib.olx_comm_export(self._h, buf))
+        return buf.raw
+
+    def comm_import(self, blobs):
+        """p2p transport: the exports of ALL ranks, in rank order."""
+        raw = b"".join(blobs)
+        if len(raw) != P2P_BLOB_BYTES * self.nranks:
+            raise ValueError(f"need {self.nranks} blobs of {P2P_BLOB_BYTES} bytes")
+        buf = ctypes.create_string_buffer(raw, len(raw))
+        self._chk(self._lib.olx_comm_import(self._h, buf))
 
     def field_allgather(self):
         self._chk(self._lib.olx_field_allgather(self._h))

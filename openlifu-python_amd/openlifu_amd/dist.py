@@ -146,17 +146,32 @@ class ShardedField:
     hot path (launch + the chosen exchange, asynchronous); ``fetch_*`` brings results to the host.  bench.py times
     ``step``; ``sweep_foci`` / ``sweep_slabs`` are plan + step + fetch."""
 
-    def __init__(self, engine, world: int, rank: int, exchange_id=None):
+    def __init__(self, engine, world: int, rank: int, exchange_id=None, allgather_bytes=None):
         self.engine, self.world, self.rank = engine, int(world), int(rank)
         self.shards, self.F, self.mode, self.comm = None, 0, None, False
+        self.transport, self._allgather_bytes = "", None
         if world > 1 and exchange_id is not None:
-            self.init_comm(exchange_id)
+            self.init_comm(exchange_id, allgather_bytes)
 
-    def init_comm(self, exchange_id):
+    def init_comm(self, exchange_id, allgather_bytes=None):
+        """``exchange_id`` broadcasts rank 0's 128-byte id.  Which transport it names is rank 0's choice (environment
+        ``OLX_GATHER=rccl|p2p``, include/olx.h); the direct peer-to-peer transport also needs ``allgather_bytes(blob) ->
+        [blob of rank 0, blob of rank 1, ...]`` from the launcher: after every plan the ranks exchange the IPC handles of their
+        output blocks through it."""
         ctx = self.engine.ctx
         uid = exchange_id(ctx.comm_unique_id() if self.rank == 0 else None)
         ctx.comm_init(uid, self.world, self.rank)
         self.comm = True
+        self.transport = ctx.comm_transport()
+        self._allgather_bytes = allgather_bytes
+        if self.transport == "p2p" and allgather_bytes is None:
+            raise ValueError("the p2p transport needs allgather_bytes (exchange of the ranks' IPC exports after every plan)")
+
+    def _publish_blocks(self):
+        """p2p transport: the output blocks were (re)allocated by the plan -- exchange their IPC handles."""
+        if self.comm and self.transport == "p2p":
+            ctx = self.engine.ctx
+            ctx.comm_import(self._allgather_bytes(ctx.comm_export()))
 
     def close(self):
         if self.comm:
@@ -183,6 +198,7 @@ class ShardedField:
                        flags=flags | (nat.FIELD_FP8_CORRECTION if fp8_correction else 0))
         ctx.aggregate_counts(self.valid[self.rank], self.F)
         eng.result_token += 1
+        self._publish_blocks()
         return self.shards[self.rank]
 
     def plan_slab_sweep(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=None, medium=None):
@@ -204,6 +220,7 @@ class ShardedField:
             ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"),
                                  planes_per_layer=int(medium.get("planes_per_layer", 1)), model=medium.get("model", "auto"))
         eng.result_token += 1
+        self._publish_blocks()
         return self.slab
 
     # ---- one pass ---------------------------------------------------------------------------------

