@@ -1,0 +1,79 @@
+"""Two REAL ranks exchanging shards through the product's reassembly path on ONE GPU: the direct peer-to-peer transport behind
+olx_field_allgather (OLX_GATHER=p2p: every rank pulls its peers' blocks out of IPC-mapped output buffers, csrc/olx_p2p.hip).
+RCCL refuses two ranks on one device; HIP IPC does not, so this is the exchange the builder's single GPU can run.  The ranks
+are fresh child processes (tests/p2p_worker.py); the assembled result must equal the single-process result bit for bit --
+with a focus count that does not divide by the world (padded shard) and in slab mode with an odd plane count."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import openlifu_amd as ol
+from openlifu_amd import _native as nat, dist as od
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu_exchange_through_p2p_transport():
+    world, n_foci = 2, 3
+    with tempfile.TemporaryDirectory(prefix="olx_p2p_") as tmp:
+        env = dict(os.environ)
+        env.pop("OLX_FIELD_VARIANT", None)
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), str(world), tmp, str(n_foci)],
+                                  env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append(o)
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, f"rank {r}:\n{outs[r][-3000:]}"
+        got = [np.load(os.path.join(tmp, f"out_{r}.npz")) for r in range(world)]
+        got = [{k: g[k] for k in g.files} for g in got]
+    # single-process reference on the same inputs (the worker's recipe)
+    F0, C, RHO, P0 = 400e3, 1500.0, 1000.0, 1e5
+    arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=None)
+    n = (45, 40, 48)
+    spacing = (0.5e-3,) * 3
+    origin = (-(n[0] - 1) / 2 * spacing[0], -(n[1] - 1) / 2 * spacing[1], 5e-3)
+    rng = np.random.default_rng(147)
+    foci = np.column_stack([rng.uniform(-3e-3, 3e-3, n_foci), rng.uniform(-3e-3, 3e-3, n_foci), rng.uniform(15e-3, 25e-3, n_foci)])
+    foci[0] = [0, 0, 20e-3]
+    eng = ol.get_engine(0)
+    ref = od.ShardedField(eng, 1, 0).sweep_foci(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0)
+    assert ref.shape == (n_foci,) + n and ref.max() > 0
+    # the same shards computed one after the other in THIS process (a shard of 2 foci, or a slab without the x mirror fold, may
+    # select another kernel family than the single whole launch: equal to ~1e-6, not to the bit): the exchange must not change a bit
+    ctx = eng.ctx
+
+    def local_blocks():
+        ctx.field_launch()
+        return np.stack([ctx.field_fetch(f, want=("pmag",))["pmag"] for f in range(ctx.n_foci)])
+    blocks, shards = [], None
+    for r in range(world):
+        sf = od.ShardedField(eng, world, r)
+        sf.plan_foci_sweep(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0)
+        blocks.append(local_blocks()); shards = sf.shards
+    exp_foci = od.assemble_foci_sharded(np.stack(blocks), shards, n_foci)
+    d, a = eng.beamform(arr, foci, C)
+    blocks = []
+    for r in range(world):
+        sf = od.ShardedField(eng, world, r)
+        sf.plan_slab_sweep(arr, d, a, origin, spacing, n, F0, C, RHO, P0)
+        blocks.append(local_blocks())
+    exp_slabs = od.assemble_slabs(np.stack(blocks), n[0])
+    for exp in (exp_foci, exp_slabs):
+        assert np.abs(exp - ref).max() <= 5e-6 * ref.max()
+    for r in range(world):
+        for key, exp in (("foci", exp_foci), ("foci_again", exp_foci), ("slabs", exp_slabs), ("slabs_again", exp_slabs)):
+            assert got[r][key].shape == ref.shape, (r, key)
+            assert np.array_equal(got[r][key], exp), (r, key, float(np.abs(got[r][key] - exp).max()))
+        assert int(got[r]["aggregate_refused"]) == 1      # the p2p transport is all-gather only and says so
