@@ -165,7 +165,7 @@ def issue_model(name, V, N, F):
     """Issue ceiling of the kernel variant in use: (peak pairs/s, model text)."""
     m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
     mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-    ml = re.search(r"field_(?:lattice|coset|cosetp|toep|toepws)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+    ml = re.search(r"field_(?:lattice|coset|cosetp|cosetp32|toep|toepws)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
     if ml:  # lattice kernels: table arithmetic amortised; the matrix pipe is the ceiling (MFMA and VALU issue add up here)
         n_mfma = int(ml.group(5))
         floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)
@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--offset-mm", type=str, default="0,0",
                     help="lateral offset of the sweep's target: a non-zero value breaks the mirror symmetry the headline shard enjoys")
     ap.add_argument("--force-comm", action="store_true", help="exercise the RCCL path even with 1 rank")
+    ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl",
+                    help="transport of the reassembly (include/olx.h OLX_GATHER): rccl = ncclAllGather (north_star), p2p = direct pulls over "
+                         "HIP IPC, one stream per peer; the other one is timed beside it (and takes over if this one cannot be initialised)")
     ap.add_argument("--medium", choices=["water", "skull"], default="water",
                     help="skull: BASELINE configs[4] synthetic skull-slab mask, heterogeneous layered-ray kernel, x-slabs per GPU")
     ap.add_argument("--hetero-planes-per-layer", type=int, default=1,
@@ -283,26 +286,58 @@ def main():
     sf = od.ShardedField(eng, world, rank)
     gather = (world > 1 or args.force_comm) and reassemble != "none"
     gather_note = None
-    if gather:
-        ok = 1
+
+    def exchange(uid):
+        box = [uid]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def allgather_bytes(blob):
+        if dist is None:
+            return [blob]
+        box = [None] * world
+        dist.all_gather_object(box, blob)
+        return box
+
+    def init_transport(kind):
+        """Initialise the reassembly transport `kind` ("rccl" | "p2p") on every rank; (ok on ALL ranks, note)."""
+        ok, note = 1, None
+        os.environ["OLX_GATHER"] = kind        # read by rank 0 when it makes the id; the id tells the others
         try:
-            def exchange(uid):
-                box = [uid]
-                if dist is not None:
-                    dist.broadcast_object_list(box, src=0)
-                return box[0]
-            sf.init_comm(exchange)  # (libolx keeps RCCL's banner off stdout)
+            sf.init_comm(exchange, allgather_bytes)  # (libolx keeps RCCL's banner off stdout)
         except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
-            ok, gather_note = 0, f"RCCL init failed: {e}"
+            ok, note = 0, f"{kind} init failed: {e}"
         if dist is not None:  # every rank must take the same branch, or the collectives below would hang
             import torch
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 0 and ok:
-                gather_note = "RCCL init failed on another rank"
+            if int(flag[0]) == 0:
+                if ok:
+                    note = f"{kind} init failed on another rank"
                 sf.close()
             ok = int(flag[0])
-        gather = bool(ok)
+        elif not ok:
+            sf.close()
+        return bool(ok), note
+
+    transport = None
+    if gather:
+        # north_star's reassembly is RCCL; the direct peer-to-peer all-gather (HIP IPC, all 7 xGMI links at once) is timed beside
+        # it, and takes over as the primary transport when RCCL cannot be brought up
+        order = [args.gather] + [k for k in ("rccl", "p2p") if k != args.gather]
+        notes = []
+        for kind in order:
+            if kind == "p2p" and reassemble != "allgather":
+                continue                      # the p2p transport is all-gather only
+            ok, note = init_transport(kind)
+            if note:
+                notes.append(note)
+            if ok:
+                transport = kind
+                break
+        gather = transport is not None
+        gather_note = "; ".join(notes) if notes else None
     out_flags = nat.OUT_PMAG | nat.OUT_INTENSITY
     skull = None
     if args.medium == "skull":  # SURVEY 8(d): 8 mm <= z < 14 mm + 2 mm sin(2 pi x / 40 mm) cos(2 pi y / 40 mm)
@@ -369,10 +404,21 @@ def main():
     if dist is not None and gather:  # reported beside the headline (never instead of it): other exchange, no exchange
         k2 = min(args.steps, 200)
         other = "aggregate" if mode == "allgather" else "allgather"
-        if skull is None:
+        if skull is None and (transport == "rccl" or other == "allgather"):   # (the p2p transport is all-gather only)
             ramp()
             e2, _ = timed(other, k2, 10)
             beside[f"with_{other}"] = {"steps": k2, "ms_per_step": e2 / k2 * 1e3, "value": pairs_per_step * k2 / e2 / 1e6}
+        if mode == "allgather" and skull is None:      # the same all-gather over the other transport
+            other_t = "p2p" if transport == "rccl" else "rccl"
+            sf.close()
+            ok_t, note_t = init_transport(other_t)
+            if ok_t:
+                plan(args.corrections == "fp8")
+                ramp()
+                e4, _ = timed("allgather", k2, 10)
+                beside[f"with_{other_t}_allgather"] = {"steps": k2, "ms_per_step": e4 / k2 * 1e3, "value": pairs_per_step * k2 / e4 / 1e6}
+            else:
+                beside[f"with_{other_t}_allgather"] = {"skipped": note_t}
         ramp()
         e3, _ = timed("none", k2, 10)
         beside["without_exchange"] = {"steps": k2, "ms_per_step": e3 / k2 * 1e3, "value": pairs_per_step * k2 / e3 / 1e6}
@@ -404,9 +450,9 @@ def main():
                        "medium": args.medium, "clock_ramp_ms": args.clock_ramp_ms,
                        "corrections": "fp8 (opt-in, OLX_FIELD_FP8_CORRECTION)" if fp8_on else "fp16 (library default)",
                        "kernel": kernel_name,
-                       "reassembly": (f"rccl-{mode}-overlapped" if gather else
+                       "reassembly": (f"{transport}-{mode}-overlapped" if gather else
                                       ("none" if (world == 1 or reassemble == "none") else "skipped")),
-                       **({"rccl_library": ctx.rccl_path()} if gather else {}),
+                       **({"rccl_library": ctx.rccl_path()} if gather and transport == "rccl" else {}),
                        **({"reassembly_note": gather_note} if gather_note else {}), **beside},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -524,7 +524,7 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetq = false; c->use_cosetr = false;
+        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
@@ -539,6 +539,8 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
+            // ... in its 32 x 32 x 16 matrix-instruction form (two positions per tile; OLX_FIELD_VARIANT=cosetp32): measured slower, A/B only
+            c->use_cosetp32 = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetp32");
             // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
             c->use_cosetq = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetq");
             // kernel 2r: 2g as one persistent block per CU with the table generation inside the K-steps (OLX_FIELD_VARIANT=cosetr);
@@ -803,6 +805,20 @@ static int configure_variant(olx_ctx* c) {
                             npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
                     n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
+                if (c->use_cosetp32) {   // 32 x 32 form: one row tile per PAIR of positions (an odd count pads one position per block part)
+                    long long nhalf = 0;
+                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
+                    for (int rx = 0; rx < 2 * A.mx; ++rx)
+                        for (int ry = 0; ry < A.my; ++ry) {
+                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                            for (int sx = 0; sx < Q.nsx; ++sx)
+                                for (int sy = 0; sy < Q.nsy; ++sy) {
+                                    const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
+                                    nhalf += 2 * ((KX * KY + 1) / 2);
+                                }
+                        }
+                    n_mfma = nhalf * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                }
                 if (c->use_cosetq) {   // kernel 2q: one row tile per PAIR of y-adjacent positions and 8-plane block
                     long long npair_all = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
@@ -817,7 +833,7 @@ static int configure_variant(olx_ctx* c) {
                     n_mfma = npair_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp32 ? "p32" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          c->fp8corr ? ",fp8corr" : "", (c->cosetp_persist && !c->use_cosetq) ? ",persistent" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 }
             } else {
@@ -1081,6 +1097,7 @@ int olx_field_launch(olx_ctx* c) {
     else if (c->use_mfma && c->use_lattice && c->use_toep && !c->toep_block) olx_launch_toepws(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetr) olx_launch_cosetr(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetq) olx_launch_cosetq(c, pm);
+    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp32) olx_launch_cosetp32(c, pm);
     else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->directivity && c->force_kind == 5) olx_launch_shfl(c, pm);
 #endif
     else if (c->use_mfma) {

@@ -744,13 +744,17 @@ def _wheel_shard(n_foci, rank=0):
     return sweep[shards[rank]]
 
 
+@pytest.mark.parametrize("form", ["16x16x32"] + (["32x32x16"] if AB else []))
 @pytest.mark.parametrize("fp8", [True, False])
-def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
+def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, form, monkeypatch):
     """The bench.py headline configuration (256 el x 256^3, rank 0's 8-focus shard of the Wheel sweep, |p| + intensity),
     FULL-volume parity against the fp64 C oracle for three foci -- the on-axis centre, spoke 0 (on the x axis) and a
     diagonal spoke -- with the fp8 correction products opted in (the bench default; stated bound 6e-6 of the focal
     peak, gate 1e-5) and with the default fp16 corrections (bound 2e-6).  16.7 M voxels x 256 elements per focus on
-    every host core."""
+    every host core.  In the developer library also kernel 2g's v_mfma_f32_32x32x16_f16 form (field_cosetp32_k,
+    OLX_FIELD_VARIANT=cosetp32: measured slower)."""
+    if form == "32x32x16":
+        monkeypatch.setenv("OLX_FIELD_VARIANT", "cosetp32")
     pos, ori, size = synthetic_array(16, 16, 3.0)
     foci = _wheel_shard(8)
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
@@ -759,7 +763,8 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8):
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0,
                    flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
     name = ctx.field_variant()
-    assert "field_cosetp_k<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name
+    kname = "field_cosetp32_k" if form == "32x32x16" else "field_cosetp_k"
+    assert kname + "<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name
     ctx.field_launch()
     worst = 0.0
     for f in (0, 1, 4):
@@ -875,7 +880,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
         ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h * 1e-3
         zs = (4.0 + np.arange(n[2]) * h) * 1e-3
         got = {}
-        for fam in ("lattice", "auto", "general"):      # lattice pins kernel 2e; auto = the planner's choice (2f / 2g where they apply)
+        for fam in ("lattice", "auto", "general") + (("cosetp32",) if AB else ()):      # lattice pins kernel 2e; auto = the planner's choice (2f / 2g where they apply); cosetp32 = 2g's 32 x 32 x 16 form (developer library)
             if fam == "auto":
                 monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
             else:
@@ -886,7 +891,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                         np.stack([ctx.field_fetch(f)["intensity"] for f in range(nf)]))
         assert "field_accum_k" in got["general"][0]
         ref_p, ref_i = got["general"][1], got["general"][2]
-        for fam in ("lattice", "auto"):
+        for fam in ("lattice", "auto") + (("cosetp32",) if AB else ()):
             name = got[fam][0]
             seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
             tol, scale_p = 5e-6, ref_p.max()      # (the gate is 1e-5; the kernels sit at 1 - 4e-6 of the volume maximum in these corners)
@@ -899,4 +904,4 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                 assert ("fp8corr" in name) == ("nt4" not in name), name
             assert np.abs(got[fam][1] - ref_p).max() <= tol * scale_p, (case, name, nax, nay, mxv, myv, n, nf)
             assert np.abs(got[fam][2] - ref_i).max() <= 2 * tol * fo.intensity_wcm2(scale_p, RHO, C), (case, name)
-    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4", "field_cosetp_k|nt2", "field_toep_k"} <= seen, seen
+    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4", "field_cosetp_k|nt2", "field_toep_k"} | ({"field_cosetp32_k|nt2"} if AB else set()) <= seen, seen
