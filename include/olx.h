@@ -231,6 +231,10 @@ int olx_field_aggregate_device(olx_ctx *ctx, int want_intensity);
 
 /* Per-focus in-place scaling (plan/solution.py:331-337): p_f *= s_f, I_f *= s_f^2. */
 int olx_field_scale(olx_ctx *ctx, const double *scale_per_focus, int n_foci);
+/* olx_field_scale followed by olx_field_aggregate_device(ctx, 1) in one pass over the volumes (the two steps
+ * Protocol.calc_solution(scale=True) runs back to back, plan/protocol.py:374-387): identical values, the volumes cross HBM
+ * twice instead of three times.  Needs intensity output. */
+int olx_field_scale_aggregate(olx_ctx *ctx, const double *scale_per_focus, int n_foci);
 
 /* Per-focus masked peak (plan/solution_analysis.py:384-442 get_mask, consumed by
  * Solution.analyze, plan/solution.py:205-262).  For focus f and voxel position r [m]:

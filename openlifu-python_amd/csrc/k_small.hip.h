@@ -296,6 +296,32 @@ __global__ __launch_bounds__(256) void field_aggregate_p_k(const float* __restri
     }
 }
 
+// Solution.scale followed by the aggregation over foci (plan/solution.py:331-337, plan/protocol.py:382-387) in ONE pass:
+// p_f *= s_f, I_f *= s_f^2 written back in place, and max_f p_f / mean_f I_f of the SCALED values written beside them -- the
+// same products, the same order of the max / sum over f as field_scale_k followed by field_aggregate_k (bit-identical), but
+// the volumes cross HBM twice (read + write) instead of three times.  float4 per lane; vox % 4 == 0 (host-checked).
+__global__ __launch_bounds__(256) void field_scale_aggregate_k(float* __restrict__ pmag, float* __restrict__ inten, const float* __restrict__ scale,
+                                                                int n_foci, long long vox, float inv, float* __restrict__ pmax, float* __restrict__ imean) {
+    const long long stride = (long long)gridDim.x * blockDim.x, v4 = vox >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m;
+#pragma unroll 4
+        for (int f = 0; f < n_foci; ++f) {
+            const float s = scale[f], s2 = s * s;
+            float4* pp = reinterpret_cast<float4*>(pmag + (long long)f * vox) + q;
+            float4* ip = reinterpret_cast<float4*>(inten + (long long)f * vox) + q;
+            float4 p = *pp, w = *ip;
+            p.x *= s; p.y *= s; p.z *= s; p.w *= s;
+            w.x *= s2; w.y *= s2; w.z *= s2; w.w *= s2;
+            *pp = p; *ip = w;
+            m.x = fmaxf(m.x, p.x); m.y = fmaxf(m.y, p.y); m.z = fmaxf(m.z, p.z); m.w = fmaxf(m.w, p.w);
+            sm.x += w.x; sm.y += w.y; sm.z += w.z; sm.w += w.w;
+        }
+        reinterpret_cast<float4*>(pmax)[q] = m;
+        reinterpret_cast<float4*>(imean)[q] = make_float4(sm.x * inv, sm.y * inv, sm.z * inv, sm.w * inv);
+    }
+}
+
 __global__ void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
                               float* __restrict__ cplx, const float* __restrict__ scale,
                               long long vox) {

@@ -524,7 +524,7 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
+        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
@@ -539,6 +539,8 @@ static int configure_variant(olx_ctx* c) {
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
+            // the same row map with FOUR column tiles (OLX_FIELD_VARIANT=cosetp4): measured slower than 2e's NT = 4 shape, A/B only
+            c->use_cosetp4 = kAbVariants && c->use_coset && !c->use_toep && c->nt == 4 && fv && !strcmp(fv, "cosetp4");
             // ... in its 32 x 32 x 16 matrix-instruction form (two positions per tile; OLX_FIELD_VARIANT=cosetp32): measured slower, A/B only
             c->use_cosetp32 = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetp32");
             // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
@@ -549,7 +551,7 @@ static int configure_variant(olx_ctx* c) {
                             (unsigned long long)F * (unsigned long long)c->fp.vox < (1ull << 32);
             c->cosetp_persist = kAbVariants && c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
             c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
-            if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
+            if (c->use_cosetp || c->use_cosetp4)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
                 for (auto& t : tiles)   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
                     for (size_t o = 0; o < t.size() && (int)t.size() < c->nt * MFMA_COLS; ++o)
                         if (t[o].ntgt > 2) {
@@ -797,7 +799,7 @@ static int configure_variant(olx_ctx* c) {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
                 long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
-                if (c->use_cosetp) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
+                if (c->use_cosetp || c->use_cosetp4) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
                     long long npos_all = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     for (int rx = 0; rx < 2 * A.mx; ++rx)
@@ -833,7 +835,7 @@ static int configure_variant(olx_ctx* c) {
                     n_mfma = npair_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp32 ? "p32" : c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp32 ? "p32" : c->use_cosetp ? "p" : c->use_cosetp4 ? "p4" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                          c->fp8corr ? ",fp8corr" : "", (c->cosetp_persist && !c->use_cosetq) ? ",persistent" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 }
             } else {
@@ -949,6 +951,21 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     if (slab) s = *slab;
     if (s.x_begin < 0 || s.x_count < 1 || s.x_begin + s.x_count > g->n[0]) return fail(c, OLX_EINVAL, "olx_field_plan: slab outside grid");
     HIPCHK(c, hipSetDevice(c->device));
+    {   // Re-planning the SAME launch (same grid, slab, foci count, medium constants, flags, element table, family pins): everything
+        // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
+        // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
+        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION");
+        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "");
+        const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
+                          c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
+                          c->p0_pa == p0_pa && c->flags == flags && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;
+        c->plan_env = env;
+        if (same) {
+            c->agg_local = -1; c->agg_total = 0;
+            if (c->packed_version != c->steer_version) return configure_variant(c);   // (names the variant for olx_field_variant; packed at launch)
+            return OLX_OK;
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->grid = *g; c->slab = s; c->plan_foci = n_foci; c->hetero = false;
     c->agg_local = -1; c->agg_total = 0;   // aggregate over all planned foci unless olx_field_aggregate_counts says otherwise
@@ -1098,6 +1115,7 @@ int olx_field_launch(olx_ctx* c) {
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetr) olx_launch_cosetr(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetq) olx_launch_cosetq(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp32) olx_launch_cosetp32(c, pm);
+    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp4) olx_launch_cosetp4(c, pm);
     else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->directivity && c->force_kind == 5) olx_launch_shfl(c, pm);
 #endif
     else if (c->use_mfma) {
@@ -1671,6 +1689,33 @@ int olx_field_scale(olx_ctx* c, const double* scale, int n_foci) {
                        (c->flags & OLX_OUT_COMPLEX) ? c->d_cplx : nullptr, c->d_scale, c->fp.vox);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return OLX_OK;
+}
+
+// olx_field_scale + olx_field_aggregate_device in one pass over the volumes (what Protocol.calc_solution(scale=True) does back to
+// back): identical values, a third less HBM traffic.  Falls back to the two separate kernels when the fused form does not apply
+// (complex output planned, voxel count not a multiple of 4).
+int olx_field_scale_aggregate(olx_ctx* c, const double* scale, int n_foci) {
+    if (!c) return OLX_EINVAL;
+    if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_scale_aggregate: nothing planned");
+    if (!scale || n_foci != c->plan_foci) return fail(c, OLX_EINVAL, "olx_field_scale_aggregate: need %d scale factors", c->plan_foci);
+    if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_field_scale_aggregate: intensity not planned");
+    if (n_foci > 4096) return fail(c, OLX_EINVAL, "olx_field_scale_aggregate: too many foci");
+    if ((c->flags & OLX_OUT_COMPLEX) || (c->fp.vox & 3)) {
+        int rc = olx_field_scale(c, scale, n_foci);
+        return rc ? rc : olx_field_aggregate_device(c, 1);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+    if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+    if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+    std::vector<float> s(n_foci);
+    for (int i = 0; i < n_foci; ++i) s[i] = (float)scale[i];
+    HIPCHK(c, hipMemcpyAsync(c->d_scale, s.data(), sizeof(float) * n_foci, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(field_scale_aggregate_k, dim3(4096), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, c->d_scale, n_foci,
+                       (long long)c->fp.vox, 1.0f / (float)n_foci, c->d_agg_p, c->d_agg_i);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // (s lives on this frame)
     return OLX_OK;
 }
 

@@ -57,6 +57,7 @@ struct olx_ctx {
     unsigned long long steer_version = 0, packed_version = ~0ull;
     // field plan
     bool planned = false;
+    std::string plan_env;   // OLX_FIELD_VARIANT | OLX_FP8_CORRECTION as seen by the last olx_field_plan (a changed pin forces a full re-plan)
     bool uploaded = false;  // volumes came from olx_field_upload: not launchable
     olx_grid grid{};
     olx_slab slab{};
@@ -87,6 +88,7 @@ struct olx_ctx {
     bool use_cosetr = false; CosetBlock* d_cprblocks = nullptr; size_t cprblocks_cap = 0; unsigned cpr_nblocks = 0;   // kernel 2r: persistent, one block per CU (non-empty records only)
     bool use_cosetq = false;   // kernel 2q: 2g in blocks of 4 waves x 8 planes (four blocks per CU)
     bool cosetp_persist = false; int cosetp_stagger = 0;   // kernel 2g, persistent form (OLX_FIELD_VARIANT=cosetpp[:stagger cycles]; A/B)
+    bool use_cosetp4 = false;  // kernel 2g's row map with four column tiles (field_cosetp4_k)
     bool use_cosetp32 = false; // kernel 2g in its 32 x 32 x 16 MFMA form (field_cosetp32_k)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
     bool toep_block = true;    // kernel 2f as one block per work item (field_toep_k); false (OLX_FIELD_VARIANT=toepws): persistent field_toepws_k

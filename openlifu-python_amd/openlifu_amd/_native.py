@@ -35,6 +35,7 @@ SYMBOLS = [
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
     "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
+    "olx_field_scale_aggregate",
 ]
 
 
@@ -97,6 +98,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_variant.argtypes = [vp]; lib.olx_field_variant.restype = c_char_p
         lib.olx_field_aggregate.argtypes = [vp, fp, fp]
         lib.olx_field_scale.argtypes = [vp, dp, c_int]
+        lib.olx_field_scale_aggregate.argtypes = [vp, dp, c_int]
         lib.olx_field_masked_peak.argtypes = [vp, c_int, dp, dp, c_double, c_int, c_int, c_double, fp]
         lib.olx_field_masked_moments.argtypes = [vp, dp, dp, c_double, fp, dp]
         lib.olx_field_sample.argtypes = [vp, c_int, c_int, dp, c_int, fp]
@@ -408,6 +410,12 @@ class Context:
     def field_scale(self, scale_per_focus):
         s = _f64(scale_per_focus)
         self._chk(self._lib.olx_field_scale(self._h, _dptr(s), int(s.shape[0])))
+
+    def field_scale_aggregate(self, scale_per_focus):
+        """``field_scale`` + ``field_aggregate_device`` in one pass (identical values)."""
+        self._aggregate_overwrite()
+        s = _f64(scale_per_focus)
+        self._chk(self._lib.olx_field_scale_aggregate(self._h, _dptr(s), int(s.shape[0])))
 
     def field_masked_peak(self, A, aspect, radius_m, op="<", which="pmag", zmin_m=None):
         """Per-focus peak of |p| (or intensity) over the focal-ellipsoid mask -> float32[F]."""

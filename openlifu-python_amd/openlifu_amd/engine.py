@@ -149,6 +149,13 @@ class Engine:
         self._live_aggregate = AggregateResult(self, self.ctx._shape)
         return self._live_aggregate
 
+    def scale_aggregate_lazy(self, factors) -> AggregateResult:
+        """Per-focus scaling of the resident volumes AND their aggregate in one pass over HBM (``olx_field_scale_aggregate``:
+        the values of ``ctx.field_scale`` followed by ``aggregate_lazy``)."""
+        self.ctx.field_scale_aggregate(factors)                              # (retires a live aggregate through the hook)
+        self._live_aggregate = AggregateResult(self, self.ctx._shape)
+        return self._live_aggregate
+
     # ---- element table ----------------------------------------------------------------------
     def bind(self, arr):
         """Upload ``arr``'s SoA element table unless the resident one is identical."""
@@ -219,6 +226,9 @@ class Engine:
         self.__dict__.pop("_plan_sig", None)
 
 
+_grid_memo: dict = {}
+
+
 def grid_from_coords(coords):
     """(origin_m[3], spacing_m[3], n[3]) from a params.coords mapping; raises ValueError for
     mixed units like the reference (sim/kwave_if.py:104-106)."""
@@ -226,10 +236,22 @@ def grid_from_coords(coords):
     units = [coords[d].attrs["units"] for d in dims]
     if not all(u == units[0] for u in units):
         raise ValueError("All dimensions must have the same units")
-    scl = getunitconversion(units[0], "m")
+    # calc_solution asks four times per call for the same three vectors: remember the last answer per (values, units)
+    vecs = [np.asarray(coords[d].data if hasattr(coords[d], "data") else coords[d], dtype=np.float64) for d in dims]
+    key = (tuple(dims), units[0], tuple(v.tobytes() for v in vecs))
+    hit = _grid_memo.get(key)
+    if hit is not None:
+        return [list(h) for h in hit]
+    out = _grid_from_vectors(dims, vecs, units[0])
+    _grid_memo.clear()
+    _grid_memo[key] = tuple(tuple(h) for h in out)
+    return out
+
+
+def _grid_from_vectors(dims, vecs, unit):
+    scl = getunitconversion(unit, "m")
     origin, spacing, n = [], [], []
-    for d in dims:
-        v = np.asarray(coords[d].data if hasattr(coords[d], "data") else coords[d], dtype=np.float64)
+    for d, v in zip(dims, vecs):
         origin.append(v[0] * scl)
         spacing.append((np.diff(v)[0] * scl) if len(v) > 1 else scl)  # dx = diff(coord)[0]*scl, kwave_if.py:20
         n.append(len(v))

@@ -208,12 +208,13 @@ class Protocol:
         if fields is not None:
             eng = get_engine()
             solution._resident = (eng, eng.result_token)
+        fused_agg = None
         if scale:
             if not simulate:
                 self.logger.error(msg=f"Cannot scale solution {solution.id} if simulation is not enabled!")
                 raise ValueError(f"Cannot scale solution {solution.id} if simulation is not enabled!")
             self.logger.info(f"Scaling solution {solution.id}...")
-            solution.scale(self.focal_pattern, analysis_options=analysis_options)
+            fused_agg = solution.scale(self.focal_pattern, analysis_options=analysis_options, _with_aggregate=simulate)
 
         if not simulate:
             return solution, None, None
@@ -221,7 +222,7 @@ class Protocol:
         eng, _, _, _ = solution._bind_device()
         # ... and left there: the three aggregate volumes reach the host when -- and if -- the caller reads them (each a
         # fresh, caller-owned array), like the per-focus volumes
-        agg = eng.aggregate_lazy(want_intensity=True)
+        agg = fused_agg if fused_agg is not None else eng.aggregate_lazy(want_intensity=True)   # (scaled and aggregated in one pass above)
         coords = params.coords
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         shape = agg.shape

@@ -25,7 +25,7 @@ from ..util import dataset as ds
 from ..util import netcdf
 from ..util.units import getunitconversion
 from ..xdc import Transducer
-from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, beam_bounds_from_samples, get_focus_matrix
+from .solution_analysis import SolutionAnalysis, SolutionAnalysisOptions, beam_bounds_from_samples, focus_frames, get_focus_matrix
 
 
 def _default_nc_path(json_filepath: Path) -> Path:
@@ -128,14 +128,14 @@ class Solution:
         return eng, origin, spacing, n
 
     def _focus_frames(self):
-        """[F, 12]: first three rows of inv(get_focus_matrix(focus, effective origin)) per focus (row-major)."""
+        """[F, 12]: first three rows of inv(get_focus_matrix(focus, effective origin)) per focus (row-major), all foci at once
+        (the per-focus arithmetic of solution_analysis.get_focus_matrix, batched)."""
         pos_m = self.transducer.get_positions(units="m")
-        A = np.zeros((self.num_foci(), 12))
-        for i, focus in enumerate(self.foci):
-            ap = np.asarray(self.apodizations[i])
-            o_m = (ap.reshape(-1, 1) * pos_m).sum(axis=0) / ap.sum()       # Transducer.get_effective_origin (transducer.py:191-201)
-            A[i] = np.linalg.inv(get_focus_matrix(focus.get_position(units="m"), origin=o_m))[:3].ravel()
-        return A
+        F = self.num_foci()
+        foci = np.array([f.get_position(units="m") for f in self.foci], dtype=float).reshape(F, 3)
+        ap = np.asarray(self.apodizations, dtype=float)
+        origins = np.stack([(ap[i].reshape(-1, 1) * pos_m).sum(axis=0) / ap[i].sum() for i in range(F)])   # get_effective_origin (transducer.py:191-201)
+        return focus_frames(foci, origins)
 
     def _mainlobe_peaks(self, options: SolutionAnalysisOptions) -> SolutionAnalysis:
         an = SolutionAnalysis()
@@ -168,14 +168,13 @@ class Solution:
         # beam-width lines: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
         offsets = [np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, int(sizes[a]) * 2)
                    for a, scale in enumerate(aspect)]
-        pts = np.empty((F, sum(len(o) for o in offsets), 3))
-        for i in range(F):
-            M = np.linalg.inv(np.vstack([A[i].reshape(3, 4), [0, 0, 0, 1]]))
-            k = 0
-            for a, off in enumerate(offsets):
-                local = np.zeros((len(off), 4)); local[:, a] = off; local[:, 3] = 1.0
-                pts[i, k:k + len(off)] = (local @ M.T)[:, :3]
-                k += len(off)
+        local = np.zeros((sum(len(o) for o in offsets), 4)); local[:, 3] = 1.0       # the three axis lines, one after the other
+        k = 0
+        for a, off in enumerate(offsets):
+            local[k:k + len(off), a] = off
+            k += len(off)
+        A4 = np.zeros((F, 4, 4)); A4[:, :3, :] = A.reshape(F, 3, 4); A4[:, 3, 3] = 1.0
+        pts = np.ascontiguousarray((local[None, :, :] @ np.transpose(np.linalg.inv(A4), (0, 2, 1)))[:, :, :3])   # [F, npts, 3]
         # ONE crossing of the C-ABI (olx_solution_analyze): mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin)
         # peaks of |p| and intensity, -3 dB centroid moments (find_centroid), time-average intensity volume (get_ita) with its
         # mainlobe / global peaks, and the -3 / -6 dB crossings along the three focal axes of every focus
@@ -193,8 +192,9 @@ class Solution:
         ele_sizes_cm2 = self.transducer.element_areas("cm")
         d_eq_cm = np.sqrt(4 * sum(ele_sizes_cm2.tolist()) / np.pi)       # Transducer.get_area: the same left-to-right sum
         power_W = np.zeros(F); tic = np.zeros(F)
+        el_sens = np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.transducer.elements])
         for i in range(F):
-            p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :])
+            p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :], _sens=el_sens)
             i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()
             power_W[i] = np.mean(np.sum(i0ta_Wcm2 * ele_sizes_cm2 * self.apodizations[i, :]))
             tic[i] = power_W[i] / (d_eq_cm * c_tic)
@@ -238,7 +238,8 @@ class Solution:
         v1 = v0 * np.max(scaling)
         return scaling / np.max(scaling), v0, v1
 
-    def scale(self, focal_pattern: FocalPattern, analysis_options: SolutionAnalysisOptions | None = None) -> None:
+    def scale(self, focal_pattern: FocalPattern, analysis_options: SolutionAnalysisOptions | None = None,
+              _with_aggregate: bool = False):
         """Scale in place to the target pressure (plan/solution.py:313-338): host arrays are mutated
         (the API contract) and the resident device copy is scaled by ``field_scale_k``."""
         # only the per-focus mainlobe peak of |p| enters the factors (compute_scaling_factors reads nothing else of the
@@ -257,9 +258,14 @@ class Solution:
             self._uploaded = None             # host copy edited: whatever the device holds of it is stale
         for i in range(self.num_foci()):
             self.apodizations[i] = self.apodizations[i] * apod_factors[i]
+        fused = None
         if on_device:
-            self._resident[0].ctx.field_scale(factors)
+            if _with_aggregate and "intensity" in res:      # calc_solution aggregates right after: one pass for both
+                fused = self._resident[0].scale_aggregate_lazy(factors)
+            else:
+                self._resident[0].ctx.field_scale(factors)
         self.voltage = v1
+        return fused
 
     # ---- (de)serialisation (plan/solution.py:390-533) ------------------------------------------
     def to_dict(self, include_simulation_data: bool = False) -> dict:

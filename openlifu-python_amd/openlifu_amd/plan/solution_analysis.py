@@ -41,6 +41,25 @@ def get_focus_matrix(focus, origin=(0, 0, 0)) -> np.ndarray:
     return M
 
 
+def focus_frames(foci, origins) -> np.ndarray:
+    """[F, 12] = first three rows of inv(get_focus_matrix(focus_f, origin_f)), row-major, for F foci at once: the same
+    arithmetic as ``get_focus_matrix`` per focus (unit vector along origin -> focus, azimuth from atan2, cross product), batched,
+    then one batched 4 x 4 inverse."""
+    foci = np.atleast_2d(np.asarray(foci, dtype=float)); origins = np.atleast_2d(np.asarray(origins, dtype=float))
+    F = foci.shape[0]
+    d = foci - origins
+    zvec = d / np.sqrt((d * d).sum(axis=1))[:, None]
+    az = -np.arctan2(zvec[:, 0], zvec[:, 2])
+    xvec = np.stack([np.cos(az), np.zeros(F), np.sin(az)], axis=1)
+    M = np.zeros((F, 4, 4))
+    M[:, :3, 0] = xvec
+    M[:, :3, 1] = np.cross(zvec, xvec)
+    M[:, :3, 2] = zvec
+    M[:, :3, 3] = foci
+    M[:, 3, 3] = 1.0
+    return np.linalg.inv(M)[:, :3, :].reshape(F, 12)
+
+
 @dataclass
 class SolutionAnalysisOptions(DictMixin):
     standoff_sound_speed: float = 1500.0

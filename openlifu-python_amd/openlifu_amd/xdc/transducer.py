@@ -91,7 +91,7 @@ class Transducer:
         s = np.array([getunitconversion(el.units, units) for el in self.elements]) if n else np.empty(0)
         return (size[:, 0] * s) * (size[:, 1] * s)
 
-    def peak_output(self, input_signal, dt, delays=None, apod=None):
+    def peak_output(self, input_signal, dt, delays=None, apod=None, _sens=None):
         """``np.max(self.calc_output(input_signal, dt, delays, apod), axis=1)`` -- the per-element emitted peak
         ``Solution.analyze`` needs (plan/solution.py:192-193) -- without building the [N, T] drive matrix; the caller's
         ``input_signal`` receives exactly the in-place scalings ``calc_output`` applies (xdc/transducer.py:100-106,
@@ -106,7 +106,7 @@ class Transducer:
         sig = input_signal
         if self.sensitivity is not None:
             sig *= self.sensitivity
-        sens = np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.elements])
+        sens = _sens if _sens is not None else np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.elements])
         v_hi, v_lo = (sig.max(), sig.min()) if sig.size else (0.0, 0.0)
         if np.all(sens == 1.0):
             hi = np.full(n, v_hi); lo = np.full(n, v_lo)
@@ -121,7 +121,7 @@ class Transducer:
         peak = np.maximum(apod * hi, apod * lo)
         # rows are zero-padded to the longest one (leading zeros of the delay, trailing zeros up to the common length): unless no
         # element is delayed at all, every row holds a zero
-        lead_max = max(int(d / dt) for d in delays)
+        lead_max = int(np.max(delays) / dt)              # = max(int(d / dt)): truncation is monotonic
         return np.maximum(peak, 0.0) if lead_max > 0 else peak
 
     def element_apertures(self):

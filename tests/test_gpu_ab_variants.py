@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "openlifu-python_amd", "lib")
-AB_KERNELS = [b"field_cosetq_kI", b"field_cosetr_kI", b"field_cosetp32_kI", b"field_toepws_kI", b"field_shfl_kI"]   # (mangled template names of the device code objects)
+AB_KERNELS = [b"field_cosetq_kI", b"field_cosetr_kI", b"field_cosetp32_kI", b"field_cosetp4_kI", b"field_toepws_kI", b"field_shfl_kI"]   # (mangled template names of the device code objects)
 
 
 def test_product_library_carries_no_ab_kernels():

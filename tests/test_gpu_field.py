@@ -880,7 +880,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
         ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h * 1e-3
         zs = (4.0 + np.arange(n[2]) * h) * 1e-3
         got = {}
-        for fam in ("lattice", "auto", "general") + (("cosetp32",) if AB else ()):      # lattice pins kernel 2e; auto = the planner's choice (2f / 2g where they apply); cosetp32 = 2g's 32 x 32 x 16 form (developer library)
+        for fam in ("lattice", "auto", "general") + (("cosetp32", "cosetp4") if AB else ()):      # lattice pins kernel 2e; auto = the planner's choice (2f / 2g where they apply); cosetp32 = 2g's 32 x 32 x 16 form (developer library)
             if fam == "auto":
                 monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
             else:
@@ -891,7 +891,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                         np.stack([ctx.field_fetch(f)["intensity"] for f in range(nf)]))
         assert "field_accum_k" in got["general"][0]
         ref_p, ref_i = got["general"][1], got["general"][2]
-        for fam in ("lattice", "auto") + (("cosetp32",) if AB else ()):
+        for fam in ("lattice", "auto") + (("cosetp32", "cosetp4") if AB else ()):
             name = got[fam][0]
             seen.add(name.split("<")[0] + ("|nt" + name.split("nt")[1][0] if "nt" in name else ""))
             tol, scale_p = 5e-6, ref_p.max()      # (the gate is 1e-5; the kernels sit at 1 - 4e-6 of the volume maximum in these corners)
@@ -904,4 +904,4 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                 assert ("fp8corr" in name) == ("nt4" not in name), name
             assert np.abs(got[fam][1] - ref_p).max() <= tol * scale_p, (case, name, nax, nay, mxv, myv, n, nf)
             assert np.abs(got[fam][2] - ref_i).max() <= 2 * tol * fo.intensity_wcm2(scale_p, RHO, C), (case, name)
-    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4", "field_cosetp_k|nt2", "field_toep_k"} | ({"field_cosetp32_k|nt2"} if AB else set()) <= seen, seen
+    assert {"field_coset_k|nt1", "field_coset_k|nt2", "field_coset_k|nt4", "field_cosetp_k|nt2", "field_toep_k"} | ({"field_cosetp32_k|nt2", "field_cosetp4_k|nt4"} if AB else set()) <= seen, seen

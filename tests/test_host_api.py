@@ -587,3 +587,15 @@ def test_peak_output_equals_max_of_calc_output(case):
     pos, nrm, area, index, pin = arr.element_table()
     assert np.array_equal(pos, np.array([el.get_position(units="m") for el in arr.elements]))
     assert np.array_equal(area, np.array([el.get_area("m") for el in arr.elements])) and pin.tolist() == [el.pin for el in arr.elements]
+
+
+def test_batched_focus_frames_equal_the_per_focus_matrices():
+    from openlifu_amd.plan.solution_analysis import focus_frames, get_focus_matrix
+    rng = np.random.default_rng(147)
+    foci = rng.uniform(-5e-3, 5e-3, (9, 3)) + [0, 0, 40e-3]
+    origins = rng.uniform(-1e-3, 1e-3, (9, 3))
+    foci[0] = [0, 0, 40e-3]; origins[0] = 0
+    A = focus_frames(foci, origins)
+    for i in range(9):
+        ref = np.linalg.inv(get_focus_matrix(foci[i], origin=origins[i]))[:3].ravel()
+        assert np.abs(A[i] - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max())
