@@ -251,11 +251,24 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
 // aggregation over foci (plan/protocol.py:384-387) and per-focus scaling
 // (plan/solution.py:331-337).  HBM-bound streaming: float4 per lane, grid-stride.
 // ------------------------------------------------------------------------------------
-__global__ void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+__global__ __launch_bounds__(256) void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
                                   int n_foci, long long vox, float inv /* 1 / total foci (all ranks) */,
                                   float* __restrict__ pmax, float* __restrict__ imean) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+    // 16-byte main loop (every focus volume starts 16-byte aligned when vox % 4 == 0), up to 8 foci = 16 independent loads in
+    // flight per lane; the max / sum run over f in the same order as the scalar tail, so both forms give the same bits
+    const long long v4 = (vox & 3) == 0 ? (vox >> 2) : 0;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m;
+#pragma unroll 8
+        for (int f = 0; f < n_foci; ++f) {
+            if (pmag) { const float4 p = reinterpret_cast<const float4*>(pmag + (long long)f * vox)[q]; m.x = fmaxf(m.x, p.x); m.y = fmaxf(m.y, p.y); m.z = fmaxf(m.z, p.z); m.w = fmaxf(m.w, p.w); }
+            if (inten) { const float4 w = reinterpret_cast<const float4*>(inten + (long long)f * vox)[q]; sm.x += w.x; sm.y += w.y; sm.z += w.z; sm.w += w.w; }
+        }
+        if (pmax) reinterpret_cast<float4*>(pmax)[q] = m;
+        if (imean) reinterpret_cast<float4*>(imean)[q] = make_float4(sm.x * inv, sm.y * inv, sm.z * inv, sm.w * inv);
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
         float m = 0.f, s = 0.f;
         for (int f = 0; f < n_foci; ++f) {
             if (pmag) m = fmaxf(m, pmag[(long long)f * vox + v]);
@@ -322,19 +335,103 @@ __global__ __launch_bounds__(256) void field_scale_aggregate_k(float* __restrict
     }
 }
 
-__global__ void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
+__global__ __launch_bounds__(256) void field_scale_k(float* __restrict__ pmag, float* __restrict__ inten,
                               float* __restrict__ cplx, const float* __restrict__ scale,
                               long long vox) {
     const int f = blockIdx.y;
     const float s = scale[f];
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+    const long long v4 = (vox & 3) == 0 ? (vox >> 2) : 0;          // 16-byte main loop, scalar tail (same products)
+    const float s2 = s * s;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        if (pmag) { float4* p = reinterpret_cast<float4*>(pmag + (long long)f * vox) + q; float4 v = *p; v.x *= s; v.y *= s; v.z *= s; v.w *= s; *p = v; }
+        if (inten) { float4* p = reinterpret_cast<float4*>(inten + (long long)f * vox) + q; float4 v = *p; v.x *= s2; v.y *= s2; v.z *= s2; v.w *= s2; *p = v; }
+        if (cplx) {
+            float4* p = reinterpret_cast<float4*>(cplx + 2 * (long long)f * vox) + 2 * q;
+            float4 a = p[0], b = p[1];
+            a.x *= s; a.y *= s; a.z *= s; a.w *= s; b.x *= s; b.y *= s; b.z *= s; b.w *= s;
+            p[0] = a; p[1] = b;
+        }
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
         const long long o = (long long)f * vox + v;
         if (pmag) pmag[o] *= s;
-        if (inten) inten[o] *= s * s;
+        if (inten) inten[o] *= s2;
         if (cplx) { cplx[2 * o] *= s; cplx[2 * o + 1] *= s; }
     }
 }
+
+// ------------------------------------------------------------------------------------
+// Two helpers that keep the fp64 mask tests of the scans cheap without changing a single decision.
+//  * quad_decode: (ix, iy, first z) of quad iq without integer divisions (there is no hardware integer divide): float
+//    reciprocal estimate, corrected by one step -- exact for every iq < 2^31.
+//  * mask_cmp: dist OP radius with dist = sqrt(d2).  sqrt is monotonic and correctly rounded, so outside a guard band of
+//    1e-12 r^2 around r^2 the comparison of the squares decides; only inside the band (a voxel within ~1e-12 of the mask
+//    surface) is the square root taken -- the same answer as taking it always, for ~10 fp64 instructions less per voxel.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void quad_decode(int iq, int nzq, int nyzq, float inv_nyzq, float inv_nzq, int& ix, int& iy, int& iz0) {
+    ix = (int)((float)iq * inv_nyzq);
+    int rem = iq - ix * nyzq;
+    if (rem < 0) { --ix; rem += nyzq; } else if (rem >= nyzq) { ++ix; rem -= nyzq; }
+    iy = (int)((float)rem * inv_nzq);
+    int r2 = rem - iy * nzq;
+    if (r2 < 0) { --iy; r2 += nzq; } else if (r2 >= nzq) { ++iy; r2 -= nzq; }
+    iz0 = r2 << 2;
+}
+
+template <int OP>   // 0 '<', 1 '<=', 2 '>', 3 '>='
+__device__ __forceinline__ bool mask_cmp(double d2, double r, double r2lo, double r2hi) {
+    if (d2 < r2lo) return OP <= 1;
+    if (d2 > r2hi) return OP >= 2;
+    const double dist = sqrt(d2);
+    return OP == 0 ? dist < r : OP == 1 ? dist <= r : OP == 2 ? dist > r : dist >= r;
+}
+
+// fp32 pre-test of the same masks.  fp64 runs at half rate and the focal-frame test is ~25 fp64 instructions per voxel: the scans were
+// bound by it (29 - 43 % of the HBM roofline).  One thread per block prepares an fp32 copy of the frame (1 / aspect folded in)
+// and a band [r_in^2, r_out^2] around the mask surface that is wider than anything the fp32 evaluation can be off by
+// (32 roundings of relative size 2^-24 on terms bounded by max_a sum_k |A_ak| |c_k|_max); a voxel whose fp32 squared distance
+// lies outside the band is decided there, a voxel inside it (within ~1e-6 m of the surface) takes the exact fp64 test -- every
+// decision is the fp64 one.  z > zmin becomes an integer plane test (first plane with oz + k hz > zmin, found with that
+// very expression: it is monotonic in k).
+struct MaskFast {
+    float a[12];            // rows of diag(1 / aspect) . A
+    float rin2[2], rout2[2];// bands of the two radii (main '<', side '>'); rin2 < 0: no voxel is surely inside
+    float ox, oy, oz, hx, hy, hz;
+    int iz_first;           // planes iz >= iz_first satisfy z > zmin (INT_MAX: none; 0: all)
+};
+__device__ inline void mask_fast_prepare(MaskFast& M, const double* sA, const PeakParams& P, double r_main, double r_side, bool use_zmin) {
+    const double ia[3] = {P.ia0, P.ia1, P.ia2};
+    const double cm[3] = {fmax(fabs(P.ox), fabs(P.ox + (P.nx - 1) * P.hx)), fmax(fabs(P.oy), fabs(P.oy + (P.ny - 1) * P.hy)),
+                          fmax(fabs(P.oz), fabs(P.oz + (P.nz - 1) * P.hz))};
+    double bound = 0;
+    for (int a = 0; a < 3; ++a) {
+        double mag = fabs(sA[4 * a + 3]);
+        for (int k = 0; k < 3; ++k) mag += fabs(sA[4 * a + k]) * cm[k];
+        bound = fmax(bound, mag * fabs(ia[a]));
+        for (int k = 0; k < 4; ++k) M.a[4 * a + k] = (float)(sA[4 * a + k] * ia[a]);
+    }
+    const double band = 2.0 * 32.0 * 5.9604645e-8 * bound;      // > sqrt(3) x the per-component error
+    const double rr[2] = {r_main, r_side};
+    for (int q = 0; q < 2; ++q) {
+        const double rin = rr[q] - band, rout = rr[q] + band;
+        M.rin2[q] = rin > 0 ? (float)(rin * rin * (1.0 - 1e-5)) : -1.f;
+        M.rout2[q] = (float)(rout * rout * (1.0 + 1e-5)) * 1.000001f + 1e-37f;
+    }
+    M.ox = (float)P.ox; M.oy = (float)P.oy; M.oz = (float)P.oz; M.hx = (float)P.hx; M.hy = (float)P.hy; M.hz = (float)P.hz;
+    int k0 = 0;
+    if (use_zmin) {
+        double est = floor((P.zmin - P.oz) / P.hz);
+        est = fmin(fmax(est, -2.0), (double)P.nz + 1.0);
+        int k = (int)est;
+        while (k >= 0 && P.oz + k * P.hz > P.zmin) --k;
+        while (k + 1 < P.nz + 2 && P.oz + (k + 1) * P.hz <= P.zmin) ++k;
+        k0 = k + 1 < 0 ? 0 : k + 1;
+    }
+    M.iz_first = k0;
+}
+// 1 = surely selected side "inside" (d < r), -1 = surely outside (d > r), 0 = inside the band: take the exact test
+__device__ __forceinline__ int mask_fast_side(float d2, float rin2, float rout2) { return d2 < rin2 ? 1 : (d2 > rout2 ? -1 : 0); }
 
 // ------------------------------------------------------------------------------------
 // masked peak per focus (get_mask + max; plan/solution_analysis.py:384-442).  HBM-bound
@@ -356,6 +453,68 @@ __global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restri
     float m = 0.f;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long nyz = (long long)P.ny * P.nz;
+    // 16-byte main loop: a lane owns four consecutive z voxels (quads never straddle a z row), the index decode is paid once per
+    // quad; the per-voxel test is the one of the scalar loop below (which serves grids with nz % 4 != 0)
+    const bool quads = (P.nz & 3) == 0 && (P.vol_stride & 3) == 0 && P.vox < (1ll << 33);
+    if (quads) {
+        const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = (int)(P.vox >> 2);
+        const float inv_nyzq = 1.0f / (float)nyzq, inv_nzq = 1.0f / (float)nzq;
+        const double r2 = P.radius * P.radius, r2lo = r2 * (1.0 - 1e-12), r2hi = r2 * (1.0 + 1e-12);
+        __shared__ MaskFast sM;
+        if (threadIdx.x == 0) mask_fast_prepare(sM, sA, P, P.radius, P.radius, P.use_zmin != 0);
+        __syncthreads();
+        const MaskFast M = sM;
+        const bool want_in = P.op <= 1;              // '<' / '<=' select the inside, '>' / '>=' the outside (op 4: no distance test)
+        constexpr int UQ = 4;                        // quads per lane and iteration: their loads are issued before any of the arithmetic
+        for (int ib = blockIdx.x * blockDim.x + threadIdx.x; ib < nq; ib += UQ * (int)stride) {
+          float4 pq[UQ];
+#pragma unroll
+          for (int u = 0; u < UQ; ++u) {
+              const long long iu = (long long)ib + (long long)u * stride;
+              pq[u] = iu < nq ? reinterpret_cast<const float4*>(v)[iu] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < UQ; ++u) {
+            const int iq = (int)min((long long)ib + (long long)u * stride, (long long)nq - 1);      // (past the end: a zero quad, harmless under max)
+            int ix, iy, iz0;
+            quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
+            const float4 p4 = pq[u];
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float fx = fmaf((float)ix, M.hx, M.ox), fy = fmaf((float)iy, M.hy, M.oy);
+            const float b0 = fmaf(M.a[1], fy, fmaf(M.a[0], fx, M.a[3])), b1 = fmaf(M.a[5], fy, fmaf(M.a[4], fx, M.a[7])), b2 = fmaf(M.a[9], fy, fmaf(M.a[8], fx, M.a[11]));
+            // branch-free fp32 pass over the quad's four voxels; the (rare) voxels inside the band are settled by ONE exact pass behind it
+            int side[4], undecided = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float fz = fmaf((float)(iz0 + e), M.hz, M.oz);
+                const float g0 = fmaf(M.a[2], fz, b0), g1 = fmaf(M.a[6], fz, b1), g2 = fmaf(M.a[10], fz, b2);
+                side[e] = mask_fast_side(fmaf(g2, g2, fmaf(g1, g1, g0 * g0)), M.rin2[0], M.rout2[0]);
+                undecided |= side[e] == 0 ? (1 << e) : 0;
+            }
+            if (P.op != 4 && undecided) {
+                const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!((undecided >> e) & 1)) continue;
+                    const double z = P.oz + (iz0 + e) * P.hz;
+                    const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+                    const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+                    const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+                    const double d2 = q0 * q0 + q1 * q1 + q2 * q2;
+                    // "inside" in the sense the op needs: '<' selects dist < r, '>=' its complement; '<=' selects dist <= r, '>' its complement
+                    const bool in = (P.op == 0 || P.op == 3) ? mask_cmp<0>(d2, P.radius, r2lo, r2hi) : mask_cmp<1>(d2, P.radius, r2lo, r2hi);
+                    side[e] = in ? 1 : -1;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool sel = P.op == 4 ? true : ((side[e] > 0) == want_in);
+                if (P.use_zmin) sel = sel && (iz0 + e) >= M.iz_first;
+                if (sel) m = fmaxf(m, pv[e]);
+            }
+          }
+        }
+    } else
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.vox; i += stride) {
         const int ix = (int)(i / nyz);
         const int rem = (int)(i - ix * nyz);
@@ -580,16 +739,26 @@ __global__ __launch_bounds__(256) void tof_spread_k(const double* __restrict__ x
 }
 
 // weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
-__global__ void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
+__global__ __launch_bounds__(256) void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
                                      long long vox, float* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
+    const long long v4 = (vox & 3) == 0 ? (vox >> 2) : 0;          // 16-byte main loop, scalar tail (same sums)
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int f = 0; f < n_foci; ++f) {
+            const float w = wts[f];
+            const float4 v = reinterpret_cast<const float4*>(vol + (long long)f * vox)[q];
+            s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+        }
+        reinterpret_cast<float4*>(out)[q] = s;
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
         float s = 0.f;
         for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * vox + v];
         out[v] = s;
     }
 }
-
 
 // ------------------------------------------------------------------------------------
 // The same six peaks with 16-byte loads: a thread owns FOUR consecutive z voxels (nz % 4 == 0), so the index decode (32-bit
@@ -609,27 +778,66 @@ __global__ __launch_bounds__(256) void field_analysis_peaks4_k(const float* __re
     float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = (int)(P.vox >> 2);
     const int stride = gridDim.x * blockDim.x;
-    for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
-        const int ix = iq / nyzq;
-        const int rem = iq - ix * nyzq;
-        const int iy = rem / nzq, iz0 = (rem - iy * nzq) << 2;
-        const float4 p4 = vp[iq], w4 = vi[iq];
+    const float inv_nyzq = 1.0f / (float)nyzq, inv_nzq = 1.0f / (float)nzq;
+    const double rm2 = P.radius * P.radius, rm2lo = rm2 * (1.0 - 1e-12), rm2hi = rm2 * (1.0 + 1e-12);
+    const double rs2 = r_side * r_side, rs2lo = rs2 * (1.0 - 1e-12), rs2hi = rs2 * (1.0 + 1e-12);
+    __shared__ MaskFast sM;
+    if (threadIdx.x == 0) mask_fast_prepare(sM, sA, P, P.radius, r_side, true);
+    __syncthreads();
+    const MaskFast M = sM;
+    constexpr int UQ = 4;                            // quads per lane and iteration: 8 independent 16-byte loads before any arithmetic
+    for (int ib = blockIdx.x * blockDim.x + threadIdx.x; ib < nq; ib += UQ * stride) {
+      float4 pq[UQ], wq[UQ];
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+          const long long iu = (long long)ib + (long long)u * stride;
+          const bool ok = iu < nq;
+          pq[u] = ok ? vp[iu] : make_float4(0.f, 0.f, 0.f, 0.f);
+          wq[u] = ok ? vi[iu] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        const int iq = (int)min((long long)ib + (long long)u * stride, (long long)nq - 1);          // (past the end: zero quads, harmless under max)
+        int ix, iy, iz0;
+        quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
+        const float4 p4 = pq[u], w4 = wq[u];
         const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
-        const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy;
+        const float fx = fmaf((float)ix, M.hx, M.ox), fy = fmaf((float)iy, M.hy, M.oy);
+        const float b0 = fmaf(M.a[1], fy, fmaf(M.a[0], fx, M.a[3])), b1 = fmaf(M.a[5], fy, fmaf(M.a[4], fx, M.a[7])), b2 = fmaf(M.a[9], fy, fmaf(M.a[8], fx, M.a[11]));
+        // branch-free fp32 pass over the quad's four voxels; voxels inside a band of either mask surface (rare) are settled by ONE exact pass
+        int in_main[4], in_side[4], undecided = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int iz = iz0 + e;
-            const double z = P.oz + iz * P.hz;
-            const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
-            const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
-            const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
-            const double dist = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
-            const bool zok = z > P.zmin;
+            const float fz = fmaf((float)(iz0 + e), M.hz, M.oz);
+            const float g0 = fmaf(M.a[2], fz, b0), g1 = fmaf(M.a[6], fz, b1), g2 = fmaf(M.a[10], fz, b2);
+            const float d2f = fmaf(g2, g2, fmaf(g1, g1, g0 * g0));
+            in_main[e] = mask_fast_side(d2f, M.rin2[0], M.rout2[0]);
+            in_side[e] = mask_fast_side(d2f, M.rin2[1], M.rout2[1]);
+            undecided |= (in_main[e] == 0 || in_side[e] == 0) ? (1 << e) : 0;
+        }
+        if (undecided) {
+            const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!((undecided >> e) & 1)) continue;
+                const double z = P.oz + (iz0 + e) * P.hz;
+                const double q0 = (sA[0] * x + sA[1] * y + sA[2] * z + sA[3]) * P.ia0;
+                const double q1 = (sA[4] * x + sA[5] * y + sA[6] * z + sA[7]) * P.ia1;
+                const double q2 = (sA[8] * x + sA[9] * y + sA[10] * z + sA[11]) * P.ia2;
+                const double d2 = q0 * q0 + q1 * q1 + q2 * q2;
+                in_main[e] = mask_cmp<0>(d2, P.radius, rm2lo, rm2hi) ? 1 : -1;
+                in_side[e] = mask_cmp<2>(d2, r_side, rs2lo, rs2hi) ? -1 : 1;      // (-1 = outside the side radius = selected)
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool zok = (iz0 + e) >= M.iz_first;
             const float p = pv[e], w = wv[e];
-            if (dist < P.radius) { m[0] = fmaxf(m[0], p); m[1] = fmaxf(m[1], w); }
-            if (zok && dist > r_side) { m[2] = fmaxf(m[2], p); m[3] = fmaxf(m[3], w); }
+            if (in_main[e] > 0) { m[0] = fmaxf(m[0], p); m[1] = fmaxf(m[1], w); }
+            if (zok && in_side[e] < 0) { m[2] = fmaxf(m[2], p); m[3] = fmaxf(m[3], w); }
             if (zok) { m[4] = fmaxf(m[4], p); m[5] = fmaxf(m[5], w); }
         }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -727,7 +935,26 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
     __shared__ float s_red[4];
     const long long stride = (long long)gridDim.x * blockDim.x;
     float m = 0.f;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P.vox; v += stride) {
+    const long long v4 = ((P.vox & 3) == 0 && (P.nz & 3) == 0 && P.vox < (1ll << 33)) ? (P.vox >> 2) : 0;   // quads never straddle a z row
+    const int nzq = P.nz >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < v4; q += stride) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int f = 0; f < n_foci; ++f) {
+            const float w = wts[f];
+            const float4 v = reinterpret_cast<const float4*>(vol + (long long)f * P.vox)[q];
+            s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+        }
+        reinterpret_cast<float4*>(out)[q] = s;
+        const int iz0 = (int)((unsigned)q % (unsigned)nzq) << 2;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double z = P.oz + (iz0 + e) * P.hz;
+            if (z > P.zmin) m = fmaxf(m, sv[e]);
+        }
+    }
+    for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P.vox; v += stride) {
         float s = 0.f;
         for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * P.vox + v];
         out[v] = s;

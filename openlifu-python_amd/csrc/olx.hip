@@ -1542,6 +1542,13 @@ int olx_field_time(olx_ctx* c, int iters, float* ms_each) {
 static int aggregate_local(olx_ctx* c, bool with_p, bool with_i);
 }
 static void fill_scan_params(const olx_ctx* c, PeakParams& P, const double* aspect);
+// Blocks per focus of the masked scans: ~2048 blocks in flight over all foci (8 per CU, all resident), each living long enough
+// that its one-thread mask preparation (fp32 frame, band, first plane above zmin) does not count -- with 2048 blocks PER focus a
+// block moved 32 KB and the prologue was most of its life.
+static unsigned scan_blocks(long long want, int F) {
+    const long long per_focus = std::max<long long>(2048 / std::max(F, 1), 128);
+    return (unsigned)std::max<long long>(1, std::min(want, per_focus));
+}
 extern "C" {
 
 // Streaming scans over the resident result, timed like olx_field_time: `iters` back-to-back launches of ONE scan kernel on the
@@ -1612,13 +1619,13 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
             *bytes_per_launch = vox * 16.0 * F; break;
         case OLX_SCAN_ANALYSIS_PEAKS:      // (the form olx_solution_analyze launches)
             if ((c->fp.nz & 3) == 0 && c->fp.vox < (1ll << 33))
-                hipLaunchKernelGGL(field_analysis_peaks4_k, dim3((unsigned)std::min<long long>((want + 3) / 4, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, 5e-3, d_pk);
+                hipLaunchKernelGGL(field_analysis_peaks4_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, 5e-3, d_pk);
             else
                 hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, d_A, P, 5e-3, d_pk);
             *bytes_per_launch = vox * 8.0 * F; break;
         case OLX_SCAN_MASKED_PEAK:         // an OUTSIDE mask ('>': every voxel is visited; inside masks only visit their index box)
             P.op = 2;
-            hipLaunchKernelGGL(field_masked_peak_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], d_A, P, d_pk);
+            hipLaunchKernelGGL(field_masked_peak_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, c->d_pmag[c->cur], d_A, P, d_pk);
             *bytes_per_launch = vox * 4.0 * F; break;
         case OLX_SCAN_OFFSET_GRID:
             hipLaunchKernelGGL(offset_grid_k, dim3((unsigned)std::min<long long>(want, 4096)), dim3(256), 0, c->stream, d_ax, d_ax + c->fp.nx, d_ax + c->fp.nx + c->fp.ny,
@@ -1798,7 +1805,7 @@ int olx_field_masked_peak(olx_ctx* c, int which, const double* A, const double* 
     P.radius = radius_m; P.op = op; P.use_zmin = use_zmin; P.zmin = zmin_m; P.vox = c->fp.vox;
     P.vol_stride = which == 2 ? 0 : c->fp.vox;
     const long long want = (P.vox + 255) / 256;
-    dim3 grid((unsigned)std::min<long long>(want, 2048), F);
+    dim3 grid(scan_blocks(want, F), F);
     const float* vol = which == 0 ? c->d_pmag[c->cur] : (which == 1 ? c->d_inten : c->d_wint);
     if (op <= 1) {   // inside-the-ellipsoid masks: only the index box around each focus' ellipsoid is visited (same per-voxel test)
         std::vector<int> boxes(6 * (size_t)F);
@@ -2040,7 +2047,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     // (1) the six masked peaks of |p| and intensity, one pass
     P.radius = o->r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = o->zmin_m;
     const long long want = (P.vox + 255) / 256;
-    if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3((unsigned)std::min<long long>((want + 3) / 4, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
+    if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     else hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     // (2) -3 dB centroid of the mainlobe: cut-off from the peak just found
     hipLaunchKernelGGL(analysis_cutoffs_k, dim3((F + 63) / 64), dim3(64), 0, c->stream, d_pk, F, o->centroid_factor, d_cut);
