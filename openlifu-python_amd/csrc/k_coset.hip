@@ -30,7 +30,7 @@ namespace olx {
 // ------------------------------------------------------------------------------------
 
 
-template <int NT, int MX, int MY, bool CLAMP, bool FP8>
+template <int NT, int MX, int MY, bool CLAMP, bool FP8, bool DIR>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
     const int* __restrict__ jobs /*[tiles][MFMA_MAX_NT][COS_JOBS + 1]: dense (column, focus, image) store jobs, [COS_JOBS] = log2 count*/,
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                         const float ri = __builtin_amdgcn_rsqf(d2);
                         const float ph = d2 * ri;
-                        const float rs = ri * P.g_scale;
+                        float rs = ri * P.g_scale;
+                        if constexpr (DIR) rs *= piston_dir(dx, dy, ri, P.dir_wx, P.dir_wy);      // (own instantiations: the default path never sees this)
                         const float gr = rs * __builtin_amdgcn_cosf(ph);
                         const float gi = rs * __builtin_amdgcn_sinf(ph);
                         // fp8 corrections: hi rounded to nearest (v_cvt_pk_f16_f32) so that |lo| <= half an ulp
@@ -432,7 +433,12 @@ static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
     const CosetParams& Q = c->cp;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q)
+#define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q)
+    if (c->dir_lattice) {   // piston directivity folded into the geometry tables (fp16 corrections only)
+        if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q);
+        else hipLaunchKernelGGL((field_coset_k<NT, MX, MY, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q);
+        return;
+    }
     if constexpr (cos_fp8(NT)) {
         if (c->fp8corr) { if (clamp) OLX_COS(true, true); else OLX_COS(false, true); return; }
     }

@@ -47,7 +47,7 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 
 // PERSIST: the grid is two blocks per CU and a block walks the records blockIdx.x, blockIdx.x + gridDim.x, ... (n_items of them);
 // `stagger` [cycles] delays the second block of each CU once, so that the two do not run their phases in lockstep.
-template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST>
+template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                     const float ri = __builtin_amdgcn_rsqf(d2);
                     const float ph = d2 * ri;
-                    const float rs = ri * P.g_scale;
+                    float rs = ri * P.g_scale;
+                    if constexpr (DIR) rs *= piston_dir(dx, dy, ri, P.dir_wx, P.dir_wy);      // (own instantiations: the default path never sees this)
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     half2_t hi;
@@ -407,6 +408,11 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
     dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
 #define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger)
+    if (c->dir_lattice) {   // piston directivity folded into the geometry tables (fp16 corrections only)
+        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0);
+        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0);
+        return;
+    }
 #ifdef OLX_AB_VARIANTS   // the persistent grid (OLX_FIELD_VARIANT=cosetpp): measured slower, developer library only
     if (persist) {
         if (c->fp8corr) { if (clamp) OLX_CP(true, true, true); else OLX_CP(false, true, true); }

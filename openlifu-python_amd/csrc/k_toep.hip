@@ -31,7 +31,7 @@ namespace olx {
 //     4 g .. 4 g + 3 = (kx = 2 g, re), (2 g, im), (2 g + 1, re), (2 g + 1, im) of plane n -- |p| and the intensity need
 //     no cross-lane step, and the 16 lanes of a k-group write 64 contiguous bytes of z per (position, target).
 // ------------------------------------------------------------------------------------
-template <int MX, int MY, bool CLAMP>
+template <int MX, int MY, bool CLAMP, bool DIR = false>
 __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
                                                                     float* __restrict__ inten, const CosetBlock* __restrict__ blocks /*[gridDim.x]*/,
                                                                     const ToepParams T) {
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                 const float ri = __builtin_amdgcn_rsqf(d2);
                 const float ph = d2 * ri;
-                const float rs = ri * P.g_scale;
+                float rs = ri * P.g_scale;
+                if constexpr (DIR) rs *= piston_dir(dx, dy, ri, P.dir_wx, P.dir_wy);      // (own instantiations: the default path never sees this)
                 const float2_t gv = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * rs;      // (one v_pk_mul_f32)
                 const float gr = gv[0], gi = gv[1];
                 const half2_t hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
@@ -280,6 +281,11 @@ static void launch_toep(olx_ctx* c, float* pm) {
     const CosetParams& Q = T.q;
     const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);
+    if (c->dir_lattice) {   // piston directivity folded into the geometry tables
+        if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+        else hipLaunchKernelGGL((field_toep_k<MX, MY, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+        return;
+    }
     if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
     else hipLaunchKernelGGL((field_toep_k<MX, MY, false>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
 }

@@ -30,6 +30,21 @@ __device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DP
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
+// Far-field factor of a flat, axis-aligned rectangular piston (the lattice kernels' opt-in DIR instantiations; definition:
+// oracle/field_oracle.py piston_directivity; same arithmetic as kernel 2a-d, field_accum_dir_k, with local axes = grid axes):
+// D = sinc(2 pi tx) sinc(2 pi ty), tx = (dx / d) w / (2 lambda), ty = (dy / d) l / (2 lambda) [revolutions]; v_sin on the argument in
+// revolutions, one v_rcp for both denominators, the series value 1 - t^2 / 6 next to the axis.
+__device__ __forceinline__ float piston_dir(float dx, float dy, float ri, float wx, float wy) {
+    constexpr float TWO_PI = 6.283185307179586f;
+    const float tx = dx * ri * wx, ty = dy * ri * wy;
+    const float sx = __builtin_amdgcn_sinf(tx), sy = __builtin_amdgcn_sinf(ty);
+    const float ax = TWO_PI * tx, ay = TWO_PI * ty;
+    const float inv = __builtin_amdgcn_rcpf(ax * ay);
+    const bool nx0 = fabsf(ax) < 1e-3f, ny0 = fabsf(ay) < 1e-3f;
+    if (!nx0 && !ny0) return sx * sy * inv;
+    return (nx0 ? fmaf(ax * ax, -1.0f / 6.0f, 1.0f) : sx / ax) * (ny0 ? fmaf(ay * ay, -1.0f / 6.0f, 1.0f) : sy / ay);
+}
+
 #ifdef OLX_EXP_STAMPS
 static __device__ unsigned long long g_stamps[4096][8];   // per translation unit; read back by olx_exp_read_stamps (k_coset.hip)
 #define OLX_STAMP(k) do { if (lane == 0 && wave < 4 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)

@@ -460,7 +460,11 @@ static int configure_variant(olx_ctx* c) {
     const bool lat_ok = c->allow_shared && c->lat.ok && (c->force_kind == 0 || c->force_kind == 4) &&
                         tile_fill(c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), c->lat.mx) >= 0.5 &&
                         tile_fill(c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), c->lat.my) >= 0.5;
-    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok);
+    if (c->directivity && !(lat_ok && c->dir_lattice)) {   // no lattice path for this array / grid: the exact per-pair kernel 2a-d
+        c->allow_shared = false; c->dir_lattice = false;
+        c->mx = c->my = c->dx = c->dy = c->nf = 1;
+    }
+    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok) && (!c->directivity || lat_ok);
     c->use_lattice = c->use_mfma && lat_ok;
     c->fp8corr = false;
     c->nt = 1;
@@ -527,6 +531,7 @@ static int configure_variant(olx_ctx* c) {
         c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
+            if (c->directivity && fv && strcmp(fv, "lattice") && strcmp(fv, "lattice2d")) fv = nullptr;   // (the A/B forms carry no directivity)
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             if (coset_fill(c->nt) > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             const int want = (c->use_coset && c->nt <= 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
@@ -652,7 +657,7 @@ static int configure_variant(olx_ctx* c) {
             // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt);
+                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->directivity;
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                     c->foci_version = c->steer_version;
@@ -669,7 +674,7 @@ static int configure_variant(olx_ctx* c) {
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && (f8 ? strcmp(f8, "0") != 0 : ok);
+                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->directivity && (f8 ? strcmp(f8, "0") != 0 : ok);
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
@@ -683,6 +688,8 @@ static int configure_variant(olx_ctx* c) {
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
                 Q.vox = L.vox; Q.flags = L.flags;
+                Q.dir_wx = c->dir_lattice ? (float)(0.5 * c->h_size[0] / lambda) : 0.f;      // element width / length over 2 lambda (DIR instantiations)
+                Q.dir_wy = c->dir_lattice ? (float)(0.5 * c->h_size[1] / lambda) : 0.f;
                 {   // dense store-job lists per (launch tile, column tile): job = c16 | image << 4 | focus << 6
                     std::vector<int> jobs((size_t)ntiles * MFMA_MAX_NT * (COS_JOBS + 1), -1);
                     for (int t = 0; t < ntiles; ++t)
@@ -875,6 +882,11 @@ static int configure_variant(olx_ctx* c) {
         snprintf(nmbuf, sizeof nmbuf, "field_shared_k<4,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", c->mx, c->my, c->dx, c->dy, c->nf,
                  c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     }
+    if (c->directivity && c->use_mfma && !(c->use_lattice && c->use_coset)) {   // only the coset kernels (2e / 2f / 2g) carry D_e: fall back to 2a-d
+        c->dir_lattice = false; c->allow_shared = false;
+        return configure_variant(c);
+    }
+    if (c->directivity && c->use_mfma) { strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1); }
     c->variant = nmbuf;
     return OLX_OK;
 }
@@ -1056,7 +1068,20 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
     c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : (kAbVariants && !strcmp(force, "shfl")) ? 5 : 0;
-    c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && !c->directivity;   // directivity: exact per-pair kernel only (v1)
+    // piston directivity: for a flat array of equal, axis-aligned elements D_e depends on the (voxel - element) offset only and folds
+    // into the lattice kernels' geometry tables (their DIR instantiations); any other array keeps the exact per-pair kernel 2a-d
+    c->dir_lattice = false;
+    if (c->directivity && !(flags & OLX_OUT_COMPLEX) && c->flat) {
+        bool ok = c->h_xaxis.size() == 3 * (size_t)n && c->h_size.size() == 2 * (size_t)n;
+        for (int e = 0; ok && e < n; ++e) {
+            const double* xa = &c->h_xaxis[3 * (size_t)e]; const double* nr = &c->h_nrm[3 * (size_t)e];
+            if (std::fabs(std::fabs(xa[0]) - 1.0) > 1e-12 || std::fabs(xa[1]) > 1e-12 || std::fabs(xa[2]) > 1e-12) ok = false;
+            if (std::fabs(std::fabs(nr[2]) - 1.0) > 1e-12) ok = false;
+            if (c->h_size[2 * (size_t)e] != c->h_size[0] || c->h_size[2 * (size_t)e + 1] != c->h_size[1]) ok = false;
+        }
+        c->dir_lattice = ok;
+    }
+    c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && (!c->directivity || c->dir_lattice);
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
     {   // worst-case kernel-2a/2b table over every (dx, dy, nf) the steering may select later: tiles = ceil(F / nf)

@@ -46,7 +46,7 @@ struct olx_ctx {
     std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
     std::vector<double> h_foci; unsigned long long foci_version = ~0ull;  // foci of the last olx_bf_solve in the element frame (M == identity)
     // optional piston directivity: local x axes [N][3] and sizes [N][2] on the host, packed frame table on the device
-    std::vector<double> h_xaxis, h_size, h_nrm; float* d_tab2 = nullptr; size_t tab2_cap = 0; bool directivity = false;
+    std::vector<double> h_xaxis, h_size, h_nrm; float* d_tab2 = nullptr; size_t tab2_cap = 0; bool directivity = false; bool dir_lattice = false;   // dir_lattice: flat, axis-aligned, equal-size elements -> D_e folds into the lattice kernels' tables
     bool allow_shared = true;
     // steering
     int n_foci = 0;

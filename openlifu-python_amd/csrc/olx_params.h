@@ -81,6 +81,7 @@ struct CosetParams {
     int ux0, uy0;
     float fx0, fy0, hx_hi, hx_lo, hy_hi, hy_lo, hz;
     float dmin2, flat_ez, g_scale, out_scale, inten_scale;
+    float dir_wx, dir_wy;      // DIR instantiations: element width / length over 2 lambda (piston directivity of a flat, axis-aligned array)
     long long vox;
     unsigned flags;
 };

@@ -580,6 +580,48 @@ def test_piston_directivity_opt_in(ctx):
         assert np.abs(ctx.field_fetch(1)["pmag"] - plain).max() / plain.max() <= TOL_P
 
 
+@pytest.mark.parametrize("case", ["one_column_2f", "off_axis_2e_nt1", "shard_2g", "sweep_2e_nt4", "rotated_fallback"])
+def test_piston_directivity_in_the_lattice_kernels(ctx, case, monkeypatch):
+    """For a flat matrix array of equal, axis-aligned elements the piston factor depends on the (voxel - element) offset only and folds
+    into the geometry tables of the lattice kernels (their own DIR instantiations; the default path is not touched): one on-axis focus
+    (kernel 2f), one off-axis focus (2e, NT = 1), an 8-focus shard with shared images (2g), a 20-focus ring (2e, NT = 4) -- each against
+    the fp64 oracle of the same definition (full volume) and against the per-pair kernel 2a-d; an array with one rotated element
+    keeps kernel 2a-d."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    if case == "rotated_fallback":
+        ori = ori.copy(); ori[37, 2] = 0.2                               # one element rolled about its normal: frames differ
+    foci = {"one_column_2f": np.array([[0, 0, 30e-3]]), "off_axis_2e_nt1": np.array([[2e-3, -1e-3, 28e-3]]),
+            "shard_2g": _wheel_shard(8), "sweep_2e_nt4": bo.wheel_targets([1.0, 0.5, 32.0], True, 19, 4.0) * 1e-3,
+            "rotated_fallback": np.array([[0, 0, 30e-3]])}[case]
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 60.0, 0.0))
+    R = bo.element_rotations(ori)
+    xaxis, normal, size_m = R[:, :, 0], R[:, :, 2], size * 1e-3
+    ctx.set_element_apertures(xaxis, size_m)
+    xs, ys, zs = centred_grid(64, 0.5)
+    h = (xs[1] - xs[0],) * 3
+    flags = nat.OUT_PMAG | nat.OUT_INTENSITY | nat.FIELD_DIRECTIVITY
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (64,) * 3, F0, C, RHO, P0, flags=flags)
+    name = ctx.field_variant()
+    expect = {"one_column_2f": "field_toep_k", "off_axis_2e_nt1": "field_coset_k<nt1", "shard_2g": "field_cosetp_k<nt2", "sweep_2e_nt4": "field_coset_k<nt4",
+              "rotated_fallback": "field_accum_dir_k"}[case]
+    assert expect in name and (("piston directivity in the tables" in name) == (case != "rotated_fallback")), name
+    ctx.field_launch()
+    got = [ctx.field_fetch(f) for f in range(len(foci))]
+    monkeypatch.setenv("OLX_FIELD_VARIANT", "general")                   # the per-pair kernel 2a-d on the same plan
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (64,) * 3, F0, C, RHO, P0, flags=flags)
+    assert "field_accum_dir_k" in ctx.field_variant()
+    ctx.field_launch()
+    for f in (0, len(foci) // 2, len(foci) - 1):
+        pair = ctx.field_fetch(f)
+        ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0], directivity=(xaxis, normal, size_m)))
+        plain = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0]))
+        assert np.abs(ref - plain).max() / plain.max() > 0.01            # the factor matters on this geometry
+        assert np.abs(got[f]["pmag"] - ref).max() / ref.max() <= TOL_P, (case, f)
+        assert np.abs(got[f]["pmag"] - pair["pmag"]).max() / ref.max() <= TOL_P
+        iref = fo.intensity_wcm2(ref, RHO, C)
+        assert np.abs(got[f]["intensity"] - iref).max() / iref.max() <= TOL_I
+
+
 def test_mirror_partner_foci_share_columns(ctx):
     """A Wheel's spokes come in mirror orbits: the steering vector of spoke -theta seen through the y-mirror
     equals spoke +theta's, so kernel 2c accumulates one column for both and stores it to both volumes.  The
