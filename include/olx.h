@@ -186,6 +186,13 @@ int olx_field_medium_layering(olx_ctx *ctx, int planes_per_layer);
 #define OLX_MEDIUM_SAMPLED 1
 #define OLX_MEDIUM_MARCHED 2
 int olx_field_medium_model(olx_ctx *ctx, int model);
+/* Uniform absorbing medium for the plans that follow (0 = lossless, the default): sound speed and density are the plan's
+ * constants and every term carries exp(-a d), a = np_per_m (the caller converts the reference's dB/cm/MHz^y: alpha f_MHz^0.9 *
+ * 100 / 8.686, alpha_power 0.9 as sim/kwave_if.py:57).  A medium that is the same everywhere is homogeneous: this runs on the
+ * homogeneous kernels (the lattice kernels' "modified table" instantiations, else the per-pair kernel 2a-d), not on the
+ * layered-ray kernels of olx_field_set_medium -- which it excludes.  Example: the reference's example_protocol.json (water with
+ * 0.0022 dB/cm/MHz). */
+int olx_field_absorption(olx_ctx *ctx, double np_per_m);
 
 /* Bind host volumes (e.g. a Solution loaded from disk) as the context's resident result so
  * that the aggregate / scale / masked-peak entry points can run on them: [n_foci * slab voxels]

@@ -135,10 +135,10 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_dir_k(
         const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
         const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
         const float phi = t[e * TAB_STRIDE + 4];
-        const float* a = tab2 + (size_t)e * 8;
+        const float* a = tab2 ? tab2 + (size_t)e * 8 : t;      // (no frames: never read)
         const float dx = x - ex, dy = y - ey;
         const float r2 = fmaf(dy, dy, dx * dx);
-        const float px = fmaf(dy, a[1], dx * a[0]), py = fmaf(dy, a[5], dx * a[4]);   // lateral part of r . ex, r . ey
+        const float px = tab2 ? fmaf(dy, a[1], dx * a[0]) : 0.f, py = tab2 ? fmaf(dy, a[5], dx * a[4]) : 0.f;   // lateral part of r . ex, r . ey
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
             const float dz = z[q] - ez;
@@ -147,14 +147,17 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_dir_k(
             const float ri = __builtin_amdgcn_rsqf(d2);
             const float ph = fmaf(d2, ri, phi);  // d [wavelengths] + phi = phase [revolutions]
             // sinc(pi w u_x / lambda) = sin(2 pi tx) / (2 pi tx), tx = u_x w / (2 lambda) [revolutions]
-            const float tx = fmaf(dz, a[2], px) * ri * a[3], ty = fmaf(dz, a[6], py) * ri * a[7];
-            const float sx = __builtin_amdgcn_sinf(tx), sy = __builtin_amdgcn_sinf(ty);
-            const float ax = TWO_PI * tx, ay = TWO_PI * ty;
-            const float inv = __builtin_amdgcn_rcpf(ax * ay);
-            const bool nx0 = fabsf(ax) < 1e-3f, ny0 = fabsf(ay) < 1e-3f;       // next to the axis: sinc = 1 - t^2 / 6
-            float D;
-            if (!nx0 && !ny0) D = sx * sy * inv;
-            else D = (nx0 ? fmaf(ax * ax, -1.0f / 6.0f, 1.0f) : sx / ax) * (ny0 ? fmaf(ay * ay, -1.0f / 6.0f, 1.0f) : sy / ay);
+            float D = 1.0f;
+            if (tab2) {                                      // (uniform: a launch has the element frames or it has not)
+                const float tx = fmaf(dz, a[2], px) * ri * a[3], ty = fmaf(dz, a[6], py) * ri * a[7];
+                const float sx = __builtin_amdgcn_sinf(tx), sy = __builtin_amdgcn_sinf(ty);
+                const float ax = TWO_PI * tx, ay = TWO_PI * ty;
+                const float inv = __builtin_amdgcn_rcpf(ax * ay);
+                const bool nx0 = fabsf(ax) < 1e-3f, ny0 = fabsf(ay) < 1e-3f;       // next to the axis: sinc = 1 - t^2 / 6
+                if (!nx0 && !ny0) D = sx * sy * inv;
+                else D = (nx0 ? fmaf(ax * ax, -1.0f / 6.0f, 1.0f) : sx / ax) * (ny0 ? fmaf(ay * ay, -1.0f / 6.0f, 1.0f) : sy / ay);
+            }
+            if (P.absorb_l2 > 0.f) D *= __builtin_amdgcn_exp2f(-P.absorb_l2 * (d2 * ri));       // uniform absorbing medium: exp(-a d)
             const float s = __builtin_amdgcn_sinf(ph);
             const float c = __builtin_amdgcn_cosf(ph);
             const float amp = w * ri * D;
@@ -355,8 +358,9 @@ void olx_launch_accum_dir(olx_ctx* c, float* pm) {
     const FieldParams& P = c->fp;
     const long long lanes = (long long)P.nx * P.ny * ((P.nz + 3) / 4);
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci), blk(FIELD_THREADS);
-    if (c->clamp) hipLaunchKernelGGL((field_accum_dir_k<4, true>), grid, blk, 0, c->stream, c->d_tab, c->d_tab2, pm, c->d_inten, c->d_cplx, P);
-    else hipLaunchKernelGGL((field_accum_dir_k<4, false>), grid, blk, 0, c->stream, c->d_tab, c->d_tab2, pm, c->d_inten, c->d_cplx, P);
+    const float* frames = c->directivity ? c->d_tab2 : nullptr;      // (absorption only: no piston factor)
+    if (c->clamp) hipLaunchKernelGGL((field_accum_dir_k<4, true>), grid, blk, 0, c->stream, c->d_tab, frames, pm, c->d_inten, c->d_cplx, P);
+    else hipLaunchKernelGGL((field_accum_dir_k<4, false>), grid, blk, 0, c->stream, c->d_tab, frames, pm, c->d_inten, c->d_cplx, P);
 }
 
 void olx_launch_accum(olx_ctx* c, float* pm) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     const float ri = __builtin_amdgcn_rsqf(d2);
                     const float ph = d2 * ri;
                     float rs = ri * P.g_scale;
-                    if constexpr (DIR) rs *= piston_dir(dx, dy, ri, P.dir_wx, P.dir_wy);      // (own instantiations: the default path never sees this)
+                    if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     half2_t hi;

@@ -45,6 +45,16 @@ __device__ __forceinline__ float piston_dir(float dx, float dy, float ri, float 
     return (nx0 ? fmaf(ax * ax, -1.0f / 6.0f, 1.0f) : sx / ax) * (ny0 ? fmaf(ay * ay, -1.0f / 6.0f, 1.0f) : sy / ay);
 }
 
+// What the lattice kernels' DIR ("modified table") instantiations multiply into a geometry-table entry: the piston factor when element
+// sizes are given, and exp(-a d) of a uniform absorbing medium (d = clamped distance [wavelengths], a as log2(e) Np per wavelength).
+// Both switches are uniform over the launch.
+__device__ __forceinline__ float table_mod(float dx, float dy, float d, float ri, float wx, float wy, float absorb_l2) {
+    float m = 1.0f;
+    if (wx > 0.f || wy > 0.f) m = piston_dir(dx, dy, ri, wx, wy);
+    if (absorb_l2 > 0.f) m *= __builtin_amdgcn_exp2f(-absorb_l2 * d);
+    return m;
+}
+
 #ifdef OLX_EXP_STAMPS
 static __device__ unsigned long long g_stamps[4096][8];   // per translation unit; read back by olx_exp_read_stamps (k_coset.hip)
 #define OLX_STAMP(k) do { if (lane == 0 && wave < 4 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)

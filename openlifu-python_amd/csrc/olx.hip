@@ -460,11 +460,11 @@ static int configure_variant(olx_ctx* c) {
     const bool lat_ok = c->allow_shared && c->lat.ok && (c->force_kind == 0 || c->force_kind == 4) &&
                         tile_fill(c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), c->lat.mx) >= 0.5 &&
                         tile_fill(c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0), c->lat.my) >= 0.5;
-    if (c->directivity && !(lat_ok && c->dir_lattice)) {   // no lattice path for this array / grid: the exact per-pair kernel 2a-d
+    if (c->modifier() && !(lat_ok && c->dir_lattice)) {   // no lattice path for this array / grid: the exact per-pair kernel 2a-d
         c->allow_shared = false; c->dir_lattice = false;
         c->mx = c->my = c->dx = c->dy = c->nf = 1;
     }
-    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok) && (!c->directivity || lat_ok);
+    c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok) && (!c->modifier() || lat_ok);
     c->use_lattice = c->use_mfma && lat_ok;
     c->fp8corr = false;
     c->nt = 1;
@@ -531,7 +531,7 @@ static int configure_variant(olx_ctx* c) {
         c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
-            if (c->directivity && fv && strcmp(fv, "lattice") && strcmp(fv, "lattice2d")) fv = nullptr;   // (the A/B forms carry no directivity)
+            if (c->modifier() && fv && strcmp(fv, "lattice") && strcmp(fv, "lattice2d")) fv = nullptr;   // (the A/B forms carry no per-term factors)
             c->use_coset = !(c->flags & OLX_OUT_COMPLEX) && !(fv && !strcmp(fv, "lattice2d"));
             if (coset_fill(c->nt) > 0 && coset_fill(c->nt) < 0.6 && !(fv && !strcmp(fv, "lattice"))) c->use_coset = false;
             const int want = (c->use_coset && c->nt <= 2) ? ((c->lat.nsb + 1) & ~1) : c->lat.nsb;
@@ -657,7 +657,7 @@ static int configure_variant(olx_ctx* c) {
             // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->directivity;
+                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                     c->foci_version = c->steer_version;
@@ -674,7 +674,7 @@ static int configure_variant(olx_ctx* c) {
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->directivity && (f8 ? strcmp(f8, "0") != 0 : ok);
+                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : ok);
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
@@ -688,8 +688,9 @@ static int configure_variant(olx_ctx* c) {
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
                 Q.vox = L.vox; Q.flags = L.flags;
-                Q.dir_wx = c->dir_lattice ? (float)(0.5 * c->h_size[0] / lambda) : 0.f;      // element width / length over 2 lambda (DIR instantiations)
-                Q.dir_wy = c->dir_lattice ? (float)(0.5 * c->h_size[1] / lambda) : 0.f;
+                Q.dir_wx = (c->dir_lattice && c->directivity) ? (float)(0.5 * c->h_size[0] / lambda) : 0.f;      // element width / length over 2 lambda (DIR instantiations)
+                Q.dir_wy = (c->dir_lattice && c->directivity) ? (float)(0.5 * c->h_size[1] / lambda) : 0.f;
+                Q.absorb_l2 = c->dir_lattice ? (float)(c->absorb_np_m * lambda * 1.4426950408889634) : 0.f;   // exp(-a d) = exp2(-a lambda log2(e) d'), d' [wavelengths]
                 {   // dense store-job lists per (launch tile, column tile): job = c16 | image << 4 | focus << 6
                     std::vector<int> jobs((size_t)ntiles * MFMA_MAX_NT * (COS_JOBS + 1), -1);
                     for (int t = 0; t < ntiles; ++t)
@@ -857,7 +858,8 @@ static int configure_variant(olx_ctx* c) {
                      n_img, ntiles);
         }
     } else if (c->mx * c->my * c->nf == 1) {
-        if (c->directivity) snprintf(nmbuf, sizeof nmbuf, "field_accum_dir_k<4,%s> (piston directivity)", c->clamp ? "clamp" : "noclamp");
+        if (c->modifier()) snprintf(nmbuf, sizeof nmbuf, "field_accum_dir_k<4,%s> (%s%s%s)", c->clamp ? "clamp" : "noclamp", c->directivity ? "piston directivity" : "",
+                                    (c->directivity && c->absorb_np_m > 0) ? ", " : "", c->absorb_np_m > 0 ? "uniform absorption" : "");
         else if (c->force_kind == 5) snprintf(nmbuf, sizeof nmbuf, "field_shfl_k<%s> (elements across lanes, __shfl reduction)", c->clamp ? "clamp" : "noclamp");
         else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
@@ -882,11 +884,12 @@ static int configure_variant(olx_ctx* c) {
         snprintf(nmbuf, sizeof nmbuf, "field_shared_k<4,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", c->mx, c->my, c->dx, c->dy, c->nf,
                  c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     }
-    if (c->directivity && c->use_mfma && !(c->use_lattice && c->use_coset)) {   // only the coset kernels (2e / 2f / 2g) carry D_e: fall back to 2a-d
+    if (c->modifier() && c->use_mfma && !(c->use_lattice && c->use_coset)) {   // only the coset kernels (2e / 2f / 2g) carry per-term factors: fall back to 2a-d
         c->dir_lattice = false; c->allow_shared = false;
         return configure_variant(c);
     }
-    if (c->directivity && c->use_mfma) { strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1); }
+    if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
+    if (c->absorb_np_m > 0 && c->use_mfma) strncat(nmbuf, " +uniform absorption in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     c->variant = nmbuf;
     return OLX_OK;
 }
@@ -970,7 +973,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "");
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
-                          c->p0_pa == p0_pa && c->flags == flags && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;
+                          c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;
         c->plan_env = env;
         if (same) {
             c->agg_local = -1; c->agg_total = 0;
@@ -981,7 +984,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->grid = *g; c->slab = s; c->plan_foci = n_foci; c->hetero = false;
     c->agg_local = -1; c->agg_total = 0;   // aggregate over all planned foci unless olx_field_aggregate_counts says otherwise
-    c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags;
+    c->freq = freq; c->c = cs; c->rho = rho; c->p0_pa = p0_pa; c->flags = flags; c->plan_absorb = c->absorb_np_m;
     const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
     const size_t total = (size_t)vox * n_foci;
     c->nbuf = c->comm_active() ? olx_ctx::NBUF : 1;
@@ -1071,9 +1074,10 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     // piston directivity: for a flat array of equal, axis-aligned elements D_e depends on the (voxel - element) offset only and folds
     // into the lattice kernels' geometry tables (their DIR instantiations); any other array keeps the exact per-pair kernel 2a-d
     c->dir_lattice = false;
-    if (c->directivity && !(flags & OLX_OUT_COMPLEX) && c->flat) {
-        bool ok = c->h_xaxis.size() == 3 * (size_t)n && c->h_size.size() == 2 * (size_t)n;
-        for (int e = 0; ok && e < n; ++e) {
+    P.absorb_l2 = (float)(c->absorb_np_m * (cs / freq) * 1.4426950408889634);       // kernel 2a-d: exp(-a d) = exp2(-a lambda log2(e) d'), d' [wavelengths]
+    if (c->modifier() && !(flags & OLX_OUT_COMPLEX) && c->flat) {
+        bool ok = !c->directivity || (c->h_xaxis.size() == 3 * (size_t)n && c->h_size.size() == 2 * (size_t)n);
+        for (int e = 0; c->directivity && ok && e < n; ++e) {
             const double* xa = &c->h_xaxis[3 * (size_t)e]; const double* nr = &c->h_nrm[3 * (size_t)e];
             if (std::fabs(std::fabs(xa[0]) - 1.0) > 1e-12 || std::fabs(xa[1]) > 1e-12 || std::fabs(xa[2]) > 1e-12) ok = false;
             if (std::fabs(std::fabs(nr[2]) - 1.0) > 1e-12) ok = false;
@@ -1081,7 +1085,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         }
         c->dir_lattice = ok;
     }
-    c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && (!c->directivity || c->dir_lattice);
+    c->allow_shared = c->force_kind != 1 && c->force_kind != 5 && (!c->modifier() || c->dir_lattice);
     c->mx = (c->allow_shared && whole_x && g->n[0] >= 2 && n <= 8192 && mirror_perm(0, c->h_px)) ? 2 : 1;
     c->my = (c->allow_shared && g->n[1] >= 2 && n <= 8192 && mirror_perm(1, c->h_py)) ? 2 : 1;
     {   // worst-case kernel-2a/2b table over every (dx, dy, nf) the steering may select later: tiles = ceil(F / nf)
@@ -1141,7 +1145,7 @@ int olx_field_launch(olx_ctx* c) {
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetq) olx_launch_cosetq(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp32) olx_launch_cosetp32(c, pm);
     else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp4) olx_launch_cosetp4(c, pm);
-    else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->directivity && c->force_kind == 5) olx_launch_shfl(c, pm);
+    else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->modifier() && c->force_kind == 5) olx_launch_shfl(c, pm);
 #endif
     else if (c->use_mfma) {
         if (!c->use_lattice) olx_launch_mfma(c, pm);
@@ -1152,7 +1156,7 @@ int olx_field_launch(olx_ctx* c) {
     }
     else if (c->mx * c->my * c->nf > 1) {
         if (!olx_launch_shared(c, pm)) return fail(c, OLX_ESTATE, "olx_field_launch: no kernel for variant %s", c->variant.c_str());
-    } else if (c->directivity) olx_launch_accum_dir(c, pm);
+    } else if (c->modifier()) olx_launch_accum_dir(c, pm);
     else olx_launch_accum(c, pm);
     HIPCHK(c, hipGetLastError());
     if (prof) { HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream)); c->prof_n++; }
@@ -1351,6 +1355,7 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
     if (!c) return OLX_EINVAL;
     if (!c->planned || c->uploaded) return fail(c, OLX_ESTATE, "olx_field_set_medium: call olx_field_plan first");
     if (c->directivity) return fail(c, OLX_EINVAL, "olx_field_set_medium: OLX_FIELD_DIRECTIVITY is not available with a heterogeneous medium");
+    if (c->absorb_np_m > 0) return fail(c, OLX_EINVAL, "olx_field_set_medium: a uniform absorption (olx_field_absorption) and a heterogeneous medium exclude each other: put the absorption into the medium volumes");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const olx_grid& g = c->grid;
@@ -1489,6 +1494,13 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
     c->hetero = true;
     c->packed_version = ~0ull;
     return configure_variant(c);
+}
+
+int olx_field_absorption(olx_ctx* c, double np_per_m) {
+    if (!c) return OLX_EINVAL;
+    if (!(np_per_m >= 0) || !std::isfinite(np_per_m)) return fail(c, OLX_EINVAL, "olx_field_absorption: absorption must be finite and >= 0");
+    c->absorb_np_m = np_per_m;
+    return OLX_OK;
 }
 
 int olx_field_medium_layering(olx_ctx* c, int planes_per_layer) {

@@ -46,7 +46,8 @@ struct olx_ctx {
     std::vector<double> h_area, h_delays, h_apod;  // host mirrors for variant decisions
     std::vector<double> h_foci; unsigned long long foci_version = ~0ull;  // foci of the last olx_bf_solve in the element frame (M == identity)
     // optional piston directivity: local x axes [N][3] and sizes [N][2] on the host, packed frame table on the device
-    std::vector<double> h_xaxis, h_size, h_nrm; float* d_tab2 = nullptr; size_t tab2_cap = 0; bool directivity = false; bool dir_lattice = false;   // dir_lattice: flat, axis-aligned, equal-size elements -> D_e folds into the lattice kernels' tables
+    std::vector<double> h_xaxis, h_size, h_nrm; float* d_tab2 = nullptr; size_t tab2_cap = 0; bool directivity = false; double absorb_np_m = 0; bool modifier() const { return directivity || absorb_np_m > 0; }   // per-term factors beyond w / d: piston directivity, uniform absorption
+    bool dir_lattice = false;   // dir_lattice: flat, axis-aligned, equal-size elements -> D_e folds into the lattice kernels' tables
     bool allow_shared = true;
     // steering
     int n_foci = 0;
@@ -57,6 +58,7 @@ struct olx_ctx {
     unsigned long long steer_version = 0, packed_version = ~0ull;
     // field plan
     bool planned = false;
+    double plan_absorb = 0;     // olx_field_absorption as seen by the last olx_field_plan
     std::string plan_env;   // OLX_FIELD_VARIANT | OLX_FP8_CORRECTION as seen by the last olx_field_plan (a changed pin forces a full re-plan)
     bool uploaded = false;  // volumes came from olx_field_upload: not launchable
     olx_grid grid{};

@@ -19,6 +19,7 @@ struct FieldParams {
     float dmin2;           // dmin^2 [wavelengths^2]
     float inten_scale;     // 1e-4 / (2 rho c)
     float flat_ez;         // common element z (FLAT only), relative to table origin [wavelengths]
+    float absorb_l2;       // uniform absorption (kernel 2a-d): log2(e) Np per wavelength; 0 = lossless
     long long vox;         // voxels per focus volume (nx*ny*nz)
     unsigned flags;        // OLX_OUT_*
 };
@@ -81,7 +82,8 @@ struct CosetParams {
     int ux0, uy0;
     float fx0, fy0, hx_hi, hx_lo, hy_hi, hy_lo, hz;
     float dmin2, flat_ez, g_scale, out_scale, inten_scale;
-    float dir_wx, dir_wy;      // DIR instantiations: element width / length over 2 lambda (piston directivity of a flat, axis-aligned array)
+    float dir_wx, dir_wy;      // DIR instantiations: element width / length over 2 lambda (piston directivity of a flat, axis-aligned array); 0 = none
+    float absorb_l2;           // DIR instantiations: uniform absorption, log2(e) Np per wavelength (table entries carry exp(-a d)); 0 = lossless
     long long vox;
     unsigned flags;
 };

@@ -35,7 +35,7 @@ SYMBOLS = [
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
     "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
-    "olx_field_scale_aggregate",
+    "olx_field_scale_aggregate", "olx_field_absorption",
 ]
 
 
@@ -121,6 +121,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_fetch_all.argtypes = [vp, fp, fp]
         lib.olx_field_medium_layering.argtypes = [vp, c_int]
         lib.olx_field_medium_model.argtypes = [vp, c_int]
+        lib.olx_field_absorption.argtypes = [vp, c_double]
         lib.olx_set_element_apertures.argtypes = [vp, dp, dp]
         lib.olx_comm_export.argtypes = [vp, vp]
         lib.olx_comm_import.argtypes = [vp, vp]
@@ -410,6 +411,10 @@ class Context:
     def field_scale(self, scale_per_focus):
         s = _f64(scale_per_focus)
         self._chk(self._lib.olx_field_scale(self._h, _dptr(s), int(s.shape[0])))
+
+    def field_absorption(self, np_per_m: float):
+        """Uniform absorbing medium for the plans that follow (0 = lossless): every term carries exp(-a d)."""
+        self._chk(self._lib.olx_field_absorption(self._h, float(np_per_m)))
 
     def field_scale_aggregate(self, scale_per_focus):
         """``field_scale`` + ``field_aggregate_device`` in one pass (identical values)."""

@@ -180,7 +180,7 @@ class ShardedField:
 
     # ---- planning ---------------------------------------------------------------------------------
     def plan_foci_sweep(self, arr, foci_m, c, apod_args, origin_m, spacing_m, n, freq, rho, p0_pa, flags=None,
-                        fp8_correction=False):
+                        fp8_correction=False, absorption=0.0):
         """mode "foci": this rank solves (kernel 1) and plans its orbit-aware block of foci over the whole grid."""
         from . import _native as nat
         foci_m = np.atleast_2d(np.asarray(foci_m, dtype=np.float64))
@@ -194,6 +194,7 @@ class ShardedField:
         kind, p0, p1 = apod_args
         ctx.bf_solve(foci_m[self.shards[self.rank]], c, apod_kind=kind, p0=p0, p1=p1, want_outputs=False)
         flags = nat.OUT_PMAG if flags is None else flags
+        ctx.field_absorption(absorption)       # (sticky context state: always say what this plan means)
         ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa,
                        flags=flags | (nat.FIELD_FP8_CORRECTION if fp8_correction else 0))
         ctx.aggregate_counts(self.valid[self.rank], self.F)
@@ -201,7 +202,7 @@ class ShardedField:
         self._publish_blocks()
         return self.shards[self.rank]
 
-    def plan_slab_sweep(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=None, medium=None):
+    def plan_slab_sweep(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=None, medium=None, absorption=0.0):
         """mode "slabs": every rank accumulates ALL foci over its x-slab (better balance when F < world; what the
         heterogeneous configuration uses -- ``medium`` = dict of WHOLE-grid volumes, replicated on every rank because
         the rays to a slab cross the full lateral extent)."""
@@ -214,6 +215,7 @@ class ShardedField:
         self.nx = int(n[0])
         per, plan = plan_slabs(self.nx, self.world)
         self.slab = (plan[self.rank][0], per)
+        ctx.field_absorption(0.0 if medium is not None else absorption)
         ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=nat.OUT_PMAG if flags is None else flags,
                        slab=self.slab)
         if medium is not None:

@@ -181,13 +181,15 @@ class Engine:
     # ---- kernel 2 -----------------------------------------------------------------------------
     def field(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa,
               want=("pmag", "intensity"), slab=None, steering_resident=False, medium=None, fp8_correction=False,
-              lazy=False, directivity=False):
+              lazy=False, directivity=False, absorption=0.0):
         """Pressure field for F foci -> dict of float32 arrays [F, nx, ny, nz] (fresh, writable,
         caller-owned).  ``steering_resident`` reuses the table the last ``beamform`` left on the
         device instead of uploading ``delays`` / ``apod``.  ``fp8_correction`` opts in to the e4m3
         correction products (include/olx.h OLX_FIELD_FP8_CORRECTION: ~12 % faster, <= 6e-6 of the focal
         peak instead of 2e-6); never set by default.  ``directivity`` opts in to the far-field piston factor of the elements
-        (OLX_FIELD_DIRECTIVITY; exact per-pair kernel, homogeneous media).  ``lazy=True`` returns a ``DeviceResult`` instead: the volumes
+        (OLX_FIELD_DIRECTIVITY; folded into the lattice kernels' tables for flat arrays of equal axis-aligned elements, else the exact
+        per-pair kernel; homogeneous media).  ``absorption`` [Np/m] > 0: uniform absorbing medium, every term carries exp(-a d)
+        (olx_field_absorption).  ``lazy=True`` returns a ``DeviceResult`` instead: the volumes
         stay in HBM until somebody reads them."""
         self.retire_results()
         if not steering_resident:        # (resident steering came from beamform(arr, ...) an instant ago: same table, bound there)
@@ -203,6 +205,7 @@ class Engine:
         if directivity:
             self.ctx.set_element_apertures(*arr.element_apertures())
             flags |= nat.FIELD_DIRECTIVITY
+        self.ctx.field_absorption(0.0 if medium is not None else absorption)
         self.ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa, flags=flags, slab=slab)
         if medium is not None:  # heterogeneous medium: layered straight-ray kernel
             self.ctx.field_set_medium(medium.get("sound_speed"), medium.get("attenuation"), medium.get("density"),

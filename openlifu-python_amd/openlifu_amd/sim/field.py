@@ -21,30 +21,39 @@ _ATTRS = {"p_max": {"units": "Pa", "long_name": "PPP"}, "p_min": {"units": "Pa",
           "intensity": {"units": "W/cm^2", "long_name": "Intensity"}}
 
 
-def _medium(params):
-    """(c_ref, rho_ref, volumes | None).  Uniform media (every voxel equals the reference value, as with the
-    reference's UniformWater / UniformTissue) use the homogeneous kernels; anything else hands the per-voxel
-    sound speed / attenuation / density volumes to the layered straight-ray kernel (olx_field_set_medium)."""
+ALPHA_POWER = 0.9      # the reference's kWaveMedium(alpha_power=0.9), sim/kwave_if.py:57
+
+
+def _medium(params, freq):
+    """(c_ref, rho_ref, volumes | None, absorption [Np/m]).  A medium whose sound speed and density equal the reference values
+    EVERYWHERE and whose absorption is one constant (the reference's UniformWater / UniformTissue; its example protocol: water with
+    0.0022 dB/cm/MHz) is homogeneous: the homogeneous kernels run, every term carrying exp(-a d) when the constant is not zero
+    (olx_field_absorption).  Anything else hands the per-voxel sound speed / attenuation / density volumes to the layered
+    straight-ray kernels (olx_field_set_medium)."""
     c = float(params["sound_speed"].attrs["ref_value"])
     rho = float(params["density"].attrs["ref_value"])
-    vols, uniform = {}, True
-    for key, ref in (("sound_speed", c), ("density", rho), ("attenuation", 0.0)):
+    vols, const = {}, {}
+    for key in ("sound_speed", "density", "attenuation"):
         if key not in params:
-            vols[key] = None
+            vols[key], const[key] = None, (c if key == "sound_speed" else rho if key == "density" else 0.0)
             continue
         declared = getattr(params[key], "uniform_value", None)
         if declared is not None:                  # constant volume nobody has touched: no 134 MB scan
-            if declared != ref:
-                uniform = False
-                vols[key] = np.asarray(params[key].data)
-            else:
-                vols[key] = None
+            vols[key], const[key] = params[key], float(declared)
             continue
         vol = np.asarray(params[key].data)
-        if vol.size and (vol.min() != ref or vol.max() != ref):
-            uniform = False
-        vols[key] = vol
-    return c, rho, (None if uniform else vols)
+        lo, hi = (vol.min(), vol.max()) if vol.size else (0.0, 0.0)
+        vols[key], const[key] = vol, (float(lo) if lo == hi else None)
+    if const["sound_speed"] == c and const["density"] == rho and const["attenuation"] is not None:
+        a = const["attenuation"] * (float(freq) * 1e-6) ** ALPHA_POWER * 100.0 / 8.685889638065035      # dB/cm/MHz^y -> Np/m
+        return c, rho, None, a
+    out = {}
+    for key, ref in (("sound_speed", c), ("density", rho), ("attenuation", 0.0)):
+        if vols[key] is None or (const[key] is not None and const[key] == ref):
+            out[key] = None                      # equals the value the kernels assume anyway
+        else:
+            out[key] = np.asarray(params[key].data)
+    return c, rho, out, 0.0
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
@@ -54,7 +63,7 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
     ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""
     coords = params.coords
     origin, spacing, n = grid_from_coords(coords)
-    c, rho, medium = _medium(params)
+    c, rho, medium, absorption = _medium(params, freq)
     if medium is not None and int(hetero_planes_per_layer) > 1:   # opt-in layered-screen quadrature (DESIGN.md section 7)
         medium["planes_per_layer"] = int(hetero_planes_per_layer)
     if medium is not None:   # "auto": marched ray sums (kernel 2m) when the elements lie below the medium, else sampled (2h)
@@ -62,7 +71,7 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
     p0 = float(amplitude) * (1.0 if arr.sensitivity is None else float(arr.sensitivity))
     return get_engine().field(arr, delays, apod, origin, spacing, n, float(freq), c, rho, p0, want=want,
                               slab=slab, steering_resident=steering_resident, medium=medium,
-                              fp8_correction=fp8_correction, lazy=lazy, directivity=directivity)
+                              fp8_correction=fp8_correction, lazy=lazy, directivity=directivity, absorption=absorption)
 
 
 def lazy_stack(result, coords, dim="focal_point_index"):

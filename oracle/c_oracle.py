@@ -31,6 +31,8 @@ def lib():
                                         ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_grid_dir.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
                                             ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
+        _lib.olo_field_grid_mod.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_points.argtypes = [dp, ctypes.c_long, dp, dp, dp, ctypes.c_int,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp]
         _lib.olo_field_grid_hetero.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, dp, dp,
@@ -62,9 +64,15 @@ def _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa):
     return pos, w, phi, 2 * np.pi * freq / c
 
 
+def absorption_np_per_m(alpha_db_cm_mhz, freq, alpha_power=0.9):
+    """a [Np/m] = alpha f_MHz^y * 100 / 8.686 (alpha in dB/cm/MHz^y as in the reference's materials; y = 0.9: kwave_if.py:57)."""
+    return float(alpha_db_cm_mhz) * (freq * 1e-6) ** alpha_power * 100.0 / 8.685889638065035
+
+
 def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0,
-                  dmin=None, nthreads=0, directivity=None):
-    """directivity = (xaxis [N,3], normal [N,3], size_m [N,2]): the optional piston factor (olo_field_grid_dir)."""
+                  dmin=None, nthreads=0, directivity=None, absorption=0.0):
+    """directivity = (xaxis [N,3], normal [N,3], size_m [N,2]): the optional piston factor (olo_field_grid_dir);
+    absorption [Np/m] > 0: uniform absorbing medium, every term carries exp(-a d) (olo_field_grid_mod)."""
     xs = np.ascontiguousarray(xs_m, dtype=np.float64)
     ys = np.ascontiguousarray(ys_m, dtype=np.float64)
     zs = np.ascontiguousarray(zs_m, dtype=np.float64)
@@ -72,6 +80,16 @@ def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c, p0_
         dmin = 0.5 * float(xs[1] - xs[0]) if len(xs) > 1 else 0.0
     pos, w, phi, k = _prep(pos_m, area_m2, delays_s, apod, freq, c, p0_pa)
     re = np.empty((len(xs), len(ys), len(zs))); im = np.empty_like(re)
+    if absorption:
+        frames = half = None
+        if directivity is not None:
+            ex = np.asarray(directivity[0], dtype=np.float64); nrm = np.asarray(directivity[1], dtype=np.float64)
+            frames = np.ascontiguousarray(np.concatenate([ex, np.cross(nrm, ex)], axis=1))
+            half = np.ascontiguousarray(np.pi * np.asarray(directivity[2], dtype=np.float64) / (c / freq))
+        lib().olo_field_grid_mod(_p(xs), len(xs), _p(ys), len(ys), _p(zs), len(zs), _p(pos), _p(w), _p(phi),
+                                 _p(frames) if frames is not None else None, _p(half) if half is not None else None,
+                                 len(w), k, dmin, float(absorption), nthreads, _p(re), _p(im))
+        return re + 1j * im
     if directivity is not None:
         ex = np.asarray(directivity[0], dtype=np.float64); nrm = np.asarray(directivity[1], dtype=np.float64)
         frames = np.ascontiguousarray(np.concatenate([ex, np.cross(nrm, ex)], axis=1))

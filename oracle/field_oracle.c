@@ -118,6 +118,54 @@ int olo_field_grid_dir(const double *xs, int nx, const double *ys, int ny, const
     return 0;
 }
 
+/* ---- uniform absorbing medium (the build's definition, PARITY UNPINNED like the rest of the field) ------------------------------
+ * A medium whose sound speed, density AND absorption are the same everywhere (the reference's example protocol: water with
+ * 0.0022 dB/cm/MHz, tests/resources/example_db/protocols/example_protocol/example_protocol.json) is homogeneous: the ray integral of
+ * the absorption is exactly a d, so every term carries exp(-a d), a [Np/m] = alpha f_MHz^0.9 * 100 / 8.686 (the reference's
+ * alpha_power, kwave_if.py:57), with the same clamped d as the amplitude.  (The layered model below would approximate the same
+ * integral by hz-thick slices; for a uniform medium there is nothing to slice.)  frames / half may be NULL (no piston factor). */
+static inline void accumulate_mod(double x, double y, double z, const double *pos, const double *w, const double *phi,
+                                  const double *frames, const double *half, int n, double k, double dmin, double absorb,
+                                  double *re, double *im) {
+    double sr = 0.0, si = 0.0;
+    for (int e = 0; e < n; ++e) {
+        double dx = x - pos[3 * e], dy = y - pos[3 * e + 1], dz = z - pos[3 * e + 2];
+        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < dmin) d = dmin;
+        double D = 1.0;
+        if (frames) {
+            const double *f = frames + 6 * e;
+            const double ux = (dx * f[0] + dy * f[1] + dz * f[2]) / d, uy = (dx * f[3] + dy * f[4] + dz * f[5]) / d;
+            D = sinc1(half[2 * e] * ux) * sinc1(half[2 * e + 1] * uy);
+        }
+        double s, c;
+        sincos(k * d + phi[e], &s, &c);
+        double a = w[e] * D * exp(-absorb * d) / d;
+        sr += a * c;
+        si += a * s;
+    }
+    *re = sr;
+    *im = si;
+}
+
+int olo_field_grid_mod(const double *xs, int nx, const double *ys, int ny, const double *zs, int nz, const double *pos,
+                       const double *w, const double *phi, const double *frames, const double *half, int n, double k,
+                       double dmin, double absorb, int nthreads, double *re_out, double *im_out) {
+    long nxy = (long)nx * ny;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (long ij = 0; ij < nxy; ++ij) {
+        int i = (int)(ij / ny), j = (int)(ij % ny);
+        for (int kz = 0; kz < nz; ++kz) {
+            size_t o = (size_t)ij * nz + kz;
+            accumulate_mod(xs[i], ys[j], zs[kz], pos, w, phi, frames, half, n, k, dmin, absorb, &re_out[o], &im_out[o]);
+        }
+    }
+    return 0;
+}
+
 int olo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -49,9 +49,10 @@ def piston_directivity(v, d, xaxis, normal, size_m, freq, c):
 
 
 def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0,
-                    dmin=0.0, chunk=8192, directivity=None):
+                    dmin=0.0, chunk=8192, directivity=None, absorption=0.0):
     """complex128 p at arbitrary points [P,3] for ONE focus (delays[N], apod[N]).  directivity = (xaxis [N,3], normal [N,3],
-    size_m [N,2]) switches the optional piston factor on."""
+    size_m [N,2]) switches the optional piston factor on; absorption [Np/m] > 0 = a uniform absorbing medium: every term
+    carries exp(-a d) (the exact ray integral of a constant absorption; definition: field_oracle.c olo_field_grid_mod)."""
     pts = np.atleast_2d(np.asarray(points_m, dtype=np.float64))
     pos = np.asarray(pos_m, dtype=np.float64)
     w = element_weights(area_m2, apod, p0_pa, freq, c)
@@ -66,6 +67,8 @@ def field_at_points(points_m, pos_m, area_m2, delays_s, apod, freq, c, p0_pa=1.0
         amp = w[None, :] / d
         if directivity is not None:
             amp = amp * piston_directivity(v, d, directivity[0], directivity[1], directivity[2], freq, c)
+        if absorption:
+            amp = amp * np.exp(-absorption * d)
         out[s:s + chunk] = (amp * np.exp(1j * (k * d + phi[None, :]))).sum(axis=1)
     return out
 
@@ -78,12 +81,12 @@ def grid_points(xs_m, ys_m, zs_m):
 
 
 def field_on_grid(xs_m, ys_m, zs_m, pos_m, area_m2, delays_s, apod, freq, c,
-                  p0_pa=1.0, dmin=None, directivity=None):
+                  p0_pa=1.0, dmin=None, directivity=None, absorption=0.0):
     """complex128 p[nx,ny,nz] for one focus.  dmin defaults to spacing/2."""
     if dmin is None:
         dmin = 0.5 * float(xs_m[1] - xs_m[0]) if len(xs_m) > 1 else 0.0
     p = field_at_points(grid_points(xs_m, ys_m, zs_m), pos_m, area_m2, delays_s, apod,
-                        freq, c, p0_pa, dmin, directivity=directivity)
+                        freq, c, p0_pa, dmin, directivity=directivity, absorption=absorption)
     return p.reshape(len(xs_m), len(ys_m), len(zs_m))
 
 

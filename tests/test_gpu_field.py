@@ -622,6 +622,50 @@ def test_piston_directivity_in_the_lattice_kernels(ctx, case, monkeypatch):
         assert np.abs(got[f]["intensity"] - iref).max() / iref.max() <= TOL_I
 
 
+@pytest.mark.parametrize("case", ["one_column_2f", "shard_2g", "off_axis_2e_nt1", "jittered_2ad", "with_directivity_2g"])
+def test_uniform_absorption(ctx, case):
+    """olx_field_absorption: a uniform absorbing medium is homogeneous -- every term carries exp(-a d).  Lattice kernels with the
+    factor in their geometry tables (2f, 2g, 2e), the per-pair kernel 2a-d for a jittered array, and together with the piston factor;
+    full volume against the fp64 oracle of the same definition (40 Np/m: tissue-like at 400 kHz, a 70 % effect over the grid).  It is
+    sticky context state, excludes a heterogeneous medium, and 0 restores the lossless path."""
+    jit = case == "jittered_2ad"
+    pos, ori, size = synthetic_array(16, 16, 3.0, jitter=jit)
+    foci = {"one_column_2f": np.array([[0, 0, 30e-3]]), "shard_2g": _wheel_shard(8), "off_axis_2e_nt1": np.array([[2e-3, -1e-3, 28e-3]]),
+            "jittered_2ad": np.array([[1e-3, 0, 30e-3]]), "with_directivity_2g": _wheel_shard(8)}[case]
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
+    R = bo.element_rotations(ori)
+    dirv = (R[:, :, 0], R[:, :, 2], size * 1e-3) if case == "with_directivity_2g" else None
+    if dirv is not None:
+        ctx.set_element_apertures(dirv[0], dirv[2])
+    xs, ys, zs = centred_grid(64, 0.5)
+    h = (xs[1] - xs[0],) * 3
+    flags = nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_DIRECTIVITY if dirv is not None else 0)
+    ctx.field_absorption(40.0)
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (64,) * 3, F0, C, RHO, P0, flags=flags)
+    name = ctx.field_variant()
+    expect = {"one_column_2f": "field_toep_k", "shard_2g": "field_cosetp_k<nt2", "off_axis_2e_nt1": "field_coset_k<nt1", "jittered_2ad": "field_accum_dir_k",
+              "with_directivity_2g": "field_cosetp_k<nt2"}[case]
+    assert expect in name and "uniform absorption" in name and ("piston directivity" in name) == (dirv is not None), name
+    ctx.field_launch()
+    for f in (0, len(foci) - 1):
+        out = ctx.field_fetch(f)
+        ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0], directivity=dirv, absorption=40.0))
+        assert np.abs(out["pmag"] - ref).max() / ref.max() <= TOL_P, (case, f)
+        iref = fo.intensity_wcm2(ref, RHO, C)
+        assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
+        lossless = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0], directivity=dirv))
+        assert np.abs(ref - lossless).max() / lossless.max() > 0.3
+    cvol = np.full((64, 64, 64), 1500.0); cvol[:, :, 20:23] = 2800.0
+    with pytest.raises((nat.NativeError, ValueError, RuntimeError)):
+        ctx.field_set_medium(cvol, None, None)
+    ctx.field_absorption(0.0)
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (64,) * 3, F0, C, RHO, P0, flags=flags)
+    assert "absorption" not in ctx.field_variant()
+    ctx.field_launch()
+    lossless0 = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], a[0], F0, C, P0, dmin=0.5 * h[0], directivity=dirv))
+    assert np.abs(ctx.field_fetch(0)["pmag"] - lossless0).max() / lossless0.max() <= TOL_P      # the lossless path again
+
+
 def test_mirror_partner_foci_share_columns(ctx):
     """A Wheel's spokes come in mirror orbits: the steering vector of spoke -theta seen through the y-mirror
     equals spoke +theta's, so kernel 2c accumulates one column for both and stores it to both volumes.  The

@@ -202,3 +202,29 @@ def test_piston_directivity_definition():
     assert np.abs(p1 - p2).max() <= 1e-12 * np.abs(p1).max()
     p3 = co.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5, directivity=(exs, nrm, np.zeros_like(sizes)))
     assert np.abs(p3 - co.field_on_grid(xs, ys, zs, pos, area, d, a, F0, C, 1e5)).max() <= 1e-12 * np.abs(p3).max()
+
+
+def test_uniform_absorption_known_answers():
+    """Uniform absorbing medium: every term carries exp(-a d).  Single element on axis: |p| = w / z * exp(-a z); C and NumPy
+    restatements agree, also together with the piston factor; a = 0 is the lossless oracle."""
+    from oracle import c_oracle as co
+    pos = np.array([[0.0, 0.0, 0.0]]); area = np.array([4e-6])
+    f0, c = 500e3, 1500.0
+    a = co.absorption_np_per_m(0.0022, f0)
+    assert np.isclose(a, 0.0022 * 0.5 ** 0.9 * 100 / 8.685889638065035, rtol=1e-15)
+    z = np.array([[0, 0, 0.03], [0, 0, 0.06]])
+    p = fo.field_at_points(z, pos, area, np.zeros(1), np.ones(1), f0, c, 1e5, absorption=200.0)
+    w = 1e5 * 4e-6 / (c / f0)
+    assert np.allclose(np.abs(p), w / z[:, 2] * np.exp(-200.0 * z[:, 2]), rtol=1e-13)
+    rng = np.random.default_rng(147)
+    pos8, size, _ = bo.gen_matrix_array(4, 4, 3.0, 0.3)
+    pos8 = pos8 * 1e-3; area8 = size[:, 0] * size[:, 1] * 1e-6
+    d, ap = bo.beamform(pos8, np.zeros_like(pos8), np.array([1e-3, 0, 25e-3]), c)
+    xs = np.linspace(-6e-3, 6e-3, 9); ys = np.linspace(-5e-3, 5e-3, 7); zs = np.linspace(2e-3, 30e-3, 11)
+    frames = (np.tile([1.0, 0, 0], (16, 1)), np.tile([0, 0, 1.0], (16, 1)), size * 1e-3)
+    for dirv in (None, frames):
+        r_np = fo.field_on_grid(xs, ys, zs, pos8, area8, d, ap, f0, c, 1e5, directivity=dirv, absorption=35.0)
+        r_c = co.field_on_grid(xs, ys, zs, pos8, area8, d, ap, f0, c, 1e5, directivity=dirv, absorption=35.0)
+        assert np.abs(r_np - r_c).max() <= 1e-12 * np.abs(r_np).max()
+        lossless = co.field_on_grid(xs, ys, zs, pos8, area8, d, ap, f0, c, 1e5, directivity=dirv)
+        assert np.abs(np.abs(r_c) - np.abs(lossless)).max() / np.abs(lossless).max() > 0.1      # 35 Np/m over 30 mm matters

@@ -11,7 +11,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" \
-  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_COEXEC_CYCLES"; do
+  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_COEXEC_CYCLES" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out/pmc$i" -- python3 bench.py --steps 50 --warmup 5 --cpu-seconds 0 "$@" > /dev/null 2>&1
   i=$((i+1))
 done
