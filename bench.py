@@ -355,45 +355,85 @@ def main():
                                   flags=out_flags, fp8_correction=fp8)
         return len(mine)
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
+    def agree(ok: bool) -> bool:
+        """True only when EVERY rank says ok (gloo all-reduce): a leg that failed on one rank is abandoned by all of them together."""
+        if dist is None:
+            return ok
+        import torch
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag[0]))
 
     def timed(mode: str, steps: int, warmup: int):
-        """(wall seconds for `steps` steps: max over ranks, per-launch kernel ms of this rank)."""
-        for _ in range(warmup):
-            sf.step(mode)
-        barrier()
-        ctx.profile_begin(steps)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sf.step(mode)
-        ctx.sync()
+        """(wall seconds for `steps` steps: max over ranks, per-launch kernel ms of this rank), or None when the leg failed on some
+        rank.  Device-side failures (an exchange that times out, a transport error) are caught per rank; the rendezvous calls below
+        are reached by every rank whatever happened, so one rank's failure cannot leave the others waiting in a barrier."""
+        err = None
+        try:
+            for _ in range(warmup):
+                sf.step(mode)
+            ctx.sync()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if dist is not None:
+            dist.barrier()
+        kern, t0 = np.zeros(0, dtype=np.float32), time.perf_counter()
+        try:
+            if err is None:
+                ctx.profile_begin(steps)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    sf.step(mode)
+                ctx.sync()
+        except Exception as e:  # noqa: BLE001
+            err = e
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        kern = ctx.profile_end()
+        try:
+            kern = ctx.profile_end() if err is None else kern
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not agree(err is None):
+            timed.last_error = str(err) if err is not None else "failed on another rank"
+            return None
         if dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
         return elapsed, kern
+    timed.last_error = ""
 
     def ramp():
         """Before EVERY timed leg: the planned launch, discarded, until the shader clock has left the idle state (the GPU idles
         for seconds during planning, parity checks and CPU legs; the first ~20 launches after idle run 15-20 % slower)."""
         if args.clock_ramp_ms > 0:
             t_ramp = time.perf_counter()
-            while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
-                ctx.field_launch()
-                ctx.sync()
+            try:
+                while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
+                    ctx.field_launch()
+                    ctx.sync()
+            except Exception:  # noqa: BLE001 - a broken exchange shows up (and is handled) in the timed leg that follows
+                pass
 
     F = plan(args.corrections == "fp8")
     ramp()
     mode = reassemble if gather else "none"
-    elapsed, kern_ms = timed(mode, args.steps, args.warmup)
+    res = timed(mode, args.steps, args.warmup)
+    if res is None and mode != "none":      # the exchange failed: the line still reports the sharded compute, and says so
+        gather_note = ((gather_note + "; ") if gather_note else "") + f"{transport} {mode} failed ({timed.last_error}); timed without exchange"
+        gather, mode = False, "none"
+        try:
+            sf.close()
+        except Exception:  # noqa: BLE001
+            pass
+        plan(args.corrections == "fp8")
+        ramp()
+        res = timed("none", args.steps, args.warmup)
+    if res is None:
+        sys.exit(f"bench: the accumulate itself failed: {timed.last_error}")
+    elapsed, kern_ms = res
     kernel_name = ctx.field_variant()
     k_ms = float(np.mean(kern_ms))
     F_total = F * world if skull is None else F   # slab mode: the same F foci on every rank's slab
@@ -404,24 +444,30 @@ def main():
     if dist is not None and gather:  # reported beside the headline (never instead of it): other exchange, no exchange
         k2 = min(args.steps, 200)
         other = "aggregate" if mode == "allgather" else "allgather"
-        if skull is None and (transport == "rccl" or other == "allgather"):   # (the p2p transport is all-gather only)
+        def beside_leg(key, m):
             ramp()
-            e2, _ = timed(other, k2, 10)
-            beside[f"with_{other}"] = {"steps": k2, "ms_per_step": e2 / k2 * 1e3, "value": pairs_per_step * k2 / e2 / 1e6}
+            r = timed(m, k2, 10)
+            beside[key] = ({"steps": k2, "ms_per_step": r[0] / k2 * 1e3, "value": pairs_per_step * k2 / r[0] / 1e6} if r is not None
+                           else {"skipped": timed.last_error})
+            return r is not None
+        if skull is None and (transport == "rccl" or other == "allgather"):   # (the p2p transport is all-gather only)
+            beside_leg(f"with_{other}", other)
         if mode == "allgather" and skull is None:      # the same all-gather over the other transport
             other_t = "p2p" if transport == "rccl" else "rccl"
+            os.environ.setdefault("OLX_P2P_TIMEOUT_S", "20")
             sf.close()
             ok_t, note_t = init_transport(other_t)
             if ok_t:
                 plan(args.corrections == "fp8")
-                ramp()
-                e4, _ = timed("allgather", k2, 10)
-                beside[f"with_{other_t}_allgather"] = {"steps": k2, "ms_per_step": e4 / k2 * 1e3, "value": pairs_per_step * k2 / e4 / 1e6}
+                if not beside_leg(f"with_{other_t}_allgather", "allgather"):
+                    try:
+                        sf.close()          # a failed transport is not used again
+                    except Exception:  # noqa: BLE001
+                        pass
+                    plan(args.corrections == "fp8")
             else:
                 beside[f"with_{other_t}_allgather"] = {"skipped": note_t}
-        ramp()
-        e3, _ = timed("none", k2, 10)
-        beside["without_exchange"] = {"steps": k2, "ms_per_step": e3 / k2 * 1e3, "value": pairs_per_step * k2 / e3 / 1e6}
+        beside_leg("without_exchange", "none")
 
     if rank == 0:
         # roofline of the dominant kernel: algorithmic HBM bytes per launch = 8 B per voxel per focus (|p| + intensity
@@ -474,7 +520,7 @@ def main():
                 sf.plan_foci_sweep(arr, foci_m, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS, flags=out_flags,
                                    fp8_correction=fp8)
                 ramp()
-                e, km = timed("none", k2, 20)
+                e, km = timed("none", k2, 20)       # (single rank: a failure here is a bug and raises below)
                 name = ctx.field_variant()
                 nf = foci_m.shape[0]
                 bytes_l = 8.0 * V * nf + 32.0 * N * nf
@@ -482,7 +528,8 @@ def main():
                 return {"what": what, "kernel": name, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else "f32-acc/f16x3",
                         "foci": nf, "columns_computed": int(m.group(1)) if m else None,
                         "kernel_ms_avg": float(np.mean(km)), "kernel_launches_timed": int(len(km)), "ms_per_step": e / k2 * 1e3, "steps": k2,
-                        "value": float(V) * N * nf * k2 / e / 1e6, "roofline_frac": bytes_l / (float(np.mean(km)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "value": float(V) * N * nf * k2 / e / 1e6, "roofline_frac": bytes_l / (float(np.mean(km)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bytes_l, "traffic": static_traffic(name, args.grid)[0]}
 
             # the other correction mode on the same workload, same box
             other_fp8 = args.corrections != "fp8"
@@ -540,7 +587,9 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
     proto.calc_solution(target, arr, simulate=True, scale=True)   # warm (allocations, first touch ...
     ol.get_engine().ctx.field_fetch_all()                         # ... and the fetch workers' pinned staging buffers); nothing kept
     walls = []
+    sol = agg = an = None
     for _ in range(7):      # the call is ~10 launches of 0.1 - 0.5 ms each: the first ones after an idle gap run at the idle clock
+        sol = agg = an = None   # (drop the previous result first: a live, unread result is rescued to the host -- 1.6 GB -- before its buffers are reused)
         t0 = time.perf_counter()
         sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
         t1 = time.perf_counter()
