@@ -192,7 +192,8 @@ class Solution:
         ele_sizes_cm2 = self.transducer.element_areas("cm")
         d_eq_cm = np.sqrt(4 * sum(ele_sizes_cm2.tolist()) / np.pi)       # Transducer.get_area: the same left-to-right sum
         power_W = np.zeros(F); tic = np.zeros(F)
-        el_sens = np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.transducer.elements])
+        el_sens = (None if any(el.impulse_response is not None for el in self.transducer.elements) else
+                   np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.transducer.elements]))
         for i in range(F):
             p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :], _sens=el_sens)
             i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()

@@ -99,7 +99,8 @@ class Transducer:
         ``chain_e = signal * s_1 * ... * s_e`` (left-to-right products): its maximum is the larger of ``a_e * max(chain_e)``
         and ``a_e * min(chain_e)`` (rounding is monotonic), and of 0 when the rows are zero-padded."""
         n = self.numelements()
-        if n == 0 or self.impulse_response is not None or any(el.impulse_response is not None for el in self.elements):
+        # (_sens: the caller has looked at the elements already -- their sensitivities, and that none carries an impulse response)
+        if n == 0 or self.impulse_response is not None or (_sens is None and any(el.impulse_response is not None for el in self.elements)):
             return np.max(self.calc_output(input_signal, dt, delays=delays, apod=apod), axis=1)
         delays = np.zeros(n) if delays is None else np.asarray(delays)
         apod = np.ones(n) if apod is None else np.asarray(apod, dtype=float)

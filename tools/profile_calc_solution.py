@@ -25,4 +25,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5):
     proto.calc_solution(target, arr, simulate=True, scale=True)
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:9000])
