@@ -552,7 +552,7 @@ def main():
             plan(args.corrections == "fp8")
             ctx.field_launch(); ctx.sync()
             scans = {}
-            for kname in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid"):
+            for kname in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid", "fused_post"):
                 ctx.scan_time(kname, 5)                                       # warm
                 ms, nbytes = ctx.scan_time(kname, 30)
                 t_ms = float(np.mean(ms))

@@ -222,6 +222,7 @@ int olx_profile_end(olx_ctx *ctx, float *ms_each, int capacity, int *n_recorded)
 #define OLX_SCAN_MASKED_PEAK 3
 #define OLX_SCAN_OFFSET_GRID 4
 #define OLX_SCAN_WEIGHTED_SUM 5
+#define OLX_SCAN_FUSED_POST 6   /* scale + aggregate + six peaks + time-average volume in ONE pass (<= 8 foci): V (16 F + 12) bytes */
 int olx_scan_time(olx_ctx *ctx, int kernel, int iters, float *ms_each, double *bytes_per_launch);
 
 /* Name of the field kernel variant the current plan dispatches to (for profiles). */
@@ -307,6 +308,10 @@ int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci
  *                      may be NULL when all n_line are 0 (no beam widths; bounds = -1)
  *   n_le[a] / i_ge[a]  number of leading samples of line a whose offset is <= 0 / index of its first sample with offset >= 0
  *   beam_factor[2]     cut-off of level l = (float)(mainlobe |p| peak * beam_factor[l])  (10^(-3/20), 10^(-6/20))
+ *   scale_per_focus    NULL: the volumes as they are.  [F] factors: olx_field_scale_aggregate happens FIRST (Solution.scale +
+ *                      the aggregation, plan/protocol.py:374-387; olx_aggregate_fetch reads the aggregate afterwards) and the
+ *                      analysis sees the scaled volumes -- for <= 8 foci in ONE pass over the volumes together with the peak
+ *                      scan and the time-average volume (the values of the separate calls)
  * bounds[a][l][0] = index within line a of the LAST sample at an offset <= 0 below the cut-off, [1] = the FIRST at an offset
  * >= 0; -1 = none (NaN samples -- outside the grid -- never qualify). */
 typedef struct olx_analysis_opts {
@@ -324,7 +329,8 @@ typedef struct olx_focus_report {
     int32_t bounds[3][2][2];
 } olx_focus_report;
 int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weights, const double *line_pts,
-                         const olx_analysis_opts *opts, olx_focus_report *reports, float *ita_global);
+                         const olx_analysis_opts *opts, const double *scale_per_focus, olx_focus_report *reports,
+                         float *ita_global);
 
 /* ---- multi-GPU reassembly (RCCL over xGMI) -------------------------------------------
  * One context per rank.  id_bytes = the 128-byte ncclUniqueId made by rank 0

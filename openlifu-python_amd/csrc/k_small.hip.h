@@ -970,6 +970,127 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
 }
 
 // ------------------------------------------------------------------------------------
+// Protocol.calc_solution(scale=True) in ONE pass over the focus volumes: Solution.scale (p_f *= s_f, I_f *= s_f^2, in place), the
+// aggregation over foci (max |p|, mean intensity), the time-average intensity volume sum_f w_f I_f with its global peak above zmin,
+// and the six masked peaks per focus of Solution.analyze -- each the arithmetic of its own kernel (field_scale_aggregate_k,
+// field_weighted_sum_peak_k, field_analysis_peaks4_k: same products, same order over f, same mask decisions), but the 1.07 GB of
+// volumes cross HBM twice (read, write back) instead of five times.  Voxel-major: a lane owns a quad of z voxels of ALL (<= 8) foci.
+// ------------------------------------------------------------------------------------
+constexpr int SAA_MAXF = 8;
+__global__ __launch_bounds__(256) void field_scale_agg_analyze_k(float* __restrict__ pmag, float* __restrict__ inten, const float* __restrict__ scale,
+                                                                  const float* __restrict__ wts, const double* __restrict__ A, int n_foci,
+                                                                  const PeakParams P /*radius = r_main*/, double r_side, float inv_n,
+                                                                  float* __restrict__ pmax, float* __restrict__ imean, float* __restrict__ wint,
+                                                                  unsigned* __restrict__ peaks /*[F][6]*/, unsigned* __restrict__ wpeak) {
+    __shared__ double sA[SAA_MAXF][12];
+    __shared__ MaskFast sM[SAA_MAXF];
+    __shared__ float s_red[4][SAA_MAXF * 6 + 1];
+    for (int q = threadIdx.x; q < 12 * n_foci; q += blockDim.x) sA[q / 12][q % 12] = A[q];
+    __syncthreads();
+    if ((int)threadIdx.x < n_foci) mask_fast_prepare(sM[threadIdx.x], sA[threadIdx.x], P, P.radius, r_side, true);
+    __syncthreads();
+    const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = (int)(P.vox >> 2);
+    const float inv_nyzq = 1.0f / (float)nyzq, inv_nzq = 1.0f / (float)nzq;
+    const double rm2 = P.radius * P.radius, rm2lo = rm2 * (1.0 - 1e-12), rm2hi = rm2 * (1.0 + 1e-12);
+    const double rs2 = r_side * r_side, rs2lo = rs2 * (1.0 - 1e-12), rs2hi = rs2 * (1.0 + 1e-12);
+    const int iz_first = sM[0].iz_first;                 // (zmin and the grid are the same for every focus)
+    const float ox = sM[0].ox, oy = sM[0].oy, oz = sM[0].oz, hx = sM[0].hx, hy = sM[0].hy, hz = sM[0].hz;
+    float pk[SAA_MAXF][6];
+#pragma unroll
+    for (int f = 0; f < SAA_MAXF; ++f)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pk[f][k] = 0.f;
+    float wmax = 0.f;
+    const int stride = gridDim.x * blockDim.x;
+    for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
+        int ix, iy, iz0;
+        quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
+        const float fx = fmaf((float)ix, hx, ox), fy = fmaf((float)iy, hy, oy);
+        float fz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fz[e] = fmaf((float)(iz0 + e), hz, oz);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m, ws = m;
+#pragma unroll
+        for (int f = 0; f < SAA_MAXF; ++f) {
+            if (f >= n_foci) break;                      // uniform
+            const float s = scale[f], s2 = s * s, w = wts[f];
+            float4* pp = reinterpret_cast<float4*>(pmag + (long long)f * P.vox) + iq;
+            float4* ip = reinterpret_cast<float4*>(inten + (long long)f * P.vox) + iq;
+            float4 p4 = *pp, w4 = *ip;
+            p4.x *= s; p4.y *= s; p4.z *= s; p4.w *= s;
+            w4.x *= s2; w4.y *= s2; w4.z *= s2; w4.w *= s2;
+            *pp = p4; *ip = w4;
+            m.x = fmaxf(m.x, p4.x); m.y = fmaxf(m.y, p4.y); m.z = fmaxf(m.z, p4.z); m.w = fmaxf(m.w, p4.w);
+            sm.x += w4.x; sm.y += w4.y; sm.z += w4.z; sm.w += w4.w;
+            ws.x += w * w4.x; ws.y += w * w4.y; ws.z += w * w4.z; ws.w += w * w4.w;
+            // the six masked peaks of this focus on the SCALED values (field_analysis_peaks4_k's decisions)
+            const MaskFast& M = sM[f];
+            const float b0 = fmaf(M.a[1], fy, fmaf(M.a[0], fx, M.a[3])), b1 = fmaf(M.a[5], fy, fmaf(M.a[4], fx, M.a[7])), b2 = fmaf(M.a[9], fy, fmaf(M.a[8], fx, M.a[11]));
+            int in_main[4], in_side[4], undecided = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g0 = fmaf(M.a[2], fz[e], b0), g1 = fmaf(M.a[6], fz[e], b1), g2 = fmaf(M.a[10], fz[e], b2);
+                const float d2f = fmaf(g2, g2, fmaf(g1, g1, g0 * g0));
+                in_main[e] = mask_fast_side(d2f, M.rin2[0], M.rout2[0]);
+                in_side[e] = mask_fast_side(d2f, M.rin2[1], M.rout2[1]);
+                undecided |= (in_main[e] == 0 || in_side[e] == 0) ? (1 << e) : 0;
+            }
+            if (undecided) {
+                const double x = P.ox + ix * P.hx, y = P.oy + iy * P.hy;
+                const double* a = sA[f];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!((undecided >> e) & 1)) continue;
+                    const double z = P.oz + (iz0 + e) * P.hz;
+                    const double q0 = (a[0] * x + a[1] * y + a[2] * z + a[3]) * P.ia0;
+                    const double q1 = (a[4] * x + a[5] * y + a[6] * z + a[7]) * P.ia1;
+                    const double q2 = (a[8] * x + a[9] * y + a[10] * z + a[11]) * P.ia2;
+                    const double d2 = q0 * q0 + q1 * q1 + q2 * q2;
+                    in_main[e] = mask_cmp<0>(d2, P.radius, rm2lo, rm2hi) ? 1 : -1;
+                    in_side[e] = mask_cmp<2>(d2, r_side, rs2lo, rs2hi) ? -1 : 1;
+                }
+            }
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool zok = (iz0 + e) >= iz_first;
+                if (in_main[e] > 0) { pk[f][0] = fmaxf(pk[f][0], pv[e]); pk[f][1] = fmaxf(pk[f][1], wv[e]); }
+                if (zok && in_side[e] < 0) { pk[f][2] = fmaxf(pk[f][2], pv[e]); pk[f][3] = fmaxf(pk[f][3], wv[e]); }
+                if (zok) { pk[f][4] = fmaxf(pk[f][4], pv[e]); pk[f][5] = fmaxf(pk[f][5], wv[e]); }
+            }
+        }
+        reinterpret_cast<float4*>(pmax)[iq] = m;
+        reinterpret_cast<float4*>(imean)[iq] = make_float4(sm.x * inv_n, sm.y * inv_n, sm.z * inv_n, sm.w * inv_n);
+        reinterpret_cast<float4*>(wint)[iq] = ws;
+        const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if ((iz0 + e) >= iz_first) wmax = fmaxf(wmax, wsv[e]);
+    }
+    // block reduction: 6 F + 1 maxima
+#pragma unroll
+    for (int f = 0; f < SAA_MAXF; ++f)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float v = pk[f][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+            if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][f * 6 + k] = v;
+        }
+    {
+        float v = wmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][SAA_MAXF * 6] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 6 * n_foci) {
+        const int k = threadIdx.x;
+        atomicMax(peaks + k, __float_as_uint(fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]))));
+    }
+    if (threadIdx.x == 255) atomicMax(wpeak, __float_as_uint(fmaxf(fmaxf(s_red[0][SAA_MAXF * 6], s_red[1][SAA_MAXF * 6]), fmaxf(s_red[2][SAA_MAXF * 6], s_red[3][SAA_MAXF * 6]))));
+}
+
+// ------------------------------------------------------------------------------------
 // Pieces of the one-call analysis (olx_solution_analyze): everything Solution.analyze reads off the resident volumes is
 // enqueued back to back on the context's stream, the intermediate numbers (mainlobe peaks -> -3 dB centroid cut-offs and beam
 // width cut-offs) never leave the device, and ONE copy brings the per-focus reports to the host.

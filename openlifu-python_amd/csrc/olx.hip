@@ -1595,7 +1595,8 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
     if (!c) return OLX_EINVAL;
     if (iters < 1 || !ms_each || !bytes_per_launch) return fail(c, OLX_EINVAL, "olx_scan_time: iters < 1 or null output");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_scan_time: nothing planned");
-    if (kernel < 0 || kernel > OLX_SCAN_WEIGHTED_SUM) return fail(c, OLX_EINVAL, "olx_scan_time: unknown kernel %d", kernel);
+    if (kernel < 0 || kernel > OLX_SCAN_FUSED_POST) return fail(c, OLX_EINVAL, "olx_scan_time: unknown kernel %d", kernel);
+    if (kernel == OLX_SCAN_FUSED_POST && (c->plan_foci > SAA_MAXF || (c->fp.nz & 3) || c->fp.vox >= (1ll << 33))) return fail(c, OLX_ESTATE, "olx_scan_time: the fused pass needs <= 8 foci and nz %% 4 == 0");
     if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_scan_time: intensity not planned");
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->plan_foci;
@@ -1631,13 +1632,17 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
         HIPCHK(c, hipMemcpy(d_w, hw.data(), sizeof(float) * F, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemset(d_pk, 0, sizeof(unsigned) * 6 * F));
     }
-    if (kernel == OLX_SCAN_WEIGHTED_SUM && (!c->d_wint || c->wint_cap < (size_t)c->fp.vox)) {
+    if ((kernel == OLX_SCAN_WEIGHTED_SUM || kernel == OLX_SCAN_FUSED_POST) && (!c->d_wint || c->wint_cap < (size_t)c->fp.vox)) {
         if (c->d_wint) hipFree(c->d_wint);
         c->d_wint = nullptr; c->wint_cap = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_wint, sizeof(float) * c->fp.vox));
         c->wint_cap = (size_t)c->fp.vox;
     }
-    if (kernel == OLX_SCAN_SCALE) {
+    if (kernel == OLX_SCAN_FUSED_POST) {
+        if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+        if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+    }
+    if (kernel == OLX_SCAN_SCALE || kernel == OLX_SCAN_FUSED_POST) {
         if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
         if (F > 4096) return fail(c, OLX_EINVAL, "olx_scan_time: too many foci");
         std::vector<float> one(F, 1.0f);        // x 1.0f is exact: the resident result is unchanged
@@ -1668,6 +1673,11 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
             hipLaunchKernelGGL(offset_grid_k, dim3((unsigned)std::min<long long>(want, 4096)), dim3(256), 0, c->stream, d_ax, d_ax + c->fp.nx, d_ax + c->fp.nx + c->fp.ny,
                                c->fp.nx, c->fp.ny, c->fp.nz, d_A, 1.0, 1.0, 0.2, d_og, d_og + 3 * (size_t)c->fp.vox);
             *bytes_per_launch = vox * 32.0; break;
+        case OLX_SCAN_FUSED_POST:          // scale (by 1.0) + aggregate + six peaks + time-average volume in one pass
+            P.op = 0;
+            hipLaunchKernelGGL(field_scale_agg_analyze_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, c->d_scale, d_w, d_A, F, P, 5e-3,
+                               1.0f / (float)F, c->d_agg_p, c->d_agg_i, c->d_wint, d_pk, d_pk + 6 * (size_t)F - 1);
+            *bytes_per_launch = vox * (16.0 * F + 12.0); break;
         default:
             hipLaunchKernelGGL(field_weighted_sum_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, d_w, F, c->fp.vox, c->d_wint);
             *bytes_per_launch = vox * (4.0 * F + 4.0); break;
@@ -2030,7 +2040,7 @@ int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) 
 // steps (mainlobe peak -> -3 dB centroid cut-off, beam-width cut-offs) stay on the device; one pinned block goes in, one
 // comes out, one synchronisation.  Scratch is owned by the context and reused.
 int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
-                         const olx_analysis_opts* o, olx_focus_report* reports, float* ita_global) {
+                         const olx_analysis_opts* o, const double* scale_per_focus, olx_focus_report* reports, float* ita_global) {
     if (!c) return OLX_EINVAL;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_solution_analyze: nothing planned");
     if (!A || !ita_weights || !o || !reports || !ita_global) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
@@ -2053,7 +2063,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     // work (device only): [cut F f32][samples npts F f32]
     auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
     const size_t in_A = 0, in_pts = in_A + sizeof(double) * 12 * F, in_w = in_pts + sizeof(double) * 3 * (size_t)npts * F;
-    const size_t in_box = in_w + sizeof(float) * F, in_bytes = up8(in_box + sizeof(int) * 6 * F);
+    const size_t in_box = in_w + sizeof(float) * F, in_sc = in_box + sizeof(int) * 6 * F, in_bytes = up8(in_sc + sizeof(float) * F);
     const size_t out_pk = in_bytes, out_ita = out_pk + sizeof(unsigned) * 6 * F, out_bd = out_ita + sizeof(unsigned) * (F + 1);
     const size_t out_mom = up8(out_bd + sizeof(int) * 12 * F), out_end = out_mom + sizeof(double) * 4 * F;
     const size_t wk_cut = out_end, wk_smp = up8(wk_cut + sizeof(float) * F), dev_bytes = wk_smp + sizeof(float) * (size_t)npts * F + 8;
@@ -2072,6 +2082,16 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     focus_boxes(c, A, o->aspect, o->r_main_m, F, reinterpret_cast<int*>(h + in_box));     // the mainlobe ellipsoids' index boxes
     const int* d_box = reinterpret_cast<const int*>(d + in_box);
     const bool quad = (c->fp.nz & 3) == 0 && c->fp.vox < (1ll << 33);
+    // scale_per_focus given: Solution.scale and the aggregation over foci happen first -- fused with the peak scan and the
+    // time-average volume into ONE pass over the volumes when the shape allows (<= 8 foci, z rows of whole quads, no complex output),
+    // otherwise as the separate olx_field_scale_aggregate pass
+    const bool fused = scale_per_focus && quad && F <= SAA_MAXF && !(c->flags & OLX_OUT_COMPLEX);
+    if (scale_per_focus && !fused) { int rc = olx_field_scale_aggregate(c, scale_per_focus, F); if (rc) return rc; }
+    if (fused) {
+        if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
+        if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
+        for (int f = 0; f < F; ++f) reinterpret_cast<float*>(h + in_sc)[f] = (float)scale_per_focus[f];
+    }
     HIPCHK(c, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d + out_pk, 0, out_end - out_pk, c->stream));
     const double* d_A = reinterpret_cast<const double*>(d + in_A);
@@ -2084,7 +2104,10 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     // (1) the six masked peaks of |p| and intensity, one pass
     P.radius = o->r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = o->zmin_m;
     const long long want = (P.vox + 255) / 256;
-    if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
+    if (fused)      // scale + aggregate + peaks + time-average volume (with its global peak) in one pass
+        hipLaunchKernelGGL(field_scale_agg_analyze_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, reinterpret_cast<const float*>(d + in_sc),
+                           reinterpret_cast<const float*>(d + in_w), d_A, F, P, o->r_side_m, 1.0f / (float)F, c->d_agg_p, c->d_agg_i, c->d_wint, d_pk, d_ita + F);
+    else if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     else hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     // (2) -3 dB centroid of the mainlobe: cut-off from the peak just found
     hipLaunchKernelGGL(analysis_cutoffs_k, dim3((F + 63) / 64), dim3(64), 0, c->stream, d_pk, F, o->centroid_factor, d_cut);
@@ -2092,7 +2115,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     hipLaunchKernelGGL(field_masked_moments_box_k, dim3(32, F), dim3(256), 0, c->stream, pm, d_A, d_cut, P, d_box, reinterpret_cast<double*>(d + out_mom));
     // (3) time-average intensity volume, its mainlobe peaks (F masks over the ONE volume) and its global peak above zmin
     P.zmin = o->zmin_m;        // (the global peak above zmin comes out of the same pass that writes the volume)
-    hipLaunchKernelGGL(field_weighted_sum_peak_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, reinterpret_cast<const float*>(d + in_w), F, P, c->d_wint, d_ita + F);
+    if (!fused) hipLaunchKernelGGL(field_weighted_sum_peak_k, dim3(2048), dim3(256), 0, c->stream, c->d_inten, reinterpret_cast<const float*>(d + in_w), F, P, c->d_wint, d_ita + F);
     P.vol_stride = 0; P.zmin = 0;
     hipLaunchKernelGGL(field_masked_peak_box_k, dim3(32, F), dim3(256), 0, c->stream, c->d_wint, d_A, P, d_box, d_ita);
     // (4) beam widths: |p| along the three focal axes of every focus, then the cut-off crossings

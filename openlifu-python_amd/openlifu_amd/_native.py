@@ -127,7 +127,7 @@ def load(require_gpu: bool = True):
         lib.olx_comm_import.argtypes = [vp, vp]
         lib.olx_comm_transport.argtypes = [vp]; lib.olx_comm_transport.restype = c_char_p
         lib.olx_scan_time.argtypes = [vp, c_int, c_int, fp, dp]
-        lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), POINTER(OlxFocusReport), fp]
+        lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), dp, POINTER(OlxFocusReport), fp]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -366,7 +366,7 @@ class Context:
         self._chk(self._lib.olx_field_time(self._h, int(iters), _fptr(ms)))
         return ms
 
-    SCANS = {"aggregate": 0, "scale": 1, "analysis_peaks": 2, "masked_peak": 3, "offset_grid": 4, "weighted_sum": 5}
+    SCANS = {"aggregate": 0, "scale": 1, "analysis_peaks": 2, "masked_peak": 3, "offset_grid": 4, "weighted_sum": 5, "fused_post": 6}
 
     def scan_time(self, kernel: str, iters: int = 20):
         """(ms per launch [iters], algorithmic bytes per launch) of one streaming scan over the resident result."""
@@ -446,12 +446,17 @@ class Context:
         return out
 
     def solution_analyze(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
-                         beam_db=(3, 6)):
+                         beam_db=(3, 6), scale=None):
         """Everything ``Solution.analyze`` reads off the resident volumes in one crossing (``olx_solution_analyze``).
         ``line_offsets`` = the three offset vectors [m] of the focal-axis lines, ``line_pts`` [F, n0 + n1 + n2, 3] their
         positions.  Returns a dict of arrays: peaks [F, 6], ita_main [F], moments [F, 4], bounds [F, 3, 2, 2] (indices into
-        the axis lines, -1 = none) and the scalar ita_global."""
+        the axis lines, -1 = none) and the scalar ita_global.  ``scale`` [F]: ``field_scale_aggregate`` happens first (one pass with the
+        peak scan for <= 8 foci); the aggregate is then resident (``aggregate_fetch``)."""
         F = self._plan_foci
+        sc = None
+        if scale is not None:
+            self._aggregate_overwrite()
+            sc = _f64(scale, (F,))
         A = _f64(A, (F, 12))
         w = _f64(ita_weights, (F,))
         o = OlxAnalysisOpts()
@@ -471,7 +476,7 @@ class Context:
             pts = _f64(line_pts, (F, sum(len(v) for v in line_offsets), 3))
         rep = (OlxFocusReport * F)()
         glob = c_float(0)
-        self._chk(self._lib.olx_solution_analyze(self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), rep, ctypes.byref(glob)))
+        self._chk(self._lib.olx_solution_analyze(self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc), rep, ctypes.byref(glob)))
         raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
                                                  ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
         return {"peaks": raw["peaks"].copy(), "ita_main": raw["ita_main"].copy(), "moments": raw["moments"].copy(),

@@ -156,6 +156,11 @@ class Engine:
         self._live_aggregate = AggregateResult(self, self.ctx._shape)
         return self._live_aggregate
 
+    def adopt_aggregate(self) -> AggregateResult:
+        """Handle on the aggregate a fused device call (``ctx.solution_analyze(..., scale=...)``) just left in the aggregate buffers."""
+        self._live_aggregate = AggregateResult(self, self.ctx._shape)
+        return self._live_aggregate
+
     # ---- element table ----------------------------------------------------------------------
     def bind(self, arr):
         """Upload ``arr``'s SoA element table unless the resident one is identical."""

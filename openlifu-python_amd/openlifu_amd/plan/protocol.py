@@ -214,7 +214,7 @@ class Protocol:
                 self.logger.error(msg=f"Cannot scale solution {solution.id} if simulation is not enabled!")
                 raise ValueError(f"Cannot scale solution {solution.id} if simulation is not enabled!")
             self.logger.info(f"Scaling solution {solution.id}...")
-            fused_agg = solution.scale(self.focal_pattern, analysis_options=analysis_options, _with_aggregate=simulate)
+            fused_agg = solution.scale(self.focal_pattern, analysis_options=analysis_options, _defer_device=simulate)
 
         if not simulate:
             return solution, None, None
@@ -222,11 +222,16 @@ class Protocol:
         eng, _, _, _ = solution._bind_device()
         # ... and left there: the three aggregate volumes reach the host when -- and if -- the caller reads them (each a
         # fresh, caller-owned array), like the per-focus volumes
-        agg = fused_agg if fused_agg is not None else eng.aggregate_lazy(want_intensity=True)   # (scaled and aggregated in one pass above)
+        analysis = None
+        if isinstance(fused_agg, np.ndarray):
+            # deferred scale: ONE crossing scales the volumes, aggregates them and runs the whole analysis (olx_solution_analyze)
+            analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints, _host_unchanged=True, _scale=fused_agg)
+            agg = eng.adopt_aggregate()
+        else:
+            agg = fused_agg if fused_agg is not None else eng.aggregate_lazy(want_intensity=True)
         coords = params.coords
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         shape = agg.shape
-
         if ds.HAVE_XARRAY:
             # real xarray objects cannot defer (xa.Dataset would turn a LazyDataArray into an unnamed-dims ndarray and raise
             # MissingDimensionsError): fetch now, like the per-focus volumes above
@@ -236,5 +241,6 @@ class Protocol:
                 return agg.lazy_array(key, lambda fetch: ds.LazyDataArray(shape, np.float32, fetch, coords=coords, dims=dims, name=name,
                                                                           attrs=_ATTRS[name]))
             aggregated = ds.make_dataset({"p_min": lazy("p_min", "pmag"), "p_max": lazy("p_max", "pmag"), "intensity": lazy("intensity", "intensity")})
-        analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints, _host_unchanged=True)
+        if analysis is None:
+            analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints, _host_unchanged=True)
         return solution, aggregated, analysis

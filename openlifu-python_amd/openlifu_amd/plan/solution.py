@@ -146,7 +146,7 @@ class Solution:
         return an
 
     def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None,
-                _host_unchanged: bool = False) -> SolutionAnalysis:
+                _host_unchanged: bool = False, _scale=None) -> SolutionAnalysis:
         """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
         options = SolutionAnalysisOptions() if options is None else options
         an = SolutionAnalysis()
@@ -178,8 +178,9 @@ class Solution:
         # ONE crossing of the C-ABI (olx_solution_analyze): mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin)
         # peaks of |p| and intensity, -3 dB centroid moments (find_centroid), time-average intensity volume (get_ita) with its
         # mainlobe / global peaks, and the -3 / -6 dB crossings along the three focal axes of every focus
+        # (_scale: the per-focus factors of a deferred Solution.scale -- the device scales and aggregates in the same crossing, see scale())
         rep = ctx.solution_analyze(A, ita_w, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin,
-                                   line_pts=pts, line_offsets=offsets)
+                                   line_pts=pts, line_offsets=offsets, scale=_scale)
         pk, mom, ita_main = rep["peaks"], rep["moments"], rep["ita_main"]
         main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
         # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
@@ -240,7 +241,7 @@ class Solution:
         return scaling / np.max(scaling), v0, v1
 
     def scale(self, focal_pattern: FocalPattern, analysis_options: SolutionAnalysisOptions | None = None,
-              _with_aggregate: bool = False):
+              _with_aggregate: bool = False, _defer_device: bool = False):
         """Scale in place to the target pressure (plan/solution.py:313-338): host arrays are mutated
         (the API contract) and the resident device copy is scaled by ``field_scale_k``."""
         # only the per-focus mainlobe peak of |p| enters the factors (compute_scaling_factors reads nothing else of the
@@ -261,7 +262,11 @@ class Solution:
             self.apodizations[i] = self.apodizations[i] * apod_factors[i]
         fused = None
         if on_device:
-            if _with_aggregate and "intensity" in res:      # calc_solution aggregates right after: one pass for both
+            if _defer_device and "intensity" in res:
+                # calc_solution analyzes right after: the device volumes are scaled by THAT call (analyze(_scale=...): scaling, aggregation,
+                # peak scan and time-average volume in one pass over HBM); everything on the host is already the scaled solution
+                fused = np.asarray(factors, dtype=np.float64)
+            elif _with_aggregate and "intensity" in res:    # aggregate right after: one pass for both
                 fused = self._resident[0].scale_aggregate_lazy(factors)
             else:
                 self._resident[0].ctx.field_scale(factors)

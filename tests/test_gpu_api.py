@@ -509,3 +509,37 @@ def test_reference_example_files_through_calc_solution_against_g1(golden):
     assert np.array_equal(agg["p_min"].data, got)                      # one focus: the aggregate is that volume
     # loose physical sanity against the k-Wave-derived example_solution_analysis.json (+-12 % on the -3 dB widths)
     assert abs(an.beamwidth_lat_3dB_mm[0] - 4.57) / 4.57 < 0.12 and abs(an.beamwidth_ax_3dB_mm[0] - 36.0) / 36.0 < 0.12
+
+
+def test_fused_scale_aggregate_analyze_equals_the_separate_steps():
+    """calc_solution(scale=True) scales the volumes, aggregates them and runs the whole analysis in ONE crossing and ONE pass over the
+    volumes (olx_solution_analyze with scale factors).  Same numbers as the separate public steps -- Solution.scale (device scaling),
+    the aggregation, Solution.analyze -- bit for bit: volumes, aggregate, every analysis entry."""
+    from dataclasses import asdict
+    arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=0.5, x_extent=(-16, 15.5), y_extent=(-16, 15.5), z_extent=(5, 44.5))      # 64 x 64 x 80
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup, sequence=ol.Sequence(pulse_count=10, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=4, spoke_radius=3.0, target_pressure=0.8, units="MPa"))
+    target = ol.Point(position=(0.5, -0.25, 30), units="mm")
+    sol_f, agg_f, an_f = proto.calc_solution(target, arr, simulate=True, scale=True)
+    fused = {k: np.array(sol_f.simulation_result[k].data) for k in ("p_min", "p_max", "intensity")}
+    fused_agg = {k: np.array(agg_f[k].data) for k in ("p_min", "p_max", "intensity")}
+    sol_s, _, _ = proto.calc_solution(target, arr, simulate=True, scale=False)
+    sol_s.scale(proto.focal_pattern, analysis_options=proto.analysis_options)          # public step 1: device scaling
+    eng = ol.get_engine()
+    pm, it = eng.ctx.field_aggregate(want_intensity=True)                               # step 2: aggregation
+    an_s = sol_s.analyze(options=proto.analysis_options)                                # step 3: analysis
+    for k in ("p_min", "p_max", "intensity"):
+        assert np.array_equal(np.asarray(sol_s.simulation_result[k].data), fused[k]), k
+    assert np.array_equal(pm, fused_agg["p_min"]) and np.array_equal(pm, fused_agg["p_max"]) and np.array_equal(it, fused_agg["intensity"])
+    assert sol_s.voltage == sol_f.voltage and np.array_equal(sol_s.apodizations, sol_f.apodizations)
+    a, b = asdict(an_f), asdict(an_s)
+    for key in a:
+        if key == "param_constraints":
+            continue
+        va, vb = np.asarray(a[key], dtype=float), np.asarray(b[key], dtype=float)
+        if key.startswith("focal_centroid"):        # (fp64 atomics: the order of the block sums is not fixed)
+            assert np.allclose(va, vb, rtol=1e-9, atol=1e-9), key
+        else:
+            assert np.array_equal(va, vb, equal_nan=True), (key, va, vb)
+    assert np.allclose(an_f.mainlobe_pnp_MPa, 0.8, rtol=1e-4)

@@ -19,7 +19,7 @@ ctx = eng.ctx
 for _ in range(50):
     ctx.field_launch()
 ctx.sync()
-for k in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid"):
+for k in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid", "fused_post"):
     ctx.scan_time(k, 10)
     ms, nb = ctx.scan_time(k, 50)
     t = float(np.mean(ms))
