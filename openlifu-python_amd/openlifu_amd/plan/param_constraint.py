@@ -8,8 +8,6 @@ from dataclasses import dataclass
 
 from ..util.dict_conversion import DictMixin
 
-PARAM_STATUS_SYMBOLS = {"ok": "✅", "warning": "❗", "error": "❌"}
-
 _SCALAR = {"<": _op.lt, "<=": _op.le, ">": _op.gt, ">=": _op.ge}
 _RANGE = {
     "within": lambda v, lo, hi: lo < v < hi,
@@ -52,18 +50,6 @@ class ParameterConstraint(DictMixin):
 
     def get_status(self, value) -> str:
         return "error" if self.is_error(value) else "warning" if self.is_warning(value) else "ok"
-
-    def get_status_symbol(self, value) -> str:
-        return PARAM_STATUS_SYMBOLS[self.get_status(value)]
-
-    def to_table(self):
-        """Two-row description of the limits as a pandas DataFrame (plan/param_constraint.py:84-96)."""
-        import pandas as pd
-        if self.operator not in _SCALAR and self.operator not in _RANGE:
-            raise ValueError(f"Unsupported operator: {self.operator}")
-        rows = [{"Name": name, "Value": f"value {self.operator} {v}", "Unit": ""}
-                for name, v in (("Warn if not", self.warning_value), ("Error if not", self.error_value)) if v is not None]
-        return pd.DataFrame.from_records(rows)
 
     @classmethod
     def from_dict(cls, parameter_dict):

@@ -20,7 +20,7 @@ import numpy as np
 
 from ..util.dict_conversion import DictMixin
 from ..util.units import getunittype
-from .param_constraint import PARAM_STATUS_SYMBOLS, ParameterConstraint
+from .param_constraint import ParameterConstraint
 
 DEFAULT_ORIGIN = np.zeros(3)
 
@@ -129,42 +129,6 @@ class SolutionAnalysis(DictMixin):
     sequence_duration_s: float | None = None
     param_constraints: Dict = field(default_factory=dict)
 
-    def to_table(self, constraints=None, focus_index=None):
-        """One row per reported quantity (pandas DataFrame): aggregate over foci (or focus ``focus_index``)
-        formatted for display, plus the pass / warn / fail status of every constrained quantity
-        (plan/solution_analysis.py:146-192)."""
-        import pandas as pd
-        constraints = self.param_constraints if constraints is None else constraints
-        for name in constraints:
-            if name not in REPORT_ROWS:
-                raise ValueError(f"Unknown parameter constraint for '{name}'. Must be one of: {list(REPORT_ROWS)}")
-        rows = []
-        for name, (how, fmt, units, title) in REPORT_ROWS.items():
-            per_focus = getattr(self, name) if how is not None else None
-            if how is None:
-                agg = getattr(self, name)
-            elif how == "max":
-                agg = max(per_focus)
-            else:
-                agg = np.mean(per_focus)
-            if agg is None:
-                continue
-            row = {"id": name, "Param": title, "Value": "", "Units": units, "Status": "", "_value": agg,
-                   "_value_by_focus": per_focus, "_warning": False, "_error": False}
-            if np.isnan(agg):
-                row["Value"] = "NaN"
-            else:
-                if focus_index is None:
-                    row["Value"] = format(agg, fmt)
-                else:
-                    row["Value"] = "N/A" if per_focus is None else format(per_focus[focus_index], fmt)
-                if name in constraints:
-                    c = constraints[name]
-                    row["_warning"], row["_error"] = c.is_warning(agg), c.is_error(agg)
-                    row["Status"] = PARAM_STATUS_SYMBOLS[c.get_status(agg)]
-            rows.append(row)
-        return pd.DataFrame.from_records(rows)
-
     @classmethod
     def from_dict(cls, parameter_dict):
         d = dict(parameter_dict)
@@ -179,34 +143,6 @@ class SolutionAnalysis(DictMixin):
     def to_json(self, compact: bool = False) -> str:
         d = self.to_dict()
         return json.dumps(d, separators=(",", ":")) if compact else json.dumps(d, indent=4)
-
-
-# quantity -> (aggregate over foci, display format, units, title); plan/solution_analysis.py:18-48
-REPORT_ROWS = {
-    **{f"mainlobe_{k}": v for k, v in {"pnp_MPa": ("max", "0.3f", "MPa", "Mainlobe Peak Negative Pressure"),
-                                       "isppa_Wcm2": ("max", "0.1f", "W/cm^2", "Mainlobe I_SPPA"),
-                                       "ispta_mWcm2": ("mean", "0.1f", "mW/cm^2", "Mainlobe I_SPTA")}.items()},
-    **{f"{what}_{ax}_mm": ("mean", "0.1f", "mm", f"{title} ({axn})")
-       for what, title in (("target_position", "Target Position"), ("focal_centroid", "Focal Centroid"))
-       for ax, axn in (("lat", "Lateral"), ("ele", "Elevation"), ("ax", "Axial"))},
-    **{f"beamwidth_{ax}_{db}dB_mm": ("mean", "0.2f", "mm", f"{db}dB Beamwidth ({axn})")
-       for db in (3, 6) for ax, axn in (("lat", "Lateral"), ("ele", "Elevational"), ("ax", "Axial"))},
-    "sidelobe_pnp_MPa": ("max", "0.3f", "MPa", "Sidelobe Peak Negative Pressure"),
-    "sidelobe_isppa_Wcm2": ("max", "0.1f", "W/cm^2", "Sidelobe I_SPPA"),
-    "sidelobe_to_mainlobe_pressure_ratio": ("mean", "0.2f", "", "Sidelobe/Mainlobe Pressure Ratio"),
-    "sidelobe_to_mainlobe_intensity_ratio": ("mean", "0.2f", "", "Sidelobe/Mainlobe Intensity Ratio"),
-    "global_pnp_MPa": ("max", "0.3f", "MPa", "Global Peak Negative Pressure"),
-    "global_isppa_Wcm2": ("max", "0.1f", "W/cm^2", "Global I_SPPA"),
-    "global_ispta_mWcm2": (None, "0.1f", "mW/cm^2", "Global I_SPTA"),
-    "MI": (None, "0.2f", "", "MI"),
-    "TIC": (None, "0.2f", "", "TIC"),
-    "voltage_V": (None, "0.1f", "V", "Voltage"),
-    "p0_MPa": ("max", "0.3f", "MPa", "Emitted Pressure"),
-    "power_W": (None, "0.2f", "W", "Emitted Power"),
-    "duty_cycle_pulse_train_pct": (None, "0.1f", "%", "Pulse Train Duty Cycle"),
-    "duty_cycle_sequence_pct": (None, "0.1f", "%", "Sequence Duty Cycle"),
-    "sequence_duration_s": (None, "0.0f", "s", "Sequence Duration"),
-}
 
 
 def beam_bounds_from_samples(offsets: np.ndarray, values: np.ndarray, cutoff: float):
