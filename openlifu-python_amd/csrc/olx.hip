@@ -1200,7 +1200,7 @@ int olx_profile_end(olx_ctx* c, float* ms_each, int capacity, int* n_recorded) {
 //             streams its part through its own two pinned chunks on its own stream -- DMA of chunk i+1 overlaps the
 //             copy-out of chunk i -- so the first touch of the destination pages and the copy-out run on several cores
 struct FetchLane {                 // one per worker thread: its own stream and two pinned chunks
-    static constexpr size_t CHUNK = (size_t)8 << 20;
+    static constexpr size_t CAPACITY = (size_t)8 << 20;   // bytes per pinned buffer; a transfer uses pieces of <= this
     hipStream_t stream = nullptr;
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1219,7 +1219,7 @@ struct FetchLane {                 // one per worker thread: its own stream and 
         release();
         bool good = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; good && i < 2; ++i)
-            good = hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) == hipSuccess &&
+            good = hipHostMalloc(&buf[i], CAPACITY, hipHostMallocDefault) == hipSuccess &&
                    hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
         if (!good) { (void)hipGetLastError(); release(); return false; }
         return ok = true;
@@ -1241,12 +1241,12 @@ static void free_fetch_lanes(olx_ctx* c) {
 
 // Worker t moves bytes [lo, hi) of the transfer: DMA of chunk i+1 into its second pinned buffer is in flight while it
 // copies chunk i into the destination (first touch of those destination pages happens on this thread).
-static hipError_t fetch_lane_run(int device, FetchLane& L, char* dst, const char* src, size_t lo, size_t hi) {
+static hipError_t fetch_lane_run(int device, FetchLane& L, char* dst, const char* src, size_t lo, size_t hi, size_t chunk) {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return e;
-    const size_t n = (hi - lo + FetchLane::CHUNK - 1) / FetchLane::CHUNK;
+    const size_t n = (hi - lo + chunk - 1) / chunk;
     auto issue = [&](size_t i) {
-        const size_t off = lo + i * FetchLane::CHUNK, cnt = std::min(FetchLane::CHUNK, hi - off);
+        const size_t off = lo + i * chunk, cnt = std::min(chunk, hi - off);
         hipError_t r = hipMemcpyAsync(L.buf[i & 1], src + off, cnt, hipMemcpyDeviceToHost, L.stream);
         return r != hipSuccess ? r : hipEventRecord(L.ev[i & 1], L.stream);
     };
@@ -1255,7 +1255,7 @@ static hipError_t fetch_lane_run(int device, FetchLane& L, char* dst, const char
         if (i + 1 < n) { e = issue(i + 1); if (e != hipSuccess) return e; }
         e = hipEventSynchronize(L.ev[i & 1]);
         if (e != hipSuccess) return e;
-        const size_t off = lo + i * FetchLane::CHUNK, cnt = std::min(FetchLane::CHUNK, hi - off);
+        const size_t off = lo + i * chunk, cnt = std::min(chunk, hi - off);
         memcpy(dst + off, L.buf[i & 1], cnt);
     }
     return hipSuccess;
@@ -1274,11 +1274,17 @@ static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
         }
         (void)hipGetLastError();   // fall through to the pageable copy
     }
-    if (mode == 2 && bytes >= 4 * FetchLane::CHUNK) {
+    if (mode == 2 && bytes >= ((size_t)8 << 20)) {
         int nthr = 8;
         if (const char* t = getenv("OLX_FETCH_THREADS")) nthr = atoi(t);
         const int hw = (int)std::thread::hardware_concurrency();
-        nthr = std::max(1, std::min({nthr, FETCH_MAX_THREADS, hw > 0 ? hw : 1, (int)(bytes / (2 * FetchLane::CHUNK))}));
+        nthr = std::max(1, std::min({nthr, FETCH_MAX_THREADS, hw > 0 ? hw : 1, (int)(bytes >> 21)}));
+        // piece size: every worker should see >= 4 pieces (DMA of piece i+1 behind the copy-out of piece i), 2 MB at least and the
+        // pinned buffer at most -- one 67 MB volume moves in 2 MB pieces (35 GB/s; 24 in 8 MB pieces, four workers), eight volumes in
+        // 8 MB pieces (46 GB/s; 43 in 2 MB pieces): tools/fetch_bench.py
+        size_t chunk = std::min(FetchLane::CAPACITY, std::max((size_t)2 << 20, (bytes / nthr / 4 + 4095) & ~(size_t)4095));
+        if (const char* t = getenv("OLX_FETCH_CHUNK_KB"))
+            chunk = std::min(FetchLane::CAPACITY, std::max((size_t)64, (size_t)atol(t)) << 10);
         FetchLane* lanes = ctx_fetch_lanes(c);
         bool ready = true;
         for (int t = 0; t < nthr; ++t) ready = ready && lanes[t].init();
@@ -1288,7 +1294,7 @@ static int fetch_to_host(olx_ctx* c, void* dst, const void* src, size_t bytes) {
             std::vector<std::thread> th;
             for (int t = 0; t < nthr; ++t) {
                 const size_t lo = std::min(per * t, bytes), hi = t == nthr - 1 ? bytes : std::min(per * (t + 1), bytes);
-                th.emplace_back([&, t, lo, hi] { rc[t] = fetch_lane_run(c->device, lanes[t], (char*)dst, (const char*)src, lo, hi); });
+                th.emplace_back([&, t, lo, hi] { rc[t] = fetch_lane_run(c->device, lanes[t], (char*)dst, (const char*)src, lo, hi, chunk); });
             }
             for (auto& t : th) t.join();
             for (int t = 0; t < nthr; ++t)
@@ -2365,8 +2371,7 @@ int olx_allgather_fetch(olx_ctx* c, int rank, float* out) {
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));
     if (c->p2p) { int rc = olx_p2p_drain(c); if (rc) return rc; }
     const size_t count = (size_t)c->fp.vox * c->plan_foci;
-    HIPCHK(c, hipMemcpy(out, c->d_gather + count * rank, sizeof(float) * count, hipMemcpyDeviceToHost));
-    return OLX_OK;
+    return fetch_to_host(c, out, c->d_gather + count * rank, sizeof(float) * count);
 }
 
 }  // extern "C"

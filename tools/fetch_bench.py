@@ -1,29 +1,37 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): device -> caller-owned NumPy bandwidth of olx_field_fetch_all per OLX_FETCH_MODE
-(pageable / register / staged x threads) for the bench.py headline result (8 foci x 256^3 x {|p|, intensity} = 1.07 GB).
-  python tools/fetch_bench.py [--grid 256] [--foci 8]"""
-import argparse, os, sys, time
+"""Developer tool: device -> fresh NumPy array rates of the staged fetch (olx_aggregate_fetch: one 67 MB volume;
+olx_field_fetch_all: 8 volumes = 537 MB) against worker count and pinned-chunk size (OLX_FETCH_THREADS, OLX_FETCH_CHUNK_KB)."""
+import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "openlifu-python_amd")]
-from openlifu_amd import _native as nat
-
-ap = argparse.ArgumentParser(); ap.add_argument("--grid", type=int, default=256); ap.add_argument("--foci", type=int, default=8)
-a = ap.parse_args()
-n = 16
-xe = (np.arange(n) - (n - 1) / 2) * 3e-3
-pos = np.stack([np.repeat(xe, n), np.tile(xe, n), np.zeros(n * n)], axis=1)
-with nat.Context(0) as ctx:
-    ctx.set_elements(pos, np.tile([0, 0, 1.0], (n * n, 1)), np.full(n * n, 7.29e-6))
-    th = 2 * np.pi * np.arange(a.foci) / 63
-    ctx.bf_solve(np.stack([5e-3 * np.cos(th), 5e-3 * np.sin(th), np.full(a.foci, 40e-3)], axis=1), 1500.0)
-    h = 64e-3 / a.grid
-    ctx.field_plan((-(a.grid - 1) / 2 * h, -(a.grid - 1) / 2 * h, 5e-3), (h,) * 3, (a.grid,) * 3, 400e3, 1500.0, 1000.0, 1e5)
-    ctx.field_launch(); ctx.sync()
-    nbytes = 2 * 4 * a.foci * a.grid ** 3
-    for mode, thr in (("pageable", 1), ("staged", 2), ("staged", 4), ("staged", 8), ("staged", 12), ("staged", 16), ("staged", 24)):
-        os.environ["OLX_FETCH_MODE"] = mode; os.environ["OLX_FETCH_THREADS"] = str(thr)
-        ts = []
-        for _ in range(3):
-            t = time.perf_counter(); out = ctx.field_fetch_all(); ts.append(time.perf_counter() - t); del out
-        print(f"{mode:9s} threads {thr}: {nbytes / min(ts) / 1e9:6.1f} GB/s best, {nbytes / max(ts) / 1e9:6.1f} GB/s worst ({min(ts) * 1e3:.0f} ms for {nbytes / 1e6:.0f} MB incl. np.empty first touch)")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "openlifu-python_amd"))
+import bench
+import openlifu_amd as ol
+from openlifu_amd import _native as nat, dist as od
+from openlifu_amd.engine import grid_from_coords
+arr, setup, target, pattern = bench.synthetic_workload(256, 0.25)
+sweep = np.array([f.get_position(units="m") for f in pattern.get_targets(target)])
+origin, spacing, n = grid_from_coords(setup.get_coords())
+eng = ol.get_engine(0)
+sf = od.ShardedField(eng, 1, 0)
+sf.plan_foci_sweep(arr, sweep[od.plan_foci_orbits(sweep, 8)[0]], 1500.0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, 400e3, 1000.0, 1e5,
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+ctx = eng.ctx
+ctx.field_launch(); ctx.field_aggregate(); ctx.sync()
+combos = [(t, c) for c in (8192, 4096, 2048, 1024, 512) for t in (4, 8, 12, 16)]
+if len(sys.argv) > 1:
+    combos = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+print(f"{'threads':>7s} {'chunk KB':>8s} {'67 MB ms':>9s} {'GB/s':>6s} {'537 MB ms':>10s} {'GB/s':>6s}")
+for thr, chunk in combos:
+    os.environ["OLX_FETCH_THREADS"] = str(thr)
+    os.environ.pop("OLX_FETCH_CHUNK_KB", None)         # chunk 0 = the library's own choice
+    if chunk:
+        os.environ["OLX_FETCH_CHUNK_KB"] = str(chunk)
+    ctx.aggregate_fetch(want_intensity=False)          # (re)allocates the pinned chunks of this size
+    small, big = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); pm, _i = ctx.aggregate_fetch(want_intensity=False); small.append(time.perf_counter() - t0); del pm
+    for _ in range(3):
+        t0 = time.perf_counter(); r = ctx.field_fetch_all(want=("pmag",)); big.append(time.perf_counter() - t0); del r
+    s, b = float(np.median(small)), float(np.median(big))
+    print(f"{thr:7d} {chunk:8d} {s * 1e3:9.2f} {67.108864e-3 / s:6.1f} {b * 1e3:10.2f} {536.870912e-3 / b:6.1f}", flush=True)
