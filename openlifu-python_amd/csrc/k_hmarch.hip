@@ -3,6 +3,7 @@
 #include "k_types.hip.h"
 #include "olx_ctx.h"
 #include "olx_launch.h"
+#include <type_traits>
 
 namespace olx {
 
@@ -24,7 +25,8 @@ namespace olx {
 //     launch writes the next running sums (U is double-buffered) -- over the WHOLE lateral grid even in an x-slab launch,
 //     because rays cross slab boundaries (field outputs stay masked to the slab).  One plane is only 1024 tiles, so the
 //     elements are split over the 16 waves of a 1024-thread block (ES = 16) and their partial sums meet in LDS.
-// U layout: [element][i][j] float2 {sum sig, sum a'}; a look-up = two 16-byte loads (rows i0, i0 + 1; 8-byte aligned).
+// U layout: [i][element][j] float2 {sum sig, sum a'} (< 4 GiB, host-checked); a look-up = two 16-byte loads (rows i0, i0 + 1; 8-byte
+// aligned).  The writers of one tile row -- concurrent blocks, consecutive in y -- fill 2 KB x n_el contiguous bytes between them.
 // The ray sums are focus-independent: up to NF = 8 foci of a launch tile share every look-up (only sin, cos and two fma
 // per extra focus).  Table entry as in kernel 2h: { x, y, z, kfirst, klast, 0, 0, 0, (w_f, phi_f) f < NF }.
 // ------------------------------------------------------------------------------------
@@ -33,15 +35,28 @@ struct MarchSeg {
     int k_src;           // grid plane the source sums U_src live on (-1: none -- nothing non-trivial below these planes)
     int write;           // 1: k_lo == k_hi is a non-trivial plane; write U_dst (launch covers the whole lateral grid)
     int i0, ni;          // lateral extent of the launch in GLOBAL x indices: the slab, or the whole grid when writing
+    unsigned nblocks;    // logical blocks of the launch (the grid is rounded up to a multiple of 8, one residue per XCD)
+    int reverse;         // walk the logical blocks downwards: consecutive writer launches alternate, so that what one wrote LAST the next
+                         // reads FIRST -- out of the Infinity Cache (two U buffers are 268 MB at 256 el x 256^2, just past its 256 MiB)
 };
 
 typedef float float4u_t __attribute__((ext_vector_type(4), aligned(8)));
+typedef float float2u_t __attribute__((ext_vector_type(2)));
 
 // ES = 1: 4 waves = 4 consecutive planes, every wave walks all elements.  ES = 16: 16 waves = 16 element subsets of ONE plane.
 template <int ES> constexpr int hm_waves() { return ES == 1 ? 4 : ES; }
+#ifndef HM_EU1
+#define HM_EU1 4
+#endif
+#ifndef HM_EUW
+#define HM_EUW 4
+#endif
 constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 voxels -- 16 consecutive y = whole 128-byte lines of a U row
 
-template <int NF, int ES, bool CLAMP>
+// SRC: the launch reads running sums (k_src >= 0).  Every element lies strictly below the first non-trivial plane (host-checked), so
+// with SRC every ray of the launch crosses the source plane upwards (0 < tt < 1) and without it no ray sees anything: the look-up is
+// compiled in or out as a whole -- no per-element branch, no zero fill of the gather registers.
+template <int NF, int ES, bool CLAMP, bool SRC>
 __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_of_k,
     const float2* __restrict__ U_src, float2* __restrict__ U_dst, const float* __restrict__ inv2z,
@@ -49,17 +64,24 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const HeteroParams H, const MarchSeg S) {
     constexpr int STRIDE = HET_TAB_HEAD + 2 * NF;
     constexpr int WAVES = hm_waves<ES>(), PB = WAVES / ES;  // planes per block
-    constexpr int EU = 4;                                   // elements in flight per wave: their gathers are issued back to back
-    constexpr int ECH = ES == 1 ? 128 : 64;                 // elements per chunk of the wave's ray table
+    constexpr int EU = ES == 1 ? HM_EU1 : HM_EUW;                             // elements in flight per wave: their gathers are issued back to back
     // per-wave ray table: what depends on (element, plane) only -- evaluated once per wave, 64 elements at a time across the
     // lanes, instead of per lane per element: { tt, cu, cv, lf | dz2, ex, ey, - } with the crossing u = tt i + cu (grid cells),
-    // tt < 0 = no look-up (nothing non-trivial between), lf = hz / |dz|
-    __shared__ float4 s_ray[WAVES][ECH][2];
+    // lf = hz / |dz|.  In the look-up launches (ES = 1, issue-bound) the steering weights { w_f, phi_f } of the tile's foci ride in
+    // the same table (RW more float4s per element): a scalar load per element and focus would stall the wave on its latency.
+    constexpr int RW = ES == 1 ? (NF + 1) / 2 : 0;
+    constexpr int ECH = ES == 1 ? (NF > 2 ? 64 : 128) : 64; // elements per chunk of the wave's ray table
+    __shared__ float4 s_ray[WAVES][ECH][2 + RW];
     __shared__ float s_red[ES > 1 ? (ES - 1) * 2 * NF * 64 : 1];
     const int ftile = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles_y = (P.ny + HM_TJ - 1) / HM_TJ, zblocks = (S.k_hi - S.k_lo + PB) / PB;
-    const int zb = blockIdx.x % zblocks, tile = blockIdx.x / zblocks;
+    // Workgroups go to the 8 XCDs round robin; each XCD takes one contiguous eighth of the logical blocks, so that the blocks that
+    // read the same lines of U -- the plane groups of a tile, the tiles next to it -- meet in ONE L2 instead of fetching them into eight
+    unsigned lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (lb >= S.nblocks) return;
+    if (S.reverse) lb = S.nblocks - 1u - lb;
+    const int zb = (int)(lb % (unsigned)zblocks), tile = (int)(lb / (unsigned)zblocks);
     const int ti = tile / tiles_y, tj = tile - ti * tiles_y;
     const int ig = S.i0 + ti * HM_TI + (lane >> 4), j = tj * HM_TJ + (lane & 15);   // global x index, y index
     const int k = S.k_lo + zb * PB + wave / ES, es = wave % ES;            // wave-uniform (scalar registers)
@@ -80,15 +102,14 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     float re[NF], im[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { re[f] = 0.f; im[f] = 0.f; }
-    const unsigned plane_sz = (unsigned)H.nxg * (unsigned)H.nyg;
+    const unsigned row_cells = (unsigned)P.n_el * (unsigned)H.nyg;         // U is [i][element][j]: one grid row of every element, then the next
     // look-up coordinates are clamped just inside the last cell, so that (i0, i0 + 1) / (j0, j0 + 1) always exist and the
     // fraction is fract(u): border values extend outwards (the oracle's clamp) to one ulp of the coordinate
     const float umax = (float)(H.nxg - 1) * (1.f - 0x1p-23f), vmax = (float)(H.nyg - 1) * (1.f - 0x1p-23f);
     const float zsrc = (float)S.k_src * P.hz;
-    const bool have_src = S.k_src >= 0;
     const float* t = tab + (size_t)ftile * P.n_el * STRIDE;
-    const bool writer = S.write && ftile == 0 && in_grid;
-    const unsigned own = (unsigned)ig * (unsigned)H.nyg + (unsigned)j;     // this voxel's cell in a U plane
+    const bool writer = ES > 1 && S.write && ftile == 0 && in_grid;        // (ES = 1 launches never write)
+    const unsigned own = (unsigned)ig * row_cells + (unsigned)j;           // this voxel's cell in element 0's rows
     const float sv2 = 2.f * sv, av2 = 2.f * av;
     if (live_k) {
         const int n_mine = (P.n_el - es + ES - 1) / ES;     // elements es, es + ES, ...
@@ -101,62 +122,87 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                 const float ex = te[0], ey = te[1], ez = te[2];
                 const float dz = z - ez;
                 const float idz = dz != 0.f ? 1.0f / dz : 0.f;
-                const bool up = have_src && dz > 0.f;
-                const float tt = up ? (zsrc - ez) * idz : -1.f;
+                const float tt = SRC ? (zsrc - ez) * idz : 0.f;
                 const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid cells
                 s_ray[wave][q][0] = make_float4(tt, eu - tt * eu, ev - tt * ev, P.hz * fabsf(idz));
                 s_ray[wave][q][1] = make_float4(dz * dz, ex, ey, 0.f);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const bool two = 2 * r + 1 < NF;
+                    s_ray[wave][q][2 + r] = make_float4(te[HET_TAB_HEAD + 4 * r], te[HET_TAB_HEAD + 4 * r + 1],
+                                                        two ? te[HET_TAB_HEAD + 4 * r + 2] : 0.f, two ? te[HET_TAB_HEAD + 4 * r + 3] : 0.f);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int q0 = 0; q0 < n_ch; q0 += EU) {
-                float4u_t lo[EU], hi[EU];
-                float fu[EU], fv[EU];
+            // EU elements at a time: all their gathers are issued before the first is consumed (one basic block, pinned by the
+            // scheduling barrier -- with a branch between the two phases the compiler sinks every gather down to its use and the
+            // wave waits out each L1 round trip); a ragged tail goes element by element
+            auto group = [&](const int q0, auto count) {
+                constexpr int E = decltype(count)::value;
+                float4u_t lo[E], hi[E];
+                float fu[E], fv[E];
+                if constexpr (SRC) {
 #pragma unroll
-                for (int s = 0; s < EU; ++s) {               // phase 1: addresses and gathers of EU elements
-                    const int q = min(q0 + s, n_ch - 1);
-                    const float4 r0 = s_ray[wave][q][0];     // same address in every lane: an LDS broadcast
-                    lo[s] = float4u_t{0.f, 0.f, 0.f, 0.f}; hi[s] = lo[s]; fu[s] = 0.f; fv[s] = 0.f;
-                    if (r0.x >= 0.f) {                       // wave-uniform
+                    for (int s = 0; s < E; ++s) {            // phase 1: addresses and gathers
+                        const float4 r0 = s_ray[wave][q0 + s][0];     // same address in every lane: an LDS broadcast
                         const float u = __builtin_amdgcn_fmed3f(fmaf(r0.x, igf, r0.y), 0.f, umax);
                         const float v = __builtin_amdgcn_fmed3f(fmaf(r0.x, jgf, r0.z), 0.f, vmax);
                         const unsigned i0 = (unsigned)(int)u, j0 = (unsigned)(int)v;
                         fu[s] = __builtin_amdgcn_fractf(u); fv[s] = __builtin_amdgcn_fractf(v);
                         // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
-                        const char* Ue = reinterpret_cast<const char*>(U_src + (size_t)(es + ES * (c0 + q)) * plane_sz);
-                        const unsigned off = (__umul24(i0, (unsigned)H.nyg) + j0) << 3;
+                        const char* Ue = reinterpret_cast<const char*>(U_src + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg);
+                        const unsigned off = (__umul24(i0, row_cells) + j0) << 3;
                         lo[s] = *reinterpret_cast<const float4u_t*>(Ue + off);                       // {s00, a00, s01, a01}
-                        hi[s] = *reinterpret_cast<const float4u_t*>(Ue + (size_t)H.nyg * 8 + off);   // {s10, a10, s11, a11}
+                        hi[s] = *reinterpret_cast<const float4u_t*>(Ue + (size_t)row_cells * 8 + off);   // {s10, a10, s11, a11}
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int s = 0; s < EU; ++s) {               // phase 2: interpolate, (write,) accumulate
-                    if (q0 + s >= n_ch) break;               // wave-uniform
+                for (int s = 0; s < E; ++s) {                // phase 2: interpolate, (write,) accumulate
                     const int e = es + ES * (c0 + q0 + s);
-                    const float* te = t + (size_t)e * STRIDE;
                     const float4 r0 = s_ray[wave][q0 + s][0], r1 = s_ray[wave][q0 + s][1];
                     const float dx = x - r1.y, dy = y - r1.z;
-                    const float s0 = fmaf(fv[s], lo[s].z - lo[s].x, lo[s].x), a0 = fmaf(fv[s], lo[s].w - lo[s].y, lo[s].y);
-                    const float s1 = fmaf(fv[s], hi[s].z - hi[s].x, hi[s].x), a1 = fmaf(fv[s], hi[s].w - hi[s].y, hi[s].y);
-                    const float ss = fmaf(fu[s], s1 - s0, s0), as = fmaf(fu[s], a1 - a0, a0);
-                    if (writer) (U_dst + (size_t)e * plane_sz)[own] = make_float2(ss + sv2, as + av2);
+                    float2u_t sa = {0.f, 0.f};               // { sum sig, sum a' } at the crossing: (s, a) pairs in packed fp32
+                    if constexpr (SRC) {
+                        const float2u_t l0 = {lo[s].x, lo[s].y}, l1 = {lo[s].z, lo[s].w}, h0 = {hi[s].x, hi[s].y}, h1 = {hi[s].z, hi[s].w};
+                        const float2u_t c0v = fv[s] * (l1 - l0) + l0, c1v = fv[s] * (h1 - h0) + h0;
+                        sa = fu[s] * (c1v - c0v) + c0v;
+                    }
+                    if (writer) (U_dst + (size_t)e * H.nyg)[own] = make_float2(sa.x + sv2, sa.y + av2);
                     float d2 = fmaf(dy, dy, fmaf(dx, dx, r1.x));
                     if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                     const float ri = __builtin_amdgcn_rsqf(d2);
                     const float d = d2 * ri;
                     const float l = d * r0.w;                // path per layer [wavelengths]; 0 level with the element
-                    const float ph0 = fmaf(l, ss + sv, d);
-                    const float amp = ri * __expf(-l * (as + av));
+                    const float ph0 = fmaf(l, sa.x + sv, d);
+                    const float amp = ri * __expf(-l * (sa.y + av));
+                    float wf[2 * NF];                         // { w_f, phi_f }: from the ray table (ES = 1) or the steering table
+                    if constexpr (RW > 0) {
+#pragma unroll
+                        for (int r = 0; r < RW; ++r) {
+                            const float4 w = s_ray[wave][q0 + s][2 + r];
+                            wf[4 * r] = w.x; wf[4 * r + 1] = w.y;
+                            if (2 * r + 1 < NF) { wf[4 * r + 2] = w.z; wf[4 * r + 3] = w.w; }
+                        }
+                    } else {
+                        const float* te = t + (size_t)e * STRIDE;
+#pragma unroll
+                        for (int f = 0; f < 2 * NF; ++f) wf[f] = te[HET_TAB_HEAD + f];
+                    }
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {           // the ray sums above serve every focus of the tile
-                        const float ph = ph0 + te[HET_TAB_HEAD + 2 * f + 1];
-                        const float a = amp * te[HET_TAB_HEAD + 2 * f];
+                        const float ph = ph0 + wf[2 * f + 1];
+                        const float a = amp * wf[2 * f];
                         re[f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[f]);
                         im[f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[f]);
                     }
                 }
-            }
+            };
+            int q0 = 0;
+            for (; q0 + EU <= n_ch; q0 += EU) group(q0, std::integral_constant<int, EU>{});
+            for (; q0 < n_ch; ++q0) group(q0, std::integral_constant<int, 1>{});
         }
     }
     if constexpr (ES > 1) {                                  // partial sums of the element subsets meet in wave 0
@@ -206,15 +252,19 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
         MarchSeg S;
         S.k_lo = k_lo; S.k_hi = k_hi; S.k_src = p_src >= 0 ? c->h_plane_k[p_src] : -1; S.write = write ? 1 : 0;
         S.i0 = write ? 0 : c->slab.x_begin; S.ni = write ? c->hp.nxg : P.nx;
+        S.reverse = write && (p_src & 1);
         const float2* src = p_src >= 0 ? c->d_U[p_src & 1] : nullptr;
         float2* dst = write ? c->d_U[(p_src + 1) & 1] : nullptr;
         const long long tiles = (long long)((S.ni + HM_TI - 1) / HM_TI) * ((P.ny + HM_TJ - 1) / HM_TJ);
-#define OLX_HM(ES_, CL) hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL>), dim3((unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)), ftiles), \
+#define OLX_HM_(ES_, CL, SR) S.nblocks = (unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)); \
+                             hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL, SR>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), \
                                            dim3(64 * hm_waves<ES_>()), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
                                            c->d_inten, c->d_cplx, P, c->hp, S)
-        if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }
+#define OLX_HM(ES_, CL) do { if (p_src >= 0) { OLX_HM_(ES_, CL, true); } else { OLX_HM_(ES_, CL, false); } } while (0)
+        if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }   // (4 or 8 element subsets per block: same time, measured)
         else       { if (c->clamp) OLX_HM(1, true); else OLX_HM(1, false); }
 #undef OLX_HM
+#undef OLX_HM_
     };
     if (np == 0) { go(0, nz - 1, -1, false); return; }
     go(0, c->h_plane_k[0] - 1, -1, false);                   // below the first non-trivial plane: homogeneous rays

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void field_scale_aggregate_k(float* __restrict
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sm = m;
 #pragma unroll 4
         for (int f = 0; f < n_foci; ++f) {
+#pragma clang fp contract(off)      // the sums take the ROUNDED products that are stored (what field_aggregate_k reads back), never an fma
             const float s = scale[f], s2 = s * s;
             float4* pp = reinterpret_cast<float4*>(pmag + (long long)f * vox) + q;
             float4* ip = reinterpret_cast<float4*>(inten + (long long)f * vox) + q;
@@ -1014,14 +1015,18 @@ __global__ __launch_bounds__(256) void field_scale_agg_analyze_k(float* __restri
         for (int f = 0; f < SAA_MAXF; ++f) {
             if (f >= n_foci) break;                      // uniform
             const float s = scale[f], s2 = s * s, w = wts[f];
+            float4 p4, w4;
+            {
+#pragma clang fp contract(off)      // sums of the ROUNDED scaled values (the stored ones), as the separate kernels form them
             float4* pp = reinterpret_cast<float4*>(pmag + (long long)f * P.vox) + iq;
             float4* ip = reinterpret_cast<float4*>(inten + (long long)f * P.vox) + iq;
-            float4 p4 = *pp, w4 = *ip;
+            p4 = *pp; w4 = *ip;
             p4.x *= s; p4.y *= s; p4.z *= s; p4.w *= s;
             w4.x *= s2; w4.y *= s2; w4.z *= s2; w4.w *= s2;
             *pp = p4; *ip = w4;
             m.x = fmaxf(m.x, p4.x); m.y = fmaxf(m.y, p4.y); m.z = fmaxf(m.z, p4.z); m.w = fmaxf(m.w, p4.w);
             sm.x += w4.x; sm.y += w4.y; sm.z += w4.z; sm.w += w4.w;
+            }
             ws.x += w * w4.x; ws.y += w * w4.y; ws.z += w * w4.z; ws.w += w * w4.w;
             // the six masked peaks of this focus on the SCALED values (field_analysis_peaks4_k's decisions)
             const MaskFast& M = sM[f];

@@ -1410,7 +1410,7 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         kfirst[e] = kf; klast[e] = kl;
     }
     // marched ray sums (kernel 2m) need rays that cross the non-trivial planes upwards only, and a 2 x 2 stencil
-    bool march_ok = c->planes_per_layer == 1 && nx >= 2 && ny >= 2;
+    bool march_ok = c->planes_per_layer == 1 && nx >= 2 && ny >= 2 && (size_t)n * nx * ny * sizeof(float2) < ((size_t)1 << 32);   // (32-bit lane offsets into U)
     if (np > 0)
         for (int e = 0; e < n && march_ok; ++e)
             if (!(c->h_pos[2 * (size_t)n + e] < g.origin[2] + plane_k[0] * g.spacing[2])) march_ok = false;

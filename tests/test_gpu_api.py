@@ -511,15 +511,17 @@ def test_reference_example_files_through_calc_solution_against_g1(golden):
     assert abs(an.beamwidth_lat_3dB_mm[0] - 4.57) / 4.57 < 0.12 and abs(an.beamwidth_ax_3dB_mm[0] - 36.0) / 36.0 < 0.12
 
 
-def test_fused_scale_aggregate_analyze_equals_the_separate_steps():
+@pytest.mark.parametrize("spokes,z_hi", [(4, 44.5), (10, 44.5), (4, 44.0)], ids=["fused", "11-foci", "ragged-z"])
+def test_fused_scale_aggregate_analyze_equals_the_separate_steps(spokes, z_hi):
     """calc_solution(scale=True) scales the volumes, aggregates them and runs the whole analysis in ONE crossing and ONE pass over the
     volumes (olx_solution_analyze with scale factors).  Same numbers as the separate public steps -- Solution.scale (device scaling),
-    the aggregation, Solution.analyze -- bit for bit: volumes, aggregate, every analysis entry."""
+    the aggregation, Solution.analyze -- bit for bit: volumes, aggregate, every analysis entry.  The one-pass kernel serves <= 8 foci on
+    z rows of whole quads; 11 foci and a 79-plane grid take the same entry point through the separate passes."""
     from dataclasses import asdict
     arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
-    setup = ol.SimSetup(spacing=0.5, x_extent=(-16, 15.5), y_extent=(-16, 15.5), z_extent=(5, 44.5))      # 64 x 64 x 80
-    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup, sequence=ol.Sequence(pulse_count=10, pulse_train_interval=0),
-                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=4, spoke_radius=3.0, target_pressure=0.8, units="MPa"))
+    setup = ol.SimSetup(spacing=0.5, x_extent=(-16, 15.5), y_extent=(-16, 15.5), z_extent=(5, z_hi))      # 64 x 64 x 80 (79)
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup, sequence=ol.Sequence(pulse_count=spokes + 1 if spokes > 4 else 10, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=spokes, spoke_radius=3.0, target_pressure=0.8, units="MPa"))
     target = ol.Point(position=(0.5, -0.25, 30), units="mm")
     sol_f, agg_f, an_f = proto.calc_solution(target, arr, simulate=True, scale=True)
     fused = {k: np.array(sol_f.simulation_result[k].data) for k in ("p_min", "p_max", "intensity")}
