@@ -497,20 +497,39 @@ static int configure_variant(olx_ctx* c) {
             return true;
         };
         struct Col { int f, m, ntgt; int tgt[4]; };
-        std::vector<std::vector<Col>> tiles(1);
-        int total_cols = 0;
-        for (int f = 0; f < F; ++f) {
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                std::vector<Col> cur = tiles.back();
+        // A column may store to ANY focus volume, so the search for an equal vector runs over every tile packed so far: mirror-partner
+        // foci share their columns wherever they sit in the sweep (a Wheel in its natural order has them at opposite ends).
+        auto pack = [&](int maxc) {
+            std::vector<std::vector<Col>> tl(1);
+            for (int f = 0; f < F; ++f)
                 for (int m = 0; m < n_img; ++m) {
-                    int hit = -1;
-                    for (size_t q = 0; q < cur.size() && hit < 0; ++q)
-                        if (cur[q].ntgt < 4 && same_vector(cur[q].f, cur[q].m, f, m)) hit = (int)q;
-                    if (hit < 0) { cur.push_back(Col{f, m, 0, {-1, -1, -1, -1}}); hit = (int)cur.size() - 1; }
-                    cur[hit].tgt[cur[hit].ntgt++] = f * 4 + m;
+                    Col* hit = nullptr;
+                    for (size_t t = 0; t < tl.size() && !hit; ++t)
+                        for (size_t q = 0; q < tl[t].size() && !hit; ++q)
+                            if (tl[t][q].ntgt < 4 && same_vector(tl[t][q].f, tl[t][q].m, f, m)) hit = &tl[t][q];
+                    if (!hit) {
+                        if ((int)tl.back().size() >= maxc) tl.emplace_back();
+                        tl.back().push_back(Col{f, m, 0, {-1, -1, -1, -1}});
+                        hit = &tl.back().back();
+                    }
+                    hit->tgt[hit->ntgt++] = f * 4 + m;
                 }
-                if ((int)cur.size() <= MAXC || tiles.back().empty()) { tiles.back() = cur; break; }
-                tiles.emplace_back();  // focus does not fit: start the next launch tile with it
+            return tl;
+        };
+        auto coset_fill = [&](int nt) {
+            const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0);
+            const long long t16 = coset_tiles16(wx, wy, c->lat.mx, c->lat.my, nt);
+            return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
+        };
+        std::vector<std::vector<Col>> tiles = pack(MAXC);
+        int total_cols = 0;
+        // A sweep that needs SEVERAL launch tiles anyway is cut into tiles of 16 columns instead of 32: kernel 2g (NT = 2) then takes every
+        // tile -- 8 x 0.43 ms against 2e's 4 x 0.92 ms on the 64-focus sweep (127 columns).  One tile of 17 - 32 columns stays with 2e's
+        // NT = 4 shape (0.82 against 2 x 0.43 ms).  OLX_FIELD_VARIANT=lattice keeps the 32-column tiles for A/B runs.
+        {
+            const char* fv = getenv("OLX_FIELD_VARIANT");
+            if (tiles.size() > 1 && c->use_lattice && !(c->flags & OLX_OUT_COMPLEX) && !fv && coset_fill(2) >= 0.6) {
+                tiles = pack(MFMA_COLS * 2);
             }
         }
         c->nt = 1;
@@ -519,11 +538,6 @@ static int configure_variant(olx_ctx* c) {
         // geometry fragment the MFMAs dominate and kernel 2c's exact z-run tiling wins (measured, steady state, 64-focus
         // sweep: 4.6 vs 4.9 ms; 8-focus shard: 0.74 vs 0.58 ms) -- unless the family is pinned for A/B runs
         // Kernel 2e's NT = 4 shape (3 tiles per wave) takes the sweep when its tiles are reasonably full.
-        auto coset_fill = [&](int nt) {
-            const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0);
-            const long long t16 = coset_tiles16(wx, wy, c->lat.mx, c->lat.my, nt);
-            return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
-        };
         if (c->use_lattice && c->nt >= 4 && c->force_kind != 4 && ((c->flags & OLX_OUT_COMPLEX) || coset_fill(c->nt) < 0.6)) c->use_lattice = false;
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position

@@ -580,18 +580,20 @@ def test_piston_directivity_opt_in(ctx):
         assert np.abs(ctx.field_fetch(1)["pmag"] - plain).max() / plain.max() <= TOL_P
 
 
-@pytest.mark.parametrize("case", ["one_column_2f", "off_axis_2e_nt1", "shard_2g", "sweep_2e_nt4", "rotated_fallback"])
+@pytest.mark.parametrize("case", ["one_column_2f", "off_axis_2e_nt1", "shard_2g", "ring_2e_nt4", "sweep_2g_tiles", "rotated_fallback"])
 def test_piston_directivity_in_the_lattice_kernels(ctx, case, monkeypatch):
     """For a flat matrix array of equal, axis-aligned elements the piston factor depends on the (voxel - element) offset only and folds
     into the geometry tables of the lattice kernels (their own DIR instantiations; the default path is not touched): one on-axis focus
-    (kernel 2f), one off-axis focus (2e, NT = 1), an 8-focus shard with shared images (2g), a 20-focus ring (2e, NT = 4) -- each against
+    (kernel 2f), one off-axis focus (2e, NT = 1), an 8-focus shard with shared images (2g), an off-axis 8-focus ring (32 columns in one tile:
+    2e, NT = 4), an off-axis 20-focus ring (80 columns: five 16-column tiles of 2g) -- each against
     the fp64 oracle of the same definition (full volume) and against the per-pair kernel 2a-d; an array with one rotated element
     keeps kernel 2a-d."""
     pos, ori, size = synthetic_array(16, 16, 3.0)
     if case == "rotated_fallback":
         ori = ori.copy(); ori[37, 2] = 0.2                               # one element rolled about its normal: frames differ
     foci = {"one_column_2f": np.array([[0, 0, 30e-3]]), "off_axis_2e_nt1": np.array([[2e-3, -1e-3, 28e-3]]),
-            "shard_2g": _wheel_shard(8), "sweep_2e_nt4": bo.wheel_targets([1.0, 0.5, 32.0], True, 19, 4.0) * 1e-3,
+            "shard_2g": _wheel_shard(8), "ring_2e_nt4": bo.wheel_targets([1.0, 0.5, 32.0], True, 7, 4.0) * 1e-3,
+            "sweep_2g_tiles": bo.wheel_targets([1.0, 0.5, 32.0], True, 19, 4.0) * 1e-3,
             "rotated_fallback": np.array([[0, 0, 30e-3]])}[case]
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 60.0, 0.0))
     R = bo.element_rotations(ori)
@@ -602,8 +604,10 @@ def test_piston_directivity_in_the_lattice_kernels(ctx, case, monkeypatch):
     flags = nat.OUT_PMAG | nat.OUT_INTENSITY | nat.FIELD_DIRECTIVITY
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (64,) * 3, F0, C, RHO, P0, flags=flags)
     name = ctx.field_variant()
-    expect = {"one_column_2f": "field_toep_k", "off_axis_2e_nt1": "field_coset_k<nt1", "shard_2g": "field_cosetp_k<nt2", "sweep_2e_nt4": "field_coset_k<nt4",
-              "rotated_fallback": "field_accum_dir_k"}[case]
+    expect = {"one_column_2f": "field_toep_k", "off_axis_2e_nt1": "field_coset_k<nt1", "shard_2g": "field_cosetp_k<nt2", "ring_2e_nt4": "field_coset_k<nt4",
+              "sweep_2g_tiles": "field_cosetp_k<nt2", "rotated_fallback": "field_accum_dir_k"}[case]
+    if case == "sweep_2g_tiles":
+        assert "in 5 tile(s)" in name, name
     assert expect in name and (("piston directivity in the tables" in name) == (case != "rotated_fallback")), name
     ctx.field_launch()
     got = [ctx.field_fetch(f) for f in range(len(foci))]
@@ -901,7 +905,7 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
 
 
 @pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp> 16 columns"),
-                                                 (64, 0, "field_coset_k<nt4,mx2,my2,flat,noclamp>")])
+                                                 (64, 0, "field_cosetp_k<nt2,mx2,my2,flat,noclamp> 127 columns for 64 foci x 4 images in 8 tile(s)")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, rank, expect):
     """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and two of the eight
     8-focus shards the product's orbit-aware planner hands to the GPUs): sampled-voxel parity per focus, the per-focus
