@@ -328,8 +328,6 @@ def main():
         order = [args.gather] + [k for k in ("rccl", "p2p") if k != args.gather]
         notes = []
         for kind in order:
-            if kind == "p2p" and reassemble != "allgather":
-                continue                      # the p2p transport is all-gather only
             ok, note = init_transport(kind)
             if note:
                 notes.append(note)
@@ -395,7 +393,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             err = e
         if not agree(err is None):
-            timed.last_error = str(err) if err is not None else "failed on another rank"
+            mine = str(err) if err is not None else ""
+            if dist is not None:        # every rank's own message (the first one to give up names the cause, the others only see the abort)
+                box = [None] * world
+                dist.all_gather_object(box, mine)
+                mine = "; ".join(f"rank {i}: {e}" for i, e in enumerate(box) if e)
+            timed.last_error = mine or "failed on another rank"
             return None
         if dist is not None:
             import torch
@@ -450,7 +453,7 @@ def main():
             beside[key] = ({"steps": k2, "ms_per_step": r[0] / k2 * 1e3, "value": pairs_per_step * k2 / r[0] / 1e6} if r is not None
                            else {"skipped": timed.last_error})
             return r is not None
-        if skull is None and (transport == "rccl" or other == "allgather"):   # (the p2p transport is all-gather only)
+        if skull is None:
             beside_leg(f"with_{other}", other)
         if mode == "allgather" and skull is None:      # the same all-gather over the other transport
             other_t = "p2p" if transport == "rccl" else "rccl"

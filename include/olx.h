@@ -346,9 +346,11 @@ int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weight
  *                   once, out of output buffers mapped with HIP IPC (works for ranks that share one device too).  The output
  *                   blocks are reallocated by olx_field_plan, so after EVERY plan each rank calls olx_comm_export
  *                   (OLX_P2P_BLOB_BYTES), the launcher all-gathers the blobs in rank order and each rank calls olx_comm_import
- *                   with all of them.  All-gather only: the aggregate exchanges return OLX_ECOMM.
+ *                   with all of them.  The aggregate exchanges take the same road: rank r owns slice r of the volume, pulls
+ *                   that slice of every peer's partial, reduces in rank order (same bits on every rank) and -- all-reduce --
+ *                   the ranks pull each other's reduced slices.
  * olx_comm_transport names what this context uses ("rccl", "p2p", "" before olx_comm_init). */
-#define OLX_P2P_BLOB_BYTES 192
+#define OLX_P2P_BLOB_BYTES 384
 int olx_comm_export(olx_ctx *ctx, void *blob_out);
 int olx_comm_import(olx_ctx *ctx, const void *blobs);
 const char *olx_comm_transport(const olx_ctx *ctx);

@@ -87,6 +87,15 @@ int olx_sync(olx_ctx* c) {
     return OLX_OK;
 }
 
+
+// The aggregate buffers are about to be rewritten: an exchange of the previous aggregate that still reads them -- RCCL on the side
+// stream, or peers pulling slices out of them over IPC -- has to be over.
+static int aggregate_buffers_free(olx_ctx* c) {
+    if (c->reduce_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red, 0)); c->reduce_pending = false; }
+    if (c->p2p) return olx_p2p_aggregate_before_overwrite(c);
+    return OLX_OK;
+}
+
 // ---- element table ---------------------------------------------------------------------
 int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, const double* area_m2, int n) {
     if (!c) return OLX_EINVAL;
@@ -1659,6 +1668,7 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
         c->wint_cap = (size_t)c->fp.vox;
     }
     if (kernel == OLX_SCAN_FUSED_POST) {
+        { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
         if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
         if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
     }
@@ -1715,6 +1725,7 @@ const char* olx_field_variant(const olx_ctx* c) { return (c && c->planned) ? c->
 // max |p| / mean intensity over the planned foci into the aggregate buffers (device only)
 static int aggregate_local(olx_ctx* c, bool with_p, bool with_i) {
     const size_t vox = (size_t)c->fp.vox;
+    { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
     if (with_p && !c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
     if (with_i && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
     hipLaunchKernelGGL(field_aggregate_k, dim3(2048), dim3(256), 0, c->stream, with_p ? c->d_pmag[c->cur] : nullptr,
@@ -1781,6 +1792,7 @@ int olx_field_scale_aggregate(olx_ctx* c, const double* scale, int n_foci) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+    { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
     if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
     if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
     std::vector<float> s(n_foci);
@@ -2108,6 +2120,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     const bool fused = scale_per_focus && quad && F <= SAA_MAXF && !(c->flags & OLX_OUT_COMPLEX);
     if (scale_per_focus && !fused) { int rc = olx_field_scale_aggregate(c, scale_per_focus, F); if (rc) return rc; }
     if (fused) {
+        { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
         if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
         if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
         for (int f = 0; f < F; ++f) reinterpret_cast<float*>(h + in_sc)[f] = (float)scale_per_focus[f];
@@ -2309,8 +2322,7 @@ int olx_field_allgather(olx_ctx* c) {
 // intensity mean) of ONE volume each on the side stream -- the exchange step the sharded path really has.
 static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
     if (!c) return OLX_EINVAL;
-    if (c->p2p) return fail(c, OLX_ECOMM, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate need the RCCL transport (this communicator is OLX_GATHER=p2p: all-gather only)");
-    if (!c->comm) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate: call olx_comm_init first");
+    if (!c->comm && !c->p2p) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate / olx_field_reduce_scatter_aggregate: call olx_comm_init first");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_field_allreduce_aggregate: nothing planned");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t vox = (size_t)c->fp.vox;
@@ -2318,10 +2330,7 @@ static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
     if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
     if (with_i && !c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
     if (!c->ev_agg) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_agg, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming)); }
-    if (c->reduce_pending) {  // the previous all-reduce still owns the aggregate buffers
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_red, 0));
-        c->reduce_pending = false;
-    }
+    { int rc = aggregate_buffers_free(c); if (rc) return rc; }   // the previous exchange still owns the aggregate buffers
     // genuine foci of this rank come first in its shard (padding repeats the last one, dist.plan_foci_orbits): only they enter
     // the local max / sum, and the mean divides by the GLOBAL number of genuine foci (olx_field_aggregate_counts)
     const int n_local = c->agg_local >= 0 ? std::min(c->agg_local, c->plan_foci) : c->plan_foci;
@@ -2334,6 +2343,8 @@ static int aggregate_exchange(olx_ctx* c, bool want_scatter) {
                            n_local, (long long)vox, inv_n, c->d_agg_p, with_i ? c->d_agg_i : nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_agg, c->stream));
+    if (c->p2p)     // peer-to-peer transport: the same two shapes, pulled slice by slice over IPC mappings (csrc/olx_p2p.hip)
+        return olx_p2p_aggregate(c, want_scatter && vox % ((size_t)4 * c->nranks) == 0, with_i);
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_agg, 0));
     // Exchange.  Reduce-scatter (in place): rank r ends up owning voxels [r vox/N, (r+1) vox/N) of the global aggregate
     // (max |p|, mean intensity), i.e. the result stays sharded in HBM like the per-focus volumes; that moves (N-1)/N of
@@ -2370,6 +2381,7 @@ int olx_aggregate_fetch(olx_ctx* c, float* pmax_out, float* imean_out) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->p2p) { int rc = olx_p2p_drain(c); if (rc) return rc; }
     const size_t vox = (size_t)c->fp.vox;
     int rc = OLX_OK;
     if (pmax_out) rc = fetch_to_host(c, pmax_out, c->d_agg_p, sizeof(float) * vox);      // (pipelined staged copy, as the per-focus fetches)

@@ -139,6 +139,8 @@ int olx_p2p_import(olx_ctx* c, const void* blobs);
 int olx_p2p_allgather(olx_ctx* c);
 int olx_p2p_before_overwrite(olx_ctx* c, int b);
 int olx_p2p_drain(olx_ctx* c);
+int olx_p2p_aggregate(olx_ctx* c, bool scatter, bool with_i);
+int olx_p2p_aggregate_before_overwrite(olx_ctx* c);
 
 static inline int fail(olx_ctx* c, int code, const char* fmt, ...) {
     char buf[512];

@@ -23,7 +23,7 @@ MEDIUM_MODELS = {"auto": 0, "sampled": 1, "marched": 2}   # OLX_MEDIUM_*
 FIELD_DIRECTIVITY = 16     # opt-in plan flag: far-field piston directivity (needs set_element_apertures; exact per-pair kernel)
 FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
 UNIQUE_ID_BYTES = 128
-P2P_BLOB_BYTES = 192
+P2P_BLOB_BYTES = 384
 
 # every symbol include/olx.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

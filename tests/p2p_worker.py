@@ -57,22 +57,34 @@ sf.init_comm(exchange_id, allgather_bytes)
 assert sf.transport == "p2p" and eng.ctx.comm_transport() == "p2p", sf.transport
 res = {}
 # foci shards (F not divisible by the world: the last shard is padded), one step, then three more steps through both output buffers
-sf.plan_foci_sweep(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0)
+sf.plan_foci_sweep(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
 sf.step("allgather")
 res["foci"] = sf.fetch_all()
 for _ in range(3):
     sf.step("allgather")
 res["foci_again"] = sf.fetch_all()
+# launches that are NOT gathered, a different number on every rank (a time-based clock ramp does this): the same generation now sits in
+# different output buffers on the two ranks, and the exchange must not care
+for _ in range(rank + 1):
+    eng.ctx.field_launch()
+eng.ctx.sync()
+for _ in range(3):
+    sf.step("allgather")
+res["foci_skewed"] = sf.fetch_all()
+# the aggregate over ALL ranks' genuine foci through the same transport: all-reduce (every rank holds the whole volume pair), then the
+# reduce-scatter form (rank r owns voxels [r V / N, (r + 1) V / N)), twice each so that the buffers are re-used while peers may still pull
+for _ in range(2):
+    pm, im = sf.aggregate()
+res["agg_p"], res["agg_i"] = pm, im
+for _ in range(2):
+    eng.ctx.field_reduce_scatter_aggregate()
+    pm, im = eng.ctx.aggregate_fetch()
+res["rs_p"], res["rs_i"] = pm, im
 # x-slabs (nx odd: the last slab is shifted inwards), all foci on every rank
 d, a = eng.beamform(arr, foci, C)
 res["slabs"] = sf.sweep_slabs(arr, d, a, origin, spacing, n, F0, C, RHO, P0)
 sf.step("allgather"); sf.step("allgather")
 res["slabs_again"] = sf.fetch_all()
-try:
-    sf.aggregate()
-    res["aggregate_refused"] = np.array(0)
-except nat.NativeError as e:
-    res["aggregate_refused"] = np.array(int("p2p" in str(e)))
 np.savez(os.path.join(tmp, f"out_{rank}.npz"), **res)
 sf.close()
 print(f"rank {rank}: ok", flush=True)

@@ -2,7 +2,8 @@
 olx_field_allgather (OLX_GATHER=p2p: every rank pulls its peers' blocks out of IPC-mapped output buffers, csrc/olx_p2p.hip).
 RCCL refuses two ranks on one device; HIP IPC does not, so this is the exchange the builder's single GPU can run.  The ranks
 are fresh child processes (tests/p2p_worker.py); the assembled result must equal the single-process result bit for bit --
-with a focus count that does not divide by the world (padded shard) and in slab mode with an odd plane count."""
+with a focus count that does not divide by the world (padded shard) and in slab mode with an odd plane count.  The aggregate
+over foci (all-reduce and reduce-scatter forms) goes through the same transport."""
 import os
 import subprocess
 import sys
@@ -50,6 +51,10 @@ def test_two_ranks_on_one_gpu_exchange_through_p2p_transport():
     eng = ol.get_engine(0)
     ref = od.ShardedField(eng, 1, 0).sweep_foci(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0)
     assert ref.shape == (n_foci,) + n and ref.max() > 0
+    whole = od.ShardedField(eng, 1, 0)
+    whole.plan_foci_sweep(arr, foci, C, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+    eng.ctx.field_launch()
+    ref_agg_p, ref_agg_i = eng.ctx.field_aggregate(want_intensity=True)         # max |p| / mean intensity over the 3 foci, one process
     # the same shards computed one after the other in THIS process (a shard of 2 foci, or a slab without the x mirror fold, may
     # select another kernel family than the single whole launch: equal to ~1e-6, not to the bit): the exchange must not change a bit
     ctx = eng.ctx
@@ -73,7 +78,15 @@ def test_two_ranks_on_one_gpu_exchange_through_p2p_transport():
     for exp in (exp_foci, exp_slabs):
         assert np.abs(exp - ref).max() <= 5e-6 * ref.max()
     for r in range(world):
-        for key, exp in (("foci", exp_foci), ("foci_again", exp_foci), ("slabs", exp_slabs), ("slabs_again", exp_slabs)):
+        for key, exp in (("foci", exp_foci), ("foci_again", exp_foci), ("foci_skewed", exp_foci), ("slabs", exp_slabs), ("slabs_again", exp_slabs)):
             assert got[r][key].shape == ref.shape, (r, key)
             assert np.array_equal(got[r][key], exp), (r, key, float(np.abs(got[r][key] - exp).max()))
-        assert int(got[r]["aggregate_refused"]) == 1      # the p2p transport is all-gather only and says so
+        # the aggregate exchange over the same transport: all-reduce = the single-process aggregate (a shard may run another kernel
+        # family: ~1e-6), the same bits on both ranks; reduce-scatter = the owner's slice of exactly that
+        assert np.abs(got[r]["agg_p"] - ref_agg_p).max() <= 5e-6 * ref_agg_p.max()
+        assert np.abs(got[r]["agg_i"] - ref_agg_i).max() <= 2e-5 * ref_agg_i.max()
+        assert np.array_equal(got[r]["agg_p"], got[0]["agg_p"]) and np.array_equal(got[r]["agg_i"], got[0]["agg_i"])
+        vox = ref_agg_p.size
+        sl = slice(r * vox // world, (r + 1) * vox // world)
+        assert np.array_equal(got[r]["rs_p"].ravel()[sl], got[0]["agg_p"].ravel()[sl])
+        assert np.array_equal(got[r]["rs_i"].ravel()[sl], got[0]["agg_i"].ravel()[sl])
