@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_gpu_exchange_through_p2p_transport():
-    world, n_foci = 2, 3
+@pytest.mark.parametrize("world,n_foci", [(2, 3), (3, 4)])
+def test_ranks_on_one_gpu_exchange_through_p2p_transport(world, n_foci):
     with tempfile.TemporaryDirectory(prefix="olx_p2p_") as tmp:
         env = dict(os.environ)
         env.pop("OLX_FIELD_VARIANT", None)
