@@ -30,18 +30,26 @@ namespace olx {
 // few cache lines.  Table entry (tile, e) = { x, y, z, kfirst, klast, 0, 0, 0, (w_f, phi_f) f < NF } with kfirst /
 // klast = first / last plane index strictly above / below the element (bit-cast ints, decided on the host in fp64).
 // ------------------------------------------------------------------------------------
+typedef float het_f2_t __attribute__((ext_vector_type(2)));
+typedef float het_f4u_t __attribute__((ext_vector_type(4), aligned(16)));
+// (every cell carries its own 2 x 2 stencil with the border already folded in, so u = n - 1 is a valid cell with weight 0; the plane
+// base is wave-uniform -- scalar registers -- and the lane adds a 32-bit byte offset: a plane of stencils, 32 bytes per cell, stays far
+// below 4 GiB for any lateral grid that fits the volumes themselves)
 __device__ __forceinline__ void hetero_sample(const float4* __restrict__ plane, float tt, float dxu, float dyv, float eu, float ev,
                                               float umax, float vmax, int nyg, float& ss, float& as) {
-    const float u = fminf(fmaxf(fmaf(tt, dxu, eu), 0.f), umax);   // border values extend outwards
-    const float v = fminf(fmaxf(fmaf(tt, dyv, ev), 0.f), vmax);
-    const int i0 = (int)u, j0 = (int)v;
-    const float fu = u - (float)i0, fv = v - (float)j0;
-    const float4* tx = plane + ((size_t)i0 * nyg + j0) * 2;
-    const float4 lo = tx[0], hi = tx[1];     // {s00,a00,s01,a01}, {s10,a10,s11,a11}
-    const float s0 = fmaf(fv, lo.z - lo.x, lo.x), a0 = fmaf(fv, lo.w - lo.y, lo.y);
-    const float s1 = fmaf(fv, hi.z - hi.x, hi.x), a1 = fmaf(fv, hi.w - hi.y, hi.y);
-    ss += fmaf(fu, s1 - s0, s0);
-    as += fmaf(fu, a1 - a0, a0);
+    const float u = __builtin_amdgcn_fmed3f(fmaf(tt, dxu, eu), 0.f, umax);   // border values extend outwards
+    const float v = __builtin_amdgcn_fmed3f(fmaf(tt, dyv, ev), 0.f, vmax);
+    const unsigned i0 = (unsigned)(int)u, j0 = (unsigned)(int)v;
+    const float fu = __builtin_amdgcn_fractf(u), fv = __builtin_amdgcn_fractf(v);
+    const unsigned off = (__umul24(i0, (unsigned)nyg) + j0) << 5;            // 32 bytes per cell
+    const char* base = reinterpret_cast<const char*>(plane);
+    const het_f4u_t lo = *reinterpret_cast<const het_f4u_t*>(base + off), hi = *reinterpret_cast<const het_f4u_t*>(base + off + 16);
+    // {s00,a00,s01,a01}, {s10,a10,s11,a11}: the (s, a) pairs interpolate in packed fp32
+    const het_f2_t l0 = {lo.x, lo.y}, l1 = {lo.z, lo.w}, h0 = {hi.x, hi.y}, h1 = {hi.z, hi.w};
+    const het_f2_t c0 = fv * (l1 - l0) + l0, c1 = fv * (h1 - h0) + h0;
+    const het_f2_t sa = fu * (c1 - c0) + c0;
+    ss += sa.x;
+    as += sa.y;
 }
 
 template <int ZPL, int NF, bool CLAMP, bool LAYERS>
