@@ -74,6 +74,37 @@ def test_c2_matrix_array_128cubed(ctx):
     check(ctx, *centred_grid(128, 0.5), pos_m, area, d, a, want_variant="flat,noclamp")
 
 
+def test_rayleigh_integral_of_a_circular_piston_on_the_device(ctx):
+    """A baffled circular piston (10 mm radius, 5185 sources of 0.25 mm, unfocused) through the HIP path: the on-axis |p| follows the closed
+    form 2 P0 |sin(k/2 (sqrt(z^2 + a^2) - z))| -- nulls, maxima, 1 / z tail -- to 0.5 % of its peak, and the fp64 oracle to 1e-5.  The
+    physics anchor of tests/test_oracle_field.py, on the device (the lattice is symmetric: a table kernel takes it, the per-pair kernel
+    is checked beside it)."""
+    from test_oracle_field import disc_sources, piston_on_axis
+    a = 10e-3
+    pos_m, area = disc_sources(a, 0.25e-3)
+    n = len(pos_m)
+    ctx.set_elements(pos_m, np.tile([0.0, 0.0, 1.0], (n, 1)), area)
+    ctx.set_steering(np.zeros((1, n)), np.ones((1, n)))
+    xs = ys = np.array([-0.5e-3, 0.0, 0.5e-3]); zs = np.linspace(4e-3, 80e-3, 153)
+    h = (0.5e-3,) * 3
+    exact = piston_on_axis(zs, a, P0)
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, np.zeros(n), np.ones(n), F0, C, P0, dmin=0.5 * h[0]))
+    seen = []
+    for variant in (None, "general"):
+        if variant:
+            os.environ["OLX_FIELD_VARIANT"] = variant
+        try:
+            ctx.field_plan((xs[0], ys[0], zs[0]), h, (3, 3, 153), F0, C, RHO, P0, flags=nat.OUT_PMAG)
+        finally:
+            os.environ.pop("OLX_FIELD_VARIANT", None)
+        seen.append(ctx.field_variant())
+        ctx.field_launch()
+        got = ctx.field_fetch(0, want=("pmag",))["pmag"]
+        assert np.abs(got - ref).max() <= TOL_P * ref.max(), seen[-1]
+        assert np.abs(got[1, 1] - exact).max() < 0.005 * 2 * P0, seen[-1]
+    assert "field_accum_k" in seen[1], seen
+
+
 def test_jittered_tilted_elements_general_variant(ctx):
     pos, ori, size = synthetic_array(16, 16, 3.0, jitter=True)
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, [[3e-3, -2e-3, 35e-3]], apod=("piecewise", 60.0, 20.0))
