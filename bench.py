@@ -201,6 +201,54 @@ def static_traffic(kernel_name: str, grid_n: int):
     return None, None
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N ...` without a launcher around it: start N fresh rank processes of this same command line
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would, one device each), relay rank 0's
+    JSON line, return the worst exit code.  The parent never imports the package and never touches HIP; children are started with
+    subprocess (never exec'd over a process that holds a GPU) and, when one of them fails, the others get a grace period to reach
+    their own error handling before they are terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL and the p2p transport both need it on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    import threading
+    box = []
+    reader = threading.Thread(target=lambda: box.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints the one JSON line
+    reader.start()
+    grace_until = None                         # set when the first rank fails: the others get 60 s to fail on their own
+    while any(p.poll() is None for p in procs):
+        if grace_until is None and any(p.poll() not in (None, 0) for p in procs):
+            grace_until = time.time() + 60.0
+        if grace_until is not None and time.time() > grace_until:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()              # (by PID: these are our own children)
+            t_kill = time.time() + 10.0
+            while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write((box[0] if box else b"").decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print(f"bench launcher: rank exit codes {rcs}", file=sys.stderr)
+        return max(min(abs(rc), 255) for rc in bad)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,12 +286,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the post-timing legs (other correction mode, parity, calc_solution)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher (it has not imported the package or touched HIP)
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     reassemble = args.reassemble or ("allgather" if world > 1 else "none")
 
@@ -437,6 +486,10 @@ def main():
     if res is None:
         sys.exit(f"bench: the accumulate itself failed: {timed.last_error}")
     elapsed, kern_ms = res
+    try:
+        ranks_seen = ctx.comm_ranks_seen() if gather else 0     # what RCCL / the p2p control block counted (0: no exchange ran)
+    except Exception:  # noqa: BLE001
+        ranks_seen = -1
     kernel_name = ctx.field_variant()
     k_ms = float(np.mean(kern_ms))
     F_total = F * world if skull is None else F   # slab mode: the same F foci on every rank's slab
@@ -488,6 +541,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if skull is None else "strong", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
+            # which exchange `value` includes: the scaling claim of this line (the other modes are reported beside it in `config`)
+            "scaling_claim": mode if gather else "none",
+            "n_ranks_rendezvous": world, "n_ranks_seen": ranks_seen if gather else world,
+            "n_ranks_seen_by": (f"{transport} communicator" if gather else "process launcher (no exchange in the timed step)"),
             "config": {"workload": f"{N}-element {args.elements} matrix array x {args.grid}^3 grid "
                                    f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
                                    f"(BASELINE configs[2] shard, planned by openlifu_amd.dist.plan_foci_orbits), |p|+intensity out"

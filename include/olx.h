@@ -349,8 +349,17 @@ int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weight
  *                   with all of them.  The aggregate exchanges take the same road: rank r owns slice r of the volume, pulls
  *                   that slice of every peer's partial, reduces in rank order (same bits on every rank) and -- all-reduce --
  *                   the ranks pull each other's reduced slices.
- * olx_comm_transport names what this context uses ("rccl", "p2p", "" before olx_comm_init). */
+ * olx_comm_transport names what this context uses ("rccl", "p2p", "" before olx_comm_init).
+ * Lifetime rules of the p2p transport: a rank's output and aggregate blocks are mapped by its peers, so every call that frees or
+ * rewrites them in place (a larger olx_field_plan, olx_field_upload, olx_field_scale*, the fused olx_solution_analyze,
+ * olx_comm_destroy / olx_ctx_destroy) first waits until every peer has finished the pulls it owes.  Any wait gives up after
+ * OLX_P2P_TIMEOUT_S seconds (default 60) and raises an abort flag shared by all ranks: after ANY call has returned OLX_ECOMM the
+ * communicator is dead on every rank -- olx_comm_destroy it and build a new one (olx_comm_unique_id / olx_comm_init); the context,
+ * its plan and its resident volumes stay usable.
+ * olx_comm_ranks_seen = the number of ranks the transport itself has counted (ncclCommCount; ranks attached to the p2p control
+ * block), 0 without a communicator -- what a launcher prints to prove how many ranks really met. */
 #define OLX_P2P_BLOB_BYTES 384
+int olx_comm_ranks_seen(olx_ctx *ctx);
 int olx_comm_export(olx_ctx *ctx, void *blob_out);
 int olx_comm_import(olx_ctx *ctx, const void *blobs);
 const char *olx_comm_transport(const olx_ctx *ctx);

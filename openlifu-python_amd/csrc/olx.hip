@@ -96,6 +96,25 @@ static int aggregate_buffers_free(olx_ctx* c) {
     return OLX_OK;
 }
 
+// p2p transport: this rank's output blocks (both buffers) and aggregate buffers are IPC-mapped by its peers, which pull from them on
+// their OWN worker threads.  olx_sync / olx_p2p_drain only wait for this rank's pulls; before an exported buffer is FREED (a larger
+// plan, an upload, the end of the communicator) or rewritten IN PLACE (scale, the fused post-pass) every peer must have finished the
+// pulls it still owes: pulled[r][me] of the generation that last sat in the buffer, agg_done[r] of the last aggregate exchange.
+// `buf` = one output buffer, or -1 = both output buffers and the aggregate buffers.  A failed wait (peer timed out / aborted) clears
+// the pending mark all the same -- the communicator is unusable after OLX_ECOMM (include/olx.h), the buffers are not.
+static int exported_buffers_quiesce(olx_ctx* c, int buf) {
+    if (!c->p2p) return OLX_OK;
+    int rc = OLX_OK;
+    for (int b = 0; b < olx_ctx::NBUF; ++b) {
+        if ((buf >= 0 && b != buf) || !c->gather_pending[b]) continue;
+        const int r = olx_p2p_before_overwrite(c, b);
+        c->gather_pending[b] = false;
+        if (r && !rc) rc = r;
+    }
+    if (buf < 0) { const int r = olx_p2p_aggregate_before_overwrite(c); if (r && !rc) rc = r; }
+    return rc;
+}
+
 // ---- element table ---------------------------------------------------------------------
 int olx_set_elements(olx_ctx* c, const double* pos_m, const double* normal, const double* area_m2, int n) {
     if (!c) return OLX_EINVAL;
@@ -1013,6 +1032,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     c->nbuf = c->comm_active() ? olx_ctx::NBUF : 1;
     // outputs
     if (c->out_cap < total || (c->nbuf == 2 && !c->d_pmag[1])) {
+        { int rc_ = exported_buffers_quiesce(c, -1); if (rc_) return rc_; }   // (p2p: peers may still be pulling from the blocks freed here)
         for (float** p : {&c->d_pmag[0], &c->d_pmag[1], &c->d_inten, &c->d_cplx, &c->d_agg_p, &c->d_agg_i}) { if (*p) hipFree(*p); *p = nullptr; }
         c->out_cap = 0;
     }
@@ -1154,7 +1174,7 @@ int olx_field_launch(olx_ctx* c) {
     if (rc) return rc;
     const int b = (c->nbuf == 2) ? (c->cur ^ 1) : 0;
     if (c->gather_pending[b]) {  // the gather that read this buffer must be done before we overwrite it
-        if (c->p2p) { rc = olx_p2p_before_overwrite(c, b); if (rc) return rc; }   // ... on EVERY rank that pulls from it
+        if (c->p2p) { rc = olx_p2p_before_overwrite(c, b); if (rc) { c->gather_pending[b] = false; return rc; } }   // ... on EVERY rank that pulls from it
         else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[b], 0));
         c->gather_pending[b] = false;
     }
@@ -1560,6 +1580,7 @@ int olx_field_upload(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const long long vox = (long long)s.x_count * g->n[1] * g->n[2];
     const size_t total = (size_t)vox * n_foci;
+    { int rc_ = exported_buffers_quiesce(c, -1); if (rc_) return rc_; }   // (p2p: buffer 0 is rewritten, all of them may be freed)
     if (c->out_cap < total) {
         for (float** p : {&c->d_pmag[0], &c->d_pmag[1], &c->d_inten, &c->d_cplx, &c->d_agg_p, &c->d_agg_i}) { if (*p) hipFree(*p); *p = nullptr; }
         c->out_cap = 0;
@@ -1628,6 +1649,8 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
     if (kernel == OLX_SCAN_FUSED_POST && (c->plan_foci > SAA_MAXF || (c->fp.nz & 3) || c->fp.vox >= (1ll << 33))) return fail(c, OLX_ESTATE, "olx_scan_time: the fused pass needs <= 8 foci and nz %% 4 == 0");
     if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_scan_time: intensity not planned");
     HIPCHK(c, hipSetDevice(c->device));
+    if (kernel == OLX_SCAN_SCALE || kernel == OLX_SCAN_FUSED_POST) { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }
+    if (kernel == OLX_SCAN_AGGREGATE || kernel == OLX_SCAN_FUSED_POST) { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
     const int F = c->plan_foci;
     const double vox = (double)c->fp.vox;
     struct Events {
@@ -1766,6 +1789,7 @@ int olx_field_scale(olx_ctx* c, const double* scale, int n_foci) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
     if (n_foci > 4096) return fail(c, OLX_EINVAL, "olx_field_scale: too many foci");
+    { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }   // (p2p: no peer may pull a half-scaled block)
     std::vector<float> s(n_foci);
     for (int i = 0; i < n_foci; ++i) s[i] = (float)scale[i];
     HIPCHK(c, hipMemcpyAsync(c->d_scale, s.data(), sizeof(float) * n_foci, hipMemcpyHostToDevice, c->stream));
@@ -1792,6 +1816,7 @@ int olx_field_scale_aggregate(olx_ctx* c, const double* scale, int n_foci) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_scale) HIPCHK(c, hipMalloc((void**)&c->d_scale, sizeof(float) * 4096));
+    { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }   // (p2p: the volumes are scaled in place)
     { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
     if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
     if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
@@ -2120,6 +2145,7 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     const bool fused = scale_per_focus && quad && F <= SAA_MAXF && !(c->flags & OLX_OUT_COMPLEX);
     if (scale_per_focus && !fused) { int rc = olx_field_scale_aggregate(c, scale_per_focus, F); if (rc) return rc; }
     if (fused) {
+        { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }   // (p2p: the fused pass scales the volumes in place)
         { int rc_ = aggregate_buffers_free(c); if (rc_) return rc_; }
         if (!c->d_agg_p) HIPCHK(c, hipMalloc((void**)&c->d_agg_p, sizeof(float) * c->out_cap));
         if (!c->d_agg_i) HIPCHK(c, hipMalloc((void**)&c->d_agg_i, sizeof(float) * c->out_cap));
@@ -2201,6 +2227,7 @@ static int load_rccl(olx_ctx* c) {
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclAllReduce");
     r.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, olx_nccl_comm, hipStream_t))dlsym(r.handle, "ncclReduceScatter");  // optional
+    r.CommCount = (int (*)(olx_nccl_comm, int*))dlsym(r.handle, "ncclCommCount");  // optional
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail(c, OLX_ECOMM, "RCCL symbols missing");
     Dl_info info;
@@ -2264,7 +2291,11 @@ int olx_comm_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
 
 int olx_comm_destroy(olx_ctx* c) {
     if (!c) return OLX_EINVAL;
-    if (c->p2p) { hipSetDevice(c->device); olx_p2p_destroy(c); }
+    if (c->p2p) {   // (the peers' mappings of this rank's blocks outlive the communicator only until the blocks are freed: wait for their pulls first;
+        hipSetDevice(c->device);                    // best effort -- a peer that is gone shows up as a timeout, and the teardown goes on)
+        (void)exported_buffers_quiesce(c, -1);
+        olx_p2p_destroy(c);
+    }
     if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
     if (c->comm) { c->rccl.CommDestroy(c->comm); c->comm = nullptr; }
     for (int b = 0; b < olx_ctx::NBUF; ++b) {
@@ -2292,6 +2323,12 @@ int olx_comm_import(olx_ctx* c, const void* blobs) {
     return olx_p2p_import(c, blobs);
 }
 const char* olx_comm_transport(const olx_ctx* c) { return !c ? "" : c->p2p ? "p2p" : c->comm ? "rccl" : ""; }
+int olx_comm_ranks_seen(olx_ctx* c) {
+    if (!c) return OLX_EINVAL;
+    if (c->p2p) return olx_p2p_attached(c);
+    if (c->comm && c->rccl.CommCount) { int n = 0; NCCLCHK(c, c->rccl.CommCount(c->comm, &n)); return n; }
+    return c->comm ? c->nranks : 0;
+}
 
 int olx_field_allgather(olx_ctx* c) {
     if (!c) return OLX_EINVAL;

@@ -26,6 +26,7 @@ struct RcclApi {
     int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t /*recvcount*/, int /*dtype*/, int /*op*/, olx_nccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(olx_nccl_comm, int*) = nullptr;
 };
 static constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
 static constexpr int kNcclSum = 0, kNcclMax = 2;  // ncclRedOp_t
@@ -134,6 +135,7 @@ bool olx_p2p_is_id(const void* id_bytes);
 int olx_p2p_unique_id(olx_ctx* c, void* id_bytes);
 int olx_p2p_init(olx_ctx* c, const void* id_bytes, int nranks, int rank);
 int olx_p2p_destroy(olx_ctx* c);
+int olx_p2p_attached(olx_ctx* c);                          // ranks that have attached to the control block
 int olx_p2p_export(olx_ctx* c, void* blob_out);
 int olx_p2p_import(olx_ctx* c, const void* blobs);
 int olx_p2p_allgather(olx_ctx* c);

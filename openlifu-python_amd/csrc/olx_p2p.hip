@@ -278,10 +278,13 @@ int olx_p2p_init(olx_ctx* c, const void* id_bytes, int nranks, int rank) {
     s->nranks = nranks; s->rank = rank;
     if (const char* t = getenv("OLX_P2P_TIMEOUT_S")) { const double v = atof(t); if (v > 0) s->timeout_s = v; }
     for (int r = 0; r < nranks; ++r) HIPCHK(c, hipStreamCreateWithFlags(&s->copy_stream[r], hipStreamNonBlocking));
-    s->ctl->attached.fetch_add(1);
+    // the last rank to attach removes the NAME: the mappings stay valid, and a rank 0 that dies later cannot leak /dev/shm/olx_p2p_*
+    if (s->ctl->attached.fetch_add(1) + 1 == (uint32_t)nranks) shm_unlink(s->shm_name.c_str());
     s->worker = std::thread(p2p_worker, c);
     return OLX_OK;
 }
+
+int olx_p2p_attached(olx_ctx* c) { return (c->p2p && c->p2p->ctl) ? (int)c->p2p->ctl->attached.load() : 0; }
 
 static void p2p_close_peers(P2PState* s) {
     for (int r = 0; r < P2P_MAX_RANKS; ++r)
@@ -320,7 +323,7 @@ int olx_p2p_destroy(olx_ctx* c) {
     for (int r = 0; r < P2P_MAX_RANKS; ++r) if (s->copy_stream[r]) hipStreamDestroy(s->copy_stream[r]);
     if (s->agg_scratch) hipFree(s->agg_scratch);
     if (s->ctl) munmap(s->ctl, sizeof(P2PControl));
-    if (s->owner) shm_unlink(s->shm_name.c_str());
+    if (s->owner) shm_unlink(s->shm_name.c_str());      // (already gone when every rank attached: ENOENT is fine)
     delete s;
     c->p2p = nullptr;
     return OLX_OK;

@@ -35,7 +35,7 @@ SYMBOLS = [
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
     "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
-    "olx_field_scale_aggregate", "olx_field_absorption",
+    "olx_field_scale_aggregate", "olx_field_absorption", "olx_comm_ranks_seen",
 ]
 
 
@@ -126,6 +126,7 @@ def load(require_gpu: bool = True):
         lib.olx_comm_export.argtypes = [vp, vp]
         lib.olx_comm_import.argtypes = [vp, vp]
         lib.olx_comm_transport.argtypes = [vp]; lib.olx_comm_transport.restype = c_char_p
+        lib.olx_comm_ranks_seen.argtypes = [vp]
         lib.olx_scan_time.argtypes = [vp, c_int, c_int, fp, dp]
         lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), dp, POINTER(OlxFocusReport), fp]
         _lib = lib
@@ -370,6 +371,8 @@ class Context:
 
     def scan_time(self, kernel: str, iters: int = 20):
         """(ms per launch [iters], algorithmic bytes per launch) of one streaming scan over the resident result."""
+        if kernel in ("aggregate", "fused_post"):      # these rewrite the aggregate buffers: lazily handed-out aggregates are read first
+            self._aggregate_overwrite()
         ms = np.empty(int(iters), dtype=np.float32)
         nbytes = c_double(0)
         self._chk(self._lib.olx_scan_time(self._h, self.SCANS[kernel], int(iters), _fptr(ms), ctypes.byref(nbytes)))
@@ -533,6 +536,13 @@ class Context:
     def comm_transport(self) -> str:
         v = self._lib.olx_comm_transport(self._h)
         return v.decode() if v else ""
+
+    def comm_ranks_seen(self) -> int:
+        """Ranks the transport itself has counted (ncclCommCount / ranks attached to the p2p control block); 0 without a communicator."""
+        n = self._lib.olx_comm_ranks_seen(self._h)
+        if n < 0:
+            self._chk(n)
+        return int(n)
 
     def comm_export(self) -> bytes:
         """p2p transport: IPC handles of this rank's output blocks (after every field_plan)."""

@@ -197,8 +197,15 @@ class Engine:
         (olx_field_absorption).  ``lazy=True`` returns a ``DeviceResult`` instead: the volumes
         stay in HBM until somebody reads them."""
         self.retire_results()
-        if not steering_resident:        # (resident steering came from beamform(arr, ...) an instant ago: same table, bound there)
-            self.bind(arr)
+        # (bind compares the element table with the resident one and uploads on a difference -- also with resident steering: a
+        # caller may hand over another transducer, or the same one with edited elements, than the last beamform() bound)
+        n_before, key_before = self.ctx.n_el, self._table_key
+        self.bind(arr)
+        if steering_resident:
+            if self._table_key != key_before or self.ctx.n_el != n_before:
+                raise ValueError("steering_resident=True, but the transducer differs from the one the resident steering table was solved for "
+                                 "(call beamform(arr, ...) again, or pass delays / apod)")
+        else:
             self.ctx.set_steering(delays, apod)
         flags = nat.OUT_PMAG
         if "intensity" in want:

@@ -85,6 +85,19 @@ d, a = eng.beamform(arr, foci, C)
 res["slabs"] = sf.sweep_slabs(arr, d, a, origin, spacing, n, F0, C, RHO, P0)
 sf.step("allgather"); sf.step("allgather")
 res["slabs_again"] = sf.fetch_all()
+# a rank that re-plans to a LARGER grid right after its own fetch, while a slower peer has not pulled that step yet: the plan frees
+# the exported blocks, so it has to wait for the peers' pulls first (use-after-free of an IPC mapping otherwise)
+time.sleep(0.5 * rank)
+sf.step("allgather")
+res["slabs_skewed"] = sf.fetch_all()
+n2 = (n[0] + 4, n[1] + 4, n[2] + 4)
+origin2 = (-(n2[0] - 1) / 2 * spacing[0], -(n2[1] - 1) / 2 * spacing[1], 5e-3)
+res["big"] = sf.sweep_slabs(arr, d, a, origin2, spacing, n2, F0, C, RHO, P0)
+# ... and a rank that scales its volumes in place while the peer is late with its pull: no half-scaled block may travel
+time.sleep(0.3 * (world - 1 - rank))
+sf.step("allgather")
+eng.ctx.field_scale(np.full(eng.ctx.n_foci, 2.0))
+res["big_after_scale"] = sf.fetch_all()
 np.savez(os.path.join(tmp, f"out_{rank}.npz"), **res)
 sf.close()
 print(f"rank {rank}: ok", flush=True)

@@ -93,3 +93,24 @@ def test_world_size_2_gloo_reassembly():
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_launcher_starts_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` without a launcher around it becomes the launcher: it starts the ranks itself (fresh children with
+    RANK / WORLD_SIZE / MASTER_* set) and returns their worst exit code instead of hanging.  Here (no GPU) every rank fails when it
+    asks for its device: the parent must come back non-zero, promptly, with nothing on stdout."""
+    import subprocess
+    import time
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    from openlifu_amd import _native
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible: the launcher is exercised for real by tests/test_gpu_p2p.py")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-seconds", "0"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert "bench launcher: rank exit codes" in p.stderr
+    assert time.time() - t0 < 240

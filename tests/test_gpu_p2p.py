@@ -77,6 +77,19 @@ def test_ranks_on_one_gpu_exchange_through_p2p_transport(world, n_foci):
     exp_slabs = od.assemble_slabs(np.stack(blocks), n[0])
     for exp in (exp_foci, exp_slabs):
         assert np.abs(exp - ref).max() <= 5e-6 * ref.max()
+    # the larger grid the ranks re-plan to at the end (one of them while its peer still owes a pull of the previous step)
+    n2 = (n[0] + 4, n[1] + 4, n[2] + 4)
+    origin2 = (-(n2[0] - 1) / 2 * spacing[0], -(n2[1] - 1) / 2 * spacing[1], 5e-3)
+    blocks = []
+    for r in range(world):
+        sf = od.ShardedField(eng, world, r)
+        sf.plan_slab_sweep(arr, d, a, origin2, spacing, n2, F0, C, RHO, P0)
+        blocks.append(local_blocks())
+    exp_big = od.assemble_slabs(np.stack(blocks), n2[0])
+    for r in range(world):
+        assert np.array_equal(got[r]["slabs_skewed"], exp_slabs), r
+        assert np.array_equal(got[r]["big"], exp_big), (r, float(np.abs(got[r]["big"] - exp_big).max()))
+        assert np.array_equal(got[r]["big_after_scale"], exp_big), r       # gathered BEFORE the in-place scaling touched the block
     for r in range(world):
         for key, exp in (("foci", exp_foci), ("foci_again", exp_foci), ("foci_skewed", exp_foci), ("slabs", exp_slabs), ("slabs_again", exp_slabs)):
             assert got[r][key].shape == ref.shape, (r, key)
@@ -90,3 +103,23 @@ def test_ranks_on_one_gpu_exchange_through_p2p_transport(world, n_foci):
         sl = slice(r * vox // world, (r + 1) * vox // world)
         assert np.array_equal(got[r]["rs_p"].ravel()[sl], got[0]["agg_p"].ravel()[sl])
         assert np.array_equal(got[r]["rs_i"].ravel()[sl], got[0]["agg_i"].ravel()[sl])
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` as typed (no torch.distributed.run around it): the parent starts the two ranks itself, both on
+    device 0 (RCCL refuses that, the p2p transport takes the exchange), relays rank 0's ONE JSON line and exits 0."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OLX_FIELD_VARIANT"):
+        env.pop(k, None)
+    env["OLX_P2P_TIMEOUT_S"] = "60"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "0", "--gather", "p2p", "--steps", "5", "--warmup", "2",
+                        "--grid", "128", "--spacing-mm", "0.5", "--no-extras", "--cpu-seconds", "0"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert out["scaling_claim"] == "allgather" and out["n_ranks_seen"] == 2 and "p2p" in out["n_ranks_seen_by"]
+    assert out["config"]["reassembly"].startswith("p2p-allgather")
