@@ -47,11 +47,22 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 
 // PERSIST: the grid is two blocks per CU and a block walks the records blockIdx.x, blockIdx.x + gridDim.x, ... (n_items of them);
 // `stagger` [cycles] delays the second block of each CU once, so that the two do not run their phases in lockstep.
-template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false>
+// GT (developer library only, OLX_GTABLE=1: measured SLOWER): every table pair BUT THE FIRST is not evaluated here but copied
+// out of the plan's precomputed table (k_gtable.hip: the same words, evaluated once per plan -- they depend on array, grid and frequency only):
+// 12 eight-byte loads per lane and pair, requested a whole pair ahead (the second pair's at block entry, behind the steering loads; 90 + 26
+// VGPRs) and written to LDS where the tables used to be evaluated: no transcendental and ~190 fewer vector instructions per lane and pair.
+// The FIRST pair stays evaluated: a block has nothing to overlap its loads with.  Round 4, same box, alternating (profiles/r04_gtable_*):
+// all pairs copied 0.53 vs 0.45 ms (fp16), 0.55 vs 0.39 (fp8, copies at the point of use) although only 226 MB reach HBM (the 4 blocks that
+// share a table class sit on one XCD: L2 serves 3 of them); this hybrid form 0.484 vs 0.453 -- the copied pair's phase gets 1.6 k cycles
+// shorter and every OTHER phase of the wave longer (first tables + 0.5 k, barrier + 0.5 k, K-steps + 0.5 k, stores + 0.8 k: 96 more
+// vector-memory instructions per block and pair in a pipe the two resident blocks' stores already fill), 38.4 k instead of 36.2 k per wave.
+template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
-    const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger) {
+    const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger,
+    const GtEntry* __restrict__ gtab = nullptr) {
+    static_assert(!(GT && (FP8 || DIR || PERSIST)), "the table-fed form exists for the default arithmetic only");
     constexpr int NT = 2, THREADS = COS_NW * 64;
     constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
     constexpr int B_BYTES = 2 * 4 * NT * 2 * 64 * 16;                           // two super-blocks of steering fragments
@@ -114,6 +125,47 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         const int idx = tid + q * THREADS;
         pre[q] = idx < n_sb * 4 * NT * 128 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
     }
+    // GT: this lane's 12 entries of a pair's tables -- planes k0 + 2 wave + z, rows RPR r + wl, column q (lane = 12 wl + q; lanes 60 .. 63 idle)
+    GtEntry gpre[GT ? NROUND * COS_P : 1];
+    [[maybe_unused]] const bool gt_planes = k0 + wave * COS_P < P.nz;
+    [[maybe_unused]] auto gt_request = [&](int sb, auto r0_c, auto r1_c) {      // rounds [r0, r1) of the pair that starts at super-block sb
+        constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
+        if constexpr (GT) {
+            const int sa_n = sb / nsbp, sbb_n = sb - sa_n * nsbp;
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int wl = lane_o / CP_UW, q = lane_o - CP_UW * wl;
+            const long long ps = (long long)P.gt_nw * P.gt_nu;
+            const GtEntry* src = gtab + ((long long)BK.gt_off + (long long)(k0 + wave * COS_P) * ps + (long long)(8 * sa_n - 8 * sbb_n * P.gt_nu));   // wave-uniform
+            const int lo = wl * P.gt_nu + q;
+#pragma unroll
+            for (int r = R0; r < R1; ++r)
+#pragma unroll
+                for (int z = 0; z < COS_P; ++z)
+                    if (gt_planes && wl < RPR && RPR * r + wl < CP_TROWS) gpre[(r - R0) * COS_P + z] = src[(long long)z * ps + RPR * r * P.gt_nu + lo];
+        }
+    };
+    [[maybe_unused]] auto gt_to_lds = [&](auto r0_c, auto r1_c) {
+        constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
+        if constexpr (GT) {
+            if (gt_planes) {
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const int wl = lane_o / CP_UW, q = lane_o - CP_UW * wl;
+                const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + q;
+#pragma unroll
+                for (int r = R0; r < R1; ++r)
+#pragma unroll
+                    for (int z = 0; z < COS_P; ++z)
+                        if (wl < RPR && RPR * r + wl < CP_TROWS) {
+                            const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
+                            s_hi[o] = gpre[(r - R0) * COS_P + z].hi;
+                            s_lo[o] = gpre[(r - R0) * COS_P + z].lo;
+                        }
+            }
+        }
+    };
+    if constexpr (GT) { if (n_sb > 2) gt_request(2, IntC<0>{}, IntC<NROUND>{}); }      // second pair: in flight during the first pair's evaluation and K-steps
     OLX_STAMP(0);
     for (int sb0 = 0; sb0 < n_sb; sb0 += 2) {
         const int sa = sb0 / nsbp, sbb0 = sb0 - sa * nsbp;       // the pair (sa, sbb0), (sa, sbb0 + 1)
@@ -121,9 +173,13 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         // __syncthreads() drains vmcnt -- the wave would wait for its first steering loads before the tables instead of behind them.)
         if (sb0 > 0) __syncthreads();
         if (sb0 == 0) OLX_STAMP(1);
+        if (sb0 == 2) OLX_STAMP(7);
         // ---- G tables of planes 2 wave, 2 wave + 1: 26 rows x 12 offsets, shared by the pair's two super-blocks
         // (fp8 shape: table generation at raised priority -- the waves a block's K-steps wait for get the VALU first: -2 ... -4 %;
         // with fp16 corrections the matrix pipe is the scarcer resource and the same setting costs 1.5 %, priority on the K-steps 2.5 %)
+        if (GT && sb0 > 0) {
+            gt_to_lds(IntC<0>{}, IntC<NROUND>{});
+        } else {
         if constexpr (FP8) __builtin_amdgcn_s_setprio(1);
         if (k0 + wave * COS_P < P.nz) {
             int lane_o = lane;
@@ -187,6 +243,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             }
         }
         if constexpr (FP8) __builtin_amdgcn_s_setprio(0);
+        }
         // this pair's steering fragments (requested one pair ahead; the first ones arrive behind the table generation above)
 #pragma unroll
         for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
@@ -200,6 +257,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 const int idx = nxt + tid + q * THREADS;
                 if (idx < lim) pre[q] = bsrc[idx];
             }
+            if constexpr (GT) { if (sb0 > 0 && sb0 + 2 < n_sb) gt_request(sb0 + 2, IntC<0>{}, IntC<NROUND>{}); }   // next pair's table entries (the second pair's are in flight since block entry)
         }
 #pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
         for (int sl = 0; sl < 2; ++sl) {
@@ -407,10 +465,18 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     int pgrid = std::min(2 * c->n_cu, n_items);
     if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
     dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger)
+#define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger, (const GtEntry*)nullptr)
+#ifdef OLX_AB_VARIANTS   // kernel 2g fed from a precomputed geometry table (OLX_GTABLE=1): measured slower, developer library only
+    if (c->use_gtable && !c->dir_lattice && !persist) {
+#define OLX_CPG(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, c->d_gtab)
+        if (clamp) OLX_CPG(true, false); else OLX_CPG(false, false);      // (fp16 corrections: the planner does not select the table for the e4m3 shape)
+#undef OLX_CPG
+        return;
+    }
+#endif
     if (c->dir_lattice) {   // piston directivity folded into the geometry tables (fp16 corrections only)
-        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0);
-        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0);
+        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
+        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
         return;
     }
 #ifdef OLX_AB_VARIANTS   // the persistent grid (OLX_FIELD_VARIANT=cosetpp): measured slower, developer library only

@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -69,7 +70,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks};
+                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks, c->d_gtab};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -481,7 +482,7 @@ static int configure_variant(olx_ctx* c) {
     const int nm = c->dx * c->dy;
     c->nf = 1;
     if (c->allow_shared) while (c->nf * 2 <= F && c->nf * 2 * nm <= 8) c->nf *= 2;
-    char nmbuf[256];
+    char nmbuf[384];
     // kernel 2d applies when the array is a lattice commensurate with the grid and the pitch-strided row tiles
     // (4 rows x pitch) do not overhang the computed region by more than 2x per axis
     auto tile_fill = [](int width, int m) { const int blk = 4 * m; return (double)width / (double)(((width + blk - 1) / blk) * blk); };
@@ -570,6 +571,7 @@ static int configure_variant(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
+        c->use_gtable = false;
         c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
@@ -765,6 +767,14 @@ static int configure_variant(olx_ctx* c) {
                     const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
                     std::vector<CosetBlock> blk(nblk);
                     const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
+                    // kernel 2g fed from a precomputed geometry table (k_gtable.hip; developer library, OLX_GTABLE=1 | order0: measured SLOWER than
+                    // the in-kernel generation).  The table offsets of a block all lie in ONE residue class (U mod mx, W mod my);
+                    // the 2 nsx nsy blocks of a plane block that share a class read overlapping windows of it, so they get consecutive ids on one
+                    // XCD (below; not with order0): L2 serves all but one of them.
+                    const char* gte = getenv("OLX_GTABLE");
+                    c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr &&
+                                    Q.nsa * Q.nsbp > 2 && gte && (!strcmp(gte, "1") || !strcmp(gte, "order0"));      // (fp8 shape: no registers for the entries in flight; one pair: nothing to copy)
+                    const bool gt_order = c->use_gtable && strcmp(gte, "order0") != 0;
                     for (unsigned id = 0; id < nblk; ++id) {
                         unsigned b = id;
                         int kblock;
@@ -775,19 +785,54 @@ static int configure_variant(olx_ctx* c) {
                         } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
                         const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
                         const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
-                        const int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
+                        int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
+                        if (gt_order) {      // cosets rx and rx + mx share their table class: neighbours in the id order
+                            const int rxh = (int)(b % 2u); b /= 2u;
+                            ry = (int)(b % (unsigned)Q.my); rx = (int)(b / (unsigned)Q.my) + Q.mx * rxh;
+                        }
                         const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * Q.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
                         const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
                         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
                         CosetBlock& B = blk[id];
                         B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
-                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.pad1 = 0;
+                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.gt_off = 0;
                         if (c->use_cosetq) {   // kernel 2q: tiles are pairs of y-adjacent positions
                             const int KYP = (B.KY + 1) / 2;
                             B.npos = (KX > 0 && KY > 0) ? KX * KYP : 0; B.ky_magic = 65536 / KYP + 1;
                             if (B.npos > 20) return fail(c, OLX_ESTATE, "kernel 2q: a block part holds more than 20 position pairs");
                         } else
                         if (c->use_cosetp && B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
+                    }
+                    if (c->use_gtable) {
+                        // offsets in use: a block's tables hold U = Ub + mx (-q - 8 sa), q = 0 .. 11 (Ub: column 0 of sa = 0) and W = Wb + my (R - 8 sbb),
+                        // R = 0 .. 25 (Wb: row 0 of sbb = 0, the first super-block row of a pair being even: sbb <= nsbp - 2)
+                        long long u_lo = LLONG_MAX, u_hi = LLONG_MIN, w_lo = LLONG_MAX, w_hi = LLONG_MIN;
+                        for (const CosetBlock& B : blk) {
+                            if (B.npos <= 0) continue;
+                            const long long Ub = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx, Wb = (long long)B.jbase + Q.uy0 - 15LL * Q.my;
+                            u_hi = std::max(u_hi, Ub); u_lo = std::min(u_lo, Ub - (11LL + 8LL * (Q.nsa - 1)) * Q.mx);
+                            w_lo = std::min(w_lo, Wb - 8LL * std::max(Q.nsbp - 2, 0) * Q.my); w_hi = std::max(w_hi, Wb + 25LL * Q.my);
+                        }
+                        auto floor_to = [](long long v, long long m) { long long q = v / m; if (q * m > v) --q; return q * m; };
+                        double max_mb = 4096.0;
+                        if (const char* e = getenv("OLX_GTABLE_MAX_MB")) { const double v = atof(e); if (v > 0) max_mb = v; }
+                        if (u_hi < u_lo) c->use_gtable = false;
+                        else {
+                            const long long ulo = floor_to(u_lo, Q.mx), wlo = floor_to(w_lo, Q.my);
+                            const long long nu = (u_hi - ulo) / Q.mx + 1, nw = (w_hi - wlo) / Q.my + 1, nzp = (long long)Q.kblocks * zb;
+                            const long long entries = (long long)Q.mx * Q.my * nzp * nw * nu;
+                            if (entries >= (1LL << 32) || (double)entries * sizeof(GtEntry) > max_mb * 1048576.0 || std::llabs(ulo) > (1LL << 23) || std::llabs(wlo) > (1LL << 23))
+                                c->use_gtable = false;       // (too large to keep: the blocks evaluate their tables themselves)
+                            else {
+                                Q.gt_nu = (int)nu; Q.gt_nw = (int)nw; Q.gt_nzp = (int)nzp; Q.gt_ulo = (int)ulo; Q.gt_wlo = (int)wlo;
+                                for (CosetBlock& B : blk) {
+                                    if (B.npos <= 0) continue;
+                                    const long long du = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx - ulo, dw = (long long)B.jbase + Q.uy0 - 15LL * Q.my - wlo;
+                                    const long long cls = (du % Q.mx) * Q.my + dw % Q.my;
+                                    B.gt_off = (unsigned)(cls * nzp * nw * nu + (dw / Q.my) * nu + (nu - 1 - du / Q.mx));
+                                }
+                            }
+                        }
                     }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);
@@ -930,6 +975,7 @@ static int configure_variant(olx_ctx* c) {
         c->dir_lattice = false; c->allow_shared = false;
         return configure_variant(c);
     }
+    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->use_gtable) strncat(nmbuf, " +precomputed geometry table", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->absorb_np_m > 0 && c->use_mfma) strncat(nmbuf, " +uniform absorption in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     c->variant = nmbuf;
@@ -951,6 +997,9 @@ static int pack_if_needed(olx_ctx* c) {
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
                            (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
+#ifdef OLX_AB_VARIANTS
+        if (c->use_lattice && c->use_cosetp && c->use_gtable) { int rc = olx_gtable_prepare(c); if (rc) return rc; }
+#endif
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -1011,8 +1060,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     {   // Re-planning the SAME launch (same grid, slab, foci count, medium constants, flags, element table, family pins): everything
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
-        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION");
-        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "");
+        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE");
+        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "");
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;

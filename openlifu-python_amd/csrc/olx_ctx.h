@@ -94,6 +94,8 @@ struct olx_ctx {
     bool use_cosetp4 = false;  // kernel 2g's row map with four column tiles (field_cosetp4_k)
     bool use_cosetp32 = false; // kernel 2g in its 32 x 32 x 16 MFMA form (field_cosetp32_k)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
+    // kernel 2g fed from the precomputed geometry table (k_gtable.hip): built once per plan, keyed by the parameters it was evaluated from
+    bool use_gtable = false; GtEntry* d_gtab = nullptr; size_t gtab_cap = 0; std::string gtab_key;
     bool toep_block = true;    // kernel 2f as one block per work item (field_toep_k); false (OLX_FIELD_VARIANT=toepws): persistent field_toepws_k
     bool use_toep = false; int toep_nsa16 = 0; int toep_targets[4] = {-1, -1, -1, -1};
     int* d_cell = nullptr; size_t cell_cap = 0; uint4* d_afrag = nullptr; size_t afrag_cap = 0;

@@ -11,6 +11,7 @@ void olx_launch_mfma(olx_ctx* c, float* pm);         // 2c  field_mfma_k
 void olx_launch_lattice(olx_ctx* c, float* pm);      // 2d  field_lattice_k
 void olx_launch_coset(olx_ctx* c, float* pm);        // 2e  field_coset_k
 void olx_launch_cosetp(olx_ctx* c, float* pm);       // 2g  field_cosetp_k (2e's NT = 2 shape, planes in the MFMA rows)
+int olx_gtable_prepare(olx_ctx* c);                  //     its precomputed geometry table (gtable_gen_k; no-op when the resident table still applies)
 void olx_launch_cosetp4(olx_ctx* c, float* pm);      // 2g  field_cosetp4_k (the same row map with four column tiles: 17 - 32 columns per launch tile)
 void olx_launch_cosetp32(olx_ctx* c, float* pm);     // 2g  field_cosetp32_k (the same with v_mfma_f32_32x32x16_f16: two positions x 16 planes x 32 columns per instruction)
 void olx_launch_cosetq(olx_ctx* c, float* pm);       // 2q  field_cosetq_k (2g in blocks of 4 waves x 8 planes)

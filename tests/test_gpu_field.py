@@ -935,6 +935,55 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
             assert np.array_equal(got[fam][1][f]["intensity"], got[None][1][f]["intensity"]), (fam, f)
 
 
+@pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("case", ["shard128", "ragged", "x_slab", "shifted_no_folds", "clamp", "padded20x12"])
+def test_kernel_2g_geometry_table_equals_in_kernel_generation(ctx, monkeypatch, case, fp8):
+    """Kernel 2g fed from a precomputed geometry table (developer library, OLX_GTABLE=1; k_gtable.hip: every entry evaluated once per plan with
+    the expression the blocks evaluate for themselves; measured slower) against the product's in-kernel generation.  Same words in LDS,
+    same matrix-instruction sequence: |p| and intensity are bit-identical, in every planning corner (ragged planes, x-slabs, grids without
+    mirror folds, clamped tables, padded arrays with several element super-blocks).  The first pair of a block stays evaluated in the kernel (nothing
+    hides its loads), the others are copied; fp16 corrections only (asserted: the e4m3 shape keeps generating)."""
+    nax, nay, pitch = (20, 12, (2.4, 1.8)) if case == "padded20x12" else (16, 16, (3.0, 3.0))
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * pitch[0], (b.ravel() - (nay - 1) / 2) * pitch[1], np.zeros(nax * nay)], axis=1)
+    size = np.tile([0.9 * pitch[0], 0.9 * pitch[1]], (nax * nay, 1))
+    foci = _wheel_shard(8)
+    rng = np.random.default_rng(147)
+    n, h, z0, shift, slab = (128, 128, 128), (0.5, 0.5, 0.5), 5.0, (0.0, 0.0), None
+    if case == "ragged":
+        n = (96, 96, 50)
+    elif case == "x_slab":          # (no x fold in a slab: 6 foci off both axes x 2 y images = 12 columns)
+        n, slab = (96, 96, 40), (37, 29)
+        foci = np.column_stack([rng.uniform(1, 4, 6), rng.uniform(1, 4, 6), rng.uniform(25, 40, 6)]) * 1e-3
+    elif case == "shifted_no_folds":    # (12 foci = 12 columns)
+        n, shift = (80, 72, 36), (3.0, -2.5)
+        foci = np.column_stack([rng.uniform(-4, 4, 12), rng.uniform(-4, 4, 12), rng.uniform(25, 40, 12)]) * 1e-3
+    elif case == "clamp":
+        n, h, z0 = (72, 72, 24), (1.0, 1.0, 1.0), -4.0
+    elif case == "padded20x12":
+        n, h = (100, 92, 70), (0.6, 0.6, 0.5)
+    setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, solve=True)
+    if fp8:
+        monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
+    xs = ((np.arange(n[0]) - (n[0] - 1) / 2) + shift[0]) * h[0] * 1e-3
+    ys = ((np.arange(n[1]) - (n[1] - 1) / 2) + shift[1]) * h[1] * 1e-3
+    got = {}
+    for gt in ("0", None):
+        monkeypatch.setenv("OLX_GTABLE", "1" if gt is None else gt)
+        ctx.field_plan((xs[0], ys[0], z0 * 1e-3), tuple(v * 1e-3 for v in h), n, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY, slab=slab)
+        ctx.field_launch()
+        got[gt] = (ctx.field_variant(), [ctx.field_fetch(f) for f in range(len(foci))])
+    assert "field_cosetp_k<nt2" in got["0"][0] and "geometry table" not in got["0"][0], got["0"][0]
+    # (the e4m3 shape has no registers for table entries in flight: the planner keeps its in-kernel generation)
+    assert "field_cosetp_k<nt2" in got[None][0] and ("+precomputed geometry table" in got[None][0]) == (not fp8) and ("fp8corr" in got[None][0]) == fp8, got[None][0]
+    assert ("flat,clamp" in got[None][0]) == (case == "clamp"), got[None][0]
+    for f in range(len(foci)):
+        assert got[None][1][f]["pmag"].max() > 0
+        assert np.array_equal(got[None][1][f]["pmag"], got["0"][1][f]["pmag"]), (case, f, float(np.abs(got[None][1][f]["pmag"] - got["0"][1][f]["pmag"]).max()))
+        assert np.array_equal(got[None][1][f]["intensity"], got["0"][1][f]["intensity"]), (case, f)
+
+
 @pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp> 16 columns"),
                                                  (64, 0, "field_cosetp_k<nt2,mx2,my2,flat,noclamp> 127 columns for 64 foci x 4 images in 8 tile(s)")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, rank, expect):

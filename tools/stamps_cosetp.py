@@ -38,5 +38,9 @@ d = np.diff(s[:, :7], axis=1)
 print(f"{ok.sum()} waves sampled; shader cycles, median / p10 / p90")
 for k, nm in enumerate(names):
     print(f"  {nm:45s} {np.median(d[:, k]):10.0f} {np.percentile(d[:, k], 10):10.0f} {np.percentile(d[:, k], 90):10.0f}")
+if (buf[ok][:, 7] > 0).all():      # second pair in detail: wait at its barrier (drains the loads in flight), then tables (evaluated or copied) + barrier + K-steps
+    w2 = s[:, 7] - s[:, 4]; r2 = s[:, 5] - s[:, 7]
+    print(f"  {'  pair 1: barrier on entry (vmcnt drain)':45s} {np.median(w2):10.0f} {np.percentile(w2, 10):10.0f} {np.percentile(w2, 90):10.0f}")
+    print(f"  {'  pair 1: tables + barrier + K-steps':45s} {np.median(r2):10.0f} {np.percentile(r2, 10):10.0f} {np.percentile(r2, 90):10.0f}")
 tot = s[:, 6] - s[:, 0]
 print(f"  {'wave lifetime':45s} {np.median(tot):10.0f} {np.percentile(tot, 10):10.0f} {np.percentile(tot, 90):10.0f}")
