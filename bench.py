@@ -138,7 +138,7 @@ def kernel1_cpu(arr, foci_m):
                         "the cost model of bf/delay_methods/direct.py:35), Direct delays + Uniform apodization, best of 5 / 2"}
 
 
-def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), medium=None):
+def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), apod=("uniform", 1.0, 0.0), ori=None):
     """Post-timing parity of the resident result against the fp64 C oracle: `n_samples` random voxels of up to three
     focus volumes, error normalised by each focus' own peak (the volume maximum for a focus inside the grid)."""
     from oracle import bf_oracle as bo, c_oracle as co
@@ -150,7 +150,7 @@ def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 
     for f in check:
         if f >= len(foci_m):
             continue
-        d, a = bo.beamform(pos_m, np.zeros_like(pos_m), foci_m[f], C0)
+        d, a = bo.beamform(pos_m, np.zeros_like(pos_m) if ori is None else ori, foci_m[f], C0, apod=apod)
         ref = np.abs(co.field_at_points(pts, pos_m, area, d, a, F0, C0, SENS))
         peak = max(np.abs(co.field_at_points([foci_m[f]], pos_m, area, d, a, F0, C0, SENS))[0], ref.max())
         got = ctx.field_fetch(f, want=("pmag",))["pmag"][idx[:, 0], idx[:, 1], idx[:, 2]]
@@ -607,6 +607,7 @@ def main():
                                          "same shard size, sweep target offset by (1.3, 0.7) mm from the array axis: the mirror folds of the grid "
                                          "still apply, but no two (focus, image) pairs share a steering column")
                 legs["sweep64"] = leg(sweep_m, False, "the whole 64-focus Wheel sweep of configs[2] on one GPU")
+            legs.update(config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags))
             out["legs"] = legs
             # HBM-bound streaming scans over the resident result of the headline shard
             plan(args.corrections == "fp8")
@@ -634,6 +635,106 @@ def main():
         dist.barrier()
         sf.close()
         dist.destroy_process_group()
+
+
+def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
+    """The other BASELINE.json configurations, and arrays the lattice kernels do not serve, as legs of the same driver line -- each planned through
+    the product's ShardedField, clock-ramped, timed over its own steps (>= 50), with the kernel the planner chose, its fraction of the 8 TB/s
+    roofline on SURVEY 8(d)'s algorithmic bytes, and the error of sampled voxels against the fp64 C oracle measured in this run:
+      c2_128         configs[1]  256-element matrix array, single focus, 128^3
+      c4_1024x512    configs[3]  1024 elements (32 x 32 @ 1.5 mm), 512^3 @ 0.125 mm, PiecewiseLinear(60, 20) apodization + Direct delays (kernel 1)
+      c5_skull_f1/f8 configs[4]  256 elements, 256^3, skull-slab medium (marched ray sums), 1 and 8 foci per launch
+      tilted2_*      a two-module TransducerArray on a cylinder (xdc/transducerarray.py:86-115), 2 x 128 elements: tilted normals, no common lattice
+      jitter_*       the 16 x 16 array with +-0.1 mm element jitter (seed 147): not a lattice, not mirror-symmetric"""
+    from oracle import bf_oracle as bo, c_oracle as co
+    from openlifu_amd.engine import grid_from_coords
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    ctx = eng.ctx
+    kinds = {"uniform": nat.APOD_UNIFORM, "maxangle": nat.APOD_MAXANGLE, "piecewise": nat.APOD_PIECEWISE}
+    res = {}
+
+    def grid(grid_n, spacing_mm):
+        half = (grid_n - 1) / 2 * spacing_mm
+        setup = ol.SimSetup(spacing=spacing_mm, x_extent=(-half, half), y_extent=(-half, half), z_extent=(5.0, 5.0 + (grid_n - 1) * spacing_mm))
+        origin, spacing, n = grid_from_coords(setup.get_coords())
+        return origin, spacing, n, [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
+
+    def run(key, what, arr, g, foci_m, apod=("uniform", 1.0, 0.0), medium=None, steps=200, check=(0,)):
+        origin, spacing, n, coords = g
+        foci_m = np.atleast_2d(np.asarray(foci_m, dtype=np.float64))
+        N, V = arr.numelements(), int(np.prod(n))
+        pos_m, _, area, _, _ = arr.element_table()
+        ori = np.array([el.orientation for el in arr.elements], dtype=np.float64)
+        if medium is None:
+            mine = sf.plan_foci_sweep(arr, foci_m, C0, (kinds[apod[0]], apod[1], apod[2]), origin, spacing, n, F0, RHO0, SENS, flags=out_flags)
+            foci_run = foci_m[mine]
+        else:
+            dl, ap = eng.beamform(arr, foci_m, C0)
+            sf.plan_slab_sweep(arr, dl, ap, origin, spacing, n, F0, C0, RHO0, SENS, flags=out_flags, medium=medium)
+            foci_run = foci_m
+        ramp()
+        r = timed("none", steps, 10)
+        if r is None:
+            res[key] = {"what": what, "skipped": timed.last_error}
+            return
+        e, km = r
+        name = ctx.field_variant()
+        nf = len(foci_run)
+        k_ms = float(np.mean(km))
+        bytes_l = (8.0 * V * nf + 32.0 * N * nf) if medium is None else (16.0 * V * nf)     # SURVEY 8(d): + 8 B / voxel of medium parameters per focus
+        ent = {"what": what, "kernel": name, "elements": N, "grid": [int(v) for v in n], "foci": nf,
+               "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else ("f32-acc/f16x3" if ("field_coset" in name or "field_toep" in name or "field_lattice" in name or "field_mfma" in name) else "f32"),
+               "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(km)), "ms_per_step": e / steps * 1e3, "steps": steps,
+               "value": float(V) * N * nf * steps / e / 1e6, "unit": "Mvoxel-elements/s",
+               "algorithmic_bytes_per_launch": bytes_l, "roofline_frac": bytes_l / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "traffic": static_traffic(name, int(n[0]))[0]}
+        if medium is None:
+            ent["parity"] = sampled_parity(ctx, coords, pos_m, area, foci_run, n_samples=8000, check=check, apod=apod, ori=ori)
+        else:       # whole z columns against the fp64 marched oracle of the same definition (oracle/field_oracle.c olo_field_columns_hetero_march)
+            rng = np.random.default_rng(147)
+            cols = np.column_stack([rng.integers(0, n[0], 16), rng.integers(0, n[1], 16)])
+            cols[:4] = [[n[0] // 2 - 1, n[1] // 2 - 1], [n[0] // 2, n[1] // 2 + 12], [n[0] // 3, n[1] // 2], [0, 0]]
+            sig, ab = co.medium_terms(medium["sound_speed"], medium["attenuation"], C0, F0)
+            worst = 0.0
+            for f in check:
+                if f >= nf:
+                    continue
+                dl1, ap1 = bo.beamform(pos_m, ori, foci_run[f], C0)
+                ref = np.abs(co.field_hetero_march(*coords, sig, ab, pos_m, area, dl1, ap1, F0, C0, SENS, columns=cols))
+                got = ctx.field_fetch(f, want=("pmag",))["pmag"][cols[:, 0], cols[:, 1], :]
+                worst = max(worst, float(np.abs(got - ref).max() / max(ref.max(), got.max())))
+            ent["parity"] = {"max_err_over_column_max": worst, "gate": 1e-5, "columns": int(len(cols)), "foci_checked": [int(f) for f in check if f < nf],
+                             "oracle": "oracle/field_oracle.c olo_field_columns_hetero_march (fp64; the build's own definition: parity unpinned)",
+                             "note": "fp32 running ray sums re-interpolated plane by plane: the measured error is what this number says, the tests assert 3e-5"}
+        res[key] = ent
+
+    focus = np.array([[0.0, 0.0, 40e-3]])
+    m16 = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
+    run("c2_128", "BASELINE configs[1]: 256-element matrix array, single focus, 128^3 @ 0.5 mm", m16, grid(128, 0.5), focus, steps=500)
+    m32 = ol.Transducer.gen_matrix_array(nx=32, ny=32, pitch=1.5, kerf=0.15, units="mm", sensitivity=SENS)
+    run("c4_1024x512", "BASELINE configs[3]: 1024-element array (32 x 32 @ 1.5 mm), 512^3 @ 0.125 mm, PiecewiseLinear(zero 60, rolloff 20) apodization + "
+        "Direct delays from kernel 1, single focus", m32, grid(512, 0.125), focus, apod=("piecewise", 60.0, 20.0), steps=100)
+    g256 = grid(256, 0.25)
+    wheel = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0)
+    sweep = np.array([f.get_position(units="m") for f in wheel.get_targets(ol.Point(position=(0, 0, 40), units="mm"))])
+    shard = sweep[od.plan_foci_orbits(sweep, 8, centre_xy=(0.0, 0.0))[0]]
+    # arrays without a grid-commensurate flat lattice: kernels 2a / 2c
+    half = ol.Transducer.gen_matrix_array(nx=8, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
+    tilted = ol.TransducerArray.get_concave_cylinder(half, rows=1, cols=2, width=24.0, gap=0.6, roc=80.0, units="mm").to_transducer()
+    run("tilted2_f1", "two-module TransducerArray on an 80 mm cylinder (2 x 128 elements, modules tilted -+ 8.8 deg), single focus, 256^3", tilted, g256, focus)
+    run("tilted2_f8", "the same array, the 8-focus shard", tilted, g256, shard, steps=100, check=(0, 3))
+    rng = np.random.default_rng(147)
+    jit = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
+    for el in jit.elements:
+        el.position = np.asarray(el.position, dtype=np.float64) + rng.uniform(-0.1, 0.1, 3) * np.array([1.0, 1.0, 0.0])
+    run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus)
+    run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3))
+    skull = skull_slab_volumes(*g256[3])
+    skull["model"] = "marched"
+    run("c5_skull_f1", "BASELINE configs[4] on one GPU: 256 elements, 256^3, skull-slab medium, marched ray sums (kernel 2m), one focus per launch",
+        m16, g256, focus, medium=skull, steps=50)
+    run("c5_skull_f8", "the same medium, the 8-focus shard in one launch sequence (look-ups shared by the foci)", m16, g256, shard, medium=skull, steps=50, check=(0, 3))
+    return res
 
 
 def end_to_end(ol, arr, setup, target, sweep, idx, args):

@@ -18,6 +18,7 @@ F0, C, RHO, P0 = 400e3, 1500.0, 1000.0, 1e5
 AB = "libolx_ab" in os.path.basename(nat.LIB_PATH)
 FAMILIES = ["general", "shared", "mfma", "lattice", "lattice2d"] + (["shfl"] if AB else [])
 TOL_P, TOL_I = 1e-5, 2e-5
+HET_TOL_P = float(os.environ.get("OLX_TEST_HET_TOL", "1e-5"))     # heterogeneous kernels: north_star's gate too
 
 
 def setup_ctx(ctx, pos, ori, size, foci_m, apod=("uniform", 1.0, 0.0), solve=False):
@@ -408,10 +409,12 @@ def test_heterogeneous_medium_layered_ray_model(ctx, model):
         out = ctx.field_fetch(f, want=("pmag", "intensity", "complex"))
         ref = oracle(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0)
         mx = np.abs(ref).max()
-        assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= 2e-5        # bilinear gathers add fp32 rounding
-        assert np.abs(out["complex"] - ref).max() / mx <= 6e-5
+        err = np.abs(out["pmag"] - np.abs(ref)).max() / mx
+        print(f"hetero full-volume error ({model}, focus {f}): {err:.2e}")
+        assert err <= HET_TOL_P, err
+        assert np.abs(out["complex"] - ref).max() / mx <= 3 * TOL_P
         iref = 1e-4 * np.abs(ref) ** 2 / (2 * rvol * cvol)                    # voxel's own rho c (kwave_if.py:140)
-        assert np.abs(out["intensity"] - iref).max() / iref.max() <= 4e-5
+        assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
     assert np.abs(ctx.field_fetch(0)["pmag"] - homog).max() / homog.max() > 0.05  # the skull visibly changes the field
     # voxels in front of the slab see the reference medium only
     assert np.abs(ctx.field_fetch(0)["pmag"][:, :, :3] - homog[:, :, :3]).max() / homog.max() <= TOL_P
@@ -451,7 +454,9 @@ def test_heterogeneous_foci_share_ray_integrals_and_layers(ctx):
         whole = np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)])
         for f in sorted({0, nfoci // 2, nfoci - 1}):
             ref = np.abs(co.field_on_grid_hetero(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0, planes_per_layer=G))
-            assert np.abs(whole[f] - ref).max() / ref.max() <= 2e-5, (nfoci, G, f)
+            err = np.abs(whole[f] - ref).max() / ref.max()
+            print(f"hetero sampled, {nfoci} foci, G = {G}, focus {f}: {err:.2e}")
+            assert err <= HET_TOL_P, (nfoci, G, f, err)
         if nfoci == 11:   # x-slabs: bit-identical to the same voxels of the whole-grid launch
             parts = []
             for b, cnt in ((0, 9), (9, 8), (17, 8)):
@@ -488,7 +493,9 @@ def test_c5_skull_slab_256cubed_sampled(ctx, G):
     for gi, f in enumerate((0, 3)):     # whole z columns (through the slab and the focus), all 256 planes each
         ref = np.abs(co.field_columns_hetero(xs, ys, zs, sig, ab, cols, pos_m, area, d[f], a[f], F0, C, P0, planes_per_layer=G))
         mine = got[gi][cols[:, 0], cols[:, 1], :]
-        assert np.abs(mine - ref).max() / max(ref.max(), mine.max()) <= 3e-5, (G, f)
+        err = np.abs(mine - ref).max() / max(ref.max(), mine.max())
+        print(f"C5 sampled columns, G = {G}, focus {f}: {err:.2e}")
+        assert err <= HET_TOL_P, (G, f, err)
     homog = np.abs(co.field_at_points(np.column_stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2] % 11]]), pos_m, area, d[0], a[0], F0, C, P0))
     assert np.abs(got[0][idx[:, 0], idx[:, 1], idx[:, 2] % 11] - homog).max() / homog.max() <= TOL_P     # z < 7.75 mm: water only
     ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG, slab=(64, 64))
@@ -516,7 +523,9 @@ def test_marched_medium_foci_tiles_slabs_and_fallback(ctx):
         whole = np.stack([ctx.field_fetch(f)["pmag"] for f in range(nfoci)])
         for f in sorted({0, nfoci // 2, nfoci - 1}):
             ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0))
-            assert np.abs(whole[f] - ref).max() / ref.max() <= 2e-5, (nfoci, f)
+            err = np.abs(whole[f] - ref).max() / ref.max()
+            print(f"hetero marched, {nfoci} foci, focus {f}: {err:.2e}")
+            assert err <= HET_TOL_P, (nfoci, f, err)
         if nfoci == 11:
             parts = []
             for b, cnt in ((0, 9), (9, 8), (17, 8)):
@@ -564,7 +573,9 @@ def test_c5_skull_slab_256cubed_marched(ctx):
     for gi, f in enumerate((0, 3)):
         ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, d[f], a[f], F0, C, P0, columns=cols))
         mine = got[gi][cols[:, 0], cols[:, 1], :]
-        assert np.abs(mine - ref).max() / max(ref.max(), mine.max()) <= 3e-5, f
+        err = np.abs(mine - ref).max() / max(ref.max(), mine.max())
+        print(f"C5 marched columns, focus {f}: {err:.2e}")
+        assert err <= HET_TOL_P, (f, err)
     homog = np.abs(co.field_at_points(np.column_stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2] % 11]]), pos_m, area, d[0], a[0], F0, C, P0))
     assert np.abs(got[0][idx[:, 0], idx[:, 1], idx[:, 2] % 11] - homog).max() / homog.max() <= TOL_P     # z < 7.75 mm: water only
     ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG, slab=(64, 64))
