@@ -30,7 +30,7 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, defines=(), out: str = OUT) -> str:
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))     # (*.cpp: host-only units, e.g. olx_plan.cpp)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "olx.h")]
     tag = "" if not defines else "_" + "_".join(d.lstrip("-D").replace("=", "") for d in defines)
     objdir = os.path.join(HERE, "build" + tag)
@@ -42,7 +42,8 @@ def build(force: bool = False, defines=(), out: str = OUT) -> str:
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append([cc] + FLAGS + list(defines) + ["-c", s, "-o", o])
+            host_only = s.endswith(".cpp")
+            jobs.append([cc] + [f for f in FLAGS if not (host_only and f.startswith("--offload-arch"))] + list(defines) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, jobs), jobs):

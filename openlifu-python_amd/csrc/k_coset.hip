@@ -388,6 +388,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 #else
                         dst[u] = qu < npos ? base + (long long)(io * P.ny + jo) * P.nz : nullptr;
 #endif
+                        if (dst[u] && !OLX_IN((long long)(job >> 6) * P.vox + kz + (long long)(io * P.ny + jo) * P.nz + (FAST ? 3 : 0), (long long)P.n_foci * P.vox, 3)) dst[u] = nullptr;
                         const float* v = sv + (qu < npos ? qu : q) * RS;
                         val[u] = make_float4(v[0], v[1], v[2], v[3]);
                     }
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
 }  // namespace olx
 
 using namespace olx;
+OLX_BOUNDS_READER(coset)
 
 template <int NT, int MX, int MY>
 static void launch_coset(olx_ctx* c, float* pm, bool clamp) {

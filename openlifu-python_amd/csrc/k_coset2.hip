@@ -236,8 +236,10 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     }
                     if (row_ok) {
                         const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
-                        s_hi[o] = __builtin_bit_cast(unsigned, hi);
-                        s_lo[o] = lo_word;
+                        if (OLX_IN(o, T_WORDS, 0)) {
+                            s_hi[o] = __builtin_bit_cast(unsigned, hi);
+                            s_lo[o] = lo_word;
+                        }
                     }
                 }
             }
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
 #pragma unroll
                         for (int ka = 0; ka < 2; ++ka) {
                             const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;   // the pair's second super-block reads 8 table rows lower
+                            if (!OLX_IN(ro + kso, T_WORDS - 3, 1)) continue;
                             const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
                             const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + ro + kso);
                             const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         int lo_t = lane_off;
                         asm volatile("" : "+v"(lo_t));
                         const int ro = lo_t + toff[t];
+                        if (!OLX_IN(ro + kso, T_WORDS - 3, 1)) continue;
                         const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
                         const unsigned long long* pl2 = reinterpret_cast<const unsigned long long*>(s_lo + ro + kso);
                         const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
 #else
                     float* dst = base + off;
 #endif
+                    if (!OLX_IN((long long)(code >> 2) * P.vox + kz + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
                     if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]);
                     else {
 #pragma unroll
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
 }  // namespace olx
 
 using namespace olx;
+OLX_BOUNDS_READER(cosetp)
 
 #ifdef OLX_EXP_CUTRACE
 extern "C" int olx_exp_read_cutrace_cosetp(unsigned long long* out) {
@@ -458,7 +464,12 @@ extern "C" int olx_exp_read_stamps_cosetp(unsigned long long* out) {
 
 template <int MX, int MY>
 static void launch_cosetp(olx_ctx* c, float* pm) {
+#ifdef OLX_DEBUG_BOUNDS   // self-test of the debug build: pretend the output arrays hold one focus less -- the last focus' stores must be reported (and skipped)
+    CosetParams Q = c->cp;
+    if (getenv("OLX_DEBUG_BOUNDS_SELFTEST")) Q.n_foci -= 1;
+#else
     const CosetParams& Q = c->cp;
+#endif
     const int n_items = (int)c->cp_nblocks;
     const bool clamp = c->clamp || c->lat.clamp;
     const bool persist = c->cosetp_persist && c->mp.n_tiles == 1;

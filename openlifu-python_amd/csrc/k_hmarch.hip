@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                         // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
                         const char* Ue = reinterpret_cast<const char*>(U_src + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg);
                         const unsigned off = (__umul24(i0, row_cells) + j0) << 3;
+                        if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * 8 + off + (long long)row_cells * 8 + 15, (long long)H.nxg * row_cells * 8, 6)) { lo[s] = float4u_t{0.f, 0.f, 0.f, 0.f}; hi[s] = lo[s]; continue; }
                         lo[s] = *reinterpret_cast<const float4u_t*>(Ue + off);                       // {s00, a00, s01, a01}
                         hi[s] = *reinterpret_cast<const float4u_t*>(Ue + (size_t)row_cells * 8 + off);   // {s10, a10, s11, a11}
                     }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                         const float2u_t c0v = fv[s] * (l1 - l0) + l0, c1v = fv[s] * (h1 - h0) + h0;
                         sa = fu[s] * (c1v - c0v) + c0v;
                     }
-                    if (writer) (U_dst + (size_t)e * H.nyg)[own] = make_float2(sa.x + sv2, sa.y + av2);
+                    if (writer && OLX_IN((long long)e * H.nyg + own, (long long)H.nxg * row_cells, 7)) (U_dst + (size_t)e * H.nyg)[own] = make_float2(sa.x + sv2, sa.y + av2);
                     float d2 = fmaf(dy, dy, fmaf(dx, dx, r1.x));
                     if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                     const float ri = __builtin_amdgcn_rsqf(d2);
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
         const int fg = ftile * NF + f;
         if (fg >= H.n_foci) break;
         const long long o = (long long)fg * P.vox + vrow;
+        if (!OLX_IN(o, (long long)H.n_foci * P.vox, 8)) continue;
         const float m2 = fmaf(re[f], re[f], im[f] * im[f]);
         if (P.flags & 1u) pmag[o] = __builtin_sqrtf(m2);
         if (P.flags & 2u) inten[o] = m2 * (inv2z ? inv2z[vrow] : P.inten_scale);
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
 }  // namespace olx
 
 using namespace olx;
+OLX_BOUNDS_READER(hmarch)
 
 template <int NF>
 static void launch_hmarch_nf(olx_ctx* c, float* pm) {

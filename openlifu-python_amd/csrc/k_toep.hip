@@ -112,6 +112,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const float2_t gv = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * rs;      // (one v_pk_mul_f32)
                 const float gr = gv[0], gi = gv[1];
                 const half2_t hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                if (!OLX_IN(z * TOEP_PSZ + o, TOEP_ZB * TOEP_PSZ, 4)) continue;
                 s_hi[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, hi);
                 // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
                 float lr, li;
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const bool fx = (MX == 2) && (m & 1), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1));
                 const unsigned oy = (unsigned)((fy ? (P.ny - 1 - j) : j) * P.nz);                 // scalar
                 float* dst = vol + (long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy);      // (32-bit offset within the focus volume)
+                if (!OLX_IN((long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy) + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 5)) continue;
                 if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else {
 #pragma unroll
@@ -258,6 +260,7 @@ __global__ void toep_pack_k(const double* __restrict__ area, int n, const double
 }  // namespace olx
 
 using namespace olx;
+OLX_BOUNDS_READER(toep)
 
 #ifdef OLX_EXP_STAMPS
 // developer build only (tools/stamps_toep.py): per-wave phase time stamps of this kernel

@@ -55,6 +55,31 @@ __device__ __forceinline__ float table_mod(float dx, float dy, float d, float ri
     return m;
 }
 
+// Debug build with teeth (build.py -DOLX_DEBUG_BOUNDS --out lib/libolx_dbg.so; tests/test_gpu_debug_bounds.py): every instrumented LDS / global
+// index of the kernels' table fills, fragment reads, ray-sum gathers and epilogue stores is compared with its extent.  A violation does NOT
+// trap (a faulting wave can take the whole node down): the access is skipped, the site's bit and a count go into a per-translation-unit device
+// word that olx_sync reads back and reports as OLX_ESTATE.  In the product build OLX_IN(...) is the constant `true`: no instruction remains.
+#ifdef OLX_DEBUG_BOUNDS
+static __device__ unsigned g_olx_bounds[4];     // [0] bit mask of violated sites, [1] violations, [2] first offending index (low word), [3] its extent (low word)
+__device__ __forceinline__ bool olx_in_bounds(long long i, long long n, int site) {
+    if (i >= 0 && i < n) return true;
+    if (atomicAdd(&g_olx_bounds[1], 1u) == 0u) { g_olx_bounds[2] = (unsigned)i; g_olx_bounds[3] = (unsigned)n; }
+    atomicOr(&g_olx_bounds[0], 1u << (site & 31));
+    return false;
+}
+#define OLX_IN(i, n, site) olx::olx_in_bounds((long long)(i), (long long)(n), (site))
+// one reader per translation unit (device globals are per unit): copies the four words out and clears them
+#define OLX_BOUNDS_READER(tag)                                                                                      \
+    extern "C" int olx_dbg_bounds_##tag(unsigned* out4) {                                                          \
+        const unsigned zero[4] = {0, 0, 0, 0};                                                                      \
+        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(olx::g_olx_bounds), sizeof zero) != hipSuccess) return -1;         \
+        return hipMemcpyToSymbol(HIP_SYMBOL(olx::g_olx_bounds), zero, sizeof zero) == hipSuccess ? 0 : -1;          \
+    }
+#else
+#define OLX_IN(i, n, site) true
+#define OLX_BOUNDS_READER(tag)
+#endif
+
 #ifdef OLX_EXP_STAMPS
 static __device__ unsigned long long g_stamps[4096][8];   // per translation unit; read back by olx_exp_read_stamps (k_coset.hip)
 #define OLX_STAMP(k) do { if (lane == 0 && wave < 4 && blockIdx.y == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 1024) g_stamps[(blockIdx.x / 37) * 4 + wave][k] = __builtin_readcyclecounter(); } while (0)

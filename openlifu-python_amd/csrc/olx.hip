@@ -14,6 +14,7 @@
 
 #include "k_small.hip.h"
 #include "olx_launch.h"
+#include "olx_plan.h"
 
 // The measured-slower A/B forms of the accumulate (kernels 2q, 2r, 2s, persistent 2g, wave-specialised 2f: DESIGN.md 5.4) are
 // compiled only into the developer library (build.py -DOLX_AB_VARIANTS --out lib/libolx_ab.so); the product library carries the
@@ -79,11 +80,30 @@ int olx_ctx_destroy(olx_ctx* c) {
 
 const char* olx_last_error(const olx_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+#ifdef OLX_DEBUG_BOUNDS   // debug build (k_types.hip.h): the kernels' index checks report here
+extern "C" { int olx_dbg_bounds_cosetp(unsigned*); int olx_dbg_bounds_coset(unsigned*); int olx_dbg_bounds_toep(unsigned*); int olx_dbg_bounds_hmarch(unsigned*); }
+static int report_bounds(olx_ctx* c) {
+    struct { const char* name; int (*read)(unsigned*); } units[] = {{"2g (k_coset2.hip)", olx_dbg_bounds_cosetp}, {"2e (k_coset.hip)", olx_dbg_bounds_coset},
+                                                                     {"2f (k_toep.hip)", olx_dbg_bounds_toep}, {"2m (k_hmarch.hip)", olx_dbg_bounds_hmarch}};
+    int rc = OLX_OK;
+    for (auto& u : units) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (u.read(w) != 0) return fail(c, OLX_EHIP, "debug build: cannot read the bounds words of kernel %s", u.name);
+        if (w[1] && rc == OLX_OK)
+            rc = fail(c, OLX_ESTATE, "debug build: kernel %s made %u accesses outside their extent (skipped; site mask 0x%x; first: index %u, extent %u)", u.name, w[1], w[0], w[2], w[3]);
+    }
+    return rc;
+}
+#endif
+
 int olx_sync(olx_ctx* c) {
     if (!c) return OLX_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+#ifdef OLX_DEBUG_BOUNDS
+    { int rc_ = report_bounds(c); if (rc_) return rc_; }
+#endif
     if (c->p2p) return olx_p2p_drain(c);     // peer-to-peer gathers run on the transport's worker thread
     return OLX_OK;
 }
@@ -292,149 +312,18 @@ int olx_bf_quantize(olx_ctx* c, double bf_clk_hz, int width_bits, uint16_t* tick
 }
 
 // ---- kernel 2 -----------------------------------------------------------------------------
-// K-slot map of the lattice kernels: slot ((sa nsbp + sbb) 4 + ks) 16 + 4 bb + aa -> element (a, b) = (8 sa + 4 (ks & 1) + aa,
-// 8 sbb + 4 (ks >> 1) + bb), -1 where the array has no element.  sa-major; nsbp = nsb, or nsb padded to an even count for
-// kernel 2e's NT = 2 shape, which shares one geometry table per pair (sa, 2p), (sa, 2p + 1) and skips the padding super-block.
-static void build_slot_map(olx_ctx::Lattice& L, int nsbp) {
-    L.nsbp = nsbp; L.n_pad = L.nsa * nsbp * 64;
-    L.slot_elem.assign((size_t)L.nsa * nsbp * 64, -1);
-    for (int sa = 0; sa < L.nsa; ++sa)
-        for (int sbb = 0; sbb < L.nsb; ++sbb)
-            for (int ks = 0; ks < 4; ++ks)
-                for (int bb = 0; bb < 4; ++bb)
-                    for (int aa = 0; aa < 4; ++aa) {
-                        const int a = 8 * sa + 4 * (ks & 1) + aa, b = 8 * sbb + 4 * (ks >> 1) + bb;
-                        if (a < L.ax && b < L.ay)
-                            L.slot_elem[((size_t)(sa * nsbp + sbb) * 4 + ks) * 16 + 4 * bb + aa] = L.cell[(size_t)a * L.ay + b];
-                    }
-}
-
-// Kernel 2d precondition: the elements fill a regular ax x ay lattice in one z plane and the pitch is a whole number
-// of voxels along x and y.  Fills c->lat (slot map in 8 x 8 super-blocks of four 4 x 4 K-steps, padded with
-// virtual elements) and the clamp / minimum-distance bounds including the virtual lattice points.
+// The pure planning code (lattice detection, K-slot map, column packing, block records, store jobs, focus inference) lives in
+// olx_plan.cpp: no HIP in it, so the CPU suite runs it under AddressSanitizer / UBSan (tools/plan_check.cpp, tests/test_plan_host.py).
+using olxplan::build_slot_map;
+using olxplan::coset_tiles16;
 static void detect_lattice(olx_ctx* c, const double lo[3], const double hi[3], double dmin) {
-    olx_ctx::Lattice& L = c->lat;
-    L = olx_ctx::Lattice();
-    const int n = c->n_el;
-    if (!c->flat || n < 16 || n > 16384) return;
-    const double* X = c->h_pos.data();
-    const double* Y = X + n;
-    const double tol = 1e-10;
-    auto axis = [&](const double* v, std::vector<double>& u) {
-        u.assign(v, v + n);
-        std::sort(u.begin(), u.end());
-        size_t m = 0;
-        for (size_t q = 0; q < u.size(); ++q)
-            if (m == 0 || u[q] - u[m - 1] > tol) u[m++] = u[q];
-        u.resize(m);
-    };
-    std::vector<double> xs, ys;
-    axis(X, xs); axis(Y, ys);
-    const int ax = (int)xs.size(), ay = (int)ys.size();
-    if (ax < 2 || ay < 2 || (long long)ax * ay != n) return;
-    const double px = (xs.back() - xs.front()) / (ax - 1), py = (ys.back() - ys.front()) / (ay - 1);
-    for (int a = 0; a < ax; ++a) if (std::fabs(xs[a] - (xs[0] + a * px)) > tol) return;
-    for (int b = 0; b < ay; ++b) if (std::fabs(ys[b] - (ys[0] + b * py)) > tol) return;
-    const double rx = px / c->grid.spacing[0], ry = py / c->grid.spacing[1];
-    const int mx = (int)std::llround(rx), my = (int)std::llround(ry);
-    if (mx < 1 || my < 1 || std::fabs(rx - mx) > 1e-9 * mx || std::fabs(ry - my) > 1e-9 * my) return;
-    const int nsa = (ax + 7) / 8, nsb = (ay + 7) / 8;
-    if ((long long)nsa * nsb * 64 > 2LL * n) return;          // padding would more than double the contraction
-    std::vector<int> cell((size_t)ax * ay, -1);
-    for (int e = 0; e < n; ++e) {
-        const int a = (int)std::llround((X[e] - xs[0]) / px), b = (int)std::llround((Y[e] - ys[0]) / py);
-        if (a < 0 || a >= ax || b < 0 || b >= ay || cell[(size_t)a * ay + b] >= 0) return;
-        cell[(size_t)a * ay + b] = e;
-    }
-    L.ax = ax; L.ay = ay; L.nsa = nsa; L.nsb = nsb;
-    L.cell.swap(cell);
-    build_slot_map(L, nsb);
-    const int nsbp = (nsb + 1) & ~1;               // the bounds below also cover the padding rows of kernel 2e's pair tables
-    // distance bounds over every lattice point of the padded array (virtual ones included: their G must stay finite)
-    const double ez = c->h_pos[2 * (size_t)n];
-    double min_d2 = 1e300; bool clamp = false;
-    const double guard = 2.0 * dmin;
-    for (int a = 0; a < std::max(8 * nsa, 16 * ((ax + 15) / 16)); ++a)   // (kernel 2f walks the columns in super-blocks of 16)
-        for (int b = 0; b < 8 * nsbp; ++b) {          // (kernel 2e's pair table also covers the padding rows)
-            const double p[3] = {xs[0] + a * px, ys[0] + b * py, ez};
-            double d2 = 0;
-            for (int k = 0; k < 3; ++k) {
-                const double d = p[k] < lo[k] ? lo[k] - p[k] : (p[k] > hi[k] ? p[k] - hi[k] : 0.0);
-                d2 += d * d;
-            }
-            min_d2 = std::min(min_d2, d2);
-            if (d2 < guard * guard) clamp = true;
-        }
-    L.mx = mx; L.my = my;
-    L.x0 = xs[0]; L.y0 = ys[0]; L.px = px; L.py = py; L.min_d2 = min_d2; L.clamp = clamp;
-    L.ok = true;
+    olxplan::detect_lattice(c->lat, c->flat, c->n_el, c->h_pos.data(), c->grid.spacing, lo, hi, dmin);
 }
-
-// Foci of an externally supplied steering table (olx_set_steering; the run_simulation seam hands over delays only).  For the
-// reference's geometric delays (bf/delay_methods/direct.py:28-38) tau_e = max(tof) - tof_e, every element satisfies
-// |x - r_e| = S - s_e with s_e = c tau_e and one unknown S per focus; subtracting element 0's equation leaves a LINEAR system in
-// (x, y, S) for a flat array:  -2 (r_e - r_0) . x + 2 (s_e - s_0) S = (s_e^2 - s_0^2) - (|r_e|^2 - |r_0|^2);  z follows from
-// element 0 on the grid's side of the array.  Accepted only if the point reproduces all delays to 1e-6 m (lambda / 3750 at
-// 400 kHz) -- arbitrary delay patterns have no such point and are reported as unknown.
 static bool infer_foci(const olx_ctx* c, std::vector<double>& foci) {
     const int n = c->n_el, F = c->plan_foci;
-    if (!c->flat || n < 4 || c->h_delays.size() != (size_t)F * n) return false;
-    const double* X = c->h_pos.data(); const double* Y = X + n; const double* Z = Y + n;
-    foci.assign(3 * (size_t)F, 0.0);
-    for (int f = 0; f < F; ++f) {
-        const double* tau = c->h_delays.data() + (size_t)f * n;
-        double A[3][4] = {{0}};   // normal equations [A | b] for u = (x, y, S)
-        const double s0 = c->c * tau[0], q0 = X[0] * X[0] + Y[0] * Y[0];
-        for (int e = 1; e < n; ++e) {
-            const double se = c->c * tau[e];
-            const double row[3] = {-2.0 * (X[e] - X[0]), -2.0 * (Y[e] - Y[0]), 2.0 * (se - s0)};
-            const double rhs = (se * se - s0 * s0) - (X[e] * X[e] + Y[e] * Y[e] - q0);
-            for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) A[i][j] += row[i] * row[j];
-                A[i][3] += row[i] * rhs;
-            }
-        }
-        for (int i = 0; i < 3; ++i) {   // Gaussian elimination with partial pivoting
-            int piv = i;
-            for (int r = i + 1; r < 3; ++r) if (std::fabs(A[r][i]) > std::fabs(A[piv][i])) piv = r;
-            if (!(std::fabs(A[piv][i]) > 1e-300)) return false;
-            if (piv != i) for (int j = 0; j < 4; ++j) std::swap(A[i][j], A[piv][j]);
-            for (int r = 0; r < 3; ++r) {
-                if (r == i) continue;
-                const double m = A[r][i] / A[i][i];
-                for (int j = i; j < 4; ++j) A[r][j] -= m * A[i][j];
-            }
-        }
-        const double x = A[0][3] / A[0][0], y = A[1][3] / A[1][1], S = A[2][3] / A[2][2];
-        const double dz2 = (S - s0) * (S - s0) - (x - X[0]) * (x - X[0]) - (y - Y[0]) * (y - Y[0]);
-        if (!(dz2 > 0) || !std::isfinite(dz2)) return false;
-        const double side = (c->grid.origin[2] + 0.5 * (c->grid.n[2] - 1) * c->grid.spacing[2]) >= Z[0] ? 1.0 : -1.0;
-        const double z = Z[0] + side * std::sqrt(dz2);
-        for (int e = 0; e < n; ++e) {
-            const double d = std::sqrt((x - X[e]) * (x - X[e]) + (y - Y[e]) * (y - Y[e]) + (z - Z[e]) * (z - Z[e]));
-            if (!(std::fabs(d - (S - c->c * tau[e])) <= 1e-6)) return false;
-        }
-        foci[3 * (size_t)f] = x; foci[3 * (size_t)f + 1] = y; foci[3 * (size_t)f + 2] = z;
-    }
-    return true;
-}
-
-// Kernel 2e: MFMA row tiles (16 rows) one plane pair needs over all cosets and parts -- per (coset, part)
-// ceil(COS_P KX KY / 16) -- for a computed region of wx x wy voxels at lattice pitch (mx, my) voxels.
-static long long coset_tiles16(int wx, int wy, int mx, int my, int nt) {
-    const int kxw = cos_kxw(nt);
-    const int nsx = ((wx + 2 * mx - 1) / (2 * mx) + kxw - 1) / kxw, nsy = ((wy + my - 1) / my + COS_KYW - 1) / COS_KYW;
-    long long t16 = 0;
-    for (int rx = 0; rx < 2 * mx; ++rx)
-        for (int ry = 0; ry < my; ++ry) {
-            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / my + 1 : 0;
-            for (int sx = 0; sx < nsx; ++sx)
-                for (int sy = 0; sy < nsy; ++sy) {
-                    const int KX = (sx + 1) * kxa / nsx - sx * kxa / nsx, KY = (sy + 1) * kya / nsy - sy * kya / nsy;
-                    t16 += (COS_P * KX * KY + 15) / 16;
-                }
-        }
-    return t16;
+    if (c->h_delays.size() != (size_t)F * n) return false;
+    return olxplan::infer_foci(c->flat, n, F, c->h_pos.data(), c->h_delays.data(), c->c,
+                               c->grid.origin[2] + 0.5 * (c->grid.n[2] - 1) * c->grid.spacing[2], foci);
 }
 
 // Steering-dependent part of the kernel-2 variant choice (runs whenever the steering table changed):
@@ -514,43 +403,18 @@ static int configure_variant(olx_ctx* c) {
                 if (m < n_img && fy) o = c->h_py[o];
                 perm[(size_t)m * n + e] = o;
             }
-        auto same_vector = [&](int f1, int m1, int f2, int m2) {
-            for (int e = 0; e < n; ++e) {
-                const size_t a = (size_t)f1 * n + perm[(size_t)m1 * n + e], b = (size_t)f2 * n + perm[(size_t)m2 * n + e];
-                double dph = (c->h_delays[a] - c->h_delays[b]) * c->freq;
-                dph -= std::nearbyint(dph);
-                const double wa = c->h_apod[a] * c->h_area[a % n], wb = c->h_apod[b] * c->h_area[b % n];
-                if (std::fabs(wa - wb) > 1e-12 * std::max(std::fabs(wa), std::fabs(wb))) return false;
-                if (wa != 0.0 && std::fabs(dph) > 1e-9) return false;
-            }
-            return true;
-        };
-        struct Col { int f, m, ntgt; int tgt[4]; };
+        olxplan::Steering SV;
+        SV.n = n; SV.F = F; SV.n_img = n_img; SV.perm = perm.data(); SV.delays = c->h_delays.data(); SV.apod = c->h_apod.data(); SV.area = c->h_area.data(); SV.freq = c->freq;
+        typedef olxplan::Col Col;
         // A column may store to ANY focus volume, so the search for an equal vector runs over every tile packed so far: mirror-partner
         // foci share their columns wherever they sit in the sweep (a Wheel in its natural order has them at opposite ends).
-        auto pack = [&](int maxc) {
-            std::vector<std::vector<Col>> tl(1);
-            for (int f = 0; f < F; ++f)
-                for (int m = 0; m < n_img; ++m) {
-                    Col* hit = nullptr;
-                    for (size_t t = 0; t < tl.size() && !hit; ++t)
-                        for (size_t q = 0; q < tl[t].size() && !hit; ++q)
-                            if (tl[t][q].ntgt < 4 && same_vector(tl[t][q].f, tl[t][q].m, f, m)) hit = &tl[t][q];
-                    if (!hit) {
-                        if ((int)tl.back().size() >= maxc) tl.emplace_back();
-                        tl.back().push_back(Col{f, m, 0, {-1, -1, -1, -1}});
-                        hit = &tl.back().back();
-                    }
-                    hit->tgt[hit->ntgt++] = f * 4 + m;
-                }
-            return tl;
-        };
+        auto pack = [&](int maxc) { return olxplan::pack_columns(SV, maxc); };
         auto coset_fill = [&](int nt) {
             const int wx = c->fp.nx - (c->mx == 2 ? c->fp.nx / 2 : 0), wy = c->fp.ny - (c->my == 2 ? c->fp.ny / 2 : 0);
             const long long t16 = coset_tiles16(wx, wy, c->lat.mx, c->lat.my, nt);
             return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
         };
-        std::vector<std::vector<Col>> tiles = pack(MAXC);
+        olxplan::Tiles tiles = pack(MAXC);
         int total_cols = 0;
         // A sweep that needs SEVERAL launch tiles anyway is cut into tiles of 16 columns instead of 32: kernel 2g (NT = 2) then takes every
         // tile -- 8 x 0.43 ms against 2e's 4 x 0.92 ms on the 64-focus sweep (127 columns).  One tile of 17 - 32 columns stays with 2e's
@@ -601,13 +465,7 @@ static int configure_variant(olx_ctx* c) {
             c->cosetp_persist = kAbVariants && c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
             c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
             if (c->use_cosetp || c->use_cosetp4)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
-                for (auto& t : tiles)   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
-                    for (size_t o = 0; o < t.size() && (int)t.size() < c->nt * MFMA_COLS; ++o)
-                        if (t[o].ntgt > 2) {
-                            Col extra{t[o].f, t[o].m, 0, {-1, -1, -1, -1}};
-                            while (t[o].ntgt > 2) { extra.tgt[extra.ntgt++] = t[o].tgt[--t[o].ntgt]; t[o].tgt[t[o].ntgt] = -1; }
-                            t.push_back(extra);
-                        }
+                olxplan::balance_store_targets(tiles, c->nt * MFMA_COLS);   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
         }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
         const int ntiles = (int)tiles.size();
@@ -723,37 +581,18 @@ static int configure_variant(olx_ctx* c) {
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
-                const int kx_max = (P.nx - L.x_lo + 2 * A.mx - 1) / (2 * A.mx), ky_max = (P.ny - L.y_lo + A.my - 1) / A.my;
                 const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
-                Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
                 const int zb = c->use_cosetq ? 8 : COS_ZB;      // planes per block (kernel 2q: 8)
-                Q.kblocks = (P.nz + zb - 1) / zb;
+                olxplan::coset_partition(Q, kxw, zb);
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
-                Q.vox = L.vox; Q.flags = L.flags;
+                Q.vox = L.vox; Q.flags = L.flags; Q.n_foci = F;
                 Q.dir_wx = (c->dir_lattice && c->directivity) ? (float)(0.5 * c->h_size[0] / lambda) : 0.f;      // element width / length over 2 lambda (DIR instantiations)
                 Q.dir_wy = (c->dir_lattice && c->directivity) ? (float)(0.5 * c->h_size[1] / lambda) : 0.f;
                 Q.absorb_l2 = c->dir_lattice ? (float)(c->absorb_np_m * lambda * 1.4426950408889634) : 0.f;   // exp(-a d) = exp2(-a lambda log2(e) d'), d' [wavelengths]
                 {   // dense store-job lists per (launch tile, column tile): job = c16 | image << 4 | focus << 6
-                    std::vector<int> jobs((size_t)ntiles * MFMA_MAX_NT * (COS_JOBS + 1), -1);
-                    for (int t = 0; t < ntiles; ++t)
-                        for (int nt = 0; nt < MFMA_MAX_NT; ++nt) {
-                            int* jb = &jobs[((size_t)t * MFMA_MAX_NT + nt) * (COS_JOBS + 1)];
-                            int cnt = 0;
-                            for (int c16 = 0; c16 < 16; ++c16) {
-                                const bool wantp = (c16 & 1) ? (P.flags & OLX_OUT_INTENSITY) != 0 : (P.flags & OLX_OUT_PMAG) != 0;
-                                const size_t o = (size_t)nt * MFMA_COLS + (c16 >> 1);
-                                if (!wantp || o >= tiles[t].size()) continue;
-                                for (int q = 0; q < 4; ++q) {
-                                    const int code = tiles[t][o].tgt[q];
-                                    if (code >= 0) jb[cnt++] = c16 | ((code & 3) << 4) | ((code >> 2) << 6);
-                                }
-                            }
-                            int lg = 0;
-                            while ((1 << lg) < cnt) ++lg;
-                            jb[COS_JOBS] = lg;
-                        }
+                    const std::vector<int> jobs = olxplan::build_store_jobs(tiles, MFMA_MAX_NT, MFMA_COLS, COS_JOBS, (P.flags & OLX_OUT_PMAG) != 0, (P.flags & OLX_OUT_INTENSITY) != 0);
                     if (c->jobs_cap < jobs.size()) {
                         if (c->d_jobs) hipFree(c->d_jobs);
                         c->d_jobs = nullptr; c->jobs_cap = 0;
@@ -764,75 +603,25 @@ static int configure_variant(olx_ctx* c) {
                 }
                 {   // kernel 2e / 2g / 2f / 2q block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
-                    const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
-                    std::vector<CosetBlock> blk(nblk);
-                    const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
                     // kernel 2g fed from a precomputed geometry table (k_gtable.hip; developer library, OLX_GTABLE=1 | order0: measured SLOWER than
                     // the in-kernel generation).  The table offsets of a block all lie in ONE residue class (U mod mx, W mod my);
                     // the 2 nsx nsy blocks of a plane block that share a class read overlapping windows of it, so they get consecutive ids on one
-                    // XCD (below; not with order0): L2 serves all but one of them.
+                    // XCD (not with order0): L2 serves all but one of them.
                     const char* gte = getenv("OLX_GTABLE");
                     c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr &&
                                     Q.nsa * Q.nsbp > 2 && gte && (!strcmp(gte, "1") || !strcmp(gte, "order0"));      // (fp8 shape: no registers for the entries in flight; one pair: nothing to copy)
                     const bool gt_order = c->use_gtable && strcmp(gte, "order0") != 0;
-                    for (unsigned id = 0; id < nblk; ++id) {
-                        unsigned b = id;
-                        int kblock;
-                        const unsigned grp = c->use_cosetq ? 4u : 2u;   // blocks that share 128-byte lines (16 / 8 planes of 4 bytes each)
-                        if ((Q.kblocks % grp) == 0 && nblk % (8 * grp) == 0) {
-                            const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % grp, u = (sft / grp) * 8 + xcd, part = (unsigned)Q.kblocks / grp;
-                            kblock = (int)(grp * (u % part) + kb_lo); b = u / part;
-                        } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
-                        const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
-                        const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
-                        int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
-                        if (gt_order) {      // cosets rx and rx + mx share their table class: neighbours in the id order
-                            const int rxh = (int)(b % 2u); b /= 2u;
-                            ry = (int)(b % (unsigned)Q.my); rx = (int)(b / (unsigned)Q.my) + Q.mx * rxh;
-                        }
-                        const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * Q.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
-                        const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
-                        const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
-                        CosetBlock& B = blk[id];
-                        B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
-                        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.gt_off = 0;
-                        if (c->use_cosetq) {   // kernel 2q: tiles are pairs of y-adjacent positions
-                            const int KYP = (B.KY + 1) / 2;
-                            B.npos = (KX > 0 && KY > 0) ? KX * KYP : 0; B.ky_magic = 65536 / KYP + 1;
-                            if (B.npos > 20) return fail(c, OLX_ESTATE, "kernel 2q: a block part holds more than 20 position pairs");
-                        } else
-                        if (c->use_cosetp && B.npos > 40) return fail(c, OLX_ESTATE, "kernel 2g: a block part holds more than 40 positions");
+                    std::vector<CosetBlock> blk;
+                    {
+                        std::string why;
+                        if (!olxplan::build_coset_blocks(Q, zb, c->use_cosetq ? 4u : 2u, gt_order, c->use_cosetq, c->use_cosetq ? 20 : (c->use_cosetp ? 40 : 0), blk, why))
+                            return fail(c, OLX_ESTATE, "kernel %s: %s", c->use_cosetq ? "2q" : "2g", why.c_str());
                     }
+                    const unsigned nblk = (unsigned)blk.size();
                     if (c->use_gtable) {
-                        // offsets in use: a block's tables hold U = Ub + mx (-q - 8 sa), q = 0 .. 11 (Ub: column 0 of sa = 0) and W = Wb + my (R - 8 sbb),
-                        // R = 0 .. 25 (Wb: row 0 of sbb = 0, the first super-block row of a pair being even: sbb <= nsbp - 2)
-                        long long u_lo = LLONG_MAX, u_hi = LLONG_MIN, w_lo = LLONG_MAX, w_hi = LLONG_MIN;
-                        for (const CosetBlock& B : blk) {
-                            if (B.npos <= 0) continue;
-                            const long long Ub = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx, Wb = (long long)B.jbase + Q.uy0 - 15LL * Q.my;
-                            u_hi = std::max(u_hi, Ub); u_lo = std::min(u_lo, Ub - (11LL + 8LL * (Q.nsa - 1)) * Q.mx);
-                            w_lo = std::min(w_lo, Wb - 8LL * std::max(Q.nsbp - 2, 0) * Q.my); w_hi = std::max(w_hi, Wb + 25LL * Q.my);
-                        }
-                        auto floor_to = [](long long v, long long m) { long long q = v / m; if (q * m > v) --q; return q * m; };
                         double max_mb = 4096.0;
                         if (const char* e = getenv("OLX_GTABLE_MAX_MB")) { const double v = atof(e); if (v > 0) max_mb = v; }
-                        if (u_hi < u_lo) c->use_gtable = false;
-                        else {
-                            const long long ulo = floor_to(u_lo, Q.mx), wlo = floor_to(w_lo, Q.my);
-                            const long long nu = (u_hi - ulo) / Q.mx + 1, nw = (w_hi - wlo) / Q.my + 1, nzp = (long long)Q.kblocks * zb;
-                            const long long entries = (long long)Q.mx * Q.my * nzp * nw * nu;
-                            if (entries >= (1LL << 32) || (double)entries * sizeof(GtEntry) > max_mb * 1048576.0 || std::llabs(ulo) > (1LL << 23) || std::llabs(wlo) > (1LL << 23))
-                                c->use_gtable = false;       // (too large to keep: the blocks evaluate their tables themselves)
-                            else {
-                                Q.gt_nu = (int)nu; Q.gt_nw = (int)nw; Q.gt_nzp = (int)nzp; Q.gt_ulo = (int)ulo; Q.gt_wlo = (int)wlo;
-                                for (CosetBlock& B : blk) {
-                                    if (B.npos <= 0) continue;
-                                    const long long du = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx - ulo, dw = (long long)B.jbase + Q.uy0 - 15LL * Q.my - wlo;
-                                    const long long cls = (du % Q.mx) * Q.my + dw % Q.my;
-                                    B.gt_off = (unsigned)(cls * nzp * nw * nu + (dw / Q.my) * nu + (nu - 1 - du / Q.mx));
-                                }
-                            }
-                        }
+                        c->use_gtable = olxplan::plan_geometry_table(Q, zb, blk, max_mb);
                     }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "olx_params.h"
+#include "olx_plan.h"
 
 using namespace olx;
 
@@ -75,15 +76,8 @@ struct olx_ctx {
     int mx = 1, my = 1, dx = 1, dy = 1, nf = 1; std::vector<int> h_px, h_py; int* d_perm = nullptr; size_t perm_cap = 0; SharedParams sp{};
     float* d_tab = nullptr; size_t tab_cap = 0;
     // lattice variant (kernel 2d): matrix array whose pitch is a whole number of voxels
-    struct Lattice {
-        bool ok = false;
-        int ax = 0, ay = 0, nsa = 0, nsb = 0, mx = 1, my = 1, n_pad = 0;
-        double x0 = 0, y0 = 0, px = 0, py = 0;     // position of lattice index (0, 0) and pitch [m]
-        double min_d2 = 0; bool clamp = false;     // incl. the zero-weight virtual elements of the padding
-        std::vector<int> slot_elem;                // K slot -> element (-1 = virtual)
-        std::vector<int> cell;                     // lattice cell (a, b) -> element
-        int nsbp = 0;                              // super-block rows of the slot map (nsb, or nsb padded to even)
-    } lat;
+    typedef olxplan::Lattice Lattice;          // olx_plan.h: regular (a, b) lattice in one z plane, pitch = whole voxels
+    Lattice lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)

@@ -1,7 +1,9 @@
 // Parameter blocks and compile-time shapes shared by the host side (olx.hip) and the kernel translation
 // units (k_*.hip).  No device code here.
 #pragma once
+#ifdef __HIPCC__
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace olx {
@@ -86,6 +88,7 @@ struct CosetParams {
     float absorb_l2;           // DIR instantiations: uniform absorption, log2(e) Np per wavelength (table entries carry exp(-a d)); 0 = lossless
     long long vox;
     unsigned flags;
+    int n_foci;                // planned foci: the output arrays hold n_foci volumes of vox floats (what the debug build's store checks compare with)
     // precomputed geometry table (GT instantiations of kernel 2g; built once per plan by gtable_gen_k, k_gtable.hip): entry
     // ((class nzp + plane) NW + w) NU + ur = {hi word, lo word} of G at integer offsets U = gt_ulo + cx + mx (NU - 1 - ur), W = gt_wlo + cy + my w,
     // class = cx my + cy -- the offsets a block's tables hold all lie in ONE residue class, a table row (12 columns) is 96 contiguous bytes

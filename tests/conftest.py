@@ -63,6 +63,8 @@ def ctx():
     from openlifu_amd import _native
     c = _native.Context(0)
     yield c
+    if "libolx_dbg" in os.path.basename(_native.LIB_PATH):      # debug library: olx_sync reports the kernels' bounds checks
+        c.sync()
     c.close()
 
 
