@@ -22,7 +22,7 @@ def test_bounds_checks_exist_only_in_the_debug_library():
 
 @pytest.mark.gpu
 def test_kernels_stay_inside_their_extents_in_the_debug_library():
-    env = dict(os.environ, OLX_LIB_PATH=os.path.join(LIB, "libolx_dbg.so"), OLX_FUZZ_CASES="24")
+    env = dict(os.environ, OLX_LIB_PATH=os.path.join(LIB, "libolx_dbg.so"))
     env.pop("OLX_FIELD_VARIANT", None)
     sel = ("fuzz or ragged or lattice_without_mirror_folds or padded_array or element_plane or single_column_toeplitz or pair_tables or "
            "marched_medium or heterogeneous_medium or mirror_partner or large_element_counts")
