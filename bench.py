@@ -353,10 +353,28 @@ def main():
         """Initialise the reassembly transport `kind` ("rccl" | "p2p") on every rank; (ok on ALL ranks, note)."""
         ok, note = 1, None
         os.environ["OLX_GATHER"] = kind        # read by rank 0 when it makes the id; the id tells the others
-        try:
-            sf.init_comm(exchange, allgather_bytes)  # (libolx keeps RCCL's banner off stdout)
-        except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
-            ok, note = 0, f"{kind} init failed: {e}"
+        if stuck:       # an earlier init never came back: this context's communicator state is not ours to touch again
+            ok, note = 0, f"{kind} not tried: {stuck[0]}"
+        else:
+            # The first multi-device ncclCommInitRank of this code happens on whatever node runs `--gpus N`: it runs on a watchdog thread, so
+            # that an init that never returns costs the exchange, not the whole line (the timed step then runs without exchange and says so).
+            import threading
+            box = []
+
+            def work():
+                try:
+                    sf.init_comm(exchange, allgather_bytes)  # (libolx keeps RCCL's banner off stdout)
+                    box.append(None)
+                except Exception as e:  # noqa: BLE001 - report, keep measuring the sharded compute
+                    box.append(e)
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("OLX_BENCH_COMM_TIMEOUT_S", "300")))
+            if th.is_alive():
+                stuck.append(f"{kind} init did not return within {os.environ.get('OLX_BENCH_COMM_TIMEOUT_S', '300')} s")
+                ok, note = 0, stuck[0]
+            elif box and box[0] is not None:
+                ok, note = 0, f"{kind} init failed: {box[0]}"
         if dist is not None:  # every rank must take the same branch, or the collectives below would hang
             import torch
             flag = torch.tensor([ok], dtype=torch.int32)
@@ -364,13 +382,15 @@ def main():
             if int(flag[0]) == 0:
                 if ok:
                     note = f"{kind} init failed on another rank"
-                sf.close()
+                if not stuck:
+                    sf.close()
             ok = int(flag[0])
-        elif not ok:
+        elif not ok and not stuck:
             sf.close()
         return bool(ok), note
 
     transport = None
+    stuck = []       # set when a communicator init never returned (see init_transport)
     if gather:
         # north_star's reassembly is RCCL; the direct peer-to-peer all-gather (HIP IPC, all 7 xGMI links at once) is timed beside
         # it, and takes over as the primary transport when RCCL cannot be brought up
@@ -477,7 +497,8 @@ def main():
         gather_note = ((gather_note + "; ") if gather_note else "") + f"{transport} {mode} failed ({timed.last_error}); timed without exchange"
         gather, mode = False, "none"
         try:
-            sf.close()
+            if not stuck:
+                sf.close()
         except Exception:  # noqa: BLE001
             pass
         plan(args.corrections == "fp8")
@@ -633,6 +654,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
+        if stuck:            # a thread is still inside a communicator init: no teardown through it
+            sys.stdout.flush()
+            os._exit(0)
         sf.close()
         dist.destroy_process_group()
 

@@ -329,7 +329,16 @@ static bool infer_foci(const olx_ctx* c, std::vector<double>& foci) {
 // Steering-dependent part of the kernel-2 variant choice (runs whenever the steering table changed):
 // dx/dy = distinct weight columns along folded axes (1 when every focus' delays and apodization are
 // mirror-symmetric), nf = foci per tile so that dx*dy*nf <= 8 accumulator columns.
+static int configure_variant_impl(olx_ctx* c);
+// (the result is remembered per steering version: olx_field_plan names the variant with it, the launch that follows packs against the same
+// decisions instead of deriving them again -- column packing, block records and their uploads were 0.28 ms of every calc_solution, twice)
 static int configure_variant(olx_ctx* c) {
+    c->configured_version = ~0ull;
+    const int rc = configure_variant_impl(c);
+    if (rc == OLX_OK) c->configured_version = c->steer_version;
+    return rc;
+}
+static int configure_variant_impl(olx_ctx* c) {
     const int n = c->n_el, F = c->plan_foci;
     auto steering_symmetric = [&](const std::vector<int>& perm) {
         if (c->h_delays.size() != (size_t)F * n || c->h_apod.size() != (size_t)F * n) return false;
@@ -506,11 +515,14 @@ static int configure_variant(olx_ctx* c) {
         if (c->use_lattice) {
             if (c->slot_cap < (size_t)n_pad) {
                 if (c->d_slot) hipFree(c->d_slot);
-                c->d_slot = nullptr; c->slot_cap = 0;
+                c->d_slot = nullptr; c->slot_cap = 0; c->up_slot.clear();
                 HIPCHK(c, hipMalloc((void**)&c->d_slot, sizeof(int) * n_pad));
                 c->slot_cap = n_pad;
             }
-            HIPCHK(c, hipMemcpy(c->d_slot, c->lat.slot_elem.data(), sizeof(int) * n_pad, hipMemcpyHostToDevice));
+            if (c->up_slot != c->lat.slot_elem) {     // (uploaded tables are remembered: a new steering table alone changes none of them)
+                HIPCHK(c, hipMemcpy(c->d_slot, c->lat.slot_elem.data(), sizeof(int) * n_pad, hipMemcpyHostToDevice));
+                c->up_slot = c->lat.slot_elem;
+            }
         }
         // power-of-two operand scales: |G| <= 1/d'_min, |W| <= wmax  ->  hi parts <= 2^14, lo parts normal
         const double dmin_w = std::max(min_dist * rev, 1e-6);
@@ -595,11 +607,14 @@ static int configure_variant(olx_ctx* c) {
                     const std::vector<int> jobs = olxplan::build_store_jobs(tiles, MFMA_MAX_NT, MFMA_COLS, COS_JOBS, (P.flags & OLX_OUT_PMAG) != 0, (P.flags & OLX_OUT_INTENSITY) != 0);
                     if (c->jobs_cap < jobs.size()) {
                         if (c->d_jobs) hipFree(c->d_jobs);
-                        c->d_jobs = nullptr; c->jobs_cap = 0;
+                        c->d_jobs = nullptr; c->jobs_cap = 0; c->up_jobs.clear();
                         HIPCHK(c, hipMalloc((void**)&c->d_jobs, sizeof(int) * jobs.size()));
                         c->jobs_cap = jobs.size();
                     }
-                    HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
+                    if (c->up_jobs != jobs) {
+                        HIPCHK(c, hipMemcpy(c->d_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
+                        c->up_jobs = jobs;
+                    }
                 }
                 {   // kernel 2e / 2g / 2f / 2q block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
@@ -625,11 +640,14 @@ static int configure_variant(olx_ctx* c) {
                     }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);
-                        c->d_cpblocks = nullptr; c->cpblocks_cap = 0;
+                        c->d_cpblocks = nullptr; c->cpblocks_cap = 0; c->up_blocks.clear();
                         HIPCHK(c, hipMalloc((void**)&c->d_cpblocks, sizeof(CosetBlock) * nblk));
                         c->cpblocks_cap = nblk;
                     }
-                    HIPCHK(c, hipMemcpy(c->d_cpblocks, blk.data(), sizeof(CosetBlock) * nblk, hipMemcpyHostToDevice));
+                    if (c->up_blocks.size() != blk.size() || memcmp(c->up_blocks.data(), blk.data(), sizeof(CosetBlock) * nblk) != 0) {
+                        HIPCHK(c, hipMemcpy(c->d_cpblocks, blk.data(), sizeof(CosetBlock) * nblk, hipMemcpyHostToDevice));
+                        c->up_blocks = blk;
+                    }
                     c->cp_nblocks = nblk;
                     if (c->use_cosetr) {   // kernel 2r walks the non-empty records only
                         std::vector<CosetBlock> live;
@@ -762,7 +780,7 @@ static int configure_variant(olx_ctx* c) {
     }
     if (c->modifier() && c->use_mfma && !(c->use_lattice && c->use_coset)) {   // only the coset kernels (2e / 2f / 2g) carry per-term factors: fall back to 2a-d
         c->dir_lattice = false; c->allow_shared = false;
-        return configure_variant(c);
+        return configure_variant_impl(c);
     }
     if (c->use_mfma && c->use_lattice && c->use_cosetp && c->use_gtable) strncat(nmbuf, " +precomputed geometry table", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
@@ -773,7 +791,7 @@ static int configure_variant(olx_ctx* c) {
 
 static int pack_if_needed(olx_ctx* c) {
     if (c->packed_version == c->steer_version) return OLX_OK;
-    { int rc = configure_variant(c); if (rc) return rc; }
+    if (c->configured_version != c->steer_version) { int rc = configure_variant(c); if (rc) return rc; }
     const double lambda = c->c / c->freq;
     if (c->hetero) {
         olx_pack_hetero(c);

@@ -57,7 +57,7 @@ struct olx_ctx {
     size_t steer_cap = 0;
     double *d_foci = nullptr, *d_M = nullptr;
     size_t foci_cap = 0;
-    unsigned long long steer_version = 0, packed_version = ~0ull;
+    unsigned long long steer_version = 0, packed_version = ~0ull, configured_version = ~0ull;   // steering table / what the operands were packed from / what configure_variant decided for
     // field plan
     bool planned = false;
     double plan_absorb = 0;     // olx_field_absorption as seen by the last olx_field_plan
@@ -82,6 +82,7 @@ struct olx_ctx {
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records
+    std::vector<CosetBlock> up_blocks; std::vector<int> up_jobs, up_slot;   // host copies of what d_cpblocks / d_jobs / d_slot hold (re-uploaded only when they change)
     bool use_cosetr = false; CosetBlock* d_cprblocks = nullptr; size_t cprblocks_cap = 0; unsigned cpr_nblocks = 0;   // kernel 2r: persistent, one block per CU (non-empty records only)
     bool use_cosetq = false;   // kernel 2q: 2g in blocks of 4 waves x 8 planes (four blocks per CU)
     bool cosetp_persist = false; int cosetp_stagger = 0;   // kernel 2g, persistent form (OLX_FIELD_VARIANT=cosetpp[:stagger cycles]; A/B)

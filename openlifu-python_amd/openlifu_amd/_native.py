@@ -448,8 +448,14 @@ class Context:
         self._chk(self._lib.olx_field_analysis_peaks(self._h, _dptr(A), _dptr(aspect), float(r_main_m), float(r_side_m), float(zmin_m), _fptr(out)))
         return out
 
-    def solution_analyze(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
-                         beam_db=(3, 6), scale=None):
+    def solution_analyze(self, *args, **kwargs):
+        """``solution_analyze_begin(...)()``: the blocking form."""
+        return self.solution_analyze_begin(*args, **kwargs)()
+
+    def solution_analyze_begin(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
+                               beam_db=(3, 6), scale=None, overlap=False):
+        """Marshals the arguments HERE and returns ``finish() -> report``.  ``overlap=True`` starts the C call (it releases the GIL and blocks for
+        the device's scans) on a helper thread at once, so that the caller's own host arithmetic runs beside it; ``finish`` joins it."""
         """Everything ``Solution.analyze`` reads off the resident volumes in one crossing (``olx_solution_analyze``).
         ``line_offsets`` = the three offset vectors [m] of the focal-axis lines, ``line_pts`` [F, n0 + n1 + n2, 3] their
         positions.  Returns a dict of arrays: peaks [F, 6], ita_main [F], moments [F, 4], bounds [F, 3, 2, 2] (indices into
@@ -479,11 +485,27 @@ class Context:
             pts = _f64(line_pts, (F, sum(len(v) for v in line_offsets), 3))
         rep = (OlxFocusReport * F)()
         glob = c_float(0)
-        self._chk(self._lib.olx_solution_analyze(self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc), rep, ctypes.byref(glob)))
-        raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
-                                                 ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
-        return {"peaks": raw["peaks"].copy(), "ita_main": raw["ita_main"].copy(), "moments": raw["moments"].copy(),
-                "bounds": raw["bounds"].copy(), "ita_global": float(glob.value)}
+        argv = (self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc), rep, ctypes.byref(glob))
+        keep = (A, w, pts, o, sc)          # (the arrays behind the pointers live as long as the closure)
+        rc_box = []
+        helper = None
+        if overlap:
+            import threading
+            helper = threading.Thread(target=lambda: rc_box.append(self._lib.olx_solution_analyze(*argv)))
+            helper.start()
+
+        def finish():
+            if helper is not None:
+                helper.join()
+            else:
+                rc_box.append(self._lib.olx_solution_analyze(*argv))
+            self._chk(rc_box[0])
+            assert keep is not None
+            raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
+                                                     ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
+            return {"peaks": raw["peaks"].copy(), "ita_main": raw["ita_main"].copy(), "moments": raw["moments"].copy(),
+                    "bounds": raw["bounds"].copy(), "ita_global": float(glob.value)}
+        return finish
 
     def field_masked_moments(self, A, aspect, radius_m, cutoff):
         """[F,4] = (sum p, sum p x, sum p y, sum p z) over the mainlobe mask where |p| > cutoff[f]."""

@@ -28,7 +28,16 @@ class Point:
         self.position = np.array(self.position).reshape(3)
 
     def copy(self) -> "Point":
-        return copy.deepcopy(self)
+        """An independent Point (geo.py: ``copy.deepcopy(self)``).  Field by field: the position array and a mutable colour are copied, the rest
+        is immutable -- a focal pattern copies every focus of every call, and deepcopy's generic walk was 25 calls per Point."""
+        new = object.__new__(type(self))
+        d = dict(self.__dict__)
+        d["position"] = np.array(self.position)
+        for k, v in d.items():
+            if k != "position" and not isinstance(v, (str, int, float, bool, tuple, type(None))):
+                d[k] = copy.deepcopy(v)
+        new.__dict__ = d
+        return new
 
     def get_position(self, dim=None, units: str | None = None):
         """geo.py:48-54."""

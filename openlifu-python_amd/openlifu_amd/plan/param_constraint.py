@@ -48,6 +48,16 @@ class ParameterConstraint(DictMixin):
     def is_error(self, value) -> bool:
         return self.error_value is not None and not self.compare(value, self.operator, self.error_value)
 
+    # Display helpers of the reference (plan/param_constraint.py:11, 81-98: PARAM_STATUS_SYMBOLS, get_status_symbol, to_table -> pandas) are
+    # outside this build's scope (no arithmetic on the path).  They exist as explicit refusals so that a caller
+    # written against the reference fails with a message instead of an AttributeError; get_status / is_warning / is_error carry the logic.
+    def get_status_symbol(self, value) -> str:
+        raise NotImplementedError("ParameterConstraint.get_status_symbol (display glyphs) is not part of openlifu_amd; use get_status(value) -> 'ok' | 'warning' | 'error'")
+
+    def to_table(self):
+        raise NotImplementedError("ParameterConstraint.to_table (pandas display table) is not part of openlifu_amd; the limits are warning_value / error_value, "
+                                  "the checks is_warning / is_error / get_status")
+
     def get_status(self, value) -> str:
         return "error" if self.is_error(value) else "warning" if self.is_warning(value) else "ok"
 

@@ -179,10 +179,10 @@ class Solution:
         # peaks of |p| and intensity, -3 dB centroid moments (find_centroid), time-average intensity volume (get_ita) with its
         # mainlobe / global peaks, and the -3 / -6 dB crossings along the three focal axes of every focus
         # (_scale: the per-focus factors of a deferred Solution.scale -- the device scales and aggregates in the same crossing, see scale())
-        rep = ctx.solution_analyze(A, ita_w, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin,
-                                   line_pts=pts, line_offsets=offsets, scale=_scale)
-        pk, mom, ita_main = rep["peaks"], rep["moments"], rep["ita_main"]
-        main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
+        # (the crossing blocks for the device's ~0.5 ms and releases the GIL: it runs on a helper thread while this one evaluates the emitted
+        # pressure / power / thermal index below, which need nothing from the device)
+        finish = ctx.solution_analyze_begin(A, ita_w, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin,
+                                            line_pts=pts, line_offsets=offsets, scale=_scale, overlap=True)
         # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
         # drive signal is created once and handed to calc_output for every focus (which scales it in place by the
         # transducer sensitivity, xdc/transducer.py:100-106); only the per-element maximum of that [N, T] matrix is used.
@@ -202,6 +202,9 @@ class Solution:
             tic[i] = power_W[i] / (d_eq_cm * c_tic)
             an.p0_MPa.append(float(1e-6 * np.max(p0_Pa)))
         an.TIC = float(np.mean(tic)); an.power_W = float(np.mean(power_W))
+        rep = finish()
+        pk, mom, ita_main = rep["peaks"], rep["moments"], rep["ita_main"]
+        main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))
         bounds = rep["bounds"]
         for i in range(F):
             mp, mi, sp, si = float(main_p[i]) * 1e-6, float(main_i[i]), float(side_p[i]) * 1e-6, float(side_i[i])

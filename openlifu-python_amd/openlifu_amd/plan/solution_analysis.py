@@ -136,6 +136,12 @@ class SolutionAnalysis(DictMixin):
                                   for k, v in d.get("param_constraints", {}).items()}
         return cls(**d)
 
+    def to_table(self, constraints=None, focus_index=None):
+        """Display table of the reference (plan/solution_analysis.py:146-195, pandas): outside this build's scope -- an explicit refusal instead of
+        an AttributeError.  The numbers are the dataclass fields; ``param_constraints[name].get_status(value)`` gives each one's status."""
+        raise NotImplementedError("SolutionAnalysis.to_table (pandas display table) is not part of openlifu_amd; read the fields and use "
+                                  "param_constraints[name].get_status(value)")
+
     @staticmethod
     def from_json(json_string: str) -> "SolutionAnalysis":
         return SolutionAnalysis.from_dict(json.loads(json_string))

@@ -580,3 +580,15 @@ def test_batched_focus_frames_equal_the_per_focus_matrices():
     for i in range(9):
         ref = np.linalg.inv(get_focus_matrix(foci[i], origin=origins[i]))[:3].ravel()
         assert np.abs(A[i] - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max())
+
+
+def test_display_tables_are_explicit_refusals():
+    """The reference's pandas display helpers (plan/param_constraint.py:81-98, plan/solution_analysis.py:146-195) are out of scope; callers written
+    against them get a NotImplementedError that names the replacement, not an AttributeError."""
+    from openlifu_amd.plan.param_constraint import ParameterConstraint
+    from openlifu_amd.plan.solution_analysis import SolutionAnalysis
+    pc = ParameterConstraint("<", 1.0, 2.0)
+    assert pc.get_status(0.5) == "ok" and pc.get_status(1.5) == "warning" and pc.get_status(2.5) == "error"
+    for call in (pc.to_table, lambda: pc.get_status_symbol(0.5), SolutionAnalysis().to_table):
+        with pytest.raises(NotImplementedError, match="openlifu_amd"):
+            call()
