@@ -56,22 +56,30 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 // share a table class sit on one XCD: L2 serves 3 of them); this hybrid form 0.484 vs 0.453 -- the copied pair's phase gets 1.6 k cycles
 // shorter and every OTHER phase of the wave longer (first tables + 0.5 k, barrier + 0.5 k, K-steps + 0.5 k, stores + 0.8 k: 96 more
 // vector-memory instructions per block and pair in a pipe the two resident blocks' stores already fill), 38.4 k instead of 36.2 k per wave.
-template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false>
+// MIX (round 4; developer library, OLX_MIXED_CORRECTION=1: measured no faster than three fp16 products at 5 x their error): mixed correction products.  The fp16 hi/lo split needs hi*hi + hi_G*lo_W + lo_G*hi_W; here the LAST term alone goes through
+// e4m3 -- one v_mfma_scale_f32_16x16x128_f8f6f4 per tile and element super-block (4 K-steps x 32 values) -- and the other correction stays an fp16
+// product: 40 matrix cycles per K-step and tile instead of 48 (three fp16 products) or 32 (both corrections in e4m3, FP8), half the e4m3
+// rounding variance of FP8.  Tables: fp16 (re, im) of hi (rounded to nearest) + TWO e4m3 bytes [lo re, lo im] per entry (a half-word array:
+// 35 KB instead of 46.6); steering stage per K-step and column tile: hi fp16, lo fp16 and 8 e4m3 bytes per lane of hi * 2^-6 (mfma_pack_k mode 2).
+template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false, bool MIX = false>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
     const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger,
     const GtEntry* __restrict__ gtab = nullptr) {
     static_assert(!(GT && (FP8 || DIR || PERSIST)), "the table-fed form exists for the default arithmetic only");
+    static_assert(!(MIX && (FP8 || DIR || PERSIST || GT)), "mixed corrections: its own instantiations");
     constexpr int NT = 2, THREADS = COS_NW * 64;
     constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
-    constexpr int B_BYTES = 2 * 4 * NT * 2 * 64 * 16;                           // two super-blocks of steering fragments
+    constexpr int B_KS_U4 = MIX ? 160 : 128;                                    // uint4 per K-step and column tile: hi, lo (64 lanes each) [, 8 e4m3 bytes per lane]
+    constexpr int B_BYTES = 2 * 4 * NT * B_KS_U4 * 16;                          // two super-blocks of steering fragments
     constexpr int T_WORDS = COS_ZB * CP_PSZ;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + 2 * T_WORDS * 4 + 64];
-    typedef uint4 (*BArr)[NT][2][64];
-    BArr s_B = reinterpret_cast<BArr>(smem);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + T_WORDS * 4 + T_WORDS * (MIX ? 2 : 4) + 64];
+    // steering stage: K-step record (sl * 4 + ks, nt) = B_KS_U4 uint4: [0] hi, [1] lo of the 64 lanes [, MIX: then 8 e4m3 bytes per lane]
+    auto s_B = [&](int rec, int nt, int part) -> const uint4* { return reinterpret_cast<const uint4*>(smem) + ((size_t)(rec * NT + nt) * B_KS_U4 + part * 64); };
     unsigned* const s_hi = reinterpret_cast<unsigned*>(smem + B_BYTES);
     unsigned* const s_lo = s_hi + T_WORDS;
+    [[maybe_unused]] unsigned short* const s_lo8 = reinterpret_cast<unsigned short*>(s_lo);      // MIX: e4m3 [lo re, lo im] per entry, same indexing as s_hi
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p16 = lane & 15;
@@ -115,15 +123,15 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int nsbp = P.nsbp;                    // even: chunks = table pairs never straddle sa
     const int n_sb = P.nsa * nsbp;
-    constexpr int CHUNK_U4 = 2 * 4 * NT * 128, PRE = CHUNK_U4 / THREADS;
+    constexpr int CHUNK_U4 = 2 * 4 * NT * B_KS_U4, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
-    const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * 128);
+    const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * B_KS_U4);
     // (the steering fragments do not depend on the item: all items of a launch tile read the same chunks)
 #pragma unroll
     for (int q = 0; q < PRE; ++q) {
         const int idx = tid + q * THREADS;
-        pre[q] = idx < n_sb * 4 * NT * 128 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
+        pre[q] = idx < n_sb * 4 * NT * B_KS_U4 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
     }
     // GT: this lane's 12 entries of a pair's tables -- planes k0 + 2 wave + z, rows RPR r + wl, column q (lane = 12 wl + q; lanes 60 .. 63 idle)
     GtEntry gpre[GT ? NROUND * COS_P : 1];
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     half2_t hi;
-                    if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
+                    if constexpr (FP8 || MIX) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
                     else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
                     // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
                     float lr, li;
@@ -231,6 +239,10 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
                         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
                         lo_word = __builtin_bit_cast(unsigned, w);
+                    } else if constexpr (MIX) {      // e4m3 bytes [lo re, lo im] (* 2^5: |lo| <= 2^-12 |hi| <= 4)
+                        short2_t w = {0, 0};
+                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
+                        lo_word = __builtin_bit_cast(unsigned, w) & 0xFFFFu;
                     } else {
                         lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
                     }
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
                         if (OLX_IN(o, T_WORDS, 0)) {
                             s_hi[o] = __builtin_bit_cast(unsigned, hi);
-                            s_lo[o] = lo_word;
+                            if constexpr (MIX) s_lo8[o] = (unsigned short)lo_word; else s_lo[o] = lo_word;
                         }
                     }
                 }
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         __syncthreads();
         if (sb0 == 0) OLX_STAMP(3);
         {   // next pair's fragments: in flight during the K-steps, drained by the next barrier
-            const int nxt = (sb0 + 2) * 4 * NT * 128, lim = n_sb * 4 * NT * 128;
+            const int nxt = (sb0 + 2) * 4 * NT * B_KS_U4, lim = n_sb * 4 * NT * B_KS_U4;
 #pragma unroll
             for (int q = 0; q < PRE; ++q) {
                 const int idx = nxt + tid + q * THREADS;
@@ -273,8 +285,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                         for (int ka = 0; ka < 2; ++ka) {
-                            bh[ka][nt].u = s_B[sl * 4 + 2 * kb + ka][nt][0][lane];
-                            const uint4 q = s_B[sl * 4 + 2 * kb + ka][nt][1][lane];
+                            bh[ka][nt].u = s_B(sl * 4 + 2 * kb + ka, nt, 0)[lane];
+                            const uint4 q = s_B(sl * 4 + 2 * kb + ka, nt, 1)[lane];
                             b8[nt][4 * ka + 0] = (int)q.x; b8[nt][4 * ka + 1] = (int)q.y; b8[nt][4 * ka + 2] = (int)q.z; b8[nt][4 * ka + 3] = (int)q.w;
                         }
                     }
@@ -309,6 +321,61 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                             acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
                     }
                 }
+            } else if constexpr (MIX) {
+                // this super-block's e4m3 steering bytes: 4 K-steps x 8 bytes per lane and column tile (the K = 128 operand of the correction product)
+                intx8_t b8[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const uint2 q = reinterpret_cast<const uint2*>(s_B(sl * 4 + ks, nt, 2))[lane];
+                        b8[nt][2 * ks] = (int)q.x; b8[nt][2 * ks + 1] = (int)q.y;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {         // fp16 products: hi * hi and hi_G * lo_W
+                    const int ka = ks & 1, kb = ks >> 1;
+                    Half8Bits bh[NT], bl[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        bh[nt].u = s_B(sl * 4 + ks, nt, 0)[lane];
+                        bl[nt].u = s_B(sl * 4 + ks, nt, 1)[lane];
+                    }
+                    const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
+#pragma unroll
+                    for (int t = 0; t < CP_MT; ++t) {
+                        if (t >= ntile) continue;            // wave-uniform
+                        Half8Bits ah;
+                        int lo_t = lane_off;
+                        asm volatile("" : "+v"(lo_t));
+                        const int ro = lo_t + toff[t];
+                        if (!OLX_IN(ro + kso, T_WORDS - 3, 1)) continue;
+                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
+                        const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        ah.w[0] = (unsigned)h0; ah.w[1] = (unsigned)(h0 >> 32); ah.w[2] = (unsigned)h1; ah.w[3] = (unsigned)(h1 >> 32);
+                        // the e4m3 product lo_G * hi_W of the whole super-block (K = 4 K-steps x 32) rides in the LAST K-step's tile loop: its eight
+                        // half-word reads are requested with this tile's hi fragment and land behind the four fp16 products
+                        intx8_t a8;
+                        if (ks == 3) {
+#pragma unroll
+                            for (int k2 = 0; k2 < 4; ++k2) {
+                                const int kso2 = 4 * (k2 & 1) - (4 * (k2 >> 1) + 8 * sl) * CP_TW;
+                                const unsigned* p8 = reinterpret_cast<const unsigned*>(s_lo8 + ro + kso2);      // 4 entries x 2 bytes, 4-byte aligned (ro, kso even)
+                                a8[2 * k2] = (int)__hip_atomic_load(p8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                a8[2 * k2 + 1] = (int)__hip_atomic_load(p8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            }
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
+                        if (ks == 3) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)      // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
+                                acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
+                        }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {         // unrolled: the K-step's table offset becomes an immediate
@@ -316,8 +383,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     Half8Bits bh[NT], bl[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        bh[nt].u = s_B[sl * 4 + ks][nt][0][lane];
-                        bl[nt].u = s_B[sl * 4 + ks][nt][1][lane];
+                        bh[nt].u = s_B(sl * 4 + ks, nt, 0)[lane];
+                        bl[nt].u = s_B(sl * 4 + ks, nt, 1)[lane];
                     }
                     const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
 #pragma unroll
@@ -477,6 +544,13 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
     dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
 #define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger, (const GtEntry*)nullptr)
+#ifdef OLX_AB_VARIANTS   // mixed correction products (OLX_MIXED_CORRECTION=1): no gain for 5 x the error of the default, developer library only
+    if (c->mixcorr && !c->dir_lattice && !persist) {
+        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
+        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
+        return;
+    }
+#endif
 #ifdef OLX_AB_VARIANTS   // kernel 2g fed from a precomputed geometry table (OLX_GTABLE=1): measured slower, developer library only
     if (c->use_gtable && !c->dir_lattice && !persist) {
 #define OLX_CPG(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, c->d_gtab)

@@ -199,7 +199,9 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                             double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]: representative focus, mirror image (-1 = unused)*/,
                             const int* __restrict__ slot_elem /*kernel 2d: element of K slot s (-1 = virtual), NULL = identity*/,
-                            int fp8corr /*kernel 2e, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element*/,
+                            int fp8corr /*1 = kernel 2e / 2g, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element;
+                                          2 = kernel 2g's mixed corrections: hi and lo fp16 fragments followed by 8 e4m3 bytes per lane [hi(k0), hi(k1)] x 4 elements
+                                          (* 2^-6), 160 instead of 128 uint4 per K-step and column tile*/,
                             float4* __restrict__ coords, uint4* __restrict__ bfrag) {
     const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
     if (!slot_elem && tile == 0 && nt == 0 && lane < 16) {
@@ -231,6 +233,19 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
         const _Float16 l = (_Float16)(float)(val - (double)(float)h);
         hi.h[jj] = h;
         lo.h[jj] = l;
+    }
+    if (fp8corr == 2) {
+        uint4* dst2 = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 160;
+        dst2[lane] = hi.u;
+        dst2[64 + lane] = lo.u;
+        uint2 q8;
+        int w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[0] * COS_F8_HI, (float)hi.h[1] * COS_F8_HI, 0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[2] * COS_F8_HI, (float)hi.h[3] * COS_F8_HI, w0, true);
+        int w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[4] * COS_F8_HI, (float)hi.h[5] * COS_F8_HI, 0, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[6] * COS_F8_HI, (float)hi.h[7] * COS_F8_HI, w1, true);
+        q8.x = (unsigned)w0; q8.y = (unsigned)w1;
+        reinterpret_cast<uint2*>(dst2 + 128)[lane] = q8;
+        return;
     }
     if (fp8corr) {
         Half8Bits q;

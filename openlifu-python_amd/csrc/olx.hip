@@ -393,7 +393,7 @@ static int configure_variant_impl(olx_ctx* c) {
     }
     c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok) && (!c->modifier() || lat_ok);
     c->use_lattice = c->use_mfma && lat_ok;
-    c->fp8corr = false;
+    c->fp8corr = false; c->mixcorr = false;
     c->nt = 1;
     if (c->use_mfma) {
         // ---- kernel 2c column plan.  A column = one distinct steering vector W[sigma_m(e), f]; every
@@ -502,7 +502,7 @@ static int configure_variant_impl(olx_ctx* c) {
             HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
             c->coords_cap = n_pad;
         }
-        const size_t need = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;
+        const size_t need = (size_t)ntiles * (n_pad / 16) * 160 * c->nt;      // (160: the mixed-correction layout of kernel 2g; 128 otherwise)
         if (c->bfrag_cap < need) {
             if (c->d_bfrag) hipFree(c->d_bfrag);
             c->d_bfrag = nullptr; c->bfrag_cap = 0;
@@ -570,8 +570,16 @@ static int configure_variant_impl(olx_ctx* c) {
             // geometric), every focus lies inside the slab and has N_eff >= 256.  Otherwise, and by default, the fp16
             // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
+                // MIXED corrections (round 4; kernel 2g; developer library, OLX_MIXED_CORRECTION=1): only the lo_G x hi_W term goes through e4m3, the
+                // other correction stays an fp16 product -- 40 instead of 48 matrix cycles per K-step and tile, half the e4m3 rounding variance of
+                // the fp8 mode.  Built to be the gated default; MEASURED (profiles/r04_mixed_ab.txt): 4.2-4.4e-6 of the peak on the full 256^3
+                // volume (fp8: 5.3-6.2e-6, fp16: 0.9e-6) and 0.432-0.443 against 0.437-0.444 ms -- no gain worth 5 x the error: the kernel hardly
+                // follows its matrix-instruction count (the same build WITHOUT the e4m3 instruction, a third of all matrix work gone: -7 %).
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
+                const char* mxe = getenv("OLX_MIXED_CORRECTION");
+                const bool asked8 = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
+                const bool mix_ok = kAbVariants && mxe && !strcmp(mxe, "1") && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->modifier() && !(c->flags & OLX_OUT_COMPLEX);
+                const bool asked = asked8;
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                     c->foci_version = c->steer_version;
@@ -588,7 +596,8 @@ static int configure_variant_impl(olx_ctx* c) {
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : ok);
+                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : (asked8 && ok));
+                c->mixcorr = mix_ok && !c->fp8corr;
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
@@ -623,7 +632,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     // the 2 nsx nsy blocks of a plane block that share a class read overlapping windows of it, so they get consecutive ids on one
                     // XCD (not with order0): L2 serves all but one of them.
                     const char* gte = getenv("OLX_GTABLE");
-                    c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr &&
+                    c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr && !c->mixcorr &&
                                     Q.nsa * Q.nsbp > 2 && gte && (!strcmp(gte, "1") || !strcmp(gte, "order0"));      // (fp8 shape: no registers for the entries in flight; one pair: nothing to copy)
                     const bool gt_order = c->use_gtable && strcmp(gte, "order0") != 0;
                     std::vector<CosetBlock> blk;
@@ -707,7 +716,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     for (int rx = 0; rx < 2 * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry)
                             npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
-                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 4 : c->mixcorr ? 5 : 6) / 2 * ntiles;   // (mixed: 2.5 units per K-step)
                 }
                 if (c->use_cosetp32) {   // 32 x 32 form: one row tile per PAIR of positions (an odd count pads one position per block part)
                     long long nhalf = 0;
@@ -782,6 +791,7 @@ static int configure_variant_impl(olx_ctx* c) {
         c->dir_lattice = false; c->allow_shared = false;
         return configure_variant_impl(c);
     }
+    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->mixcorr) strncat(nmbuf, " +mixed corrections (lo_G x hi_W in e4m3)", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->use_mfma && c->use_lattice && c->use_cosetp && c->use_gtable) strncat(nmbuf, " +precomputed geometry table", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->absorb_np_m > 0 && c->use_mfma) strncat(nmbuf, " +uniform absorption in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
@@ -802,7 +812,7 @@ static int pack_if_needed(olx_ctx* c) {
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
-                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
+                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : (c->use_lattice && c->use_cosetp && c->mixcorr) ? 2 : 0, c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
 #ifdef OLX_AB_VARIANTS
         if (c->use_lattice && c->use_cosetp && c->use_gtable) { int rc = olx_gtable_prepare(c); if (rc) return rc; }
@@ -867,8 +877,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     {   // Re-planning the SAME launch (same grid, slab, foci count, medium constants, flags, element table, family pins): everything
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
-        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE");
-        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "");
+        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE"); const char* e4 = getenv("OLX_MIXED_CORRECTION");
+        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "") + "|" + (e4 ? e4 : "");
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;

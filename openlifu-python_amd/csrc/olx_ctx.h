@@ -79,7 +79,7 @@ struct olx_ctx {
     typedef olxplan::Lattice Lattice;          // olx_plan.h: regular (a, b) lattice in one z plane, pitch = whole voxels
     Lattice lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
+    bool use_coset = false; bool fp8corr = false; bool mixcorr = false;   /* mixcorr: kernel 2g's mixed correction products (the gated default) */ CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records
     std::vector<CosetBlock> up_blocks; std::vector<int> up_jobs, up_slot;   // host copies of what d_cpblocks / d_jobs / d_slot hold (re-uploaded only when they change)

@@ -947,6 +947,33 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
 
 
 @pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
+@pytest.mark.parametrize("shape", [(128, 128, 128), (96, 96, 50)])
+def test_kernel_2g_mixed_corrections(ctx, monkeypatch, shape):
+    """Kernel 2g with MIXED correction products (developer library, OLX_MIXED_CORRECTION=1): hi x hi and hi_G x lo_W as fp16 products, lo_G x hi_W
+    through ONE e4m3 instruction per tile and element super-block.  Full-volume parity against the fp64 oracle: between the three fp16
+    products (<= 2e-6 of the peak) and the e4m3 corrections (<= 6.5e-6); measured 4.4e-6 at 256^3 -- and no faster than the default
+    (profiles/r04_mixed_ab.txt), which is why the planner does not select it."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = _wheel_shard(8)
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    xs, ys, _ = centred_grid(shape[0], 0.5)
+    zs = (5.0 + 0.5 * np.arange(shape[2])) * 1e-3
+    h = (xs[1] - xs[0],) * 3
+    monkeypatch.setenv("OLX_MIXED_CORRECTION", "1")
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, shape, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+    assert "field_cosetp_k<nt2" in ctx.field_variant() and "+mixed corrections" in ctx.field_variant(), ctx.field_variant()
+    ctx.field_launch()
+    for f in (0, 1, 4):
+        out = ctx.field_fetch(f)
+        ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0]))
+        peak = max(ref.max(), np.abs(co.field_at_points([foci[f]], pos_m, area, d[f], a[f], F0, C, P0))[0])
+        err = np.abs(out["pmag"] - ref).max() / peak
+        assert err <= 6e-6, (f, err)
+        iref = fo.intensity_wcm2(ref, RHO, C)
+        assert np.abs(out["intensity"] - iref).max() <= TOL_I * fo.intensity_wcm2(peak, RHO, C)
+
+
+@pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("case", ["shard128", "ragged", "x_slab", "shifted_no_folds", "clamp", "padded20x12"])
 def test_kernel_2g_geometry_table_equals_in_kernel_generation(ctx, monkeypatch, case, fp8):
