@@ -635,8 +635,13 @@ static int configure_variant_impl(olx_ctx* c) {
                     c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr && !c->mixcorr &&
                                     Q.nsa * Q.nsbp > 2 && gte && (!strcmp(gte, "1") || !strcmp(gte, "order0"));      // (fp8 shape: no registers for the entries in flight; one pair: nothing to copy)
                     const bool gt_order = c->use_gtable && strcmp(gte, "order0") != 0;
+                    // (the records depend on the partition only, not on the steering table: a call that changes nothing but the foci finds the
+                    // records it uploaded last time still valid -- 9 216 of them on the headline grid, 0.1 ms to derive and compare)
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, c->use_cosetq ? 4 : 2, gt_order ? 1 : 0,
+                                             c->use_cosetq ? 1 : 0, c->use_cosetq ? 20 : (c->use_cosetp ? 40 : 0), c->use_gtable ? 1 : 0};
                     std::vector<CosetBlock> blk;
-                    {
+                    if (!c->use_gtable && !c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
+                    else {
                         std::string why;
                         if (!olxplan::build_coset_blocks(Q, zb, c->use_cosetq ? 4u : 2u, gt_order, c->use_cosetq, c->use_cosetq ? 20 : (c->use_cosetp ? 40 : 0), blk, why))
                             return fail(c, OLX_ESTATE, "kernel %s: %s", c->use_cosetq ? "2q" : "2g", why.c_str());
@@ -657,6 +662,7 @@ static int configure_variant_impl(olx_ctx* c) {
                         HIPCHK(c, hipMemcpy(c->d_cpblocks, blk.data(), sizeof(CosetBlock) * nblk, hipMemcpyHostToDevice));
                         c->up_blocks = blk;
                     }
+                    memcpy(c->up_blocks_key, rec_key, sizeof rec_key);
                     c->cp_nblocks = nblk;
                     if (c->use_cosetr) {   // kernel 2r walks the non-empty records only
                         std::vector<CosetBlock> live;

@@ -82,6 +82,7 @@ struct olx_ctx {
     bool use_coset = false; bool fp8corr = false; bool mixcorr = false;   /* mixcorr: kernel 2g's mixed correction products (the gated default) */ CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records
+    int up_blocks_key[16] = {0};               // the partition up_blocks was derived from
     std::vector<CosetBlock> up_blocks; std::vector<int> up_jobs, up_slot;   // host copies of what d_cpblocks / d_jobs / d_slot hold (re-uploaded only when they change)
     bool use_cosetr = false; CosetBlock* d_cprblocks = nullptr; size_t cprblocks_cap = 0; unsigned cpr_nblocks = 0;   // kernel 2r: persistent, one block per CU (non-empty records only)
     bool use_cosetq = false;   // kernel 2q: 2g in blocks of 4 waves x 8 planes (four blocks per CU)
