@@ -61,19 +61,29 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 // product: 40 matrix cycles per K-step and tile instead of 48 (three fp16 products) or 32 (both corrections in e4m3, FP8), half the e4m3
 // rounding variance of FP8.  Tables: fp16 (re, im) of hi (rounded to nearest) + TWO e4m3 bytes [lo re, lo im] per entry (a half-word array:
 // 35 KB instead of 46.6); steering stage per K-step and column tile: hi fp16, lo fp16 and 8 e4m3 bytes per lane of hi * 2^-6 (mfma_pack_k mode 2).
-template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false, bool MIX = false>
-__global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
+// PAIR (round 4): super-blocks per table stage.  2 = the pair tables above (26 rows, <= 40 positions per block, 79 KB: two blocks per CU) = the product.
+// 1 (developer library, OLX_COSETP_SHAPE=single) = ONE super-block per stage: 18-row tables (32 KB) + one super-block of steering fragments (16 KB) =
+// 48.7 KB and <= 24 positions per block (3 tiles per wave, 66 VGPRs): THREE blocks per CU.  Motive: one block per CU is only 1.28 x slower than two
+// (profiles/r04_occupancy_ab.txt) -- two resident blocks interleave by chance -- so a third entity per SIMD looked like where the idle matrix cycles
+// are.  Measured: bit-identical and 20 % SLOWER (profiles/r04_cosetp_single_ab.txt) -- per position 1.85 x the table entries, 1.8 x the steering
+// fragment bytes and twice the barriers; the vector issue port (matrix + vector instructions ~ 90 % of the SIMD cycles) has no room for them.
+template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false, bool MIX = false, int PAIR = 2>
+__global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
     const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger,
     const GtEntry* __restrict__ gtab = nullptr) {
     static_assert(!(GT && (FP8 || DIR || PERSIST)), "the table-fed form exists for the default arithmetic only");
     static_assert(!(MIX && (FP8 || DIR || PERSIST || GT)), "mixed corrections: its own instantiations");
+    static_assert(PAIR == 2 || !(FP8 || DIR || PERSIST || GT || MIX), "one super-block per stage: the default arithmetic only");
     constexpr int NT = 2, THREADS = COS_NW * 64;
-    constexpr int RPR = 64 / CP_UW, NROUND = (CP_TROWS + RPR - 1) / RPR;       // 5 table rows per generation round, 6 rounds
+    constexpr int TROWS = 10 + 8 * PAIR, ROW0 = 8 * PAIR - 1, PSZ = TROWS * CP_TW, MT = PAIR == 2 ? 5 : 3;   // 26 / 15 / 364 / 5 for pairs; 18 / 7 / 252 / 3
+    static_assert(PAIR != 2 || (TROWS == 26 && ROW0 == 15 && PSZ == 364 && MT == 5), "pair shape");
+    static_assert((PSZ / 2) % 2 == 0 && ((PSZ / 2) % 32 == 22 || (PSZ / 2) % 32 == 30), "16 planes on 16 distinct even 8-byte slots");
+    constexpr int RPR = 64 / CP_UW, NROUND = (TROWS + RPR - 1) / RPR;       // 5 table rows per generation round: 6 rounds (pairs) / 4
     constexpr int B_KS_U4 = MIX ? 160 : 128;                                    // uint4 per K-step and column tile: hi, lo (64 lanes each) [, 8 e4m3 bytes per lane]
-    constexpr int B_BYTES = 2 * 4 * NT * B_KS_U4 * 16;                          // two super-blocks of steering fragments
-    constexpr int T_WORDS = COS_ZB * CP_PSZ;
+    constexpr int B_BYTES = PAIR * 4 * NT * B_KS_U4 * 16;                       // PAIR super-blocks of steering fragments
+    constexpr int T_WORDS = COS_ZB * PSZ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + T_WORDS * 4 + T_WORDS * (MIX ? 2 : 4) + 64];
     // steering stage: K-step record (sl * 4 + ks, nt) = B_KS_U4 uint4: [0] hi, [1] lo of the 64 lanes [, MIX: then 8 e4m3 bytes per lane]
     auto s_B = [&](int rec, int nt, int part) -> const uint4* { return reinterpret_cast<const uint4*>(smem) + ((size_t)(rec * NT + nt) * B_KS_U4 + part * 64); };
@@ -102,28 +112,28 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     if (npos <= 0) continue;                            // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
-    const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= CP_MT)
+    const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= MT)
     // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl.
     // (Its per-lane constants are formed inside the pair loop from an opaque copy of the lane index: hoisted, they would be live
     // across the K-steps, where the fp8 shape has no register to spare -- 5 spilled registers cost 190 MB of scratch traffic.)
     // fragment read offset [words] of a tile's row for K-step (0, 0) = per-lane part (plane, k-group) + the tile's position
     // (wave-uniform: kept in scalar registers, added per tile and K-step group -- five registers fewer across the K-steps)
-    const int lane_off = p16 * CP_PSZ - g * CP_TW;
-    int toff[CP_MT];
+    const int lane_off = p16 * PSZ - g * CP_TW;
+    int toff[MT];
 #pragma unroll
-    for (int t = 0; t < CP_MT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         const int pos = min(wave + COS_NW * t, npos - 1);
         const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;                // scalar: pos / KY, exact for pos <= 40 (host checks)
-        toff[t] = (ky + CP_ROW0) * CP_TW + (CP_UW - 8 - 2 * kx);
+        toff[t] = (ky + ROW0) * CP_TW + (CP_UW - 8 - 2 * kx);
     }
-    floatx4_t acc[CP_MT][NT];
+    floatx4_t acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < CP_MT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int nsbp = P.nsbp;                    // even: chunks = table pairs never straddle sa
     const int n_sb = P.nsa * nsbp;
-    constexpr int CHUNK_U4 = 2 * 4 * NT * B_KS_U4, PRE = CHUNK_U4 / THREADS;
+    constexpr int CHUNK_U4 = PAIR * 4 * NT * B_KS_U4, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
     const uint4* const bsrc = bfrag + (size_t)tile * n_sb * (4 * NT * B_KS_U4);
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             for (int r = R0; r < R1; ++r)
 #pragma unroll
                 for (int z = 0; z < COS_P; ++z)
-                    if (gt_planes && wl < RPR && RPR * r + wl < CP_TROWS) gpre[(r - R0) * COS_P + z] = src[(long long)z * ps + RPR * r * P.gt_nu + lo];
+                    if (gt_planes && wl < RPR && RPR * r + wl < TROWS) gpre[(r - R0) * COS_P + z] = src[(long long)z * ps + RPR * r * P.gt_nu + lo];
         }
     };
     [[maybe_unused]] auto gt_to_lds = [&](auto r0_c, auto r1_c) {
@@ -160,13 +170,13 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 int lane_o = lane;
                 asm volatile("" : "+v"(lane_o));
                 const int wl = lane_o / CP_UW, q = lane_o - CP_UW * wl;
-                const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + q;
+                const int tw_off = (wave * COS_P) * PSZ + wl * CP_TW + q;
 #pragma unroll
                 for (int r = R0; r < R1; ++r)
 #pragma unroll
                     for (int z = 0; z < COS_P; ++z)
-                        if (wl < RPR && RPR * r + wl < CP_TROWS) {
-                            const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
+                        if (wl < RPR && RPR * r + wl < TROWS) {
+                            const int o = z * PSZ + tw_off + RPR * r * CP_TW;
                             s_hi[o] = gpre[(r - R0) * COS_P + z].hi;
                             s_lo[o] = gpre[(r - R0) * COS_P + z].lo;
                         }
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     };
     if constexpr (GT) { if (n_sb > 2) gt_request(2, IntC<0>{}, IntC<NROUND>{}); }      // second pair: in flight during the first pair's evaluation and K-steps
     OLX_STAMP(0);
-    for (int sb0 = 0; sb0 < n_sb; sb0 += 2) {
+    for (int sb0 = 0; sb0 < n_sb; sb0 += PAIR) {
         const int sa = sb0 / nsbp, sbb0 = sb0 - sa * nsbp;       // the pair (sa, sbb0), (sa, sbb0 + 1)
         // previous pair consumed: steering stage and tables are free.  (Not before the first pair: nothing to protect yet, and
         // __syncthreads() drains vmcnt -- the wave would wait for its first steering loads before the tables instead of behind them.)
@@ -195,8 +205,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             const int wl = lane_o / CP_UW, ui = lane_o - CP_UW * wl;
             const bool gen_lane = wl < RPR;
             const int Ulane = ibase + P.x_begin + P.ux0 + P.mx * (ui - 7);
-            const int Wlane = jbase + P.uy0 + P.my * (wl - CP_ROW0);
-            const int tw_off = (wave * COS_P) * CP_PSZ + wl * CP_TW + (CP_UW - 1 - ui);   // + z PSZ + RPR r TW
+            const int Wlane = jbase + P.uy0 + P.my * (wl - ROW0);
+            const int tw_off = (wave * COS_P) * PSZ + wl * CP_TW + (CP_UW - 1 - ui);   // + z PSZ + RPR r TW
             float dz2[COS_P];
 #pragma unroll
             for (int z = 0; z < COS_P; ++z) {
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             const int Wsb = Wlane - 8 * P.my * sbb0;
 #pragma unroll 2
             for (int r = 0; r < NROUND; ++r) {
-                const bool row_ok = gen_lane && RPR * r + wl < CP_TROWS;  // the last round may run past the table
+                const bool row_ok = gen_lane && RPR * r + wl < TROWS;  // the last round may run past the table
                 const float W = (float)(Wsb + RPR * P.my * r);
                 const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
                 const float r2 = fmaf(dy, dy, dx2);
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
                     }
                     if (row_ok) {
-                        const int o = z * CP_PSZ + tw_off + RPR * r * CP_TW;
+                        const int o = z * PSZ + tw_off + RPR * r * CP_TW;
                         if (OLX_IN(o, T_WORDS, 0)) {
                             s_hi[o] = __builtin_bit_cast(unsigned, hi);
                             if constexpr (MIX) s_lo8[o] = (unsigned short)lo_word; else s_lo[o] = lo_word;
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         __syncthreads();
         if (sb0 == 0) OLX_STAMP(3);
         {   // next pair's fragments: in flight during the K-steps, drained by the next barrier
-            const int nxt = (sb0 + 2) * 4 * NT * B_KS_U4, lim = n_sb * 4 * NT * B_KS_U4;
+            const int nxt = (sb0 + PAIR) * 4 * NT * B_KS_U4, lim = n_sb * 4 * NT * B_KS_U4;
 #pragma unroll
             for (int q = 0; q < PRE; ++q) {
                 const int idx = nxt + tid + q * THREADS;
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             if constexpr (GT) { if (sb0 > 0 && sb0 + 2 < n_sb) gt_request(sb0 + 2, IntC<0>{}, IntC<NROUND>{}); }   // next pair's table entries (the second pair's are in flight since block entry)
         }
 #pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
-        for (int sl = 0; sl < 2; ++sl) {
+        for (int sl = 0; sl < PAIR; ++sl) {
             if (sbb0 + sl >= P.nsb) break;              // padding super-block of an odd count: zero weights, nothing to do
             if constexpr (FP8) {
 #pragma unroll
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < CP_MT; ++t) {
+                    for (int t = 0; t < MT; ++t) {
                         if (t >= ntile) continue;            // wave-uniform
                         Half8Bits ah[2];
                         intx8_t a8;
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     }
                     const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
 #pragma unroll
-                    for (int t = 0; t < CP_MT; ++t) {
+                    for (int t = 0; t < MT; ++t) {
                         if (t >= ntile) continue;            // wave-uniform
                         Half8Bits ah;
                         int lo_t = lane_off;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                     }
                     const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
 #pragma unroll
-                    for (int t = 0; t < CP_MT; ++t) {
+                    for (int t = 0; t < MT; ++t) {
                         if (t >= ntile) continue;            // wave-uniform
                         Half8Bits ah, al;
                         int lo_t = lane_off;
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     for (int nt = 0; nt < NT; ++nt)
         tq[nt] = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (c16 >> 1)) * 4);
 #pragma unroll
-    for (int t = 0; t < CP_MT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t >= ntile) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 float* const base = vol + (long long)(code >> 2) * P.vox + kz;
 #endif
 #pragma unroll
-                for (int t = 0; t < CP_MT; ++t) {
+                for (int t = 0; t < MT; ++t) {
                     if (t >= ntile) continue;
                     const int pos = wave + COS_NW * t;
                     const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;
@@ -544,6 +554,13 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
     dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
 #define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger, (const GtEntry*)nullptr)
+#ifdef OLX_AB_VARIANTS   // one super-block per table stage, three blocks per CU (OLX_COSETP_SHAPE=single): bit-identical, 20 % slower, developer library only
+    if (c->cosetp_single && !c->dir_lattice && !persist && !c->fp8corr && !c->mixcorr && !c->use_gtable) {
+        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, false, false, false, 1>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
+        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, false, false, false, 1>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
+        return;
+    }
+#endif
 #ifdef OLX_AB_VARIANTS   // mixed correction products (OLX_MIXED_CORRECTION=1): no gain for 5 x the error of the default, developer library only
     if (c->mixcorr && !c->dir_lattice && !persist) {
         if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);

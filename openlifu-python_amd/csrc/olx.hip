@@ -444,7 +444,7 @@ static int configure_variant_impl(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_gtable = false;
+        c->use_gtable = false; c->cosetp_single = false;
         c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
@@ -473,6 +473,15 @@ static int configure_variant_impl(olx_ctx* c) {
                             (unsigned long long)F * (unsigned long long)c->fp.vox < (1ull << 32);
             c->cosetp_persist = kAbVariants && c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
             c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
+            {   // kernel 2g with ONE super-block per table stage and <= 24 positions per block: 48 KB of LDS, three blocks per CU (developer library,
+                // OLX_COSETP_SHAPE=single; default arithmetic only).  Bit-identical and 20 % SLOWER than the pair tables (profiles/r04_cosetp_single_ab.txt).
+                const char* shp = getenv("OLX_COSETP_SHAPE");
+                const char* f8e = getenv("OLX_FP8_CORRECTION");
+                c->cosetp_single = kAbVariants && c->use_cosetp && !fv && !c->modifier() && !(c->flags & (OLX_FIELD_FP8_CORRECTION | OLX_OUT_COMPLEX)) && !(f8e && strcmp(f8e, "0") != 0) &&
+                                   !getenv("OLX_MIXED_CORRECTION") && !getenv("OLX_GTABLE") && (shp ? !strcmp(shp, "single") : false);
+                const int want_s = c->cosetp_single ? c->lat.nsb : want;      // (no pairs: no padding row of super-blocks either)
+                if (want_s != c->lat.nsbp) build_slot_map(c->lat, want_s);
+            }
             if (c->use_cosetp || c->use_cosetp4)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
                 olxplan::balance_store_targets(tiles, c->nt * MFMA_COLS);   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
         }
@@ -604,7 +613,7 @@ static int configure_variant_impl(olx_ctx* c) {
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
                 const int zb = c->use_cosetq ? 8 : COS_ZB;      // planes per block (kernel 2q: 8)
-                olxplan::coset_partition(Q, kxw, zb);
+                olxplan::coset_partition(Q, kxw, zb, c->cosetp_single ? 6 : COS_KYW);
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
@@ -638,12 +647,12 @@ static int configure_variant_impl(olx_ctx* c) {
                     // (the records depend on the partition only, not on the steering table: a call that changes nothing but the foci finds the
                     // records it uploaded last time still valid -- 9 216 of them on the headline grid, 0.1 ms to derive and compare)
                     const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, c->use_cosetq ? 4 : 2, gt_order ? 1 : 0,
-                                             c->use_cosetq ? 1 : 0, c->use_cosetq ? 20 : (c->use_cosetp ? 40 : 0), c->use_gtable ? 1 : 0};
+                                             c->use_cosetq ? 1 : 0, c->use_cosetq ? 20 : (c->use_cosetp ? (c->cosetp_single ? 24 : 40) : 0), c->use_gtable ? 1 : 0};
                     std::vector<CosetBlock> blk;
                     if (!c->use_gtable && !c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
                         std::string why;
-                        if (!olxplan::build_coset_blocks(Q, zb, c->use_cosetq ? 4u : 2u, gt_order, c->use_cosetq, c->use_cosetq ? 20 : (c->use_cosetp ? 40 : 0), blk, why))
+                        if (!olxplan::build_coset_blocks(Q, zb, c->use_cosetq ? 4u : 2u, gt_order, c->use_cosetq, c->use_cosetq ? 20 : (c->use_cosetp ? (c->cosetp_single ? 24 : 40) : 0), blk, why))
                             return fail(c, OLX_ESTATE, "kernel %s: %s", c->use_cosetq ? "2q" : "2g", why.c_str());
                     }
                     const unsigned nblk = (unsigned)blk.size();
@@ -797,6 +806,7 @@ static int configure_variant_impl(olx_ctx* c) {
         c->dir_lattice = false; c->allow_shared = false;
         return configure_variant_impl(c);
     }
+    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->cosetp_single) strncat(nmbuf, " +one super-block per stage (3 blocks per CU)", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->use_mfma && c->use_lattice && c->use_cosetp && c->mixcorr) strncat(nmbuf, " +mixed corrections (lo_G x hi_W in e4m3)", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->use_mfma && c->use_lattice && c->use_cosetp && c->use_gtable) strncat(nmbuf, " +precomputed geometry table", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
@@ -883,8 +893,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     {   // Re-planning the SAME launch (same grid, slab, foci count, medium constants, flags, element table, family pins): everything
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
-        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE"); const char* e4 = getenv("OLX_MIXED_CORRECTION");
-        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "") + "|" + (e4 ? e4 : "");
+        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE"); const char* e4 = getenv("OLX_MIXED_CORRECTION"); const char* e5 = getenv("OLX_COSETP_SHAPE");
+        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "") + "|" + (e4 ? e4 : "") + "|" + (e5 ? e5 : "");
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;

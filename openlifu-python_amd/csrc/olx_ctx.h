@@ -89,6 +89,7 @@ struct olx_ctx {
     bool cosetp_persist = false; int cosetp_stagger = 0;   // kernel 2g, persistent form (OLX_FIELD_VARIANT=cosetpp[:stagger cycles]; A/B)
     bool use_cosetp4 = false;  // kernel 2g's row map with four column tiles (field_cosetp4_k)
     bool use_cosetp32 = false; // kernel 2g in its 32 x 32 x 16 MFMA form (field_cosetp32_k)
+    bool cosetp_single = false; // kernel 2g with ONE super-block per table stage (18-row tables, <= 24 positions, 48 KB: three blocks per CU)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
     // kernel 2g fed from the precomputed geometry table (k_gtable.hip): built once per plan, keyed by the parameters it was evaluated from
     bool use_gtable = false; GtEntry* d_gtab = nullptr; size_t gtab_cap = 0; std::string gtab_key;

@@ -145,9 +145,9 @@ void balance_store_targets(Tiles& tiles, int max_cols) {
             }
 }
 
-void coset_partition(CosetParams& Q, int kxw, int zb) {
+void coset_partition(CosetParams& Q, int kxw, int zb, int kyw) {
     const int kx_max = (Q.nx - Q.x_lo + 2 * Q.mx - 1) / (2 * Q.mx), ky_max = (Q.ny - Q.y_lo + Q.my - 1) / Q.my;
-    Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + COS_KYW - 1) / COS_KYW;
+    Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + kyw - 1) / kyw;
     Q.kblocks = (Q.nz + zb - 1) / zb;
 }
 

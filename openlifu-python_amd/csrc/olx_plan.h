@@ -55,9 +55,9 @@ Tiles pack_columns(const Steering& S, int maxc);
 // kernel 2g stores per column slot: a column with 3 - 4 targets hands half of them to a free slot of its tile (same weights)
 void balance_store_targets(Tiles& tiles, int max_cols);
 
-// parts the cosets' position grids are cut into (at most kxw x COS_KYW positions per part) and plane blocks of zb planes: Q.nsx, Q.nsy, Q.kblocks
+// parts the cosets' position grids are cut into (at most kxw x kyw positions per part) and plane blocks of zb planes: Q.nsx, Q.nsy, Q.kblocks
 // from Q.nx, ny, nz, x_lo, y_lo, mx, my
-void coset_partition(CosetParams& Q, int kxw, int zb);
+void coset_partition(CosetParams& Q, int kxw, int zb, int kyw = olx::COS_KYW);
 
 // Block records of kernels 2e / 2f / 2g / 2q: blockIdx.x -> (coset, part, plane block).  zb = planes per block, grp = blocks that share
 // 128-byte output lines (ids 8 apart = one XCD), class_order = cosets rx and rx + mx neighbours in the id order (geometry-table form).

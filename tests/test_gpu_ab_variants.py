@@ -26,7 +26,7 @@ def test_product_library_carries_no_ab_kernels():
 def test_ab_forms_against_oracle_and_default_in_developer_library():
     env = dict(os.environ, OLX_LIB_PATH=os.path.join(LIB, "libolx_ab.so"))
     env.pop("OLX_FIELD_VARIANT", None)
-    sel = "shfl or toepws or test_kernel_2g_block_forms_agree or 32x32x16 or fuzz or geometry_table or mixed_corrections"
+    sel = "shfl or toepws or test_kernel_2g_block_forms_agree or 32x32x16 or fuzz or geometry_table or mixed_corrections or single_stage"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_field.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]

@@ -947,6 +947,33 @@ def test_kernel_2g_block_forms_agree(ctx, monkeypatch, fp8, grid_n, nz):
 
 
 @pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
+@pytest.mark.parametrize("shape", [(128, 128, 128), (96, 96, 50), (100, 92, 70)])
+def test_kernel_2g_single_stage_shape_is_bit_identical(ctx, monkeypatch, shape):
+    """Kernel 2g with ONE element super-block per table stage (developer library, OLX_COSETP_SHAPE=single: 18-row tables, <= 24 positions per block,
+    48.7 KB of LDS, three blocks per CU) evaluates the same table words and the same matrix-instruction sequence per voxel as the pair-table product
+    shape: bit-identical |p| and intensity -- also on a padded 20 x 12 array with three super-block columns.  Measured 20 % slower."""
+    nax, nay, pitch = (20, 12, (2.4, 1.8)) if shape[0] == 100 else (16, 16, (3.0, 3.0))
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * pitch[0], (b.ravel() - (nay - 1) / 2) * pitch[1], np.zeros(nax * nay)], axis=1)
+    size = np.tile([0.9 * pitch[0], 0.9 * pitch[1]], (nax * nay, 1))
+    h = 0.6 if shape[0] == 100 else 0.5
+    setup_ctx(ctx, pos, np.zeros_like(pos), size, _wheel_shard(8), solve=True)
+    xs = (np.arange(shape[0]) - (shape[0] - 1) / 2) * h * 1e-3
+    ys = (np.arange(shape[1]) - (shape[1] - 1) / 2) * h * 1e-3
+    got = {}
+    for shp in ("pair", "single"):
+        monkeypatch.setenv("OLX_COSETP_SHAPE", shp)
+        ctx.field_plan((xs[0], ys[0], 5e-3), (h * 1e-3,) * 3, shape, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+        ctx.field_launch()
+        got[shp] = (ctx.field_variant(), [ctx.field_fetch(f) for f in range(8)])
+    assert "field_cosetp_k<nt2" in got["pair"][0] and "per stage" not in got["pair"][0], got["pair"][0]
+    assert "+one super-block per stage" in got["single"][0], got["single"][0]
+    for f in range(8):
+        assert got["single"][1][f]["pmag"].max() > 0
+        assert np.array_equal(got["single"][1][f]["pmag"], got["pair"][1][f]["pmag"]) and np.array_equal(got["single"][1][f]["intensity"], got["pair"][1][f]["intensity"]), f
+
+
+@pytest.mark.skipif(not AB, reason="A/B forms live in the developer library: tests/test_gpu_ab_variants.py runs this case against lib/libolx_ab.so")
 @pytest.mark.parametrize("shape", [(128, 128, 128), (96, 96, 50)])
 def test_kernel_2g_mixed_corrections(ctx, monkeypatch, shape):
     """Kernel 2g with MIXED correction products (developer library, OLX_MIXED_CORRECTION=1): hi x hi and hi_G x lo_W as fp16 products, lo_G x hi_W
