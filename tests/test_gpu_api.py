@@ -545,3 +545,25 @@ def test_fused_scale_aggregate_analyze_equals_the_separate_steps(spokes, z_hi):
         else:
             assert np.array_equal(va, vb, equal_nan=True), (key, va, vb)
     assert np.allclose(an_f.mainlobe_pnp_MPa, 0.8, rtol=1e-4)
+
+
+def test_resident_steering_is_refused_for_another_transducer():
+    """Engine.field(steering_resident=True) re-validates the element table: a transducer other than the one the resident steering table was solved
+    for (or the same one with an edited element) is refused instead of silently using the stale device table; without a communicator
+    the transport has counted no ranks."""
+    import openlifu_amd as ol
+    from openlifu_amd.engine import grid_from_coords
+    eng = ol.get_engine()
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4, kerf=0.4, units="mm", sensitivity=1e5)
+    other = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4, kerf=0.4, units="mm", sensitivity=1e5)
+    other.elements[5].position = np.asarray(other.elements[5].position, dtype=float) + np.array([0.2, 0.0, 0.0])
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-15.5, 15.5), y_extent=(-15.5, 15.5), z_extent=(5, 36))
+    origin, spacing, n = grid_from_coords(setup.get_coords())
+    target = ol.Point(position=(0, 0, 25), units="mm")
+    d, a = eng.beamform(arr, [target], 1500.0)
+    out = eng.field(arr, d, a, origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, steering_resident=True)
+    assert out["pmag"].shape == (1,) + tuple(n) and out["pmag"].max() > 0
+    eng.beamform(arr, [target], 1500.0)
+    with pytest.raises(ValueError, match="steering_resident"):
+        eng.field(other, d, a, origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, steering_resident=True)
+    assert eng.ctx.comm_ranks_seen() == 0
