@@ -165,7 +165,7 @@ def issue_model(name, V, N, F):
     """Issue ceiling of the kernel variant in use: (peak pairs/s, model text)."""
     m = re.search(r"mx(\d),my(\d),dx(\d),dy(\d),nf(\d+)", name)
     mm = re.search(r"field_mfma_k<mt\d+,nt(\d+),.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile", name)
-    ml = re.search(r"field_(?:lattice|coset|cosetp|cosetp4|cosetp32|toep|toepws)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
+    ml = re.search(r"field_(?:lattice|coset|cosetp|toep)_k<.*> (\d+) columns for (\d+) foci x (\d+) images in (\d+) tile.* (\d+) MFMA/launch", name)
     if ml:  # lattice kernels: table arithmetic amortised; the matrix pipe is the ceiling (MFMA and VALU issue add up here)
         n_mfma = int(ml.group(5))
         floor_s = n_mfma * 16.0 / (N_SIMD * CLK_GHZ * 1e9)

@@ -45,51 +45,23 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 #define OLX_CUTRACE(k, v)
 #endif
 
-// PERSIST: the grid is two blocks per CU and a block walks the records blockIdx.x, blockIdx.x + gridDim.x, ... (n_items of them);
-// `stagger` [cycles] delays the second block of each CU once, so that the two do not run their phases in lockstep.
-// GT (developer library only, OLX_GTABLE=1: measured SLOWER): every table pair BUT THE FIRST is not evaluated here but copied
-// out of the plan's precomputed table (k_gtable.hip: the same words, evaluated once per plan -- they depend on array, grid and frequency only):
-// 12 eight-byte loads per lane and pair, requested a whole pair ahead (the second pair's at block entry, behind the steering loads; 90 + 26
-// VGPRs) and written to LDS where the tables used to be evaluated: no transcendental and ~190 fewer vector instructions per lane and pair.
-// The FIRST pair stays evaluated: a block has nothing to overlap its loads with.  Round 4, same box, alternating (profiles/r04_gtable_*):
-// all pairs copied 0.53 vs 0.45 ms (fp16), 0.55 vs 0.39 (fp8, copies at the point of use) although only 226 MB reach HBM (the 4 blocks that
-// share a table class sit on one XCD: L2 serves 3 of them); this hybrid form 0.484 vs 0.453 -- the copied pair's phase gets 1.6 k cycles
-// shorter and every OTHER phase of the wave longer (first tables + 0.5 k, barrier + 0.5 k, K-steps + 0.5 k, stores + 0.8 k: 96 more
-// vector-memory instructions per block and pair in a pipe the two resident blocks' stores already fill), 38.4 k instead of 36.2 k per wave.
-// MIX (round 4; developer library, OLX_MIXED_CORRECTION=1: measured no faster than three fp16 products at 5 x their error): mixed correction products.  The fp16 hi/lo split needs hi*hi + hi_G*lo_W + lo_G*hi_W; here the LAST term alone goes through
-// e4m3 -- one v_mfma_scale_f32_16x16x128_f8f6f4 per tile and element super-block (4 K-steps x 32 values) -- and the other correction stays an fp16
-// product: 40 matrix cycles per K-step and tile instead of 48 (three fp16 products) or 32 (both corrections in e4m3, FP8), half the e4m3
-// rounding variance of FP8.  Tables: fp16 (re, im) of hi (rounded to nearest) + TWO e4m3 bytes [lo re, lo im] per entry (a half-word array:
-// 35 KB instead of 46.6); steering stage per K-step and column tile: hi fp16, lo fp16 and 8 e4m3 bytes per lane of hi * 2^-6 (mfma_pack_k mode 2).
-// PAIR (round 4): super-blocks per table stage.  2 = the pair tables above (26 rows, <= 40 positions per block, 79 KB: two blocks per CU) = the product.
-// 1 (developer library, OLX_COSETP_SHAPE=single) = ONE super-block per stage: 18-row tables (32 KB) + one super-block of steering fragments (16 KB) =
-// 48.7 KB and <= 24 positions per block (3 tiles per wave, 66 VGPRs): THREE blocks per CU.  Motive: one block per CU is only 1.28 x slower than two
-// (profiles/r04_occupancy_ab.txt) -- two resident blocks interleave by chance -- so a third entity per SIMD looked like where the idle matrix cycles
-// are.  Measured: bit-identical and 20 % SLOWER (profiles/r04_cosetp_single_ab.txt) -- per position 1.85 x the table entries, 1.8 x the steering
-// fragment bytes and twice the barriers; the vector issue port (matrix + vector instructions ~ 90 % of the SIMD cycles) has no room for them.
-template <int MX, int MY, bool CLAMP, bool FP8, bool PERSIST, bool DIR = false, bool GT = false, bool MIX = false, int PAIR = 2>
-__global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k(
+template <int MX, int MY, bool CLAMP, bool FP8, bool DIR = false>
+__global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
-    const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P, const int n_items, const int stagger,
-    const GtEntry* __restrict__ gtab = nullptr) {
-    static_assert(!(GT && (FP8 || DIR || PERSIST)), "the table-fed form exists for the default arithmetic only");
-    static_assert(!(MIX && (FP8 || DIR || PERSIST || GT)), "mixed corrections: its own instantiations");
-    static_assert(PAIR == 2 || !(FP8 || DIR || PERSIST || GT || MIX), "one super-block per stage: the default arithmetic only");
-    constexpr int NT = 2, THREADS = COS_NW * 64;
-    constexpr int TROWS = 10 + 8 * PAIR, ROW0 = 8 * PAIR - 1, PSZ = TROWS * CP_TW, MT = PAIR == 2 ? 5 : 3;   // 26 / 15 / 364 / 5 for pairs; 18 / 7 / 252 / 3
-    static_assert(PAIR != 2 || (TROWS == 26 && ROW0 == 15 && PSZ == 364 && MT == 5), "pair shape");
+    const CosetBlock* __restrict__ blocks /*[n_items]*/, const CosetParams P) {
+    constexpr int NT = 2, THREADS = COS_NW * 64, PAIR = 2;
+    constexpr int TROWS = CP_TROWS, ROW0 = CP_ROW0, PSZ = CP_PSZ, MT = CP_MT;   // 26-row pair tables, 364 words per plane, <= 5 tiles per wave
     static_assert((PSZ / 2) % 2 == 0 && ((PSZ / 2) % 32 == 22 || (PSZ / 2) % 32 == 30), "16 planes on 16 distinct even 8-byte slots");
     constexpr int RPR = 64 / CP_UW, NROUND = (TROWS + RPR - 1) / RPR;       // 5 table rows per generation round: 6 rounds (pairs) / 4
-    constexpr int B_KS_U4 = MIX ? 160 : 128;                                    // uint4 per K-step and column tile: hi, lo (64 lanes each) [, 8 e4m3 bytes per lane]
+    constexpr int B_KS_U4 = 128;                                                // uint4 per K-step and column tile: hi, lo (64 lanes each)
     constexpr int B_BYTES = PAIR * 4 * NT * B_KS_U4 * 16;                       // PAIR super-blocks of steering fragments
     constexpr int T_WORDS = COS_ZB * PSZ;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + T_WORDS * 4 + T_WORDS * (MIX ? 2 : 4) + 64];
-    // steering stage: K-step record (sl * 4 + ks, nt) = B_KS_U4 uint4: [0] hi, [1] lo of the 64 lanes [, MIX: then 8 e4m3 bytes per lane]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + T_WORDS * 4 + T_WORDS * 4 + 64];
+    // steering stage: K-step record (sl * 4 + ks, nt) = B_KS_U4 uint4: [0] hi, [1] lo of the 64 lanes
     auto s_B = [&](int rec, int nt, int part) -> const uint4* { return reinterpret_cast<const uint4*>(smem) + ((size_t)(rec * NT + nt) * B_KS_U4 + part * 64); };
     unsigned* const s_hi = reinterpret_cast<unsigned*>(smem + B_BYTES);
     unsigned* const s_lo = s_hi + T_WORDS;
-    [[maybe_unused]] unsigned short* const s_lo8 = reinterpret_cast<unsigned short*>(s_lo);      // MIX: e4m3 [lo re, lo im] per entry, same indexing as s_hi
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p16 = lane & 15;
@@ -99,17 +71,11 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
     // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip; blockIdx order as in kernel 2e,
     // the two blocks that write the two 64-byte halves of the same 128-byte lines 8 ids apart = same XCD).  Decoded here it was
     // ~350 VALU instructions per wave -- a fifth of the wave's vector instructions: integer divisions have no scalar form.
-    if constexpr (PERSIST) {
-        if (stagger > 0 && blockIdx.x >= gridDim.x / 2) {       // (dispatch order: the second half of the grid lands on the CUs' second slots)
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-    int item = blockIdx.x;
-    do {
+    const int item = blockIdx.x;
+    {
     const CosetBlock BK = blocks[item];
     const int npos = BK.npos, KY = BK.KY, ky_magic = BK.ky_magic;
-    if (npos <= 0) continue;                            // block-uniform
+    if (npos <= 0) return;                              // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= MT)
@@ -143,47 +109,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
         const int idx = tid + q * THREADS;
         pre[q] = idx < n_sb * 4 * NT * B_KS_U4 ? bsrc[idx] : make_uint4(0, 0, 0, 0);
     }
-    // GT: this lane's 12 entries of a pair's tables -- planes k0 + 2 wave + z, rows RPR r + wl, column q (lane = 12 wl + q; lanes 60 .. 63 idle)
-    GtEntry gpre[GT ? NROUND * COS_P : 1];
-    [[maybe_unused]] const bool gt_planes = k0 + wave * COS_P < P.nz;
-    [[maybe_unused]] auto gt_request = [&](int sb, auto r0_c, auto r1_c) {      // rounds [r0, r1) of the pair that starts at super-block sb
-        constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
-        if constexpr (GT) {
-            const int sa_n = sb / nsbp, sbb_n = sb - sa_n * nsbp;
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
-            const int wl = lane_o / CP_UW, q = lane_o - CP_UW * wl;
-            const long long ps = (long long)P.gt_nw * P.gt_nu;
-            const GtEntry* src = gtab + ((long long)BK.gt_off + (long long)(k0 + wave * COS_P) * ps + (long long)(8 * sa_n - 8 * sbb_n * P.gt_nu));   // wave-uniform
-            const int lo = wl * P.gt_nu + q;
-#pragma unroll
-            for (int r = R0; r < R1; ++r)
-#pragma unroll
-                for (int z = 0; z < COS_P; ++z)
-                    if (gt_planes && wl < RPR && RPR * r + wl < TROWS) gpre[(r - R0) * COS_P + z] = src[(long long)z * ps + RPR * r * P.gt_nu + lo];
-        }
-    };
-    [[maybe_unused]] auto gt_to_lds = [&](auto r0_c, auto r1_c) {
-        constexpr int R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
-        if constexpr (GT) {
-            if (gt_planes) {
-                int lane_o = lane;
-                asm volatile("" : "+v"(lane_o));
-                const int wl = lane_o / CP_UW, q = lane_o - CP_UW * wl;
-                const int tw_off = (wave * COS_P) * PSZ + wl * CP_TW + q;
-#pragma unroll
-                for (int r = R0; r < R1; ++r)
-#pragma unroll
-                    for (int z = 0; z < COS_P; ++z)
-                        if (wl < RPR && RPR * r + wl < TROWS) {
-                            const int o = z * PSZ + tw_off + RPR * r * CP_TW;
-                            s_hi[o] = gpre[(r - R0) * COS_P + z].hi;
-                            s_lo[o] = gpre[(r - R0) * COS_P + z].lo;
-                        }
-            }
-        }
-    };
-    if constexpr (GT) { if (n_sb > 2) gt_request(2, IntC<0>{}, IntC<NROUND>{}); }      // second pair: in flight during the first pair's evaluation and K-steps
     OLX_STAMP(0);
     for (int sb0 = 0; sb0 < n_sb; sb0 += PAIR) {
         const int sa = sb0 / nsbp, sbb0 = sb0 - sa * nsbp;       // the pair (sa, sbb0), (sa, sbb0 + 1)
@@ -195,9 +120,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
         // ---- G tables of planes 2 wave, 2 wave + 1: 26 rows x 12 offsets, shared by the pair's two super-blocks
         // (fp8 shape: table generation at raised priority -- the waves a block's K-steps wait for get the VALU first: -2 ... -4 %;
         // with fp16 corrections the matrix pipe is the scarcer resource and the same setting costs 1.5 %, priority on the K-steps 2.5 %)
-        if (GT && sb0 > 0) {
-            gt_to_lds(IntC<0>{}, IntC<NROUND>{});
-        } else {
         if constexpr (FP8) __builtin_amdgcn_s_setprio(1);
         if (k0 + wave * COS_P < P.nz) {
             int lane_o = lane;
@@ -234,7 +156,7 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     half2_t hi;
-                    if constexpr (FP8 || MIX) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
+                    if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
                     else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
                     // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
                     float lr, li;
@@ -249,10 +171,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
                         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
                         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
                         lo_word = __builtin_bit_cast(unsigned, w);
-                    } else if constexpr (MIX) {      // e4m3 bytes [lo re, lo im] (* 2^5: |lo| <= 2^-12 |hi| <= 4)
-                        short2_t w = {0, 0};
-                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
-                        lo_word = __builtin_bit_cast(unsigned, w) & 0xFFFFu;
                     } else {
                         lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
                     }
@@ -260,14 +178,13 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
                         const int o = z * PSZ + tw_off + RPR * r * CP_TW;
                         if (OLX_IN(o, T_WORDS, 0)) {
                             s_hi[o] = __builtin_bit_cast(unsigned, hi);
-                            if constexpr (MIX) s_lo8[o] = (unsigned short)lo_word; else s_lo[o] = lo_word;
+                            s_lo[o] = lo_word;
                         }
                     }
                 }
             }
         }
         if constexpr (FP8) __builtin_amdgcn_s_setprio(0);
-        }
         // this pair's steering fragments (requested one pair ahead; the first ones arrive behind the table generation above)
 #pragma unroll
         for (int q = 0; q < PRE; ++q) reinterpret_cast<uint4*>(smem)[tid + q * THREADS] = pre[q];
@@ -281,7 +198,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
                 const int idx = nxt + tid + q * THREADS;
                 if (idx < lim) pre[q] = bsrc[idx];
             }
-            if constexpr (GT) { if (sb0 > 0 && sb0 + 2 < n_sb) gt_request(sb0 + 2, IntC<0>{}, IntC<NROUND>{}); }   // next pair's table entries (the second pair's are in flight since block entry)
         }
 #pragma unroll                                          // (unrolled: the pair position becomes part of the immediate table offsets)
         for (int sl = 0; sl < PAIR; ++sl) {
@@ -331,61 +247,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
                             acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
                     }
                 }
-            } else if constexpr (MIX) {
-                // this super-block's e4m3 steering bytes: 4 K-steps x 8 bytes per lane and column tile (the K = 128 operand of the correction product)
-                intx8_t b8[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const uint2 q = reinterpret_cast<const uint2*>(s_B(sl * 4 + ks, nt, 2))[lane];
-                        b8[nt][2 * ks] = (int)q.x; b8[nt][2 * ks + 1] = (int)q.y;
-                    }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {         // fp16 products: hi * hi and hi_G * lo_W
-                    const int ka = ks & 1, kb = ks >> 1;
-                    Half8Bits bh[NT], bl[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        bh[nt].u = s_B(sl * 4 + ks, nt, 0)[lane];
-                        bl[nt].u = s_B(sl * 4 + ks, nt, 1)[lane];
-                    }
-                    const int kso = 4 * ka - (4 * kb + 8 * sl) * CP_TW;
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        if (t >= ntile) continue;            // wave-uniform
-                        Half8Bits ah;
-                        int lo_t = lane_off;
-                        asm volatile("" : "+v"(lo_t));
-                        const int ro = lo_t + toff[t];
-                        if (!OLX_IN(ro + kso, T_WORDS - 3, 1)) continue;
-                        const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(s_hi + ro + kso);
-                        const unsigned long long h0 = __hip_atomic_load(ph2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        const unsigned long long h1 = __hip_atomic_load(ph2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        ah.w[0] = (unsigned)h0; ah.w[1] = (unsigned)(h0 >> 32); ah.w[2] = (unsigned)h1; ah.w[3] = (unsigned)(h1 >> 32);
-                        // the e4m3 product lo_G * hi_W of the whole super-block (K = 4 K-steps x 32) rides in the LAST K-step's tile loop: its eight
-                        // half-word reads are requested with this tile's hi fragment and land behind the four fp16 products
-                        intx8_t a8;
-                        if (ks == 3) {
-#pragma unroll
-                            for (int k2 = 0; k2 < 4; ++k2) {
-                                const int kso2 = 4 * (k2 & 1) - (4 * (k2 >> 1) + 8 * sl) * CP_TW;
-                                const unsigned* p8 = reinterpret_cast<const unsigned*>(s_lo8 + ro + kso2);      // 4 entries x 2 bytes, 4-byte aligned (ro, kso even)
-                                a8[2 * k2] = (int)__hip_atomic_load(p8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                a8[2 * k2 + 1] = (int)__hip_atomic_load(p8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            }
-                        }
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
-                        if (ks == 3) {
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)      // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
-                                acc[t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[nt], acc[t][nt], 0, 0, 0, 128, 0, 127);
-                        }
-                    }
-                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {         // unrolled: the K-step's table offset becomes an immediate
@@ -426,9 +287,6 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
         if (sb0 == 0) OLX_STAMP(4);
     }
     OLX_STAMP(5);
-    // (persistent form) every wave has left this record's K-steps: tables and steering stage are free for the next record.  LDS-only,
-    // and BEFORE the epilogue: no wave waits for another wave's stores
-    if constexpr (PERSIST) lds_barrier();
     // ---- epilogue, straight from the accumulators.  Lane (g, c16): rows 4 g .. 4 g + 3 = planes k0 + 4 g .. + 3 of the tile's
     // position, column c16 = (o, re | im).  The |p| lane (part 0) and its partner (part 1, the intensity lane) hold the same
     // (S re)^2 + (S im)^2 after one quad swap; per pair of rows the |p| lane takes the root of the first and the partner lane of
@@ -438,8 +296,8 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
     //   B  per store-target slot of the lane's column (outer) the 64-bit base of its focus volume and its mirror masks once, then
     //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU) -- 4 vector
     //      instructions per 16-byte store (the former tile-outer loop formed every address from scratch: 17).
-    int lane_e = lane;                                   // (opaque per item: the persistent form would otherwise keep the epilogue's
-    asm volatile("" : "+v"(lane_e));                     // per-lane constants -- targets, bases, scales -- in registers across the K-steps)
+    int lane_e = lane;                                   // (opaque: the epilogue's per-lane constants -- targets, bases, scales -- are formed here,
+    asm volatile("" : "+v"(lane_e));                     // not kept in registers across the K-steps)
     const int c16 = lane_e & 15, part = c16 & 1;
     const int kz = k0 + 4 * (lane_e >> 4);
     if (kz < P.nz) {
@@ -520,7 +378,7 @@ __global__ __launch_bounds__(COS_NW * 64, PAIR == 2 ? 4 : 6) void field_cosetp_k
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     OLX_CUTRACE(4, __builtin_readcyclecounter());
 #endif
-    } while (PERSIST && (item += gridDim.x) < n_items);
+    }
 }
 
 }  // namespace olx
@@ -547,49 +405,15 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
 #else
     const CosetParams& Q = c->cp;
 #endif
-    const int n_items = (int)c->cp_nblocks;
     const bool clamp = c->clamp || c->lat.clamp;
-    const bool persist = c->cosetp_persist && c->mp.n_tiles == 1;
-    int pgrid = std::min(2 * c->n_cu, n_items);
-    if (const char* e = getenv("OLX_EXP_PP_GRID")) { const int v = atoi(e); if (v > 0) pgrid = std::min(v, n_items); }   // A/B: records per block = n_items / grid
-    dim3 grid(persist ? (unsigned)pgrid : (unsigned)n_items, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_CP(CL, F8, PS) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, PS>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, c->cosetp_stagger, (const GtEntry*)nullptr)
-#ifdef OLX_AB_VARIANTS   // one super-block per table stage, three blocks per CU (OLX_COSETP_SHAPE=single): bit-identical, 20 % slower, developer library only
-    if (c->cosetp_single && !c->dir_lattice && !persist && !c->fp8corr && !c->mixcorr && !c->use_gtable) {
-        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, false, false, false, 1>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, false, false, false, 1>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        return;
-    }
-#endif
-#ifdef OLX_AB_VARIANTS   // mixed correction products (OLX_MIXED_CORRECTION=1): no gain for 5 x the error of the default, developer library only
-    if (c->mixcorr && !c->dir_lattice && !persist) {
-        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        return;
-    }
-#endif
-#ifdef OLX_AB_VARIANTS   // kernel 2g fed from a precomputed geometry table (OLX_GTABLE=1): measured slower, developer library only
-    if (c->use_gtable && !c->dir_lattice && !persist) {
-#define OLX_CPG(CL, F8) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, c->d_gtab)
-        if (clamp) OLX_CPG(true, false); else OLX_CPG(false, false);      // (fp16 corrections: the planner does not select the table for the e4m3 shape)
-#undef OLX_CPG
-        return;
-    }
-#endif
-    if (c->dir_lattice) {   // piston directivity folded into the geometry tables (fp16 corrections only)
-        if (clamp) hipLaunchKernelGGL((field_cosetp_k<MX, MY, true, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        else hipLaunchKernelGGL((field_cosetp_k<MX, MY, false, false, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q, n_items, 0, (const GtEntry*)nullptr);
-        return;
-    }
-#ifdef OLX_AB_VARIANTS   // the persistent grid (OLX_FIELD_VARIANT=cosetpp): measured slower, developer library only
-    if (persist) {
-        if (c->fp8corr) { if (clamp) OLX_CP(true, true, true); else OLX_CP(false, true, true); }
-        else            { if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true); }
-    } else
-#endif
-    {
-        if (c->fp8corr) { if (clamp) OLX_CP(true, true, false); else OLX_CP(false, true, false); }
-        else            { if (clamp) OLX_CP(true, false, false); else OLX_CP(false, false, false); }
+    dim3 grid((unsigned)c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);
+#define OLX_CP(CL, F8, DR) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q)
+    if (c->dir_lattice) {   // piston directivity / uniform absorption folded into the geometry tables (fp16 corrections only)
+        if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true);
+    } else if (c->fp8corr) {
+        if (clamp) OLX_CP(true, true, false); else OLX_CP(false, true, false);
+    } else {
+        if (clamp) OLX_CP(true, false, false); else OLX_CP(false, false, false);
     }
 #undef OLX_CP
 }

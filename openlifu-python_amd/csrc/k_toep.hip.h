@@ -1,5 +1,5 @@
-// Shapes and parameters shared by the two forms of kernel 2f (k_toep.hip: one block per work item; k_toepws.hip: persistent,
-// wave-specialised).  No device code here.
+// Shapes and parameters of kernel 2f (k_toep.hip; shared with its operand packer).
+// No device code here.
 #pragma once
 #include "olx_params.h"
 

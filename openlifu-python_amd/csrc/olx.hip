@@ -16,15 +16,6 @@
 #include "olx_launch.h"
 #include "olx_plan.h"
 
-// The measured-slower A/B forms of the accumulate (kernels 2q, 2r, 2s, persistent 2g, wave-specialised 2f: DESIGN.md 5.4) are
-// compiled only into the developer library (build.py -DOLX_AB_VARIANTS --out lib/libolx_ab.so); the product library carries the
-// kernels its planner can select, and ignores their OLX_FIELD_VARIANT names.
-#ifdef OLX_AB_VARIANTS
-static constexpr bool kAbVariants = true;
-#else
-static constexpr bool kAbVariants = false;
-#endif
-
 extern "C" {
 
 int olx_abi_version(void) { return OLX_ABI_VERSION; }
@@ -71,7 +62,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks, c->d_cprblocks, c->d_gtab};
+                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -393,7 +384,7 @@ static int configure_variant_impl(olx_ctx* c) {
     }
     c->use_mfma = c->allow_shared && c->force_kind != 2 && (c->force_kind == 3 || nm * c->nf >= 2 || lat_ok) && (!c->modifier() || lat_ok);
     c->use_lattice = c->use_mfma && lat_ok;
-    c->fp8corr = false; c->mixcorr = false;
+    c->fp8corr = false;
     c->nt = 1;
     if (c->use_mfma) {
         // ---- kernel 2c column plan.  A column = one distinct steering vector W[sigma_m(e), f]; every
@@ -444,8 +435,7 @@ static int configure_variant_impl(olx_ctx* c) {
         // kernel 2e: whole cosets per wave (no row-tile padding, one table per plane); 2d stays for complex output and A/B runs.
         // MFMA tiles of kernel 2e: per (coset, part, plane pair) ceil(2 KX KY / 16); with very coarse pitches the position
         // grids get so small that most of a tile is padding -- then 2d's fixed 2 x 4 x 2 tiles are the better shape
-        c->use_gtable = false; c->cosetp_single = false;
-        c->use_coset = false; c->use_toep = false; c->use_cosetp = false; c->use_cosetp4 = false; c->use_cosetp32 = false; c->use_cosetq = false; c->use_cosetr = false;
+        c->use_coset = false; c->use_toep = false; c->use_cosetp = false;
         if (c->use_lattice) {
             const char* fv = getenv("OLX_FIELD_VARIANT");
             if (c->modifier() && fv && strcmp(fv, "lattice") && strcmp(fv, "lattice2d")) fv = nullptr;   // (the A/B forms carry no per-term factors)
@@ -456,33 +446,10 @@ static int configure_variant_impl(olx_ctx* c) {
             // kernel 2f: ONE distinct steering vector in the whole launch (an on-axis SinglePoint focus on a mirror-symmetric
             // array): Toeplitz weights stationary, 16 planes per MFMA tile -- 2e would use 2 of 16 matrix columns
             c->use_toep = c->use_coset && tiles.size() == 1 && total_cols == 1 && !(fv && !strcmp(fv, "lattice"));
-            // (the persistent wave-specialised form of kernel 2f, field_toepws_k, measured 13 - 35 % SLOWER -- DESIGN.md 5.4; A/B only)
-            c->toep_block = !(kAbVariants && fv && !strcmp(fv, "toepws"));
             // kernel 2g: the NT = 2 shape with the planes in the MFMA rows (stores straight from the accumulators, no staging):
             // 6 - 9 % faster than 2e on the headline shard; OLX_FIELD_VARIANT=lattice pins kernel 2e for A/B runs
             c->use_cosetp = c->use_coset && !c->use_toep && c->nt == 2 && !(fv && !strcmp(fv, "lattice"));
-            // the same row map with FOUR column tiles (OLX_FIELD_VARIANT=cosetp4): measured slower than 2e's NT = 4 shape, A/B only
-            c->use_cosetp4 = kAbVariants && c->use_coset && !c->use_toep && c->nt == 4 && fv && !strcmp(fv, "cosetp4");
-            // ... in its 32 x 32 x 16 matrix-instruction form (two positions per tile; OLX_FIELD_VARIANT=cosetp32): measured slower, A/B only
-            c->use_cosetp32 = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetp32");
-            // kernel 2q: 2g in blocks of 4 waves x 8 planes, four per CU (OLX_FIELD_VARIANT=cosetq; A/B against 2g)
-            c->use_cosetq = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetq");
-            // kernel 2r: 2g as one persistent block per CU with the table generation inside the K-steps (OLX_FIELD_VARIANT=cosetr);
-            // steering fragments of at most 4 super-blocks stay resident in LDS, one launch tile
-            c->use_cosetr = kAbVariants && c->use_cosetp && fv && !strcmp(fv, "cosetr") && c->lat.nsa * c->lat.nsbp <= 4 && tiles.size() == 1 && (c->fp.nz & 3) == 0 &&
-                            (unsigned long long)F * (unsigned long long)c->fp.vox < (1ull << 32);
-            c->cosetp_persist = kAbVariants && c->use_cosetp && fv && !strncmp(fv, "cosetpp", 7);
-            c->cosetp_stagger = (c->cosetp_persist && fv[7] == ':') ? atoi(fv + 8) : 0;
-            {   // kernel 2g with ONE super-block per table stage and <= 24 positions per block: 48 KB of LDS, three blocks per CU (developer library,
-                // OLX_COSETP_SHAPE=single; default arithmetic only).  Bit-identical and 20 % SLOWER than the pair tables (profiles/r04_cosetp_single_ab.txt).
-                const char* shp = getenv("OLX_COSETP_SHAPE");
-                const char* f8e = getenv("OLX_FP8_CORRECTION");
-                c->cosetp_single = kAbVariants && c->use_cosetp && !fv && !c->modifier() && !(c->flags & (OLX_FIELD_FP8_CORRECTION | OLX_OUT_COMPLEX)) && !(f8e && strcmp(f8e, "0") != 0) &&
-                                   !getenv("OLX_MIXED_CORRECTION") && !getenv("OLX_GTABLE") && (shp ? !strcmp(shp, "single") : false);
-                const int want_s = c->cosetp_single ? c->lat.nsb : want;      // (no pairs: no padding row of super-blocks either)
-                if (want_s != c->lat.nsbp) build_slot_map(c->lat, want_s);
-            }
-            if (c->use_cosetp || c->use_cosetp4)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
+            if (c->use_cosetp)   // kernel 2g stores per column slot: a column with 3 - 4 store targets (an on-axis focus) makes every
                 olxplan::balance_store_targets(tiles, c->nt * MFMA_COLS);   // lane wait for its extra passes -- hand half of them to a free column slot (same weights, no extra MFMA)
         }
         const int n_pad = c->use_lattice ? c->lat.n_pad : (n + 15) / 16 * 16;
@@ -511,7 +478,7 @@ static int configure_variant_impl(olx_ctx* c) {
             HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
             c->coords_cap = n_pad;
         }
-        const size_t need = (size_t)ntiles * (n_pad / 16) * 160 * c->nt;      // (160: the mixed-correction layout of kernel 2g; 128 otherwise)
+        const size_t need = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;      // uint4 per K-step and column tile: hi, lo of the 64 lanes
         if (c->bfrag_cap < need) {
             if (c->d_bfrag) hipFree(c->d_bfrag);
             c->d_bfrag = nullptr; c->bfrag_cap = 0;
@@ -579,15 +546,8 @@ static int configure_variant_impl(olx_ctx* c) {
             // geometric), every focus lies inside the slab and has N_eff >= 256.  Otherwise, and by default, the fp16
             // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
             {
-                // MIXED corrections (round 4; kernel 2g; developer library, OLX_MIXED_CORRECTION=1): only the lo_G x hi_W term goes through e4m3, the
-                // other correction stays an fp16 product -- 40 instead of 48 matrix cycles per K-step and tile, half the e4m3 rounding variance of
-                // the fp8 mode.  Built to be the gated default; MEASURED (profiles/r04_mixed_ab.txt): 4.2-4.4e-6 of the peak on the full 256^3
-                // volume (fp8: 5.3-6.2e-6, fp16: 0.9e-6) and 0.432-0.443 against 0.437-0.444 ms -- no gain worth 5 x the error: the kernel hardly
-                // follows its matrix-instruction count (the same build WITHOUT the e4m3 instruction, a third of all matrix work gone: -7 %).
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const char* mxe = getenv("OLX_MIXED_CORRECTION");
                 const bool asked8 = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
-                const bool mix_ok = kAbVariants && mxe && !strcmp(mxe, "1") && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->modifier() && !(c->flags & OLX_OUT_COMPLEX);
                 const bool asked = asked8;
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
@@ -606,14 +566,13 @@ static int configure_variant_impl(olx_ctx* c) {
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
                 c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : (asked8 && ok));
-                c->mixcorr = mix_ok && !c->fp8corr;
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
-                const int zb = c->use_cosetq ? 8 : COS_ZB;      // planes per block (kernel 2q: 8)
-                olxplan::coset_partition(Q, kxw, zb, c->cosetp_single ? 6 : COS_KYW);
+                const int zb = COS_ZB;      // planes per block
+                olxplan::coset_partition(Q, kxw, zb, COS_KYW);
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
@@ -636,31 +595,17 @@ static int configure_variant_impl(olx_ctx* c) {
                 }
                 {   // kernel 2e / 2g / 2f / 2q block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
-                    // kernel 2g fed from a precomputed geometry table (k_gtable.hip; developer library, OLX_GTABLE=1 | order0: measured SLOWER than
-                    // the in-kernel generation).  The table offsets of a block all lie in ONE residue class (U mod mx, W mod my);
-                    // the 2 nsx nsy blocks of a plane block that share a class read overlapping windows of it, so they get consecutive ids on one
-                    // XCD (not with order0): L2 serves all but one of them.
-                    const char* gte = getenv("OLX_GTABLE");
-                    c->use_gtable = kAbVariants && c->use_cosetp && !c->use_cosetq && !c->use_cosetr && !c->use_cosetp32 && !c->cosetp_persist && !c->dir_lattice && !c->fp8corr && !c->mixcorr &&
-                                    Q.nsa * Q.nsbp > 2 && gte && (!strcmp(gte, "1") || !strcmp(gte, "order0"));      // (fp8 shape: no registers for the entries in flight; one pair: nothing to copy)
-                    const bool gt_order = c->use_gtable && strcmp(gte, "order0") != 0;
                     // (the records depend on the partition only, not on the steering table: a call that changes nothing but the foci finds the
                     // records it uploaded last time still valid -- 9 216 of them on the headline grid, 0.1 ms to derive and compare)
-                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, c->use_cosetq ? 4 : 2, gt_order ? 1 : 0,
-                                             c->use_cosetq ? 1 : 0, c->use_cosetq ? 20 : (c->use_cosetp ? (c->cosetp_single ? 24 : 40) : 0), c->use_gtable ? 1 : 0};
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, 2, c->use_cosetp ? 40 : 0};
                     std::vector<CosetBlock> blk;
-                    if (!c->use_gtable && !c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
+                    if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
                         std::string why;
-                        if (!olxplan::build_coset_blocks(Q, zb, c->use_cosetq ? 4u : 2u, gt_order, c->use_cosetq, c->use_cosetq ? 20 : (c->use_cosetp ? (c->cosetp_single ? 24 : 40) : 0), blk, why))
-                            return fail(c, OLX_ESTATE, "kernel %s: %s", c->use_cosetq ? "2q" : "2g", why.c_str());
+                        if (!olxplan::build_coset_blocks(Q, zb, 2u, c->use_cosetp ? 40 : 0, blk, why))
+                            return fail(c, OLX_ESTATE, "kernel 2g: %s", why.c_str());
                     }
                     const unsigned nblk = (unsigned)blk.size();
-                    if (c->use_gtable) {
-                        double max_mb = 4096.0;
-                        if (const char* e = getenv("OLX_GTABLE_MAX_MB")) { const double v = atof(e); if (v > 0) max_mb = v; }
-                        c->use_gtable = olxplan::plan_geometry_table(Q, zb, blk, max_mb);
-                    }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);
                         c->d_cpblocks = nullptr; c->cpblocks_cap = 0; c->up_blocks.clear();
@@ -673,21 +618,6 @@ static int configure_variant_impl(olx_ctx* c) {
                     }
                     memcpy(c->up_blocks_key, rec_key, sizeof rec_key);
                     c->cp_nblocks = nblk;
-                    if (c->use_cosetr) {   // kernel 2r walks the non-empty records only
-                        std::vector<CosetBlock> live;
-                        for (const CosetBlock& B : blk) if (B.npos > 0) live.push_back(B);
-                        if (live.empty()) c->use_cosetr = false;
-                        else {
-                            if (c->cprblocks_cap < live.size()) {
-                                if (c->d_cprblocks) hipFree(c->d_cprblocks);
-                                c->d_cprblocks = nullptr; c->cprblocks_cap = 0;
-                                HIPCHK(c, hipMalloc((void**)&c->d_cprblocks, sizeof(CosetBlock) * live.size()));
-                                c->cprblocks_cap = live.size();
-                            }
-                            HIPCHK(c, hipMemcpy(c->d_cprblocks, live.data(), sizeof(CosetBlock) * live.size(), hipMemcpyHostToDevice));
-                            c->cpr_nblocks = (unsigned)live.size();
-                        }
-                    }
                 }
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     c->toep_nsa16 = (A.ax + 15) / 16;
@@ -719,50 +649,23 @@ static int configure_variant_impl(olx_ctx* c) {
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->toep_block ? "" : "ws", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
                              total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
                 long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
-                if (c->use_cosetp || c->use_cosetp4) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
+                if (c->use_cosetp) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
                     long long npos_all = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     for (int rx = 0; rx < 2 * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry)
                             npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
-                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 4 : c->mixcorr ? 5 : 6) / 2 * ntiles;   // (mixed: 2.5 units per K-step)
-                }
-                if (c->use_cosetp32) {   // 32 x 32 form: one row tile per PAIR of positions (an odd count pads one position per block part)
-                    long long nhalf = 0;
-                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
-                    for (int rx = 0; rx < 2 * A.mx; ++rx)
-                        for (int ry = 0; ry < A.my; ++ry) {
-                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
-                            for (int sx = 0; sx < Q.nsx; ++sx)
-                                for (int sy = 0; sy < Q.nsy; ++sy) {
-                                    const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    nhalf += 2 * ((KX * KY + 1) / 2);
-                                }
-                        }
-                    n_mfma = nhalf * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
-                }
-                if (c->use_cosetq) {   // kernel 2q: one row tile per PAIR of y-adjacent positions and 8-plane block
-                    long long npair_all = 0;
-                    const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
-                    for (int rx = 0; rx < 2 * A.mx; ++rx)
-                        for (int ry = 0; ry < A.my; ++ry) {
-                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
-                            for (int sy = 0; sy < Q.nsy; ++sy) {
-                                const int KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                npair_all += (long long)kxa * ((KY + 1) / 2);
-                            }
-                        }
-                    n_mfma = npair_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetr ? "r" : c->use_cosetq ? "q" : c->use_cosetp32 ? "p32" : c->use_cosetp ? "p" : c->use_cosetp4 ? "p4" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                         c->fp8corr ? ",fp8corr" : "", (c->cosetp_persist && !c->use_cosetq) ? ",persistent" : "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         c->fp8corr ? ",fp8corr" : "", "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 }
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
@@ -778,7 +681,6 @@ static int configure_variant_impl(olx_ctx* c) {
     } else if (c->mx * c->my * c->nf == 1) {
         if (c->modifier()) snprintf(nmbuf, sizeof nmbuf, "field_accum_dir_k<4,%s> (%s%s%s)", c->clamp ? "clamp" : "noclamp", c->directivity ? "piston directivity" : "",
                                     (c->directivity && c->absorb_np_m > 0) ? ", " : "", c->absorb_np_m > 0 ? "uniform absorption" : "");
-        else if (c->force_kind == 5) snprintf(nmbuf, sizeof nmbuf, "field_shfl_k<%s> (elements across lanes, __shfl reduction)", c->clamp ? "clamp" : "noclamp");
         else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
     } else {
         std::vector<int> perm((size_t)nm * n);
@@ -806,9 +708,6 @@ static int configure_variant_impl(olx_ctx* c) {
         c->dir_lattice = false; c->allow_shared = false;
         return configure_variant_impl(c);
     }
-    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->cosetp_single) strncat(nmbuf, " +one super-block per stage (3 blocks per CU)", sizeof nmbuf - strlen(nmbuf) - 1);
-    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->mixcorr) strncat(nmbuf, " +mixed corrections (lo_G x hi_W in e4m3)", sizeof nmbuf - strlen(nmbuf) - 1);
-    if (c->use_mfma && c->use_lattice && c->use_cosetp && c->use_gtable) strncat(nmbuf, " +precomputed geometry table", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->directivity && c->use_mfma) strncat(nmbuf, " +piston directivity in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     if (c->absorb_np_m > 0 && c->use_mfma) strncat(nmbuf, " +uniform absorption in the tables", sizeof nmbuf - strlen(nmbuf) - 1);
     c->variant = nmbuf;
@@ -828,11 +727,8 @@ static int pack_if_needed(olx_ctx* c) {
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
-                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : (c->use_lattice && c->use_cosetp && c->mixcorr) ? 2 : 0, c->d_coords, c->d_bfrag);
+                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
-#ifdef OLX_AB_VARIANTS
-        if (c->use_lattice && c->use_cosetp && c->use_gtable) { int rc = olx_gtable_prepare(c); if (rc) return rc; }
-#endif
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -995,7 +891,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     };
     const bool whole_x = (s.x_begin == 0 && s.x_count == g->n[0]);
     const char* force = getenv("OLX_FIELD_VARIANT");  // general | shared | mfma | lattice: pin a kernel family (A/B measurements)
-    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : (kAbVariants && !strcmp(force, "shfl")) ? 5 : 0;
+    c->force_kind = !force ? 0 : !strcmp(force, "general") ? 1 : !strcmp(force, "shared") ? 2 : !strcmp(force, "mfma") ? 3 : (!strcmp(force, "lattice") || !strcmp(force, "lattice2d")) ? 4 : 0;
     // piston directivity: for a flat array of equal, axis-aligned elements D_e depends on the (voxel - element) offset only and folds
     // into the lattice kernels' geometry tables (their DIR instantiations); any other array keeps the exact per-pair kernel 2a-d
     c->dir_lattice = false;
@@ -1064,14 +960,6 @@ int olx_field_launch(olx_ctx* c) {
     const bool prof = c->prof_on && (size_t)(2 * c->prof_n + 1) < c->prof_ev.size();
     if (prof) HIPCHK(c, hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
-#ifdef OLX_AB_VARIANTS
-    else if (c->use_mfma && c->use_lattice && c->use_toep && !c->toep_block) olx_launch_toepws(c, pm);
-    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetr) olx_launch_cosetr(c, pm);
-    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetq) olx_launch_cosetq(c, pm);
-    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp32) olx_launch_cosetp32(c, pm);
-    else if (c->use_mfma && c->use_lattice && !c->use_toep && c->use_cosetp4) olx_launch_cosetp4(c, pm);
-    else if (!c->use_mfma && c->mx * c->my * c->nf == 1 && !c->modifier() && c->force_kind == 5) olx_launch_shfl(c, pm);
-#endif
     else if (c->use_mfma) {
         if (!c->use_lattice) olx_launch_mfma(c, pm);
         else if (c->use_toep) olx_launch_toep(c, pm);

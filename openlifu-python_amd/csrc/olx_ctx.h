@@ -79,21 +79,12 @@ struct olx_ctx {
     typedef olxplan::Lattice Lattice;          // olx_plan.h: regular (a, b) lattice in one z plane, pitch = whole voxels
     Lattice lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    bool use_coset = false; bool fp8corr = false; bool mixcorr = false;   /* mixcorr: kernel 2g's mixed correction products (the gated default) */ CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
+    bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records
     int up_blocks_key[16] = {0};               // the partition up_blocks was derived from
     std::vector<CosetBlock> up_blocks; std::vector<int> up_jobs, up_slot;   // host copies of what d_cpblocks / d_jobs / d_slot hold (re-uploaded only when they change)
-    bool use_cosetr = false; CosetBlock* d_cprblocks = nullptr; size_t cprblocks_cap = 0; unsigned cpr_nblocks = 0;   // kernel 2r: persistent, one block per CU (non-empty records only)
-    bool use_cosetq = false;   // kernel 2q: 2g in blocks of 4 waves x 8 planes (four blocks per CU)
-    bool cosetp_persist = false; int cosetp_stagger = 0;   // kernel 2g, persistent form (OLX_FIELD_VARIANT=cosetpp[:stagger cycles]; A/B)
-    bool use_cosetp4 = false;  // kernel 2g's row map with four column tiles (field_cosetp4_k)
-    bool use_cosetp32 = false; // kernel 2g in its 32 x 32 x 16 MFMA form (field_cosetp32_k)
-    bool cosetp_single = false; // kernel 2g with ONE super-block per table stage (18-row tables, <= 24 positions, 48 KB: three blocks per CU)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
-    // kernel 2g fed from the precomputed geometry table (k_gtable.hip): built once per plan, keyed by the parameters it was evaluated from
-    bool use_gtable = false; GtEntry* d_gtab = nullptr; size_t gtab_cap = 0; std::string gtab_key;
-    bool toep_block = true;    // kernel 2f as one block per work item (field_toep_k); false (OLX_FIELD_VARIANT=toepws): persistent field_toepws_k
     bool use_toep = false; int toep_nsa16 = 0; int toep_targets[4] = {-1, -1, -1, -1};
     int* d_cell = nullptr; size_t cell_cap = 0; uint4* d_afrag = nullptr; size_t afrag_cap = 0;
     static constexpr int NBUF = 2;

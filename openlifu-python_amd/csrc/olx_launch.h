@@ -5,19 +5,12 @@
 struct olx_ctx;
 void olx_launch_accum(olx_ctx* c, float* pm);        // 2a  field_accum_k
 void olx_launch_accum_dir(olx_ctx* c, float* pm);    // 2a-d field_accum_dir_k (piston directivity; needs c->d_tab2)
-void olx_launch_shfl(olx_ctx* c, float* pm);         // 2s  field_shfl_k (elements across lanes + __shfl: evidence variant)
 bool olx_launch_shared(olx_ctx* c, float* pm);       // 2b  field_shared_k (false: no instantiation for the planned shape)
 void olx_launch_mfma(olx_ctx* c, float* pm);         // 2c  field_mfma_k
 void olx_launch_lattice(olx_ctx* c, float* pm);      // 2d  field_lattice_k
 void olx_launch_coset(olx_ctx* c, float* pm);        // 2e  field_coset_k
 void olx_launch_cosetp(olx_ctx* c, float* pm);       // 2g  field_cosetp_k (2e's NT = 2 shape, planes in the MFMA rows)
-int olx_gtable_prepare(olx_ctx* c);                  //     its precomputed geometry table (gtable_gen_k; no-op when the resident table still applies)
-void olx_launch_cosetp4(olx_ctx* c, float* pm);      // 2g  field_cosetp4_k (the same row map with four column tiles: 17 - 32 columns per launch tile)
-void olx_launch_cosetp32(olx_ctx* c, float* pm);     // 2g  field_cosetp32_k (the same with v_mfma_f32_32x32x16_f16: two positions x 16 planes x 32 columns per instruction)
-void olx_launch_cosetq(olx_ctx* c, float* pm);       // 2q  field_cosetq_k (2g in blocks of 4 waves x 8 planes)
-void olx_launch_cosetr(olx_ctx* c, float* pm);       // 2r  field_cosetr_k (2g as one persistent block per CU, tables generated inside the K-steps)
 void olx_launch_toep(olx_ctx* c, float* pm);         // 2f  field_toep_k (single steering column on a lattice array)
-void olx_launch_toepws(olx_ctx* c, float* pm);       //     wave-specialised persistent form (A/B only: slower)
 void olx_pack_toep(olx_ctx* c);                      //     its Toeplitz weight fragments
 void olx_launch_hetero(olx_ctx* c, float* pm);       // 2h  field_hetero_k
 void olx_launch_hmarch(olx_ctx* c, float* pm);       // 2m  field_hmarch_k (marched ray sums: one launch per plane segment)

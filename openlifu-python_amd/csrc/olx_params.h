@@ -89,16 +89,7 @@ struct CosetParams {
     long long vox;
     unsigned flags;
     int n_foci;                // planned foci: the output arrays hold n_foci volumes of vox floats (what the debug build's store checks compare with)
-    // precomputed geometry table (GT instantiations of kernel 2g; built once per plan by gtable_gen_k, k_gtable.hip): entry
-    // ((class nzp + plane) NW + w) NU + ur = {hi word, lo word} of G at integer offsets U = gt_ulo + cx + mx (NU - 1 - ur), W = gt_wlo + cy + my w,
-    // class = cx my + cy -- the offsets a block's tables hold all lie in ONE residue class, a table row (12 columns) is 96 contiguous bytes
-    int gt_nu, gt_nw, gt_nzp;  // columns / rows per plane and class, planes (nz padded to whole plane blocks)
-    int gt_ulo, gt_wlo;        // U / W of (class (0, 0), u = 0, w = 0); multiples of mx / my below every offset in use
 };
-
-// One entry of the precomputed geometry table: the two words kernel 2g keeps per table entry (fp16 (re, im) of hi; fp16 (re, im) of lo, or
-// with fp8 corrections the e4m3 bytes [lo re, lo im | hi re, hi im]).
-struct GtEntry { unsigned hi, lo; };
 
 // kernels 2g / 2f: one record per blockIdx.x, written by the host (olx.hip, configure) -- the block's share of the coset decomposition.
 // (Decoded in the kernel these were ~350 VALU instructions per wave: every integer division of a block-uniform value runs
@@ -110,8 +101,7 @@ struct CosetBlock {
     int KY;                    // positions along y
     int ky_magic;              // floor(65536 / KY) + 1: pos / KY == (pos * ky_magic) >> 16 for pos < 2048 / ... (pos <= 40 here)
     int KX;                    // positions along x (kernel 2f)
-    unsigned gt_off;           // GT instantiations of kernel 2g: table entry of (plane 0, table row 0, column 0) of super-block (sa, sbb) = (0, 0); the
-                               // pair (sa, sbb0) reads 8 sa columns higher and 8 sbb0 rows lower
+    int pad_;                  // (record stays 32 bytes: one s_load_dwordx8)
 };
 
 constexpr int COS_NW = 8;                  // waves per block

@@ -153,7 +153,7 @@ void coset_partition(CosetParams& Q, int kxw, int zb, int kyw) {
 
 // blockIdx.x -> (coset, part, plane block), in the kernels' former decode order (the two blocks that write the two 64-byte halves of the
 // same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
-bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, bool class_order, bool pair_positions, int max_pos,
+bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, int max_pos,
                         std::vector<CosetBlock>& blk, std::string& msg) {
     const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
     blk.assign(nblk, CosetBlock{});
@@ -167,49 +167,14 @@ bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, bool class_o
         } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
         const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
         const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
-        int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
-        if (class_order) {      // cosets rx and rx + mx share their table class: neighbours in the id order
-            const int rxh = (int)(b % 2u); b /= 2u;
-            ry = (int)(b % (unsigned)Q.my); rx = (int)(b / (unsigned)Q.my) + Q.mx * rxh;
-        }
+        const int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
         const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * Q.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
         const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
         CosetBlock& B = blk[id];
         B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
-        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.gt_off = 0;
-        if (pair_positions) {   // kernel 2q: tiles are pairs of y-adjacent positions
-            const int KYP = (B.KY + 1) / 2;
-            B.npos = (KX > 0 && KY > 0) ? KX * KYP : 0; B.ky_magic = 65536 / KYP + 1;
-        }
+        B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.pad_ = 0;
         if (max_pos > 0 && B.npos > max_pos) { msg = "a block part holds more than " + std::to_string(max_pos) + " positions"; return false; }
-    }
-    return true;
-}
-
-// offsets in use: a block's tables hold U = Ub + mx (-q - 8 sa), q = 0 .. 11 (Ub: column 0 of sa = 0) and W = Wb + my (R - 8 sbb),
-// R = 0 .. 25 (Wb: row 0 of sbb = 0, the first super-block row of a pair being even: sbb <= nsbp - 2)
-bool plan_geometry_table(CosetParams& Q, int zb, std::vector<CosetBlock>& blk, double max_mb) {
-    long long u_lo = LLONG_MAX, u_hi = LLONG_MIN, w_lo = LLONG_MAX, w_hi = LLONG_MIN;
-    for (const CosetBlock& B : blk) {
-        if (B.npos <= 0) continue;
-        const long long Ub = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx, Wb = (long long)B.jbase + Q.uy0 - 15LL * Q.my;
-        u_hi = std::max(u_hi, Ub); u_lo = std::min(u_lo, Ub - (11LL + 8LL * (Q.nsa - 1)) * Q.mx);
-        w_lo = std::min(w_lo, Wb - 8LL * std::max(Q.nsbp - 2, 0) * Q.my); w_hi = std::max(w_hi, Wb + 25LL * Q.my);
-    }
-    auto floor_to = [](long long v, long long m) { long long q = v / m; if (q * m > v) --q; return q * m; };
-    if (u_hi < u_lo) return false;
-    const long long ulo = floor_to(u_lo, Q.mx), wlo = floor_to(w_lo, Q.my);
-    const long long nu = (u_hi - ulo) / Q.mx + 1, nw = (w_hi - wlo) / Q.my + 1, nzp = (long long)Q.kblocks * zb;
-    const long long entries = (long long)Q.mx * Q.my * nzp * nw * nu;
-    if (entries >= (1LL << 32) || (double)entries * sizeof(olx::GtEntry) > max_mb * 1048576.0 || std::llabs(ulo) > (1LL << 23) || std::llabs(wlo) > (1LL << 23))
-        return false;       // (too large to keep: the blocks evaluate their tables themselves)
-    Q.gt_nu = (int)nu; Q.gt_nw = (int)nw; Q.gt_nzp = (int)nzp; Q.gt_ulo = (int)ulo; Q.gt_wlo = (int)wlo;
-    for (CosetBlock& B : blk) {
-        if (B.npos <= 0) continue;
-        const long long du = (long long)B.ibase + Q.x_begin + Q.ux0 + 4LL * Q.mx - ulo, dw = (long long)B.jbase + Q.uy0 - 15LL * Q.my - wlo;
-        const long long cls = (du % Q.mx) * Q.my + dw % Q.my;
-        B.gt_off = (unsigned)(cls * nzp * nw * nu + (dw / Q.my) * nu + (nu - 1 - du / Q.mx));
     }
     return true;
 }

@@ -59,14 +59,9 @@ void balance_store_targets(Tiles& tiles, int max_cols);
 // from Q.nx, ny, nz, x_lo, y_lo, mx, my
 void coset_partition(CosetParams& Q, int kxw, int zb, int kyw = olx::COS_KYW);
 
-// Block records of kernels 2e / 2f / 2g / 2q: blockIdx.x -> (coset, part, plane block).  zb = planes per block, grp = blocks that share
-// 128-byte output lines (ids 8 apart = one XCD), class_order = cosets rx and rx + mx neighbours in the id order (geometry-table form).
-// pair_positions: kernel 2q counts pairs of y-adjacent positions.  Returns false (msg) when a part exceeds max_pos positions.
-bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, bool class_order, bool pair_positions, int max_pos,
-                        std::vector<CosetBlock>& blk, std::string& msg);
-
-// geometry-table form of kernel 2g: table extents (Q.gt_*) and every record's gt_off; false = table too large / nothing to do
-bool plan_geometry_table(CosetParams& Q, int zb, std::vector<CosetBlock>& blk, double max_mb);
+// Block records of kernels 2e / 2f / 2g: blockIdx.x -> (coset, part, plane block).  zb = planes per block, grp = blocks that share
+// 128-byte output lines (ids 8 apart = one XCD).  Returns false (msg) when a part exceeds max_pos positions (0 = no limit).
+bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, int max_pos, std::vector<CosetBlock>& blk, std::string& msg);
 
 // dense store-job lists of kernel 2e per (launch tile, column tile): job = c16 | image << 4 | focus << 6; entry [jobs_per_tile] = log2 ceil
 std::vector<int> build_store_jobs(const Tiles& tiles, int max_nt, int cols_per_nt, int jobs_per_tile, bool want_p, bool want_i);

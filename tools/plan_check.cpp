@@ -7,7 +7,6 @@
 //                tiles hold at most maxc columns, at most 4 (2 after balancing, where slots were free) targets per column
 //   blocks       the positions of all records x their plane blocks cover every voxel of the computed region exactly once, lie inside it,
 //                respect the per-part limit, and the kernels' magic division pos / KY is exact for every position
-//   table plan   every table window a record reads lies inside the geometry table, inside the record's residue class
 //   store jobs   the dense job lists name exactly the targets of their columns
 //   foci         geometric delays are recognised and reproduce the foci; scrambled delays are refused
 // Exit code 0 = all shapes passed; any violation prints the shape and exits 1 (sanitizer reports abort on their own).
@@ -27,7 +26,7 @@ using namespace olx;
 using namespace olxplan;
 
 static int g_fail = 0;
-static long long g_lattices = 0, g_records = 0, g_columns = 0, g_windows = 0;
+static long long g_lattices = 0, g_records = 0, g_columns = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++g_fail; fprintf(stderr, "FAIL %s:%d (%s): ", __FILE__, __LINE__, #cond); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); if (g_fail > 20) exit(1); } } while (0)
 
 // the checker's own notion of "the same steering vector" (independent of the planner's): equal drive weights and equal phases (mod one period)
@@ -181,9 +180,9 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         for (int e = 0; e < n; e += 3) bad[e] += 1e-7 * (1 + e % 5);
         CHECK(!infer_foci(true, n, F, pos.data(), bad.data(), c0, origin[2], got), "scrambled delays accepted");
     }
-    // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8, 16, 2, 0), 2q (3, 8, 4, 20 pairs)
-    struct Form { const char* name; int kxw, zb; unsigned grp; bool pairs; int max_pos; bool table; };
-    const Form forms[] = {{"2g", 3, 16, 2, false, 40, true}, {"2e nt1", 6, 16, 2, false, 0, false}, {"2e nt4", 2, 16, 2, false, 0, false}, {"2f", 8, 16, 2, false, 0, false}, {"2q", 3, 8, 4, true, 20, false}};
+    // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8, 16, 2, 0)
+    struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; };
+    const Form forms[] = {{"2g", 3, 16, 2, 40}, {"2e nt1", 6, 16, 2, 0}, {"2e nt4", 2, 16, 2, 0}, {"2f", 8, 16, 2, 0}};
     for (const Form& fm : forms) {
         if (nt_force && fm.kxw != nt_force) continue;
         CosetParams Q{};
@@ -194,8 +193,8 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         coset_partition(Q, fm.kxw, fm.zb);
         std::vector<CosetBlock> blk;
         std::string why;
-        for (int order = 0; order < (fm.table ? 2 : 1); ++order) {
-            const bool ok = build_coset_blocks(Q, fm.zb, fm.grp, order == 1, fm.pairs, fm.max_pos, blk, why);
+        {
+            const bool ok = build_coset_blocks(Q, fm.zb, fm.grp, fm.max_pos, blk, why);
             CHECK(ok, "%s: %s", fm.name, why.c_str());
             if (!ok) continue;
             CHECK(blk.size() == (size_t)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks), "record count");
@@ -205,9 +204,8 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
                 if (B.npos <= 0) continue;
                 ++g_records;
                 CHECK(B.k0 % fm.zb == 0 && B.k0 >= 0 && B.k0 < Q.kblocks * fm.zb, "plane block %d", B.k0);
-                const int KYe = fm.pairs ? (B.KY + 1) / 2 : B.KY;      // (2q: tiles are pairs of y-adjacent positions)
-                CHECK(B.KX >= 1 && B.KX <= fm.kxw && B.KY >= 1 && B.KY <= COS_KYW && B.npos == B.KX * KYe, "part %d x %d (npos %d)", B.KX, B.KY, B.npos);
-                for (int pq = 0; pq < B.npos; ++pq) CHECK(((pq * B.ky_magic) >> 16) == pq / KYe, "magic division %d / %d", pq, KYe);
+                CHECK(B.KX >= 1 && B.KX <= fm.kxw && B.KY >= 1 && B.KY <= COS_KYW && B.npos == B.KX * B.KY, "part %d x %d (npos %d)", B.KX, B.KY, B.npos);
+                for (int pq = 0; pq < B.npos; ++pq) CHECK(((pq * B.ky_magic) >> 16) == pq / B.KY, "magic division %d / %d", pq, B.KY);
                 for (int kx = 0; kx < B.KX; ++kx)
                     for (int ky = 0; ky < B.KY; ++ky) {
                         const int i = B.ibase + 2 * Q.mx * kx, j = B.jbase + Q.my * ky;
@@ -224,32 +222,6 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
                 for (size_t id = 0; id + 8 < blk.size(); ++id)
                     if ((id / 8) % fm.grp == 0 && blk[id].npos > 0)
                         CHECK(blk[id + 8].ibase == blk[id].ibase && blk[id + 8].jbase == blk[id].jbase && blk[id + 8].k0 == blk[id].k0 + fm.zb, "line partners not 8 ids apart");
-            if (fm.table && Q.nsa * Q.nsbp > 2) {      // geometry-table form: every window inside the table and inside ONE residue class
-                CosetParams T = Q;
-                std::vector<CosetBlock> tb = blk;
-                if (plan_geometry_table(T, fm.zb, tb, 1e9)) {
-                    const long long ps = (long long)T.gt_nw * T.gt_nu, cls_sz = (long long)T.gt_nzp * ps;
-                    for (const CosetBlock& B : tb) {
-                        if (B.npos <= 0) continue;
-                        const long long cls = (long long)B.gt_off / cls_sz;
-                        for (int sa = 0; sa < T.nsa; ++sa)
-                            for (int sbb = 0; sbb + 1 < T.nsbp || sbb == 0; sbb += 2)
-                                for (int R : {0, 25})
-                                    for (int q : {0, 11})
-                                        for (int k : {B.k0, B.k0 + fm.zb - 1}) {
-                                            const long long e = (long long)B.gt_off + (long long)k * ps + (long long)(R - 8 * sbb) * T.gt_nu + q + 8 * sa;
-                                            ++g_windows;
-                                            CHECK(e >= cls * cls_sz && e < (cls + 1) * cls_sz, "table window leaves its class");
-                                            const long long in = e - cls * cls_sz - (long long)k * ps, w = in / T.gt_nu, ur = in % T.gt_nu;
-                                            CHECK(in >= 0 && w >= 0 && w < T.gt_nw && ur >= 0 && ur < T.gt_nu, "table window outside the plane");
-                                            // ... and names the offset the kernel would evaluate there
-                                            const long long Uk = (long long)B.ibase + T.x_begin + T.ux0 + (long long)T.mx * (4 - q - 8 * sa), Wk = (long long)B.jbase + T.uy0 + (long long)T.my * (R - 15 - 8 * sbb);
-                                            const long long cx = cls / T.my, cy = cls % T.my;
-                                            CHECK(T.gt_ulo + cx + (long long)T.mx * (T.gt_nu - 1 - ur) == Uk && T.gt_wlo + cy + (long long)T.my * w == Wk, "table entry names another offset");
-                                        }
-                    }
-                }
-            }
         }
     }
 }
@@ -275,7 +247,6 @@ int main(int argc, char** argv) {
         check_shape(S, rng, 0);
         ++done;
     }
-    printf("plan_check: %d shapes (%lld recognised lattices, %lld columns, %lld block records, %lld table windows checked), %d violations\n", done, g_lattices, g_columns, g_records,
-           g_windows, g_fail);
+    printf("plan_check: %d shapes (%lld recognised lattices, %lld columns, %lld block records), %d violations\n", done, g_lattices, g_columns, g_records, g_fail);
     return g_fail ? 1 : 0;
 }
