@@ -11,16 +11,18 @@ in HBM, plus -- for N > 1 -- the reassembly exchange.  The foci of a rank are wh
 `ShardedField` (plan_foci_sweep / step); `--foci-per-gpu 1` is the single-focus accumulate (configs[1] / configs[3]).
 
 For N > 1 (launched by torch.distributed.run, one rank per GPU; weak scaling: 8 foci per GPU, 64 at N = 8) the timed
-step uses `--reassemble allgather` by default -- north_star's reassembly, every per-focus |p| volume to every rank over
-RCCL/xGMI on a side stream, overlapped with the next step's compute; the same run then reports `aggregate`
-(reduce-scatter of max |p| / mean intensity, plan/protocol.py:382-387) and the compute without any exchange beside it.
+step uses `--reassemble aggregate` by default -- the reduce-scatter of max |p| / mean intensity (plan/protocol.py:382-387), the
+one cross-rank dependency of calc_solution's result, on a side stream, overlapped with the next step's compute; the same run
+then reports north_star's `allgather` (every per-focus |p| volume to every rank over RCCL/xGMI: 3.8 GB inbound per rank and
+step at N = 8, link-bound by construction) and the compute without any exchange beside it.  A line whose
+exchange did not run as asked carries "degraded": true and the process exits non-zero.
 torch is used only for the rendezvous / barrier (gloo); the product path is ctypes -> HIP.
 
-Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `value` is measured in the LIBRARY DEFAULT mode --
-`--corrections fp16`, three fp16 products, <= 2e-6 of the focal peak: what Protocol.calc_solution runs unless told otherwise.
-`--corrections fp8` times the opt-in mode (plan flag OLX_FIELD_FP8_CORRECTION / SimSetup.options["fp8_correction"]: the two
-hi x lo correction products in e4m3, <= 6e-6 of the focal peak) as the headline instead.  At N = 1 the line carries the other mode
-beside it (`fp8_optin` / `precision_safe`), a `parity` block measured in this run against the fp64 C oracle, and the other
+Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `value` is measured in the LIBRARY DEFAULT mode
+(`--corrections auto`): what Protocol.calc_solution runs unless told otherwise -- on this shard the two hi x lo correction products
+go through e4m3 (<= 6.5e-6 of the focal peak; north_star's gate is 1e-5).  `--corrections fp16` times the opted-out mode (plan flag
+OLX_FIELD_FP16_CORRECTION / SimSetup.options["fp8_correction"] = "0": three fp16 products, <= 2e-6) as the headline instead.  At
+N = 1 the line carries the other mode beside it (`precision_safe` / `library_default`), a `parity` block measured in this run against the fp64 C oracle, and the other
 shapes of the path (`legs`: single focus on / off axis, off-axis shard, 64-focus sweep), each planned, clock-ramped and timed
 over its own >= 200 steps; `scans` = GB/s of the HBM-bound streaming kernels; `kernel1` with its CPU baselines.
 
@@ -138,7 +140,8 @@ def kernel1_cpu(arr, foci_m):
                         "the cost model of bf/delay_methods/direct.py:35), Direct delays + Uniform apodization, best of 5 / 2"}
 
 
-def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), apod=("uniform", 1.0, 0.0), ori=None):
+def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 1, 4), apod=("uniform", 1.0, 0.0), ori=None,
+                   full_volume_test="tests/test_gpu_field.py::test_headline_shard_256cubed_full_volume_parity"):
     """Post-timing parity of the resident result against the fp64 C oracle: `n_samples` random voxels of up to three
     focus volumes, error normalised by each focus' own peak (the volume maximum for a focus inside the grid)."""
     from oracle import bf_oracle as bo, c_oracle as co
@@ -158,7 +161,7 @@ def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 
         checked.append(int(f))
     return {"max_err_over_peak": worst, "gate": 1e-5, "sampled_voxels_per_focus": n_samples, "foci_checked": checked,
             "oracle": "oracle/field_oracle.c (fp64, C/OpenMP)",
-            "full_volume_test": "tests/test_gpu_field.py::test_headline_shard_256cubed_full_volume_parity"}
+            "full_volume_test": full_volume_test}
 
 
 def issue_model(name, V, N, F):
@@ -249,11 +252,9 @@ def launch_ranks(n: int) -> int:
     return 0
 
 
-def live_traffic(kernel_name: str, argv_workload):
-    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child runs of this same bench (same workload, 20 steps) under
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md prescribes -- and
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 averaged over the kernel's dispatches (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes).
-    Returns (bytes, source) or (None, reason); any failure (no rocprofv3, a pass that times out) leaves the static figure in place."""
+def pmc_pass(kernel_name: str, argv_workload, counters):
+    """One child run of this same bench (same workload, 20 steps) under `rocprofv3 --kernel-trace --pmc <counters>`: ({counter: mean over the
+    dominant kernel's dispatches}, mean dispatch duration [us] under the counters).  Raises on any failure."""
     import csv
     import glob
     import shutil
@@ -261,36 +262,78 @@ def live_traffic(kernel_name: str, argv_workload):
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return None, "rocprofv3 not found"
+        raise RuntimeError("rocprofv3 not found")
     fn = kernel_name.split("<")[0].split(" ")[0]           # e.g. field_cosetp_k
-    vals = {}
     tmp = tempfile.mkdtemp(prefix="olx_pmc_", dir="/tmp")
     try:
+        cmd = [prof, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+               "--no-extras", "--cpu-seconds", "0", "--steps", "20", "--warmup", "3"] + list(argv_workload)
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
+        if r.returncode != 0:
+            raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode})")
+        acc, dur, seen = {c: [] for c in counters}, [], set()
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if fn in row.get("Kernel_Name", "") and row.get("Counter_Name") in acc:
+                    acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    if row["Dispatch_Id"] not in seen:
+                        seen.add(row["Dispatch_Id"])
+                        dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+        if any(len(v) < 5 for v in acc.values()):
+            raise RuntimeError(f"no {fn} dispatches in the {' '.join(counters)} pass")
+        return {c: sum(v) / len(v) for c, v in acc.items()}, sum(dur) / len(dur)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_traffic(kernel_name: str, argv_workload):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child runs of this same bench (same workload, 20 steps) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md prescribes -- and
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 averaged over the kernel's dispatches (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes).
+    Returns (bytes, source) or (None, reason); any failure (no rocprofv3, a pass that times out) leaves the static figure in place."""
+    fn = kernel_name.split("<")[0].split(" ")[0]
+    try:
+        vals = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--no-extras", "--cpu-seconds", "0", "--steps", "20", "--warmup", "3"] + list(argv_workload)
-            env = dict(os.environ, TMPDIR="/tmp")
-            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-                env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
-            acc = []
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if fn in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        acc.append(float(row["Counter_Value"]))
-            if len(acc) < 5:
-                return None, f"no {fn} dispatches in the {ctr} pass"
-            vals[ctr] = sum(acc) / len(acc)
+            vals[ctr] = pmc_pass(kernel_name, argv_workload, [ctr])[0][ctr]
         nbytes = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
         return nbytes, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate child passes of this bench, 20 steps each), "
                         f"(2 x {vals['FETCH_SIZE']:.0f} + {vals['WRITE_SIZE']:.0f}) KiB per {fn} launch; FETCH_SIZE doubled per the gfx950 correction")
     except Exception as e:  # noqa: BLE001 - the static figure stays
         return None, f"live counter passes failed: {e}"
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+
+
+N_CU = 256
+STORE_DRAIN_GBS = 6300.0     # sustained write / stream-copy rate of this part (tools/ubench_store.hip: 5.1 - 6.6 TB/s; DESIGN.md 5.3: 6.3 TB/s)
+
+
+def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
+    """What THIS FORMULATION permits, from counters measured in this run (one more child pass: SQ_BUSY_CU_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA,
+    SQ_INSTS_VALU_TRANS_F32): a SIMD has ONE vector issue port that its matrix and its other vector instructions share, so
+    the launch cannot be shorter than (16 cycles per matrix instruction + 4 per other vector instruction [+ 4 more per transcendental])
+    / 1024 SIMDs at the clock the chip holds under this load (power cap), nor than the HBM write drain of its result."""
+    try:
+        v, dur_us = pmc_pass(kernel_name, argv_workload, ["SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32"])
+    except Exception as e:  # noqa: BLE001
+        return {"skipped": str(e)}
+    clk = v["SQ_BUSY_CU_CYCLES"] / N_CU / (dur_us * 1e-6) / 1e9
+    n_mfma, n_other, n_trans = v["SQ_INSTS_MFMA"], v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"], v["SQ_INSTS_VALU_TRANS_F32"]
+    matrix_cyc, other_cyc = 16.0 * n_mfma, 4.0 * n_other + 4.0 * n_trans
+    matrix_ms = matrix_cyc / (N_SIMD * clk * 1e9) * 1e3
+    port_ms = (matrix_cyc + other_cyc) / (N_SIMD * clk * 1e9) * 1e3
+    store_ms = alg_bytes / (STORE_DRAIN_GBS * 1e9) * 1e3
+    floor_ms = max(port_ms, store_ms)
+    return {"what": "floors of this formulation at the clock measured under this load: vector issue port of the SIMDs (matrix + other vector "
+                    "instructions share it) and the HBM write drain of the result; `floor_ms` = the larger one (perfect overlap of the two)",
+            "clock_ghz": clk, "clock_source": "SQ_BUSY_CU_CYCLES / 256 CUs / dispatch duration, child pass of this run",
+            "matrix_instructions": n_mfma, "other_vector_instructions": n_other, "transcendentals": n_trans,
+            "matrix_only_ms": matrix_ms, "issue_port_ms": port_ms, "store_drain_ms": store_ms, "store_drain_rate_GBps": STORE_DRAIN_GBS,
+            "floor_ms": floor_ms, "roofline_frac_at_floor": alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "measured_ms": k_ms, "measured_over_floor": k_ms / floor_ms,
+            "matrix_only_ms_at_2p4ghz": matrix_cyc / (N_SIMD * CLK_GHZ * 1e9) * 1e3}
 
 
 def main():
@@ -303,10 +346,13 @@ def main():
                          "(the first ~20 launches after idle run 15-20 %% slower, tools/launch_series.py); 0 disables")
     ap.add_argument("--foci-per-gpu", type=int, default=8)
     ap.add_argument("--reassemble", choices=["allgather", "aggregate", "none"], default=None,
-                    help="default: allgather for N > 1 (north_star), none for N = 1")
-    ap.add_argument("--corrections", choices=["fp8", "fp16"], default="fp16",
-                    help="hi x lo correction products of the fp16 operand split: fp16 = the library default (<= 2e-6 of the focal "
-                         "peak; the default here too), fp8 = opt-in e4m3 products (<= 6e-6); the other one is timed beside it at N = 1")
+                    help="what the timed step exchanges.  Default for N > 1: aggregate -- the reduce-scatter of max |p| / mean intensity, the one cross-rank "
+                         "dependency of calc_solution's result (plan/protocol.py:382-387) and the exchange that can scale on point-to-point xGMI "
+                         "(DESIGN.md 6); north_star's all-gather of every per-focus volume and the compute without exchange are timed beside it.  N = 1: none")
+    ap.add_argument("--corrections", choices=["auto", "fp8", "fp16"], default="auto",
+                    help="hi x lo correction products of the fp16 operand split: auto (= fp8) = the library default, e4m3 products where their "
+                         "bound (<= 6.5e-6 of the focal peak) is a bound on the planned volume; fp16 = opted out (plan flag "
+                         "OLX_FIELD_FP16_CORRECTION, <= 2e-6); the other one is timed beside it at N = 1")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--spacing-mm", type=float, default=0.25)
     ap.add_argument("--elements", type=str, default="16x16")
@@ -339,7 +385,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         args.gpus = world
-    reassemble = args.reassemble or ("allgather" if world > 1 else "none")
+    reassemble = args.reassemble or ("aggregate" if world > 1 else "none")
 
     import openlifu_amd as ol  # loads libolx.so (system ROCm runtime) before any torch import
     from openlifu_amd import _native as nat, dist as od
@@ -464,7 +510,7 @@ def main():
             sf.plan_slab_sweep(arr, dl, ap, origin, spacing, n, F0, C0, RHO0, SENS, flags=out_flags, medium=skull)
             return fpg
         mine = sf.plan_foci_sweep(arr, run_foci, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS,
-                                  flags=out_flags, fp8_correction=fp8)
+                                  flags=out_flags, fp8_correction=(None if fp8 else False))
         return len(mine)
 
     def agree(ok: bool) -> bool:
@@ -534,7 +580,7 @@ def main():
             except Exception:  # noqa: BLE001 - a broken exchange shows up (and is handled) in the timed leg that follows
                 pass
 
-    F = plan(args.corrections == "fp8")
+    F = plan(args.corrections != "fp16")
     ramp()
     mode = reassemble if gather else "none"
     res = timed(mode, args.steps, args.warmup)
@@ -546,7 +592,7 @@ def main():
                 sf.close()
         except Exception:  # noqa: BLE001
             pass
-        plan(args.corrections == "fp8")
+        plan(args.corrections != "fp16")
         ramp()
         res = timed("none", args.steps, args.warmup)
     if res is None:
@@ -574,19 +620,19 @@ def main():
             return r is not None
         if skull is None:
             beside_leg(f"with_{other}", other)
-        if mode == "allgather" and skull is None:      # the same all-gather over the other transport
+        if skull is None:      # the all-gather over the other transport
             other_t = "p2p" if transport == "rccl" else "rccl"
             os.environ.setdefault("OLX_P2P_TIMEOUT_S", "20")
             sf.close()
             ok_t, note_t = init_transport(other_t)
             if ok_t:
-                plan(args.corrections == "fp8")
+                plan(args.corrections != "fp16")
                 if not beside_leg(f"with_{other_t}_allgather", "allgather"):
                     try:
                         sf.close()          # a failed transport is not used again
                     except Exception:  # noqa: BLE001
                         pass
-                    plan(args.corrections == "fp8")
+                    plan(args.corrections != "fp16")
             else:
                 beside[f"with_{other_t}_allgather"] = {"skipped": note_t}
         beside_leg("without_exchange", "none")
@@ -611,6 +657,9 @@ def main():
             "scaling_claim": mode if gather else "none",
             "n_ranks_rendezvous": world, "n_ranks_seen": ranks_seen if gather else world,
             "n_ranks_seen_by": (f"{transport} communicator" if gather else "process launcher (no exchange in the timed step)"),
+            # a line whose exchange did not run as asked (a transport that never came up, fewer ranks counted than launched) says so and the
+            # process exits non-zero after printing it
+            "degraded": bool(stuck) or (world > 1 and reassemble != "none" and (not gather or ranks_seen != world)),
             "config": {"workload": f"{N}-element {args.elements} matrix array x {args.grid}^3 grid "
                                    f"({args.spacing_mm} mm), {F} foci per GPU of the 64-focus Wheel sweep "
                                    f"(BASELINE configs[2] shard, planned by openlifu_amd.dist.plan_foci_orbits), |p|+intensity out"
@@ -620,7 +669,7 @@ def main():
                        "elements": N, "grid": [int(v) for v in n], "foci_per_gpu": F, "frequency_hz": F0,
                        "focus_indices_rank0": [int(v) for v in run_idx[:F]], "target_offset_mm": list(off),
                        "medium": args.medium, "clock_ramp_ms": args.clock_ramp_ms,
-                       "corrections": "fp8 (opt-in, OLX_FIELD_FP8_CORRECTION)" if fp8_on else "fp16 (library default)",
+                       "corrections": "e4m3 (library default where the foci lie in the planned volume and N_eff >= 256)" if fp8_on else ("fp16 (opted out: OLX_FIELD_FP16_CORRECTION)" if args.corrections == "fp16" else "fp16 (library default for this shape)"),
                        "kernel": kernel_name,
                        "reassembly": (f"{transport}-{mode}-overlapped" if gather else
                                       ("none" if (world == 1 or reassemble == "none") else "skipped")),
@@ -643,16 +692,17 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = nbytes, src
             else:
                 out["roofline"]["traffic_source"] = (traffic_src or "none") + f" [live measurement unavailable: {src}]"
+            out["achievable"] = achievable(kernel_name, wl, alg_bytes, k_ms)
         if world == 1 and not args.no_extras and skull is None:
             pos_m, _, area, _, _ = arr.element_table()
-            out["parity"] = {args.corrections: sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])}
+            out["parity"] = {("e4m3" if fp8_on else "fp16"): sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])}
             k2 = max(200, min(args.steps, 500))     # secondary legs: their own floor, whatever --steps says
 
             def leg(foci_m, fp8, what):
                 """plan -> clock ramp -> 20 warm-up + k2 timed steps of one more shape of the path."""
                 foci_m = np.atleast_2d(foci_m)
                 sf.plan_foci_sweep(arr, foci_m, C0, (nat.APOD_UNIFORM, 1.0, 0.0), origin, spacing, n, F0, RHO0, SENS, flags=out_flags,
-                                   fp8_correction=fp8)
+                                   fp8_correction=(None if fp8 else False))
                 ramp()
                 e, km = timed("none", k2, 20)       # (single rank: a failure here is a bug and raises below)
                 name = ctx.field_variant()
@@ -666,25 +716,25 @@ def main():
                         "algorithmic_bytes_per_launch": bytes_l, "traffic": static_traffic(name, args.grid)[0]}
 
             # the other correction mode on the same workload, same box
-            other_fp8 = args.corrections != "fp8"
+            other_fp8 = args.corrections == "fp16"
             o = leg(run_foci[:F], other_fp8, "the headline shard in the other correction mode")
-            out["fp8_optin" if other_fp8 else "precision_safe"] = o
-            out["parity"]["fp8" if other_fp8 else "fp16"] = sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])
+            out["library_default" if other_fp8 else "precision_safe"] = o
+            out["parity"]["e4m3" if "fp8corr" in o["kernel"] else "fp16"] = sampled_parity(ctx, coords_m, pos_m, area, run_foci[:F])
             legs = {}
             if off == (0.0, 0.0):
                 on_axis = sweep_m[0]                                          # the Wheel's centre = the target itself
                 t2 = ol.Point(position=(1.3, 0.7, 40), units="mm")           # off the array axis: no (focus, image) pair shares a column
                 sw2 = np.array([f.get_position(units="m") for f in pattern.get_targets(t2)])
-                legs["single_focus_on_axis"] = leg(on_axis, False, "one focus on the array axis (SinglePoint, the reference's default pattern)")
-                legs["single_focus_off_axis"] = leg(sw2[0], False, "one focus 1.3 / 0.7 mm off the array axis (an arbitrary target: 4 mirror images = 4 columns)")
-                legs["asymmetric"] = leg(sw2[od.plan_foci_orbits(sw2, -(-len(sw2) // fpg), centre_xy=centre)[0]], False,
+                legs["single_focus_on_axis"] = leg(on_axis, True, "one focus on the array axis (SinglePoint, the reference's default pattern)")
+                legs["single_focus_off_axis"] = leg(sw2[0], True, "one focus 1.3 / 0.7 mm off the array axis (an arbitrary target: 4 mirror images = 4 columns)")
+                legs["asymmetric"] = leg(sw2[od.plan_foci_orbits(sw2, -(-len(sw2) // fpg), centre_xy=centre)[0]], True,
                                          "same shard size, sweep target offset by (1.3, 0.7) mm from the array axis: the mirror folds of the grid "
                                          "still apply, but no two (focus, image) pairs share a steering column")
-                legs["sweep64"] = leg(sweep_m, False, "the whole 64-focus Wheel sweep of configs[2] on one GPU")
+                legs["sweep64"] = leg(sweep_m, True, "the whole 64-focus Wheel sweep of configs[2] on one GPU")
             legs.update(config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags))
             out["legs"] = legs
             # HBM-bound streaming scans over the resident result of the headline shard
-            plan(args.corrections == "fp8")
+            plan(args.corrections != "fp16")
             ctx.field_launch(); ctx.sync()
             scans = {}
             for kname in ("aggregate", "scale", "analysis_peaks", "masked_peak", "weighted_sum", "offset_grid", "fused_post"):
@@ -696,7 +746,7 @@ def main():
             out["scans"] = {"what": f"streaming kernels over the {F} resident focus volumes of the headline shard (offset_grid: one fp64 grid), "
                                     "30 launches each, HIP events (olx_scan_time)", **scans}
             # kernel 1: microseconds per F x N solve, HIP events around 50 repeats, with its CPU restatements beside it
-            plan(args.corrections == "fp8")
+            plan(args.corrections != "fp16")
             us = ctx.bf_time(50)
             out["kernel1"] = {"us_per_solve": float(np.median(us)), "foci": F, "elements": N, "dtype": "f64", **kernel1_cpu(arr, run_foci[:F])}
             out["end_to_end"] = end_to_end(ol, arr, setup, target, sweep, run_idx[:F], args)
@@ -705,13 +755,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pos_m, area, coords_m, run_foci[0], args.cpu_seconds)
             out["cpu_baseline_c"] = cpu_baseline_c(pos_m, area, coords_m, run_foci[0], min(args.cpu_seconds, 10.0))
         print(json.dumps(out))
+        degraded = out["degraded"]
+    else:
+        degraded = False
     if dist is not None:
         dist.barrier()
-        if stuck:            # a thread is still inside a communicator init: no teardown through it
+        if stuck:            # a thread is still inside a communicator init: no teardown through it -- and the run did not do what was asked
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
         sf.close()
         dist.destroy_process_group()
+    if degraded:
+        sys.exit(4)          # (the launcher returns the worst exit code of its ranks)
 
 
 def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
@@ -736,7 +791,7 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
         origin, spacing, n = grid_from_coords(setup.get_coords())
         return origin, spacing, n, [np.asarray(c.data) * 1e-3 for c in setup.get_coords().values()]
 
-    def run(key, what, arr, g, foci_m, apod=("uniform", 1.0, 0.0), medium=None, steps=200, check=(0,)):
+    def run(key, what, arr, g, foci_m, apod=("uniform", 1.0, 0.0), medium=None, steps=200, check=(0,), covered_by=None):
         origin, spacing, n, coords = g
         foci_m = np.atleast_2d(np.asarray(foci_m, dtype=np.float64))
         N, V = arr.numelements(), int(np.prod(n))
@@ -766,7 +821,7 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
                "algorithmic_bytes_per_launch": bytes_l, "roofline_frac": bytes_l / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "traffic": static_traffic(name, int(n[0]))[0]}
         if medium is None:
-            ent["parity"] = sampled_parity(ctx, coords, pos_m, area, foci_run, n_samples=8000, check=check, apod=apod, ori=ori)
+            ent["parity"] = sampled_parity(ctx, coords, pos_m, area, foci_run, n_samples=8000, check=check, apod=apod, ori=ori, full_volume_test=covered_by)
         else:       # whole z columns against the fp64 marched oracle of the same definition (oracle/field_oracle.c olo_field_columns_hetero_march)
             rng = np.random.default_rng(147)
             cols = np.column_stack([rng.integers(0, n[0], 16), rng.integers(0, n[1], 16)])
@@ -782,15 +837,16 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
                 worst = max(worst, float(np.abs(got - ref).max() / max(ref.max(), got.max())))
             ent["parity"] = {"max_err_over_column_max": worst, "gate": 1e-5, "columns": int(len(cols)), "foci_checked": [int(f) for f in check if f < nf],
                              "oracle": "oracle/field_oracle.c olo_field_columns_hetero_march (fp64; the build's own definition: parity unpinned)",
-                             "note": "fp32 running ray sums re-interpolated plane by plane: the measured error is what this number says, the tests assert 3e-5"}
+                             "covered_by": covered_by}
         res[key] = ent
 
     focus = np.array([[0.0, 0.0, 40e-3]])
     m16 = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
-    run("c2_128", "BASELINE configs[1]: 256-element matrix array, single focus, 128^3 @ 0.5 mm", m16, grid(128, 0.5), focus, steps=500)
+    run("c2_128", "BASELINE configs[1]: 256-element matrix array, single focus, 128^3 @ 0.5 mm", m16, grid(128, 0.5), focus, steps=500, covered_by="tests/test_gpu_field.py::test_c2_matrix_array_128cubed (full volume)")
     m32 = ol.Transducer.gen_matrix_array(nx=32, ny=32, pitch=1.5, kerf=0.15, units="mm", sensitivity=SENS)
     run("c4_1024x512", "BASELINE configs[3]: 1024-element array (32 x 32 @ 1.5 mm), 512^3 @ 0.125 mm, PiecewiseLinear(zero 60, rolloff 20) apodization + "
-        "Direct delays from kernel 1, single focus", m32, grid(512, 0.125), focus, apod=("piecewise", 60.0, 20.0), steps=100)
+        "Direct delays from kernel 1, single focus", m32, grid(512, 0.125), focus, apod=("piecewise", 60.0, 20.0), steps=100,
+        covered_by="tests/test_gpu_field.py::test_c4_1024_elements_512cubed_sampled (sampled voxels at 512^3); full volumes of kernel 2f: test_single_column_toeplitz_kernel")
     g256 = grid(256, 0.25)
     wheel = ol.focal_patterns.Wheel(center=True, num_spokes=63, spoke_radius=5.0)
     sweep = np.array([f.get_position(units="m") for f in wheel.get_targets(ol.Point(position=(0, 0, 40), units="mm"))])
@@ -798,19 +854,19 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
     # arrays without a grid-commensurate flat lattice: kernels 2a / 2c
     half = ol.Transducer.gen_matrix_array(nx=8, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
     tilted = ol.TransducerArray.get_concave_cylinder(half, rows=1, cols=2, width=24.0, gap=0.6, roc=80.0, units="mm").to_transducer()
-    run("tilted2_f1", "two-module TransducerArray on an 80 mm cylinder (2 x 128 elements, modules tilted -+ 8.8 deg), single focus, 256^3", tilted, g256, focus)
-    run("tilted2_f8", "the same array, the 8-focus shard", tilted, g256, shard, steps=100, check=(0, 3))
+    run("tilted2_f1", "two-module TransducerArray on an 80 mm cylinder (2 x 128 elements, modules tilted -+ 8.8 deg), single focus, 256^3", tilted, g256, focus, covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
+    run("tilted2_f8", "the same array, the 8-focus shard", tilted, g256, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     rng = np.random.default_rng(147)
     jit = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=SENS)
     for el in jit.elements:
         el.position = np.asarray(el.position, dtype=np.float64) + rng.uniform(-0.1, 0.1, 3) * np.array([1.0, 1.0, 0.0])
-    run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus)
-    run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3))
+    run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus, covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
+    run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     skull = skull_slab_volumes(*g256[3])
     skull["model"] = "marched"
     run("c5_skull_f1", "BASELINE configs[4] on one GPU: 256 elements, 256^3, skull-slab medium, marched ray sums (kernel 2m), one focus per launch",
-        m16, g256, focus, medium=skull, steps=50)
-    run("c5_skull_f8", "the same medium, the 8-focus shard in one launch sequence (look-ups shared by the foci)", m16, g256, shard, medium=skull, steps=50, check=(0, 3))
+        m16, g256, focus, medium=skull, steps=50, covered_by="tests/test_gpu_field.py::test_c5_skull_slab_256cubed_marched (whole z columns at 256^3), test_heterogeneous_medium_layered_ray_model (full volumes, small grids)")
+    run("c5_skull_f8", "the same medium, the 8-focus shard in one launch sequence (look-ups shared by the foci)", m16, g256, shard, medium=skull, steps=50, check=(0, 3), covered_by="tests/test_gpu_field.py::test_c5_skull_slab_256cubed_marched (whole z columns at 256^3), test_heterogeneous_medium_layered_ray_model (full volumes, small grids)")
     return res
 
 

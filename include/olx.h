@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OLX_ABI_VERSION 1
+#define OLX_ABI_VERSION 2
 
 /* error codes */
 #define OLX_OK 0
@@ -47,8 +47,9 @@ extern "C" {
 #define OLX_OUT_PMAG 1u      /* |p| [Pa]  -> p_max and p_min of kwave_if.py:131-139 */
 #define OLX_OUT_INTENSITY 2u /* 1e-4 |p|^2 / (2 rho c) [W/cm^2]  (kwave_if.py:140-144) */
 #define OLX_OUT_COMPLEX 4u   /* (re, im) interleaved, float32 */
-/* accuracy / speed option of olx_field_plan (OR-ed into flags; see the accuracy note there) */
-#define OLX_FIELD_FP8_CORRECTION 8u
+/* accuracy / speed options of olx_field_plan (OR-ed into flags; see the accuracy note there) */
+#define OLX_FIELD_FP8_CORRECTION 8u   /* accepted for source compatibility: asks for what is the default since ABI v2 */
+#define OLX_FIELD_FP16_CORRECTION 32u /* opt out of the e4m3 correction products: three fp16 products everywhere (<= 2e-6) */
 /* physics option of olx_field_plan (OR-ed into flags): optional far-field piston directivity, SURVEY.md 8(c) "flagged v1"; needs
  * olx_set_element_apertures.  Served by the exact per-pair kernel only (kernel 2a-d). */
 #define OLX_FIELD_DIRECTIVITY 16u
@@ -140,13 +141,16 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  * launch: asynchronous on the context's stream.  fetch: blocking D2H of one focus
  *   volume into caller-owned host arrays [nx*ny*nz] (cplx: 2 floats per voxel); any
  *   pointer may be NULL.
- * accuracy: fp32 results within 2e-6 of the volume's maximum |p| against the fp64 definition (measured
- *   0.8e-6 ... 1.9e-6; gate in tests 1e-5).  OPT-IN: with OLX_FIELD_FP8_CORRECTION in `flags`, matrix
- *   arrays on a commensurate grid compute the two small correction products of the fp16 hi/lo split
- *   in fp8 (e4m3): ~12 % faster, error <= 6e-6 of the FOCAL PEAK.  The library honours the request only
- *   when every focus of the steering table is known to lie inside the planned slab and drives >= 256
- *   elements effectively ((sum w)^2 / sum w^2); otherwise it silently keeps the 2e-6 path.  Nothing
- *   selects fp8 unasked.  olx_field_variant() names the kernel in use ("fp8corr" when active). */
+ * accuracy: fp32 results within 1e-5 of the volume's maximum |p| against the fp64 definition (north_star's gate; the
+ *   per-pair and fp16-split kernels measure 0.8e-6 ... 1.9e-6).  Matrix arrays on a commensurate grid (the lattice
+ *   kernels 2e / 2g) compute the two small correction products of their fp16 hi/lo operand split in fp8 (e4m3)
+ *   BY DEFAULT -- ~14 % faster, error <= 6.5e-6 of the FOCAL PEAK (measured 4.1e-6 ... 6.2e-6 on full 256^3 volumes) --
+ *   but only when that bound is a bound on the planned volume: every focus of the steering table is known (it came
+ *   from olx_bf_solve in the element frame, or its external delays are recognised as geometric), lies inside the
+ *   planned slab, and drives >= 256 elements effectively ((sum w)^2 / sum w^2).  Everything else -- small or
+ *   strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, the single-column kernel 2f, complex
+ *   output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION in `flags` opts out everywhere.
+ *   olx_field_variant() names the kernel in use ("fp8corr" when the e4m3 products are active). */
 int olx_field_plan(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab /*NULL = whole grid*/,
                    int n_foci, double freq, double c, double rho, double p0_pa, unsigned flags);
 int olx_field_launch(olx_ctx *ctx);

@@ -537,17 +537,18 @@ static int configure_variant_impl(olx_ctx* c) {
             L.vox = P.vox; L.flags = P.flags;
             const char* fv = getenv("OLX_FIELD_VARIANT");
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
-            // fp8 correction products (kernel 2e, NT <= 2), OPT-IN (OLX_FIELD_FP8_CORRECTION in the plan flags): the e4m3
-            // rounding of the two hi x lo terms adds ~2^-16 |w_e G| per element and term with random signs -- an absolute error
-            // that falls off only slowly with depth and, against the coherent focal peak sum |w_e G|, is ~ 1 / sqrt(N_eff),
-            // N_eff = (sum w)^2 / sum w^2 over the focus' drive weights: 5.8e-6 of the peak at N_eff = 256 (gate: 1e-5 of the
-            // volume's maximum).  Even when asked for they are used only if the planned SLAB is known to contain that peak:
-            // the foci are known (olx_bf_solve in the element frame, or external delays that infer_foci recognises as
-            // geometric), every focus lies inside the slab and has N_eff >= 256.  Otherwise, and by default, the fp16
-            // corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for A/B runs and fuzz tests.
+            // e4m3 correction products (kernels 2e / 2g, NT <= 2), the DEFAULT since round 5 wherever their error bound is a bound on the
+            // planned volume; OLX_FIELD_FP16_CORRECTION in the plan flags opts out.  The e4m3 rounding of the two hi x lo terms adds
+            // ~2^-16 |w_e G| per element and term with random signs -- an absolute error that falls off only slowly with depth and,
+            // against the coherent focal peak sum |w_e G|, is ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive
+            // weights: 4.1e-6 ... 6.2e-6 of the peak at N_eff = 256, measured on full 256^3 volumes (gate: 1e-5 of the volume's
+            // maximum).  So they run only if the planned SLAB is known to contain that peak: the foci are known (olx_bf_solve in the
+            // element frame, or external delays that infer_foci recognises as geometric), every focus lies inside the slab and has
+            // N_eff >= 256.  Otherwise the fp16 corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for
+            // A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked8 = (c->flags & OLX_FIELD_FP8_CORRECTION) != 0 && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
+                const bool asked8 = !(c->flags & OLX_FIELD_FP16_CORRECTION) && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
                 const bool asked = asked8;
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
@@ -779,7 +780,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         if (g->n[a] < 1 || !(g->spacing[a] > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: bad grid axis %d", a);
     if (!(freq > 0) || !(cs > 0) || !(rho > 0)) return fail(c, OLX_EINVAL, "olx_field_plan: freq, c, rho must be > 0");
     if (!(flags & (OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX))) return fail(c, OLX_EINVAL, "olx_field_plan: no outputs selected");
-    if (flags & ~(OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX | OLX_FIELD_FP8_CORRECTION | OLX_FIELD_DIRECTIVITY)) return fail(c, OLX_EINVAL, "olx_field_plan: unknown flag bits 0x%x", flags);
+    if (flags & ~(OLX_OUT_PMAG | OLX_OUT_INTENSITY | OLX_OUT_COMPLEX | OLX_FIELD_FP8_CORRECTION | OLX_FIELD_FP16_CORRECTION | OLX_FIELD_DIRECTIVITY)) return fail(c, OLX_EINVAL, "olx_field_plan: unknown flag bits 0x%x", flags);
     if ((flags & OLX_FIELD_DIRECTIVITY) && c->h_xaxis.size() != 3 * (size_t)c->n_el)
         return fail(c, OLX_ESTATE, "olx_field_plan: OLX_FIELD_DIRECTIVITY needs olx_set_element_apertures");
     olx_slab s{0, g->n[0]};

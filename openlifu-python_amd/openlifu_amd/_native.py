@@ -21,7 +21,8 @@ APOD_UNIFORM, APOD_MAXANGLE, APOD_PIECEWISE = 0, 1, 2
 OUT_PMAG, OUT_INTENSITY, OUT_COMPLEX = 1, 2, 4
 MEDIUM_MODELS = {"auto": 0, "sampled": 1, "marched": 2}   # OLX_MEDIUM_*
 FIELD_DIRECTIVITY = 16     # opt-in plan flag: far-field piston directivity (needs set_element_apertures; exact per-pair kernel)
-FIELD_FP8_CORRECTION = 8   # opt-in plan flag (include/olx.h): e4m3 correction products, <= 6e-6 of the focal peak
+FIELD_FP8_CORRECTION = 8   # (source compatibility: asks for what is the default since ABI v2)
+FIELD_FP16_CORRECTION = 32  # plan flag (include/olx.h): opt OUT of the e4m3 correction products -- three fp16 products everywhere (<= 2e-6)
 UNIQUE_ID_BYTES = 128
 P2P_BLOB_BYTES = 384
 
@@ -454,9 +455,11 @@ class Context:
 
     def solution_analyze_begin(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
                                beam_db=(3, 6), scale=None, overlap=False):
-        """Marshals the arguments HERE and returns ``finish() -> report``.  ``overlap=True`` starts the C call (it releases the GIL and blocks for
-        the device's scans) on a helper thread at once, so that the caller's own host arithmetic runs beside it; ``finish`` joins it."""
         """Everything ``Solution.analyze`` reads off the resident volumes in one crossing (``olx_solution_analyze``).
+        Marshals the arguments HERE and returns ``finish() -> report``.  ``overlap=True`` starts the C call (it releases the GIL and
+        blocks for the device's scans) on a helper thread at once, so that the caller's own host arithmetic runs beside it; ``finish()``
+        joins it and ``finish.abandon()`` joins it WITHOUT reading the report -- the context is not thread-safe, so a caller whose host
+        arithmetic raises must call one of the two before it touches the context again (``Solution.analyze`` does, try / except).
         ``line_offsets`` = the three offset vectors [m] of the focal-axis lines, ``line_pts`` [F, n0 + n1 + n2, 3] their
         positions.  Returns a dict of arrays: peaks [F, 6], ita_main [F], moments [F, 4], bounds [F, 3, 2, 2] (indices into
         the axis lines, -1 = none) and the scalar ita_global.  ``scale`` [F]: ``field_scale_aggregate`` happens first (one pass with the
@@ -487,24 +490,41 @@ class Context:
         glob = c_float(0)
         argv = (self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc), rep, ctypes.byref(glob))
         keep = (A, w, pts, o, sc)          # (the arrays behind the pointers live as long as the closure)
-        rc_box = []
+        box = {}                           # "rc": the C call's return code, "exc": what the helper thread raised instead
+
+        def call():
+            try:
+                box["rc"] = self._lib.olx_solution_analyze(*argv)
+            except BaseException as e:     # (a ctypes argument error, a KeyboardInterrupt delivered to the helper, ...)
+                box["exc"] = e
         helper = None
         if overlap:
             import threading
-            helper = threading.Thread(target=lambda: rc_box.append(self._lib.olx_solution_analyze(*argv)))
+            helper = threading.Thread(target=call)
             helper.start()
 
-        def finish():
+        def join():
             if helper is not None:
                 helper.join()
-            else:
-                rc_box.append(self._lib.olx_solution_analyze(*argv))
-            self._chk(rc_box[0])
+            elif not box:
+                call()
+
+        def finish():
+            join()
+            if "exc" in box:
+                raise box["exc"]
+            self._chk(box["rc"])
             assert keep is not None
             raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
                                                      ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
             return {"peaks": raw["peaks"].copy(), "ita_main": raw["ita_main"].copy(), "moments": raw["moments"].copy(),
                     "bounds": raw["bounds"].copy(), "ita_global": float(glob.value)}
+
+        def abandon():
+            """The caller failed on its side: wait for the crossing to leave the context, drop whatever it reported."""
+            if helper is not None:
+                helper.join()
+        finish.abandon = abandon
         return finish
 
     def field_masked_moments(self, A, aspect, radius_m, cutoff):

@@ -180,7 +180,7 @@ class ShardedField:
 
     # ---- planning ---------------------------------------------------------------------------------
     def plan_foci_sweep(self, arr, foci_m, c, apod_args, origin_m, spacing_m, n, freq, rho, p0_pa, flags=None,
-                        fp8_correction=False, absorption=0.0):
+                        fp8_correction=None, absorption=0.0):
         """mode "foci": this rank solves (kernel 1) and plans its orbit-aware block of foci over the whole grid."""
         from . import _native as nat
         foci_m = np.atleast_2d(np.asarray(foci_m, dtype=np.float64))
@@ -196,7 +196,7 @@ class ShardedField:
         flags = nat.OUT_PMAG if flags is None else flags
         ctx.field_absorption(absorption)       # (sticky context state: always say what this plan means)
         ctx.field_plan(origin_m, spacing_m, n, freq, c, rho, p0_pa,
-                       flags=flags | (nat.FIELD_FP8_CORRECTION if fp8_correction else 0))
+                       flags=flags | (nat.FIELD_FP16_CORRECTION if fp8_correction is False else 0))
         ctx.aggregate_counts(self.valid[self.rank], self.F)
         eng.result_token += 1
         self._publish_blocks()

@@ -162,14 +162,19 @@ class Engine:
         return self._live_aggregate
 
     # ---- element table ----------------------------------------------------------------------
-    def bind(self, arr):
-        """Upload ``arr``'s SoA element table unless the resident one is identical."""
+    @staticmethod
+    def _table_of(arr):
+        """(pos, nrm, area * sensitivity, key): ``arr``'s SoA element table as the device takes it, and its hash."""
         pos, nrm, area, _, _ = arr.element_table()
         # per-element sensitivity factors (Transducer.merge, xdc/transducer.py:236-247) scale the
         # element's drive exactly like its area does in the source weight
         sens = np.array([1.0 if el.sensitivity is None else el.sensitivity for el in arr.elements])
         area = area * sens
-        key = hash((pos.tobytes(), nrm.tobytes(), area.tobytes()))
+        return pos, nrm, area, hash((pos.tobytes(), nrm.tobytes(), area.tobytes()))
+
+    def bind(self, arr):
+        """Upload ``arr``'s SoA element table unless the resident one is identical."""
+        pos, nrm, area, key = self._table_of(arr)
         if key != self._table_key:
             self.ctx.set_elements(pos, nrm, area)
             self._table_key = key
@@ -185,35 +190,34 @@ class Engine:
 
     # ---- kernel 2 -----------------------------------------------------------------------------
     def field(self, arr, delays, apod, origin_m, spacing_m, n, freq, c, rho, p0_pa,
-              want=("pmag", "intensity"), slab=None, steering_resident=False, medium=None, fp8_correction=False,
+              want=("pmag", "intensity"), slab=None, steering_resident=False, medium=None, fp8_correction=None,
               lazy=False, directivity=False, absorption=0.0):
         """Pressure field for F foci -> dict of float32 arrays [F, nx, ny, nz] (fresh, writable,
         caller-owned).  ``steering_resident`` reuses the table the last ``beamform`` left on the
-        device instead of uploading ``delays`` / ``apod``.  ``fp8_correction`` opts in to the e4m3
-        correction products (include/olx.h OLX_FIELD_FP8_CORRECTION: ~12 % faster, <= 6e-6 of the focal
-        peak instead of 2e-6); never set by default.  ``directivity`` opts in to the far-field piston factor of the elements
+        device instead of uploading ``delays`` / ``apod``.  ``fp8_correction=False`` opts OUT of the e4m3
+        correction products the lattice kernels use by default where their bound (<= 6.5e-6 of the focal peak) is a bound on the
+        planned volume (include/olx.h OLX_FIELD_FP16_CORRECTION: three fp16 products everywhere, <= 2e-6).  ``directivity`` opts in to the far-field piston factor of the elements
         (OLX_FIELD_DIRECTIVITY; folded into the lattice kernels' tables for flat arrays of equal axis-aligned elements, else the exact
         per-pair kernel; homogeneous media).  ``absorption`` [Np/m] > 0: uniform absorbing medium, every term carries exp(-a d)
         (olx_field_absorption).  ``lazy=True`` returns a ``DeviceResult`` instead: the volumes
         stay in HBM until somebody reads them."""
         self.retire_results()
-        # (bind compares the element table with the resident one and uploads on a difference -- also with resident steering: a
-        # caller may hand over another transducer, or the same one with edited elements, than the last beamform() bound)
-        n_before, key_before = self.ctx.n_el, self._table_key
-        self.bind(arr)
         if steering_resident:
-            if self._table_key != key_before or self.ctx.n_el != n_before:
+            # the resident steering table belongs to the resident element table: another transducer (or the same one with edited
+            # elements) is refused BEFORE anything is uploaded -- the context, its steering and its plan stay as they were
+            if self._table_of(arr)[3] != self._table_key:
                 raise ValueError("steering_resident=True, but the transducer differs from the one the resident steering table was solved for "
                                  "(call beamform(arr, ...) again, or pass delays / apod)")
         else:
+            self.bind(arr)      # (compares the element table with the resident one and uploads on a difference)
             self.ctx.set_steering(delays, apod)
         flags = nat.OUT_PMAG
         if "intensity" in want:
             flags |= nat.OUT_INTENSITY
         if "complex" in want:
             flags |= nat.OUT_COMPLEX
-        if fp8_correction:
-            flags |= nat.FIELD_FP8_CORRECTION
+        if fp8_correction is False:
+            flags |= nat.FIELD_FP16_CORRECTION
         if directivity:
             self.ctx.set_element_apertures(*arr.element_apertures())
             flags |= nat.FIELD_DIRECTIVITY

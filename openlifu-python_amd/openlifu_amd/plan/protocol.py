@@ -174,8 +174,9 @@ class Protocol:
         custom_seam = run_simulation is not sim.run_simulation  # patched seam (reference tests mock it)
         if simulate and not custom_seam:
             self.logger.info(f"Simulate for {len(foci)} foci...")
-            # opt-in speed option, SimSetup.options["fp8_correction"] = "1" (sim_setup.py:51 "Additional simulation options")
-            fp8 = str(getattr(sim_options, "options", {}).get("fp8_correction", "0")).lower() in ("1", "true", "yes")
+            # precision option, SimSetup.options["fp8_correction"] = "0" (sim_setup.py:51 "Additional simulation options"): keeps three fp16
+            # products where the lattice kernels would use their e4m3 correction products (the default; <= 6.5e-6 of the focal peak)
+            fp8 = False if str(getattr(sim_options, "options", {}).get("fp8_correction", "auto")).lower() in ("0", "false", "no") else None
             # the per-focus volumes stay in HBM (scale / aggregate / analyze below run there); the Dataset hands them to
             # the host on first access.  Real xarray objects cannot defer, so with xarray installed they are fetched now.
             fields = simulate_foci(transducer, params, delays, apod, self.pulse.frequency,

@@ -183,25 +183,29 @@ class Solution:
         # pressure / power / thermal index below, which need nothing from the device)
         finish = ctx.solution_analyze_begin(A, ita_w, aspect, options.mainlobe_radius * to_m, options.sidelobe_radius * to_m, zmin,
                                             line_pts=pts, line_offsets=offsets, scale=_scale, overlap=True)
-        # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
-        # drive signal is created once and handed to calc_output for every focus (which scales it in place by the
-        # transducer sensitivity, xdc/transducer.py:100-106); only the per-element maximum of that [N, T] matrix is used.
-        dt = 1 / (self.pulse.frequency * 20)
-        input_signal_V = self.pulse.calc_pulse(self.pulse.calc_time(dt)) * self.voltage
-        standoff_Z = options.standoff_density * 1500
-        c_tic = 40e-3  # W cm-1
-        ele_sizes_cm2 = self.transducer.element_areas("cm")
-        d_eq_cm = np.sqrt(4 * sum(ele_sizes_cm2.tolist()) / np.pi)       # Transducer.get_area: the same left-to-right sum
-        power_W = np.zeros(F); tic = np.zeros(F)
-        el_sens = (None if any(el.impulse_response is not None for el in self.transducer.elements) else
-                   np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.transducer.elements]))
-        for i in range(F):
-            p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :], _sens=el_sens)
-            i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()
-            power_W[i] = np.mean(np.sum(i0ta_Wcm2 * ele_sizes_cm2 * self.apodizations[i, :]))
-            tic[i] = power_W[i] / (d_eq_cm * c_tic)
-            an.p0_MPa.append(float(1e-6 * np.max(p0_Pa)))
-        an.TIC = float(np.mean(tic)); an.power_W = float(np.mean(power_W))
+        try:
+            # emitted pressure / power / thermal index (plan/solution.py:152-154, 163-167, 191-193, 268-276).  Like the reference the
+            # drive signal is created once and handed to calc_output for every focus (which scales it in place by the
+            # transducer sensitivity, xdc/transducer.py:100-106); only the per-element maximum of that [N, T] matrix is used.
+            dt = 1 / (self.pulse.frequency * 20)
+            input_signal_V = self.pulse.calc_pulse(self.pulse.calc_time(dt)) * self.voltage
+            standoff_Z = options.standoff_density * 1500
+            c_tic = 40e-3  # W cm-1
+            ele_sizes_cm2 = self.transducer.element_areas("cm")
+            d_eq_cm = np.sqrt(4 * sum(ele_sizes_cm2.tolist()) / np.pi)       # Transducer.get_area: the same left-to-right sum
+            power_W = np.zeros(F); tic = np.zeros(F)
+            el_sens = (None if any(el.impulse_response is not None for el in self.transducer.elements) else
+                       np.array([1.0 if el.sensitivity is None else float(el.sensitivity) for el in self.transducer.elements]))
+            for i in range(F):
+                p0_Pa = self.transducer.peak_output(input_signal_V, dt, delays=self.delays[i, :], apod=self.apodizations[i, :], _sens=el_sens)
+                i0ta_Wcm2 = (p0_Pa ** 2 / (2 * standoff_Z)) * 1e-4 * self.get_sequence_dutycycle()
+                power_W[i] = np.mean(np.sum(i0ta_Wcm2 * ele_sizes_cm2 * self.apodizations[i, :]))
+                tic[i] = power_W[i] / (d_eq_cm * c_tic)
+                an.p0_MPa.append(float(1e-6 * np.max(p0_Pa)))
+            an.TIC = float(np.mean(tic)); an.power_W = float(np.mean(power_W))
+        except BaseException:
+            finish.abandon()      # the helper thread must have left the (not thread-safe) context before anyone touches it again
+            raise
         rep = finish()
         pk, mom, ita_main = rep["peaks"], rep["moments"], rep["ita_main"]
         main_p, main_i, side_p, side_i, glob_p, glob_i = (pk[:, k] for k in range(6))

@@ -57,7 +57,7 @@ def _medium(params, freq):
 
 
 def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "intensity"),
-                  steering_resident=False, slab=None, fp8_correction=False, lazy=False, hetero_planes_per_layer=1,
+                  steering_resident=False, slab=None, fp8_correction=None, lazy=False, hetero_planes_per_layer=1,
                   hetero_model="auto", directivity=False):
     """Batched core: F foci in one launch -> dict of float32 arrays [F, nx, ny, nz], or with ``lazy`` a
     ``DeviceResult`` whose volumes stay in HBM until read (``lazy_stack`` wraps it in the reference's schema)."""

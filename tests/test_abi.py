@@ -24,14 +24,14 @@ def test_library_exports_every_header_symbol():
     lib = _native.load(require_gpu=False)
     missing = [s for s in header_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.olx_abi_version() == 1
+    assert lib.olx_abi_version() == 2
 
 
 def test_header_is_plain_c(tmp_path):
     """Compiles as C (no C++ in the header)."""
     import subprocess
     c = tmp_path / "t.c"
-    c.write_text('#include "olx.h"\nint main(void){ olx_grid g; (void)g; return OLX_ABI_VERSION - 1; }\n')
+    c.write_text('#include "olx.h"\nint main(void){ olx_grid g; (void)g; return OLX_ABI_VERSION - 2; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            "-c", str(c), "-o", str(tmp_path / "t.o")])
 

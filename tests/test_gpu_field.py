@@ -35,13 +35,13 @@ def setup_ctx(ctx, pos, ori, size, foci_m, apod=("uniform", 1.0, 0.0), solve=Fal
     return pos_m, area, delays, ap
 
 
-def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P, complex_out=True, fp8=False):
+def check(ctx, xs, ys, zs, pos_m, area, delays, ap, want_variant=None, tol=TOL_P, complex_out=True, fp8=None):
     """complex_out=False plans |p| + intensity only (kernel 2e serves that; complex output goes through 2d / 2c).
-    fp8=True opts in to the e4m3 correction products (OLX_FIELD_FP8_CORRECTION)."""
+    fp8=False opts out of the e4m3 correction products (OLX_FIELD_FP16_CORRECTION); None / True = the library default."""
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (len(xs), len(ys), len(zs)), F0, C, RHO, P0,
                    flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.OUT_COMPLEX if complex_out else 0) |
-                   (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+                   (nat.FIELD_FP16_CORRECTION if fp8 is False else 0))
     if want_variant:
         assert want_variant in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
@@ -724,7 +724,7 @@ def test_mirror_partner_foci_share_columns(ctx):
 
 
 def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0.0), z0=5e-3, foci=None, apod=("uniform", 1.0, 0.0),
-                  slab=None, expect=None, solve=False, fp8=False):
+                  slab=None, expect=None, solve=False, fp8=None):
     """Flat nax x nay array with pitch (px, py) [mm]; grid of grid_n voxels with spacing [mm] centred on the array
     (+ origin_shift voxels); full-volume parity against the oracle.  Default expectation: kernel 2e, or kernel 2f for the
     default single on-axis focus (one steering column)."""
@@ -749,7 +749,7 @@ def _lattice_case(ctx, nax, nay, pitch_xy, grid_n, spacing, origin_shift=(0.0, 0
             check(ctx, xs, ys, zs, pos_m, area, d, ap, want_variant="field_lattice_k")
         return
     ctx.field_plan((xs[0], ys[0], zs[0]), h, grid_n, F0, C, RHO, P0, slab=slab,
-                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP16_CORRECTION if fp8 is False else 0))
     assert expect in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     for f in range(len(foci)):
@@ -818,40 +818,41 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
     _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
 
 
-def test_fp8_correction_products_are_opt_in_and_gated(ctx, monkeypatch):
-    """Kernel 2e's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
-    grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  They are OPT-IN (plan flag OLX_FIELD_FP8_CORRECTION): never
-    selected unasked -- neither on the olx_bf_solve path nor at the run_simulation seam -- and, when asked for, used only
-    if the planned SLAB is known to hold the focal peak (foci known and inside the slab) and N_eff >= 256; the fp16
-    corrections (0.8e-6) otherwise.  OLX_FP8_CORRECTION pins either for A/B runs.  Full-volume parity in every mode."""
+def test_fp8_correction_products_are_the_gated_default(ctx, monkeypatch):
+    """Kernel 2e / 2g's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
+    grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  They are the DEFAULT (round 5) -- on the olx_bf_solve path and at the
+    run_simulation seam (external geometric delays: the foci are inferred) -- but only where that bound is a bound on the planned
+    volume: the planned SLAB is known to hold the focal peak (foci known and inside the slab) and N_eff >= 256; the fp16
+    corrections (0.8e-6) otherwise, and everywhere with the plan flag OLX_FIELD_FP16_CORRECTION.  OLX_FP8_CORRECTION pins either
+    for A/B runs.  Full-volume parity in every mode."""
     foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 33e-3]])
     grid, h = (48, 48, 32), (1.0, 1.0, 1.0)      # z = 5 .. 36 mm: both foci inside
     fp8, f16 = "noclamp,fp8corr>", "noclamp> "
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, solve=True)                 # default: never fp8
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16)                             # nor at the external-delay seam
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[1:], expect=fp8, solve=True, fp8=True)   # NT = 1 (4 columns)
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep", solve=True, fp8=True)   # one column: kernel 2f, fp16 products only
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True, fp8=True)       # NT = 2
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, fp8=True)   # external geometric delays: the foci are inferred
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True, fp8=True)   # z = 5 .. 28 mm: foci outside
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect=f16, solve=True, fp8=True)   # few active elements
-    _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect=f16, solve=True, fp8=True)     # 64 elements
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, solve=True, fp8=False)      # opted out: never fp8
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, fp8=False)                  # nor at the external-delay seam
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[1:], expect=fp8, solve=True)   # NT = 1 (4 columns)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep", solve=True)   # one column: kernel 2f, fp16 products only
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True)       # NT = 2
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8)   # external geometric delays: the foci are inferred
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True)   # z = 5 .. 28 mm: foci outside
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, apod=("maxangle", 25.0, 0.0), expect=f16, solve=True)   # few active elements
+    _lattice_case(ctx, 8, 8, (4.0, 4.0), (40, 40, 32), h, foci=foci, expect=f16, solve=True)     # 64 elements
     # x-slabs (the multi-GPU shard unit): only the slab that holds BOTH foci (x = -0.5 mm and 2.5 mm: voxels 23 and 26) may use
     # fp8; a slab next to them keeps fp16 and its error is bounded against its OWN maximum
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(16, 16), expect=fp8, solve=True, fp8=True)
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(0, 16), expect=f16, solve=True, fp8=True)
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(32, 16), expect=f16, solve=True, fp8=True)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(16, 16), expect=fp8, solve=True)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(0, 16), expect=f16, solve=True)
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, slab=(32, 16), expect=f16, solve=True)
     pos, ori, size = synthetic_array(16, 16, 3.0)
     xs, ys, zs = centred_grid(48, 1.0)
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci)
     d = d + np.random.default_rng(147).uniform(0, 2e-7, d.shape)       # external delays that no focus explains (0.3 mm of path)
     ctx.set_steering(d, a)
-    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False, fp8=True)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
     monkeypatch.setenv("OLX_FP8_CORRECTION", "0")
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
-    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False, fp8=True)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant=f16, tol=2e-6, complex_out=False)
     monkeypatch.setenv("OLX_FP8_CORRECTION", "1")
-    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="fp8corr", complex_out=False)
+    check(ctx, xs, ys, zs, pos_m, area, d, a, want_variant="fp8corr", complex_out=False, fp8=False)
 
 
 def _wheel_shard(n_foci, rank=0):
@@ -869,8 +870,8 @@ def _wheel_shard(n_foci, rank=0):
 def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, monkeypatch):
     """The bench.py headline configuration (256 el x 256^3, rank 0's 8-focus shard of the Wheel sweep, |p| + intensity),
     FULL-volume parity against the fp64 C oracle for three foci -- the on-axis centre, spoke 0 (on the x axis) and a
-    diagonal spoke -- with the fp8 correction products opted in (the bench default; stated bound 6e-6 of the focal
-    peak, gate 1e-5) and with the default fp16 corrections (bound 2e-6).  16.7 M voxels x 256 elements per focus on
+    diagonal spoke -- with the e4m3 correction products (the library default on this shard; stated bound 6.5e-6 of the focal
+    peak, gate 1e-5) and opted out of them (three fp16 products, bound 2e-6).  16.7 M voxels x 256 elements per focus on
     every host core."""
     pos, ori, size = synthetic_array(16, 16, 3.0)
     foci = _wheel_shard(8)
@@ -878,7 +879,7 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, monkeypatch):
     xs, ys, zs = centred_grid(256, 0.25)
     h = (xs[1] - xs[0],) * 3
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (256,) * 3, F0, C, RHO, P0,
-                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+                   flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (0 if fp8 else nat.FIELD_FP16_CORRECTION))
     name = ctx.field_variant()
     kname = "field_cosetp_k"
     assert kname + "<nt2,mx2,my2,flat,noclamp" in name and ("fp8corr" in name) == fp8 and " 15 columns" in name, name

@@ -121,5 +121,7 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
-    assert out["scaling_claim"] == "allgather" and out["n_ranks_seen"] == 2 and "p2p" in out["n_ranks_seen_by"]
-    assert out["config"]["reassembly"].startswith("p2p-allgather")
+    # default exchange of an N > 1 run: the aggregate (reduce-scatter of max |p| / mean intensity); north_star's all-gather is timed beside it
+    assert out["scaling_claim"] == "aggregate" and out["n_ranks_seen"] == 2 and "p2p" in out["n_ranks_seen_by"] and out["degraded"] is False
+    assert out["config"]["reassembly"].startswith("p2p-aggregate")
+    assert out["config"]["with_allgather"]["value"] > 0 and out["config"]["without_exchange"]["value"] > 0

@@ -24,7 +24,7 @@ shard = od.plan_foci_orbits(sweep, 8, centre_xy=(0.0, 0.0))[0]
 eng = ol.get_engine(0); ctx = eng.ctx; eng.bind(arr)
 ctx.bf_solve(sweep[shard], 1500.0)
 origin, spacing, n = grid_from_coords(setup.get_coords())
-ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (0 if fp8 else nat.FIELD_FP16_CORRECTION))
 for _ in range(20):
     ctx.field_launch()
 ctx.sync()

@@ -24,7 +24,7 @@ for name, foci in cases.items():
     f = np.asarray(foci, dtype=float) * 1e-3
     ctx.bf_solve(f, 1500.0)
     for fp8 in (False, True):
-        ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP8_CORRECTION if fp8 else 0))
+        ctx.field_plan(origin, spacing, n, 400e3, 1500.0, 1000.0, 1e5, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (0 if fp8 else nat.FIELD_FP16_CORRECTION))
         for _ in range(5): ctx.field_launch()
         ms = ctx.field_time(60)
         print(f"{name:26s} fp8={int(fp8)} {np.median(ms):8.4f} ms  {ctx.field_variant()[:90]}")
