@@ -321,7 +321,11 @@ def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
         return {"skipped": str(e)}
     clk = v["SQ_BUSY_CU_CYCLES"] / N_CU / (dur_us * 1e-6) / 1e9
     n_mfma, n_other, n_trans = v["SQ_INSTS_MFMA"], v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"], v["SQ_INSTS_VALU_TRANS_F32"]
-    matrix_cyc, other_cyc = 16.0 * n_mfma, 4.0 * n_other + 4.0 * n_trans
+    # matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): the e4m3 instruction (K = 128) takes two units, so where the
+    # planner states the launch's units (lattice kernels) they are used instead of the instruction count
+    mu = re.search(r"(\d+) MFMA/launch", kernel_name)
+    units = float(mu.group(1)) if mu else n_mfma
+    matrix_cyc, other_cyc = 16.0 * units, 4.0 * n_other + 4.0 * n_trans
     matrix_ms = matrix_cyc / (N_SIMD * clk * 1e9) * 1e3
     port_ms = (matrix_cyc + other_cyc) / (N_SIMD * clk * 1e9) * 1e3
     store_ms = alg_bytes / (STORE_DRAIN_GBS * 1e9) * 1e3
@@ -329,7 +333,7 @@ def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
     return {"what": "floors of this formulation at the clock measured under this load: vector issue port of the SIMDs (matrix + other vector "
                     "instructions share it) and the HBM write drain of the result; `floor_ms` = the larger one (perfect overlap of the two)",
             "clock_ghz": clk, "clock_source": "SQ_BUSY_CU_CYCLES / 256 CUs / dispatch duration, child pass of this run",
-            "matrix_instructions": n_mfma, "other_vector_instructions": n_other, "transcendentals": n_trans,
+            "matrix_instructions": n_mfma, "matrix_units_of_16_cycles": units, "other_vector_instructions": n_other, "transcendentals": n_trans,
             "matrix_only_ms": matrix_ms, "issue_port_ms": port_ms, "store_drain_ms": store_ms, "store_drain_rate_GBps": STORE_DRAIN_GBS,
             "floor_ms": floor_ms, "roofline_frac_at_floor": alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_ms": k_ms, "measured_over_floor": k_ms / floor_ms,

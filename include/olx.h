@@ -298,6 +298,10 @@ int olx_tof_spread(olx_ctx *ctx, const double *xs, int nx, const double *ys, int
  * (Solution.get_ita, plan/solution.py:365-388); olx_field_masked_peak(which = 2) then scans THAT single
  * volume with every focus' mask. */
 int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci);
+/* Blocking copy of that volume ([slab voxels] floats) into a caller-owned array: what Solution.get_ita returns
+ * (plan/solution.py:365-388) when somebody reads it.  The volume is the one the last olx_field_weighted_intensity or
+ * olx_solution_analyze left on the device. */
+int olx_field_weighted_fetch(olx_ctx *ctx, float *out);
 
 /* ---- one-call analysis (Solution.analyze, plan/solution.py:135-281) ---------------------
  * Everything analyze() reads off the resident volumes in ONE crossing: the six masked peaks of olx_field_analysis_peaks,

@@ -769,7 +769,11 @@ __global__ __launch_bounds__(256) void tof_spread_k(const double* __restrict__ x
     }
 }
 
-// weighted sum over foci into one volume: out[v] = sum_f w_f vol_f[v]  (get_ita, plan/solution.py:365-388)
+// "time-average" intensity volume of Solution.analyze: out[v] = max_f w_f vol_f[v].  The reference's get_ita (plan/solution.py:365-388) means a
+// pulse-count-weighted average over the foci, but on its [focal_point_index, x, y, z] arrays its broadcast (`expand_dims(..., -1) * counts`,
+// counts shaped [1, 1, 1, F]) returns every focus' OWN intensity times the two duty cycles, and analyze takes `.where(mask).max()` /
+// `(ita * z_mask).max()` over that whole stack (plan/solution.py:243, 274) -- i.e. the maximum over foci AND voxels.  This volume is the
+// maximum over foci, so that the masked peaks taken from it are the reference's numbers.  (The kernel keeps its round-2 name.)
 __global__ __launch_bounds__(256) void field_weighted_sum_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
                                      long long vox, float* __restrict__ out) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -780,13 +784,13 @@ __global__ __launch_bounds__(256) void field_weighted_sum_k(const float* __restr
         for (int f = 0; f < n_foci; ++f) {
             const float w = wts[f];
             const float4 v = ld4s(reinterpret_cast<const float4*>(vol + (long long)f * vox) + q);
-            s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+            s.x = fmaxf(s.x, w * v.x); s.y = fmaxf(s.y, w * v.y); s.z = fmaxf(s.z, w * v.z); s.w = fmaxf(s.w, w * v.w);
         }
         st4s(reinterpret_cast<float4*>(out) + q, s);
     }
     for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += stride) {
         float s = 0.f;
-        for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * vox + v];
+        for (int f = 0; f < n_foci; ++f) s = fmaxf(s, wts[f] * vol[(long long)f * vox + v]);
         out[v] = s;
     }
 }
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(256) void field_masked_moments_box_k(const float* _
                                                                 s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
-// out[v] = sum_f w_f I_f[v] (field_weighted_sum_k) and, in the same pass, the maximum of out over the voxels with z > zmin
+// out[v] = max_f w_f I_f[v] (field_weighted_sum_k) and, in the same pass, the maximum of out over the voxels with z > zmin
 // (field_masked_peak_k with op 4 on that volume): the global time-average intensity peak costs no second scan.
 __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __restrict__ vol, const float* __restrict__ wts, int n_foci,
                                                                   const PeakParams P, float* __restrict__ out, unsigned* __restrict__ peak) {
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
         for (int f = 0; f < n_foci; ++f) {
             const float w = wts[f];
             const float4 v = ld4s(reinterpret_cast<const float4*>(vol + (long long)f * P.vox) + q);
-            s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+            s.x = fmaxf(s.x, w * v.x); s.y = fmaxf(s.y, w * v.y); s.z = fmaxf(s.z, w * v.z); s.w = fmaxf(s.w, w * v.w);
         }
         st4s(reinterpret_cast<float4*>(out) + q, s);
         const int iz0 = (int)((unsigned)q % (unsigned)nzq) << 2;
@@ -987,7 +991,7 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
     }
     for (long long v = (v4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P.vox; v += stride) {
         float s = 0.f;
-        for (int f = 0; f < n_foci; ++f) s += wts[f] * vol[(long long)f * P.vox + v];
+        for (int f = 0; f < n_foci; ++f) s = fmaxf(s, wts[f] * vol[(long long)f * P.vox + v]);
         out[v] = s;
         const int iz = P.vox < (1ll << 31) ? (int)((unsigned)v % (unsigned)P.nz) : (int)(v % P.nz);
         const double z = P.oz + iz * P.hz;
@@ -1057,7 +1061,7 @@ __global__ __launch_bounds__(256) void field_scale_agg_analyze_k(float* __restri
             m.x = fmaxf(m.x, p4.x); m.y = fmaxf(m.y, p4.y); m.z = fmaxf(m.z, p4.z); m.w = fmaxf(m.w, p4.w);
             sm.x += w4.x; sm.y += w4.y; sm.z += w4.z; sm.w += w4.w;
             }
-            ws.x += w * w4.x; ws.y += w * w4.y; ws.z += w * w4.z; ws.w += w * w4.w;
+            ws.x = fmaxf(ws.x, w * w4.x); ws.y = fmaxf(ws.y, w * w4.y); ws.z = fmaxf(ws.z, w * w4.z); ws.w = fmaxf(ws.w, w * w4.w);
             // the six masked peaks of this focus on the SCALED values (field_analysis_peaks4_k's decisions)
             const MaskFast& M = sM[f];
             const float b0 = fmaf(M.a[1], fy, fmaf(M.a[0], fx, M.a[3])), b1 = fmaf(M.a[5], fy, fmaf(M.a[4], fx, M.a[7])), b2 = fmaf(M.a[9], fy, fmaf(M.a[8], fx, M.a[11]));

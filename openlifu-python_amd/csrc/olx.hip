@@ -1861,6 +1861,14 @@ int olx_field_weighted_intensity(olx_ctx* c, const double* weights, int n_foci) 
     return OLX_OK;
 }
 
+int olx_field_weighted_fetch(olx_ctx* c, float* out) {
+    if (!c || !out) return OLX_EINVAL;
+    if (!c->planned || !c->d_wint || c->wint_cap < (size_t)c->fp.vox) return fail(c, OLX_ESTATE, "olx_field_weighted_fetch: no time-average volume on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return fetch_to_host(c, out, c->d_wint, sizeof(float) * (size_t)c->fp.vox);
+}
+
 // ---- one-call analysis ------------------------------------------------------------------------------------------
 // Solution.analyze used to cross the C-ABI ~40 times per 8-focus solution (6-peak scan, moments, weighted intensity, two masked
 // peaks, 24 line samplings), every crossing with its own scratch hipMalloc / hipFree, pageable copies and a stream

@@ -32,7 +32,7 @@ SYMBOLS = [
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_bf_quantize", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
-    "olx_field_weighted_intensity", "olx_comm_unique_id", "olx_comm_init",
+    "olx_field_weighted_intensity", "olx_field_weighted_fetch", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
     "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
@@ -104,6 +104,7 @@ def load(require_gpu: bool = True):
         lib.olx_field_masked_moments.argtypes = [vp, dp, dp, c_double, fp, dp]
         lib.olx_field_sample.argtypes = [vp, c_int, c_int, dp, c_int, fp]
         lib.olx_field_weighted_intensity.argtypes = [vp, dp, c_int]
+        lib.olx_field_weighted_fetch.argtypes = [vp, fp]
         lib.olx_offset_grid.argtypes = [vp, dp, c_int, dp, c_int, dp, c_int, dp, dp, dp, dp]
         lib.olx_tof_spread.argtypes = [vp, dp, c_int, dp, c_int, dp, c_int, dp, c_double, dp]
         lib.olx_comm_unique_id.argtypes = [vp, vp]
@@ -466,6 +467,7 @@ class Context:
         peak scan for <= 8 foci); the aggregate is then resident (``aggregate_fetch``)."""
         F = self._plan_foci
         sc = None
+        self._weighted_overwrite()         # (the crossing rewrites the time-average volume)
         if scale is not None:
             self._aggregate_overwrite()
             sc = _f64(scale, (F,))
@@ -543,9 +545,22 @@ class Context:
         self._chk(self._lib.olx_field_sample(self._h, 0 if which == "pmag" else 1, int(focus), _dptr(pts), pts.shape[0], _fptr(out)))
         return out
 
+    def _weighted_overwrite(self):
+        """The time-average volume is about to be rewritten: whoever handed out a lazy array on it (Engine.weighted_lazy) reads it first."""
+        hook = getattr(self, "before_weighted", None)
+        if hook is not None:
+            hook()
+
     def field_weighted_intensity(self, weights):
+        self._weighted_overwrite()
         w = _f64(weights)
         self._chk(self._lib.olx_field_weighted_intensity(self._h, _dptr(w), int(w.shape[0])))
+
+    def field_weighted_fetch(self):
+        """The time-average volume the last ``field_weighted_intensity`` / ``solution_analyze`` left in HBM -> fresh float32 [nx, ny, nz]."""
+        out = np.empty(self._shape, dtype=np.float32)
+        self._chk(self._lib.olx_field_weighted_fetch(self._h, _fptr(out)))
+        return out
 
     # -- multi-GPU
     @staticmethod

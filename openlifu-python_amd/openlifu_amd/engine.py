@@ -117,6 +117,35 @@ class AggregateResult:
         self.retired = True
 
 
+class WeightedResult:
+    """Handle on the time-average intensity volume (``Solution.get_ita``, plan/solution.py:365-388) that ``Engine.weighted_lazy`` left in
+    HBM; same contract as ``AggregateResult``: ``retire()`` reads a lazily handed-out array nobody has read yet before the buffer is rewritten."""
+
+    def __init__(self, engine, shape):
+        self.engine, self.shape = engine, tuple(int(v) for v in shape)
+        self._lazies = []
+        self.retired = False
+
+    def fetch(self):
+        if self.retired:
+            raise RuntimeError("the device volume this array belongs to has been overwritten")
+        return self.engine.ctx.field_weighted_fetch()
+
+    def lazy_array(self, make):
+        da = make(self.fetch)
+        self._lazies.append(weakref.ref(da))
+        return da
+
+    def retire(self):
+        if self.retired:
+            return
+        for ref in self._lazies:
+            da = ref()
+            if da is not None and not da.materialized:
+                _ = da.data
+        self.retired = True
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.ctx = nat.Context(device)
@@ -128,6 +157,13 @@ class Engine:
         # every path that rewrites the aggregate buffers -- ctx.field_aggregate, the cross-rank all-reduce / reduce-scatter of
         # dist.ShardedField, another aggregate_lazy -- first brings a lazily handed-out aggregate Dataset to the host
         self.ctx.before_aggregate = self._retire_aggregate
+        self._live_weighted = None
+        self.ctx.before_weighted = self._retire_weighted      # (field_weighted_intensity and solution_analyze rewrite the time-average volume)
+
+    def _retire_weighted(self):
+        if self._live_weighted is not None:
+            live, self._live_weighted = self._live_weighted, None
+            live.retire()
 
     def _retire_aggregate(self):
         if self._live_aggregate is not None:
@@ -139,6 +175,7 @@ class Engine:
         if self._live_aggregate is not None:      # (a plan / upload that needs larger volumes frees the aggregate buffers too)
             self._live_aggregate.retire()
             self._live_aggregate = None
+        self._retire_weighted()
         if self._live_result is not None:
             self._live_result.retire()
             self._live_result = None
@@ -155,6 +192,12 @@ class Engine:
         self.ctx.field_scale_aggregate(factors)                              # (retires a live aggregate through the hook)
         self._live_aggregate = AggregateResult(self, self.ctx._shape)
         return self._live_aggregate
+
+    def weighted_lazy(self, weights) -> WeightedResult:
+        """sum_f weights[f] intensity_f over the resident focus volumes (``field_weighted_sum_k``), left in HBM."""
+        self.ctx.field_weighted_intensity(weights)                           # (retires a live one through the hook)
+        self._live_weighted = WeightedResult(self, self.ctx._shape)
+        return self._live_weighted
 
     def adopt_aggregate(self) -> AggregateResult:
         """Handle on the aggregate a fused device call (``ctx.solution_analyze(..., scale=...)``) just left in the aggregate buffers."""

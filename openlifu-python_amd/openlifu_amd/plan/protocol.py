@@ -113,6 +113,14 @@ class Protocol:
     def to_json(self, compact: bool = False) -> str:
         return json.dumps(self.to_dict(), separators=(",", ":")) if compact else json.dumps(self.to_dict(), indent=4)
 
+    def to_file(self, filename: str):
+        """Save the protocol as (pretty) JSON, creating up to two missing directory levels like the reference (plan/protocol.py:152-162)."""
+        from pathlib import Path
+        Path(filename).parent.parent.mkdir(exist_ok=True)
+        Path(filename).parent.mkdir(exist_ok=True)
+        with open(filename, "w") as file:
+            file.write(self.to_json(compact=False))
+
     # ---- beamforming ------------------------------------------------------------------------------
     def _fused(self) -> bool:
         return (type(self.delay_method) is Direct and isinstance(self.apod_method, ApodizationMethod)

@@ -95,6 +95,33 @@ class Solution:
         between = 1 if s.pulse_train_interval == 0 else (s.pulse_count * s.pulse_interval) / s.pulse_train_interval
         return self.get_pulsetrain_dutycycle() * between
 
+    def get_ita(self, units: str = "mW/cm^2"):
+        """Intensity-time-average of the solution (plan/solution.py:365-388) in ``units``: a DataArray shaped like
+        ``simulation_result['intensity']`` ([focal_point_index, x, y, z], float64).  The values are the reference's OWN expression, evaluated
+        when somebody reads them (the volumes stay in HBM until then): its pulse counts are shaped [1, 1, 1, F] and multiply an array
+        expanded on the LAST axis, so the count-weighted sum it forms is every focus' own intensity times sum(counts) -- divided by
+        sum(counts) again -- times the pulse-train and sequence duty cycles.  ``analyze`` takes its masked maxima over that whole stack
+        (the device does the same: ``olx_solution_analyze`` scans max_f of these volumes)."""
+        src = self.simulation_result["intensity"]
+        scale = getunitconversion(src.attrs["units"], units)
+        pt, seq = self.get_pulsetrain_dutycycle(), self.get_sequence_dutycycle()
+        F = self.num_foci()
+        pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % F + 1
+        counts = np.zeros((1, 1, 1, F))
+        for i in range(F):
+            counts[0, 0, 0, i] = np.sum(pulse_seq == (i + 1))
+        attrs = dict(src.attrs); attrs["units"] = units
+
+        def values():
+            scaled = np.array(src.data, copy=True)          # rescale_data_arr: a deep copy, scaled in place (keeps float32)
+            scaled *= scale
+            avg = np.sum(np.expand_dims(scaled, axis=-1) * counts, axis=-1) / np.sum(counts)
+            return avg * pt * seq
+        coords = {d: src.coords[d] for d in src.dims if d in src.coords}
+        if ds.HAVE_XARRAY:  # pragma: no cover - xarray absent in the image
+            return ds.make_dataarray(values(), coords, dims=src.dims, name="intensity", attrs=attrs)
+        return ds.LazyDataArray(tuple(src.shape), np.float64, values, coords=coords, dims=src.dims, name="intensity", attrs=attrs)
+
     # ---- device-side analysis -----------------------------------------------------------------
     def _device_is_current(self) -> bool:
         """True while the GPU still holds THIS solution's volumes and the host cannot have changed them: the result
@@ -161,9 +188,9 @@ class Solution:
         ctx = eng.ctx
         zmin = options.sidelobe_zmin * to_m
         F = self.num_foci()
-        pulse_seq = (np.arange(self.sequence.pulse_count) - 1) % F + 1
-        counts = np.array([np.sum(pulse_seq == (i + 1)) for i in range(F)], dtype=float)
-        ita_w = 1e3 * counts / counts.sum() * self.get_pulsetrain_dutycycle() * self.get_sequence_dutycycle()  # W -> mW
+        # time-average intensity: see get_ita -- on [focal_point_index, x, y, z] arrays the reference's pulse-count weights cancel, every focus
+        # volume is its intensity times the two duty cycles, and the masked peaks run over the whole stack (max over foci and voxels)
+        ita_w = np.full(F, 1e3 * self.get_pulsetrain_dutycycle() * self.get_sequence_dutycycle())  # W -> mW
         sizes = ctx._shape
         # beam-width lines: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
         offsets = [np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, int(sizes[a]) * 2)

@@ -205,3 +205,87 @@ def get_mask(da, focus, distance: float, origin=DEFAULT_ORIGIN, aspect_ratio=(1,
     dist = calc_dist_from_focus(da, focus, origin=origin, aspect_ratio=aspect_ratio, as_dataarray=False, engine=engine)
     mask = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}[operator](dist, distance)
     return make_dataarray(mask, da.coords, dims=tuple(da.dims))
+
+
+# ---- standalone reductions over ONE volume (plan/solution_analysis.py:306-317, 444-574), evaluated on the device ---------------
+def _volume_on_device(da, engine=None):
+    """Bind the 3-D DataArray ``da`` as the engine's resident one-focus result (``olx_field_upload``; outstanding lazy results are
+    brought to the host first) and return (engine, dims, axes in metres, metres per coordinate unit)."""
+    from .. import get_engine
+    from ..engine import grid_from_coords
+    from ..util.units import getunitconversion
+    dims, axes = _grid_axes(da)
+    if len(dims) != 3:
+        raise ValueError("expected a 3-D DataArray (one focus volume)")
+    units = [da.coords[d].attrs.get("units", "m") for d in dims]
+    coords = {d: da.coords[d] for d in dims}
+    for d, u in zip(dims, units):
+        if "units" not in coords[d].attrs:
+            coords[d].attrs["units"] = u
+    origin, spacing, n = grid_from_coords(coords)
+    eng = engine or get_engine()
+    vol = np.ascontiguousarray(np.asarray(da.data), dtype=np.float32)[None]
+    eng.upload_result(origin, spacing, n, vol)
+    to_m = getunitconversion(units[0], "m")
+    return eng, dims, [a * to_m for a in axes], to_m
+
+
+def find_centroid(da, cutoff: float, units=None, engine=None) -> np.ndarray:
+    """Centroid of the region where ``da > cutoff`` (plan/solution_analysis.py:306-317): sum(da x) / sum(da) over the thresholded
+    voxels, per dimension, in the coordinates' own units or converted to ``units``.  The four sums are ``field_masked_moments_k``'s
+    (fp64 accumulation on the device over an all-embracing mask)."""
+    from ..util.units import getunitconversion
+    if units is not None and getunittype(units) != "distance":
+        raise ValueError(f"Units must be a length unit, got {units}")
+    eng, dims, _, to_m = _volume_on_device(da, engine)
+    A = np.zeros((1, 12)); A[0, 0] = A[0, 5] = A[0, 10] = 1.0            # identity frame, radius beyond every voxel: no mask
+    mom = eng.ctx.field_masked_moments(A, (1.0, 1.0, 1.0), 1e30, np.array([cutoff], dtype=np.float32))[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        centroid = mom[1:] / mom[0] / to_m                               # metres -> the coordinates' units
+    if units is not None:
+        da_units = [da.coords[d].attrs.get("units", None) for d in dims]
+        centroid = np.array([getunitconversion(cu, units) * c for cu, c in zip(da_units, centroid)])
+    return centroid
+
+
+def interp_transformed_axis(da, focus, dim, origin=DEFAULT_ORIGIN, min_offset=None, max_offset=None, engine=None):
+    """``da`` sampled along one axis of the focal coordinate system (plan/solution_analysis.py:444-486): ``2 * da.sizes[dim]`` points
+    between ``min_offset`` and ``max_offset`` (default: as far as the grid reaches along that focal axis), trilinear interpolation on the
+    device (``field_sample_k``; NaN outside the grid, like ``DataArray.interp``).  Returns a 1-D DataArray over ``offset_d<dim>``."""
+    from ..util.dataset import make_dataarray
+    eng, dims, axes_m, to_m = _volume_on_device(da, engine)
+    matrix = get_focus_matrix(focus, origin=origin)
+    a = dims.index(dim)
+    if min_offset is None or max_offset is None:
+        # extreme focal coordinates of the grid: the offset is affine in (x, y, z), so its extremes sit at the eight corners
+        inv = np.linalg.inv(matrix)
+        _, axes = _grid_axes(da)
+        corners = np.array([[axes[0][i], axes[1][j], axes[2][k], 1.0] for i in (0, -1) for j in (0, -1) for k in (0, -1)])
+        d = corners @ inv[a]
+        min_offset = float(d.min()) if min_offset is None else min_offset
+        max_offset = float(d.max()) if max_offset is None else max_offset
+    n = int(da.sizes[dim]) * 2
+    interp_dim = np.linspace(min_offset, max_offset, n)
+    local = np.zeros((n, 4)); local[:, a] = interp_dim; local[:, 3] = 1.0
+    xyz = (matrix @ local.T).T[:, :3]
+    vals = eng.ctx.field_sample(0, xyz * to_m, which="pmag")
+    name = f"offset_d{dim}"
+    return make_dataarray(vals.astype(np.asarray(da.data).dtype if np.asarray(da.data).dtype.kind == "f" else np.float64),
+                          {name: interp_dim}, dims=(name,), name=getattr(da, "name", None), attrs=dict(getattr(da, "attrs", {})))
+
+
+def get_beam_bounds(da, focus, dim, cutoff: float, origin=DEFAULT_ORIGIN, min_offset=None, max_offset=None, engine=None):
+    """(negoff, posoff): how far along the negative / positive focal ``dim`` axis ``da`` stays above ``cutoff``
+    (plan/solution_analysis.py:488-535); NaN where it never drops below."""
+    line = interp_transformed_axis(da, focus=focus, dim=dim, origin=origin, min_offset=min_offset, max_offset=max_offset, engine=engine)
+    off = np.asarray(line.coords[f"offset_d{dim}"].data, dtype=np.float64)
+    return beam_bounds_from_samples(off, np.asarray(line.data), float(cutoff))
+
+
+def get_beamwidth(da, focus, dim, cutoff=None, origin=DEFAULT_ORIGIN, min_offset=None, max_offset=None, engine=None) -> float:
+    """FWHM (or the width at ``cutoff``) of ``da`` along a focal axis (plan/solution_analysis.py:537-574)."""
+    if cutoff is None:
+        cutoff = float(np.asarray(da.data).max()) / 2
+    negoff, posoff = get_beam_bounds(da, focus=focus, dim=dim, cutoff=float(cutoff), origin=origin, min_offset=min_offset, max_offset=max_offset,
+                                     engine=engine)
+    return posoff - negoff

@@ -8,6 +8,8 @@ scale factors bit for bit: mm->m must be exactly 1e-3 / 1.0.
 """
 from __future__ import annotations
 
+import numpy as np
+
 _TIME_WORDS = {"minute", "minutes", "min", "mins", "hour", "hours", "hr", "hrs", "day", "days", "d"}
 _ANGLE_WORDS = {"rad", "deg", "radian", "radians", "degree", "degrees", "°"}
 
@@ -139,3 +141,31 @@ def _getunitconversion(from_unit, to_unit, unitratio=None, constant=None) -> flo
         base = from_unit[-i:]
         i += 1
     return getsiscale(from_unit, base) / getsiscale(to_unit, base)
+
+
+def rescale_data_arr(data_arr, units: str):
+    """Copy of ``data_arr`` with its values converted to ``units`` (util/units.py:182-198): ``attrs['units']`` names the current units."""
+    rescaled = data_arr.copy(deep=True)
+    scale = getunitconversion(data_arr.attrs["units"], units)
+    rescaled.data *= scale
+    rescaled.attrs["units"] = units
+    return rescaled
+
+
+def rescale_coords(data_arr, units: str):
+    """Copy of ``data_arr`` with every coordinate that carries ``attrs['units']`` converted to ``units`` (util/units.py:200-222)."""
+    rescaled = data_arr.copy(deep=True)
+    for key in list(data_arr.coords):
+        attrs = rescaled.coords[key].attrs
+        if "units" in attrs:
+            scale = getunitconversion(attrs["units"], units)
+            new_attrs = dict(attrs)
+            new_attrs["units"] = units
+            values = scale * np.asarray(rescaled.coords[key].data)
+            if hasattr(rescaled, "assign_coords") and type(rescaled).__module__.startswith("xarray"):     # pragma: no cover - xarray absent in the image
+                rescaled = rescaled.assign_coords({key: (key, values, new_attrs)})
+            else:
+                c = rescaled.coords[key]
+                c.data = values
+                c.attrs = new_attrs
+    return rescaled

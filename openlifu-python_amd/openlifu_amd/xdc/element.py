@@ -67,6 +67,16 @@ class Element:
     pin: int = -1
     units: str = "mm"
 
+    # scalar accessors of the reference (xdc/element.py:81-137): views into position / orientation / size, readable and writable
+    x = _vec_prop("position", 0)
+    y = _vec_prop("position", 1)
+    z = _vec_prop("position", 2)
+    az = _vec_prop("orientation", 0)
+    el = _vec_prop("orientation", 1)
+    roll = _vec_prop("orientation", 2)
+    width = _vec_prop("size", 0)
+    length = _vec_prop("size", 1)
+
     def __post_init__(self):
         self.position = np.array(self.position, dtype=np.float64)
         if self.position.shape != (3,):
@@ -203,10 +213,3 @@ class Element:
         if d.get("impulse_dt") is not None:
             d["impulse_dt"] = float(d["impulse_dt"])
         return Element(**d)
-
-
-# scalar accessors of the reference (x, y, z, az, el, roll, width, length; element.py:80-142)
-for _name, (_attr, _i) in {"x": ("position", 0), "y": ("position", 1), "z": ("position", 2),
-                           "az": ("orientation", 0), "el": ("orientation", 1), "roll": ("orientation", 2),
-                           "width": ("size", 0), "length": ("size", 1)}.items():
-    setattr(Element, _name, _vec_prop(_attr, _i))

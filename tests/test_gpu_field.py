@@ -897,8 +897,8 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, monkeypatch):
     print(f"full-volume 256^3 parity, fp8={fp8}: max error {worst:.2e} of the volume maximum")
 
 
-@pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp> 16 columns"),
-                                                 (64, 0, "field_cosetp_k<nt2,mx2,my2,flat,noclamp> 127 columns for 64 foci x 4 images in 8 tile(s)")])
+@pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp,fp8corr> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp,fp8corr> 16 columns"),
+                                                 (64, 0, "field_cosetp_k<nt2,mx2,my2,flat,noclamp,fp8corr> 127 columns for 64 foci x 4 images in 8 tile(s)")])
 def test_c3_wheel_sweep_256cubed_sampled(ctx, n_foci, rank, expect):
     """BASELINE config 3 at full size (256 el, 256^3, Wheel(center, 63 spokes, 5 mm) = 64 foci; and two of the eight
     8-focus shards the product's orbit-aware planner hands to the GPUs): sampled-voxel parity per focus, the per-focus

@@ -592,3 +592,38 @@ def test_display_tables_are_explicit_refusals():
     for call in (pc.to_table, lambda: pc.get_status_symbol(0.5), SolutionAnalysis().to_table):
         with pytest.raises(NotImplementedError, match="openlifu_amd"):
             call()
+
+
+def test_rescale_functions_element_accessors_and_protocol_to_file(golden, tmp_path):
+    """util/units.py:182-222 (rescale_data_arr against values the REAL reference function produced on a duck-typed array, G12;
+    rescale_coords by known answers), xdc/element.py:81-137 (scalar accessors, G12), plan/protocol.py:152-162 (to_file)."""
+    from openlifu_amd.util import dataset as ds
+    from openlifu_amd.util.units import rescale_coords, rescale_data_arr
+    g = golden.json("g12_units_accessors.json")
+    for c in g["cases"]:
+        x = np.array(c["in"], dtype=c["dtype"])
+        da = ds.DataArray(x.copy(), dims=("q",), attrs={"units": c["from"], "long_name": "q"})
+        r = rescale_data_arr(da, c["to"])
+        assert r is not da and np.array_equal(da.data, x) and da.attrs["units"] == c["from"]            # a deep copy: the input is untouched
+        assert str(r.data.dtype) == c["out_dtype"] and r.attrs["units"] == c["out_units"] and r.attrs["long_name"] == "q"
+        assert np.array_equal(r.data.astype(np.float64), np.array(c["out"])), c                                  # bit for bit
+    xs = ds.DataArray(np.array([-1.0, 0.0, 2.5]), dims=("lat",), name="lat", attrs={"units": "mm", "long_name": "Lateral"})
+    idx = ds.DataArray(np.arange(2), dims=("k",), name="k")                                                      # no units: left alone
+    da = ds.DataArray(np.ones((2, 3), dtype=np.float32), coords={"k": idx, "lat": xs}, dims=("k", "lat"), attrs={"units": "Pa"})
+    r = rescale_coords(da, "m")
+    assert np.array_equal(r.coords["lat"].data, 1e-3 * np.array([-1.0, 0.0, 2.5])) and r.coords["lat"].attrs == {"units": "m", "long_name": "Lateral"}
+    assert np.array_equal(r.coords["k"].data, np.arange(2)) and "units" not in r.coords["k"].attrs
+    assert da.coords["lat"].attrs["units"] == "mm" and np.array_equal(da.coords["lat"].data, [-1.0, 0.0, 2.5])     # the input keeps its coordinates
+    assert r.attrs == {"units": "Pa"} and np.array_equal(r.data, da.data)
+    # Element accessors: views into position / orientation / size
+    el = ol.Element(position=[1.0, -2.0, 3.5], orientation=[0.1, -0.2, 0.3], size=[0.7, 1.9])
+    a = g["element_accessors"]
+    assert [el.x, el.y, el.z, el.az, el.el, el.roll, el.width, el.length] == a["before"]
+    el.x, el.y, el.z, el.az, el.el, el.roll, el.width, el.length = 9.0, 8.0, 7.0, 0.6, 0.5, 0.4, 2.5, 3.5
+    assert el.position.tolist() == a["position_after"] and el.orientation.tolist() == a["orientation_after"] and el.size.tolist() == a["size_after"]
+    # Protocol.to_file: pretty JSON, up to two missing directory levels are created
+    proto = ol.Protocol(name="p", pulse=ol.Pulse(frequency=400e3, duration=2e-5), focal_pattern=ol.focal_patterns.Wheel(num_spokes=3))
+    path = tmp_path / "protocols" / "p" / "p.json"
+    proto.to_file(str(path))
+    assert path.read_text() == proto.to_json(compact=False)
+    assert ol.Protocol.from_file(str(path)).to_dict() == proto.to_dict()

@@ -344,6 +344,29 @@ def main():
     json.dump({"reference_calc_output_with_array_impulse_response_raises": raised},
               open(os.path.join(OUT, "g11_impulse_response.json"), "w"))
 
+    # ---- G12: rescale_data_arr (util/units.py:182-198), executed as is on a duck-typed array (copy / attrs / data: all it touches);
+    # Element's scalar accessors (xdc/element.py:81-137) read and written through the reference class
+    from openlifu.util.units import rescale_data_arr
+
+    class Duck:
+        def __init__(self, data, attrs):
+            self.data, self.attrs = data, attrs
+
+        def copy(self, deep=True):
+            return Duck(self.data.copy(), dict(self.attrs))
+    g12 = {"cases": []}
+    for dtype, frm, to in (("float32", "W/cm^2", "mW/cm^2"), ("float64", "Pa", "MPa"), ("float32", "mm", "m"), ("float64", "W/cm^2", "W/m^2")):
+        x = rng.uniform(0.1, 50.0, 7).astype(dtype)
+        r = rescale_data_arr(Duck(x.copy(), {"units": frm, "long_name": "q"}), to)
+        g12["cases"].append({"dtype": dtype, "from": frm, "to": to, "in": x.astype(np.float64).tolist(), "out": r.data.astype(np.float64).tolist(),
+                             "out_dtype": str(r.data.dtype), "out_units": r.attrs["units"]})
+    el = Element(position=[1.0, -2.0, 3.5], orientation=[0.1, -0.2, 0.3], size=[0.7, 1.9])
+    before = [el.x, el.y, el.z, el.az, el.el, el.roll, el.width, el.length]
+    el.x, el.y, el.z, el.az, el.el, el.roll, el.width, el.length = 9.0, 8.0, 7.0, 0.6, 0.5, 0.4, 2.5, 3.5
+    g12["element_accessors"] = {"before": [float(v) for v in before], "position_after": el.position.tolist(),
+                                "orientation_after": el.orientation.tolist(), "size_after": el.size.tolist()}
+    json.dump(g12, open(os.path.join(OUT, "g12_units_accessors.json"), "w"))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
