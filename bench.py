@@ -898,7 +898,44 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
     for k in ("p_min", "intensity"):
         nbytes += np.asarray(sol.simulation_result[k].data).nbytes
     t2 = time.perf_counter()
-    return {"calc_solution_ms": float(np.median(walls)), "calc_solution_ms_all": [round(w, 3) for w in walls], "foci": len(foci), "what": "Protocol.calc_solution(simulate=True, scale=True): "
+    # The same call when the Dataset factories cannot defer -- what happens with xarray installed, the reference's hard dependency: an
+    # xa.Dataset cannot hold a LazyDataArray, so plan/protocol.py fetches the per-focus and the aggregate volumes before it returns.  xarray
+    # is absent from this image; the eager stand-ins below (the ones tests/test_gpu_api.py patches in) force that path.
+    from openlifu_amd.util import dataset as ds
+
+    class EagerDataArray(ds.DataArray):
+        def __init__(self, data, coords=None, dims=None, name=None, attrs=None):
+            if isinstance(data, ds.LazyDataArray):
+                raise TypeError("cannot defer")
+            super().__init__(data, coords=coords, dims=dims, name=name, attrs=attrs)
+
+    class EagerDataset(ds.Dataset):
+        def __setitem__(self, name, da):
+            if isinstance(da, ds.LazyDataArray):
+                raise ValueError("MissingDimensionsError")
+            super().__setitem__(name, da)
+
+    class FakeXarray:
+        DataArray, Dataset, Coordinates = EagerDataArray, EagerDataset, ds.Coordinates
+    sol = agg = an = None
+    saved = ds.HAVE_XARRAY, ds._xa
+    eager = []
+    try:
+        ds.HAVE_XARRAY, ds._xa = True, FakeXarray
+        for _ in range(4):
+            t0 = time.perf_counter()
+            sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=True)
+            eager.append((time.perf_counter() - t0) * 1e3)
+            sol = agg = an = None
+    except Exception as e:  # noqa: BLE001 - reported, not fatal
+        eager = [float("nan")]
+        eager_note = f"eager path failed: {e}"
+    else:
+        eager_note = ("the same call with the Dataset factories forced eager (what real xarray objects require): the 2 x F per-focus volumes and the "
+                      "three aggregate volumes cross PCIe before the call returns")
+    finally:
+        ds.HAVE_XARRAY, ds._xa = saved
+    return {"calc_solution_ms": float(np.median(walls)), "with_xarray_ms": float(np.median(eager[1:] or eager)), "with_xarray_what": eager_note, "calc_solution_ms_all": [round(w, 3) for w in walls], "foci": len(foci), "what": "Protocol.calc_solution(simulate=True, scale=True): "
             "kernel 1 + kernel 2 + device-side scale / aggregate / analyze; aggregate and per-focus volumes left in HBM until read",
             "aggregate_fetch_ms": (ta - t1) * 1e3, "aggregate_fetch_bytes": int(abytes),
             "aggregate_fetch_what": "first .data access of the aggregate Dataset's p_min, p_max and intensity (three fresh NumPy arrays)",

@@ -208,6 +208,11 @@ class Engine:
     @staticmethod
     def _table_of(arr):
         """(pos, nrm, area * sensitivity, key): ``arr``'s SoA element table as the device takes it, and its hash."""
+        cached = getattr(arr, "_cached", None)
+        return cached("engine_table", lambda: Engine._table_of_now(arr)) if cached is not None else Engine._table_of_now(arr)
+
+    @staticmethod
+    def _table_of_now(arr):
         pos, nrm, area, _, _ = arr.element_table()
         # per-element sensitivity factors (Transducer.merge, xdc/transducer.py:236-247) scale the
         # element's drive exactly like its area does in the source weight

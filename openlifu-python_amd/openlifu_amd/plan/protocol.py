@@ -165,6 +165,14 @@ class Protocol:
                       on_pulse_mismatch=OnPulseMismatchAction.ERROR, use_gpu: bool | None = None,
                       voltage: float = 1.0):
         """Returns (Solution, aggregated Dataset | None, SolutionAnalysis | None) -- plan/protocol.py:242-398."""
+        # (the transducer's elements are looked at once for the whole call: Transducer.frozen)
+        freeze = getattr(transducer, "frozen", None)
+        if freeze is None:
+            return self._calc_solution(target, transducer, volume, session, simulate, scale, sim_options, analysis_options, on_pulse_mismatch, use_gpu, voltage)
+        with freeze():
+            return self._calc_solution(target, transducer, volume, session, simulate, scale, sim_options, analysis_options, on_pulse_mismatch, use_gpu, voltage)
+
+    def _calc_solution(self, target, transducer, volume, session, simulate, scale, sim_options, analysis_options, on_pulse_mismatch, use_gpu, voltage):
         if use_gpu is None:
             use_gpu = gpu_available()
         sim_options = self.sim_setup if sim_options is None else sim_options
@@ -223,6 +231,8 @@ class Protocol:
                 self.logger.error(msg=f"Cannot scale solution {solution.id} if simulation is not enabled!")
                 raise ValueError(f"Cannot scale solution {solution.id} if simulation is not enabled!")
             self.logger.info(f"Scaling solution {solution.id}...")
+            if fields is not None:      # the accumulate kernel is still running: form what the analysis needs besides the scaled apodizations now
+                solution._prep = solution._analysis_prep(analysis_options, get_engine().ctx._shape)
             fused_agg = solution.scale(self.focal_pattern, analysis_options=analysis_options, _defer_device=simulate)
 
         if not simulate:

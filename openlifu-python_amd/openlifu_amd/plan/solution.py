@@ -172,34 +172,44 @@ class Solution:
         an.mainlobe_pnp_MPa = [float(v) * 1e-6 for v in peaks]
         return an
 
-    def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None,
-                _host_unchanged: bool = False, _scale=None) -> SolutionAnalysis:
-        """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
-        options = SolutionAnalysisOptions() if options is None else options
-        an = SolutionAnalysis()
-        eng, _, _, _ = self._bind_device(assume_host_unchanged=_host_unchanged)
-        to_m = getunitconversion(options.distance_units, "m")
-        A = self._focus_frames()
-        for i, focus in enumerate(self.foci):
-            f_mm = focus.get_position(units="mm")
-            an.target_position_lat_mm.append(f_mm[0]); an.target_position_ele_mm.append(f_mm[1])
-            an.target_position_ax_mm.append(f_mm[2])
-        aspect = options.mainlobe_aspect_ratio
-        ctx = eng.ctx
-        zmin = options.sidelobe_zmin * to_m
+    def _analysis_prep(self, options: SolutionAnalysisOptions, shape):
+        """The inputs of ``analyze`` that depend on neither the apodizations nor the voltage (``scale`` changes both): unit scale, mask
+        radii, time-average weights, the offsets of the beam-width lines and their local coordinates, the target positions."""
         F = self.num_foci()
+        to_m = getunitconversion(options.distance_units, "m")
+        aspect = options.mainlobe_aspect_ratio
         # time-average intensity: see get_ita -- on [focal_point_index, x, y, z] arrays the reference's pulse-count weights cancel, every focus
         # volume is its intensity times the two duty cycles, and the masked peaks run over the whole stack (max over foci and voxels)
         ita_w = np.full(F, 1e3 * self.get_pulsetrain_dutycycle() * self.get_sequence_dutycycle())  # W -> mW
-        sizes = ctx._shape
         # beam-width lines: 2*size samples along each focal axis within +-scale*beamwidth_radius (solution.py:224-239)
-        offsets = [np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, int(sizes[a]) * 2)
+        offsets = [np.linspace(-scale * options.beamwidth_radius * to_m, scale * options.beamwidth_radius * to_m, int(shape[a]) * 2)
                    for a, scale in enumerate(aspect)]
         local = np.zeros((sum(len(o) for o in offsets), 4)); local[:, 3] = 1.0       # the three axis lines, one after the other
         k = 0
         for a, off in enumerate(offsets):
             local[k:k + len(off), a] = off
             k += len(off)
+        return {"key": (id(options), F, tuple(shape)), "to_m": to_m, "aspect": aspect, "zmin": options.sidelobe_zmin * to_m, "ita_w": ita_w,
+                "offsets": offsets, "local": local, "targets_mm": [focus.get_position(units="mm") for focus in self.foci]}
+
+    def analyze(self, options: SolutionAnalysisOptions | None = None, param_constraints=None,
+                _host_unchanged: bool = False, _scale=None) -> SolutionAnalysis:
+        """Masked peaks per focus (subset of plan/solution.py:135-281; see solution_analysis.py)."""
+        options = SolutionAnalysisOptions() if options is None else options
+        an = SolutionAnalysis()
+        eng, _, _, _ = self._bind_device(assume_host_unchanged=_host_unchanged)
+        ctx = eng.ctx
+        F = self.num_foci()
+        # what does not depend on the (possibly just scaled) apodizations and voltage: calc_solution evaluates it while the accumulate
+        # kernel runs (``_analysis_prep``), any other caller here
+        prep = self.__dict__.pop("_prep", None)
+        if prep is None or prep["key"] != (id(options), F, tuple(ctx._shape)):
+            prep = self._analysis_prep(options, ctx._shape)
+        to_m, aspect, zmin, ita_w, offsets, local = (prep[k] for k in ("to_m", "aspect", "zmin", "ita_w", "offsets", "local"))
+        A = self._focus_frames()
+        for f_mm in prep["targets_mm"]:
+            an.target_position_lat_mm.append(f_mm[0]); an.target_position_ele_mm.append(f_mm[1])
+            an.target_position_ax_mm.append(f_mm[2])
         A4 = np.zeros((F, 4, 4)); A4[:, :3, :] = A.reshape(F, 3, 4); A4[:, 3, 3] = 1.0
         pts = np.ascontiguousarray((local[None, :, :] @ np.transpose(np.linalg.inv(A4), (0, 2, 1)))[:, :, :3])   # [F, npts, 3]
         # ONE crossing of the C-ABI (olx_solution_analyze): mainlobe (dist < r), sidelobe (dist > r, z > zmin) and global (z > zmin)

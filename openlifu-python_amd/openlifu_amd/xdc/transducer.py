@@ -56,8 +56,45 @@ class Transducer:
             if self.impulse_dt is None:
                 raise ValueError("Impulse response timestep must be set if impulse response is set.")
 
+    # ---- one gather per call of the hot path -------------------------------------------------
+    def frozen(self):
+        """Context manager: while it is open, the gathers over the element list (``element_table``, ``element_areas``, ``get_positions``
+        without a transform, the engine's table key) are evaluated once and remembered -- ``Protocol.calc_solution`` looks at the same
+        256 Python objects five times per call otherwise.  The elements must not be edited inside (the hot path does not); results handed
+        out are the cached arrays themselves and must not be modified in place."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            outer = self.__dict__.get("_frozen_cache")
+            if outer is None:
+                self.__dict__["_frozen_cache"] = {}
+            try:
+                yield self
+            finally:
+                if outer is None:
+                    self.__dict__["_frozen_cache"] = None
+        return cm()
+
+    def __getstate__(self):
+        """Copies and pickles never carry the gather cache of an open ``frozen()`` block (it belongs to that call)."""
+        state = dict(self.__dict__)
+        state.pop("_frozen_cache", None)
+        return state
+
+    def _cached(self, key, fn):
+        cache = self.__dict__.get("_frozen_cache")
+        if cache is None:
+            return fn()
+        if key not in cache:
+            cache[key] = fn()
+        return cache[key]
+
     # ---- SoA bridge to the device --------------------------------------------------------
     def element_table(self):
+        return self._cached("element_table", self._element_table)
+
+    def _element_table(self):
         """(pos_m[N,3], normal[N,3], area_m2[N], index[N], pin[N]) in ``elements`` order.
 
         pos_m   = Element.get_position(units="m")            (xdc/element.py:166-172)
@@ -86,6 +123,9 @@ class Transducer:
     def element_areas(self, units=None):
         """[N] Element.get_area(units) (xdc/element.py:181-184: (w * scl) * (l * scl)), one gather."""
         units = self.units if units is None else units
+        return self._cached(("element_areas", units), lambda: self._element_areas(units))
+
+    def _element_areas(self, units):
         n = len(self.elements)
         size = np.array([el.size for el in self.elements], dtype=np.float64).reshape(n, 2)
         s = np.array([getunitconversion(el.units, units) for el in self.elements]) if n else np.empty(0)
@@ -206,6 +246,11 @@ class Transducer:
         """[N, 3] element positions (xdc/transducer.py:203-207): (M . [p * scl, 1])[:3] per element, evaluated for all
         elements at once when they share one length unit (the normal state: __post_init__ rescales them)."""
         units = self.units if units is None else units
+        if transform is None:
+            return self._cached(("get_positions", units), lambda: self._get_positions(None, units))
+        return self._get_positions(transform, units)
+
+    def _get_positions(self, transform, units):
         el_units = {el.units for el in self.elements}
         if len(el_units) != 1:
             return np.array([el.get_position(units=units, matrix=transform) for el in self.elements])

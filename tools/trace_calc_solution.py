@@ -26,6 +26,16 @@ for nm in names:
             t0 = time.perf_counter(); r = fn(self, *a, **k); events.append((nm, t0, time.perf_counter())); return r
         return inner
     setattr(nat.Context, nm, wrap(getattr(nat.Context, nm)))
+# the analysis crossing runs on a helper thread: stamp when it is started (begin returns), when the host side asks for the report
+# (finish called) and when the report is there (finish returns)
+_begin = nat.Context.solution_analyze_begin
+def begin(self, *a, **k):
+    t0 = time.perf_counter(); fin = _begin(self, *a, **k); events.append(("analyze_begin", t0, time.perf_counter()))
+    def finish():
+        t1 = time.perf_counter(); r = fin(); events.append(("analyze_finish(wait)", t1, time.perf_counter())); return r
+    finish.abandon = fin.abandon
+    return finish
+nat.Context.solution_analyze_begin = begin
 for _ in range(3):
     proto.calc_solution(target, arr, simulate=True, scale=True)
 rows = []
