@@ -31,7 +31,16 @@ namespace olx {
 //     4 g .. 4 g + 3 = (kx = 2 g, re), (2 g, im), (2 g + 1, re), (2 g + 1, im) of plane n -- |p| and the intensity need
 //     no cross-lane step, and the 16 lanes of a k-group write 64 contiguous bytes of z per (position, target).
 // ------------------------------------------------------------------------------------
-template <int MX, int MY, bool CLAMP, bool DIR = false>
+// FP8 (round 5; the planner's default where the foci lie inside the planned volume and N_eff >= 256, as for kernels 2e / 2g): the two hi x lo
+// correction products of BOTH K-steps of an element row go through ONE v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 operands, 32 cycles)
+// instead of four fp16 products (64 cycles): 64 instead of 96 matrix cycles per (element row, y position).  The table keeps fp16
+// (re, im) of hi (rounded to nearest) and four e4m3 bytes [lo re, lo im | hi re, hi im] per entry (same two words as before); the
+// Toeplitz weights carry [hi(c0), hi(c1), lo(c0), lo(c1)] * (2^-6, 2^5) in the same byte positions (toep_pack_k), and the instruction's
+// E8M0 block scales (2^1, 2^0) undo the 2^-1 of each product.  A lane's 32 operand bytes are the entries 4 g .. 4 g + 3 and
+// 16 + 4 g .. 16 + 4 g + 3 of the table row -- the two 16-byte pieces the hi fragments of the two K-steps sit at, so the e4m3 reads hit
+// the same conflict-free slots.  The instruction spans both K-steps, so the block's two wave groups split the ELEMENT ROWS of a
+// super-block (b = 0 .. 3 | 4 .. 7) instead of the K-steps; their partial sums meet in LDS as before.
+template <int MX, int MY, bool CLAMP, bool DIR = false, bool FP8 = false>
 __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
                                                                     float* __restrict__ inten, const CosetBlock* __restrict__ blocks /*[gridDim.x]*/,
                                                                     const ToepParams T) {
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     unsigned* const s_hi = s_T;
     unsigned* const s_lo = s_T + TOEP_ZB * TOEP_PSZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kyg = wave & 3, ks = wave >> 2;
+    const int kyg = wave & 3, ks = wave >> 2;              // ks: this wave's K-step -- FP8: its half of the super-block's element rows
     // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip, as kernel 2g; the two blocks
     // that write the two 64-byte halves of the same 128-byte lines have ids 8 apart -- the same XCD, i.e. the same L2, under
     // round-robin dispatch).  Decoded here, the chain of integer divisions was ~160 vector and ~400 scalar instructions per wave.
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     }
     // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4), this wave's K-step
     const int n16 = lane & 15, g = lane >> 4;
-    const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + 16 * ks);
+    const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + (FP8 ? 0 : 16 * ks));
     floatx4_t acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -77,13 +86,19 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         const int sa = sb / P.nsb, sbb = sb - sa * P.nsb;
         // Toeplitz weights of the super-block's 8 element rows (this wave's K-step: hi + lo = 2 x 16 bytes per lane and row),
         // requested before the table is generated so that they arrive from L2 behind it
-        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb) * 4 * 64 + ks * 64 + lane;
-        uint4 afr[TOEP_SB][2];
+        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb + (FP8 ? 4 * ks : 0)) * 4 * 64 + (FP8 ? 0 : ks * 64) + lane;
+        constexpr int NB = FP8 ? TOEP_SB / 2 : TOEP_SB, NA = FP8 ? 4 : 2;      // element rows per wave and super-block; 16-byte weight pieces per row
+        uint4 afr[NB][NA];
         __syncthreads();                                // table free (previous super-block consumed)
         if (sb == 0) OLX_STAMP(1);
         // (requested behind the barrier: __syncthreads() drains vmcnt, the loads would be waited for right there)
 #pragma unroll
-        for (int bl = 0; bl < TOEP_SB; ++bl) { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
+        for (int bl = 0; bl < NB; ++bl) {
+            if constexpr (FP8) {       // hi of both K-steps, then the 32 e4m3 bytes of the row
+#pragma unroll
+                for (int q = 0; q < 4; ++q) afr[bl][q] = ab[(bl * 4 + q) * 64];
+            } else { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
+        }
         // ---- G tables of the 16 planes: (row, column) pairs across the threads
         // Sliding rows: logical row r of super-block (sa, sbb) is the offset wd = r - 7 - 8 sbb against element row 0 of the
         // column of super-blocks, so rows 8 .. NR - 1 of super-block sbb + 1 ARE rows 0 .. NR - 9 of super-block sbb.  The table is a
@@ -111,7 +126,9 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
                 const float2_t gv = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * rs;      // (one v_pk_mul_f32)
                 const float gr = gv[0], gi = gv[1];
-                const half2_t hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                half2_t hi;
+                if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
+                else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
                 if (!OLX_IN(z * TOEP_PSZ + o, TOEP_ZB * TOEP_PSZ, 4)) continue;
                 s_hi[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, hi);
                 // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
@@ -119,7 +136,12 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const unsigned hw = __builtin_bit_cast(unsigned, hi);
                 asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
                 asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
-                s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
+                if constexpr (FP8) {   // e4m3 bytes [lo re, lo im | hi re, hi im] (the scaled convert DIVIDES by its scale operand: k_coset2.hip)
+                    short2_t w;
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
+                    s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, w);
+                } else s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
             }
         }
         if (sb == 0) OLX_STAMP(2);
@@ -127,9 +149,15 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         if (sb == 0) OLX_STAMP(3);
         // ---- contraction: element rows b of the super-block, this wave's y positions and K-step
 #pragma unroll
-        for (int bl = 0; bl < TOEP_SB; ++bl) {
+        for (int bi = 0; bi < NB; ++bi) {
+            const int bl = FP8 ? 4 * ks + bi : bi;      // element row of the super-block (FP8: wave-uniform)
             Half8Bits ah, al;
-            ah.u = afr[bl][0]; al.u = afr[bl][1];
+            ah.u = afr[bi][0]; al.u = afr[bi][1];      // (FP8: hi of K-step 0 and 1)
+            intx8_t a8;
+            if constexpr (FP8) {
+                a8[0] = (int)afr[bi][2].x; a8[1] = (int)afr[bi][2].y; a8[2] = (int)afr[bi][2].z; a8[3] = (int)afr[bi][2].w;
+                a8[4] = (int)afr[bi][3].x; a8[5] = (int)afr[bi][3].y; a8[6] = (int)afr[bi][3].z; a8[7] = (int)afr[bi][3].w;
+            }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int ky = kyg + 4 * t;
@@ -140,10 +168,22 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const unsigned w0 = bbase + (unsigned)(prow * TOEP_TW);
                 Half8Bits bh, bw;
                 bh.u = *reinterpret_cast<const uint4*>(s_hi + w0);
-                bw.u = *reinterpret_cast<const uint4*>(s_lo + w0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[t], 0, 0, 0);
+                if constexpr (FP8) {
+                    bw.u = *reinterpret_cast<const uint4*>(s_hi + w0 + 16);                      // hi, K-step 1
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(s_lo + w0), q1 = *reinterpret_cast<const uint4*>(s_lo + w0 + 16);
+                    intx8_t b8;
+                    b8[0] = (int)q0.x; b8[1] = (int)q0.y; b8[2] = (int)q0.z; b8[3] = (int)q0.w;
+                    b8[4] = (int)q1.x; b8[5] = (int)q1.y; b8[6] = (int)q1.z; b8[7] = (int)q1.w;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[t], 0, 0, 0);
+                    // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
+                    acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[t], 0, 0, 0, 128, 0, 127);
+                } else {
+                    bw.u = *reinterpret_cast<const uint4*>(s_lo + w0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[t], 0, 0, 0);
+                }
             }
         }
         if (sb == 0) OLX_STAMP(4);
@@ -223,7 +263,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
 __global__ void toep_pack_k(const double* __restrict__ area, int n, const double* __restrict__ delays, const double* __restrict__ apod,
                             const int* __restrict__ perm, double freq, double w_scale, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]*/, const int* __restrict__ cell /*[ax][ay] -> element*/,
-                            int ax, int ay, int ay_pad, uint4* __restrict__ afrag) {
+                            int ax, int ay, int ay_pad, int fp8corr /*1: the two lo pieces hold the row's e4m3 bytes instead*/, uint4* __restrict__ afrag) {
     const int lane = threadIdx.x, tile = blockIdx.y;
     const int sa = blockIdx.x / ay_pad, b = blockIdx.x - sa * ay_pad;
     const int m = lane & 15, g = lane >> 4, kx = m >> 1, o = m & 1;
@@ -253,6 +293,16 @@ __global__ void toep_pack_k(const double* __restrict__ area, int n, const double
             lo.h[jj] = (_Float16)(float)(val - (double)(float)h);
         }
         dst[s * 64 + lane] = hi.u;
+        if (fp8corr) {      // e4m3 [hi(c0), hi(c1), lo(c0), lo(c1)] * (2^-6, 2^5) of this K-step's four offsets: 16 of the lane's 32 operand bytes
+            Half8Bits q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[2 * e] * COS_F8_HI, (float)hi.h[2 * e + 1] * COS_F8_HI, 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo.h[2 * e] * COS_F8_LO, (float)lo.h[2 * e + 1] * COS_F8_LO, w, true);
+                q.w[e] = (unsigned)w;
+            }
+            lo.u = q.u;
+        }
         dst[(2 + s) * 64 + lane] = lo.u;
     }
 }
@@ -273,7 +323,7 @@ void olx_pack_toep(olx_ctx* c) {
     const olx_ctx::Lattice& A = c->lat;
     dim3 g(c->toep_nsa16 * 8 * A.nsb, c->mp.n_tiles);
     hipLaunchKernelGGL(toep_pack_k, g, dim3(64), 0, c->stream, c->d_area, c->n_el, c->d_delays, c->d_apod, c->d_perm, c->freq,
-                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->d_afrag);
+                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->fp8corr ? 1 : 0, c->d_afrag);
 }
 
 template <int MX, int MY>
@@ -287,6 +337,11 @@ static void launch_toep(olx_ctx* c, float* pm) {
     if (c->dir_lattice) {   // piston directivity folded into the geometry tables
         if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         else hipLaunchKernelGGL((field_toep_k<MX, MY, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+        return;
+    }
+    if (c->fp8corr) {       // e4m3 correction products (the planner's gated default)
+        if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+        else hipLaunchKernelGGL((field_toep_k<MX, MY, false, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         return;
     }
     if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);

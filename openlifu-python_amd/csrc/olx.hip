@@ -548,7 +548,7 @@ static int configure_variant_impl(olx_ctx* c) {
             // A/B runs and fuzz tests.
             {
                 const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked8 = !(c->flags & OLX_FIELD_FP16_CORRECTION) && c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier();
+                const bool asked8 = !(c->flags & OLX_FIELD_FP16_CORRECTION) && c->use_coset && cos_fp8(c->nt) && !c->modifier();
                 const bool asked = asked8;
                 bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
                 if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
@@ -566,7 +566,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
                     if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
                 }
-                c->fp8corr = c->use_coset && !c->use_toep && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : (asked8 && ok));
+                c->fp8corr = c->use_coset && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : (asked8 && ok));
             }
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
@@ -637,7 +637,8 @@ static int configure_variant_impl(olx_ctx* c) {
                         HIPCHK(c, hipMalloc((void**)&c->d_afrag, sizeof(uint4) * need));
                         c->afrag_cap = need;
                     }
-                    // matrix instructions: per block and element row, 2 K-steps x 3 products for each of its KY y positions
+                    // matrix-pipe units (one v_mfma_f32_16x16x32_f16 = 16 cycles): per block and element row, for each of its KY y positions 2 K-steps x 3 fp16
+                    // products -- or, with e4m3 corrections, 2 fp16 products + one K = 128 e4m3 instruction (2 units)
                     long long n_mfma = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     for (int rx = 0; rx < 2 * A.mx; ++rx)
@@ -646,11 +647,11 @@ static int configure_variant_impl(olx_ctx* c) {
                             for (int sx = 0; sx < Q.nsx; ++sx)
                                 for (int sy = 0; sy < Q.nsy; ++sy) {
                                     const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * 6 * c->toep_nsa16 * 8 * A.nsb * Q.kblocks;
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * (c->fp8corr ? 4 : 6) * c->toep_nsa16 * 8 * A.nsb * Q.kblocks;
                                 }
                         }
-                    snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                    snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", c->fp8corr ? ",fp8corr" : "",
                              total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8

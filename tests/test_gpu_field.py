@@ -781,14 +781,22 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
                   slab=(13, 14), expect="field_coset")
 
 
-@pytest.mark.parametrize("case", ["16x16", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
+@pytest.mark.parametrize("case", ["16x16", "16x16_e4m3", "32x32_e4m3_opted_out", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
 def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
     """Kernel 2f (one steering column: an on-axis focus on a mirror-symmetric lattice array; Toeplitz weights stationary, 16
     planes per MFMA tile) against the fp64 oracle, full volume: element counts that pad the 16 x 8 super-blocks, arrays of
     several super-blocks in both directions with position grids cut into parts, plane counts that are not multiples of 16, an
-    x-slab launch (only the y mirror folds), angle apodization; OLX_FIELD_VARIANT=lattice pins kernel 2e on the same case."""
-    if case == "16x16":
+    x-slab launch (only the y mirror folds), angle apodization; OLX_FIELD_VARIANT=lattice pins kernel 2e on the same case.  With the
+    focus inside the planned volume and >= 256 effective elements the e4m3 correction products are the default (round 5: one
+    K = 128 instruction per element row and y position, the block's wave groups split the element rows instead of the K-steps);
+    OLX_FIELD_FP16_CORRECTION opts out."""
+    if case == "16x16":     # z = 5 .. 28.5 mm: the focus (30 mm) lies outside the planned volume -> three fp16 products
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (64, 64, 48), (0.5, 0.5, 0.5), expect="field_toep_k<mx2,my2,flat,noclamp> 1 columns")
+    elif case == "16x16_e4m3":      # z = 5 .. 36.5 mm holds the focus
+        _lattice_case(ctx, 16, 16, (3.0, 3.0), (64, 64, 64), (0.5, 0.5, 0.5), expect="field_toep_k<mx2,my2,flat,noclamp,fp8corr> 1 columns")
+    elif case == "32x32_e4m3_opted_out":      # several super-blocks in both directions, e4m3 and opted out
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (72, 72, 40), (0.5, 0.5, 0.5), foci=[[0, 0, 15e-3]], expect="field_toep_k<mx2,my2,flat,noclamp,fp8corr>", solve=True)
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (72, 72, 40), (0.5, 0.5, 0.5), foci=[[0, 0, 15e-3]], expect="field_toep_k<mx2,my2,flat,noclamp> 1", solve=True, fp8=False)
     elif case == "padded20x12":
         _lattice_case(ctx, 20, 12, (2.4, 1.8), (50, 46, 37), (0.6, 0.6, 0.5), expect="field_toep")
     elif case == "32x32_parts":       # 4 x 4 super-blocks of 8 x 8 -> 2 x 4 of 16 x 8; 11 positions per coset along x, 22 along y: parts
@@ -831,7 +839,7 @@ def test_fp8_correction_products_are_the_gated_default(ctx, monkeypatch):
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, solve=True, fp8=False)      # opted out: never fp8
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=f16, fp8=False)                  # nor at the external-delay seam
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[1:], expect=fp8, solve=True)   # NT = 1 (4 columns)
-    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep", solve=True)   # one column: kernel 2f, fp16 products only
+    _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci[:1], expect="field_toep_k<mx2,my2,flat,noclamp,fp8corr>", solve=True)   # one column: kernel 2f
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8, solve=True)       # NT = 2
     _lattice_case(ctx, 16, 16, (3.0, 3.0), grid, h, foci=foci, expect=fp8)   # external geometric delays: the foci are inferred
     _lattice_case(ctx, 16, 16, (3.0, 3.0), (48, 48, 24), h, foci=foci, expect=f16, solve=True)   # z = 5 .. 28 mm: foci outside
@@ -983,7 +991,7 @@ def test_lattice_kernels_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
                 tol = 1.2e-5 * np.sqrt(256.0 / ((w.sum(axis=1) ** 2) / (w ** 2).sum(axis=1)).min())
                 peaks = [np.abs(co.field_at_points([foci[f]], pos_m, area, d[f], ap[f], F0, C, P0))[0] for f in range(nf)]
                 scale_p = max(scale_p, max(peaks))
-            if fp8 and "field_coset" in name:
+            if fp8 and ("field_coset" in name or "field_toep" in name):
                 assert ("fp8corr" in name) == ("nt4" not in name), name
             assert np.abs(got[fam][1] - ref_p).max() <= tol * scale_p, (case, name, nax, nay, mxv, myv, n, nf)
             assert np.abs(got[fam][2] - ref_i).max() <= 2 * tol * fo.intensity_wcm2(scale_p, RHO, C), (case, name)
