@@ -191,6 +191,17 @@ def issue_model(name, V, N, F):
     return N_SIMD * CLK_GHZ * 1e9 * 64 * pairs / cyc, model + "; per 64 lanes per SIMD, 1024 SIMDs @2.4 GHz (tools/ubench_valu.hip)"
 
 
+def mfma_useful(name: str) -> dict:
+    """{"mfma_issued", "mfma_dense", "mfma_useful"} for the lattice kernels (their planner states both counts in units of one
+    v_mfma_f32_16x16x32_f16): useful = what the dense contraction needs / what the launch issues -- row, column and K-slot padding and the
+    Toeplitz band of kernel 2f all show up here."""
+    m = re.search(r"(\d+) MFMA/launch \((\d+) dense\)", name)
+    if not m:
+        return {}
+    issued, dense = int(m.group(1)), int(m.group(2))
+    return {"mfma_issued": issued, "mfma_dense": dense, "mfma_useful": dense / issued if issued else None}
+
+
 def static_traffic(kernel_name: str, grid_n: int):
     """HBM bytes per launch from the committed PMC summaries (profiles/traffic.json), matched on the kernel variant
     string: a STATIC figure from tools/profile_round.sh's counter passes, not measured in this run; None when the
@@ -685,6 +696,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the accumulate is issue bound (matrix pipe + VALU), not HBM bound "
                                  "(SURVEY 8(d), DESIGN.md 5); see issue_ceiling"},
+            **mfma_useful(kernel_name),
             "issue_ceiling": {"achieved_Mpairs_s": float(vox_launch) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
                               "frac": float(vox_launch) * N * F / (k_ms * 1e-3) / ceil_pairs, "model": model},
         }
@@ -713,7 +725,7 @@ def main():
                 nf = foci_m.shape[0]
                 bytes_l = 8.0 * V * nf + 32.0 * N * nf
                 m = re.search(r"(\d+) columns for (\d+) foci x (\d+) images", name)
-                return {"what": what, "kernel": name, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else "f32-acc/f16x3",
+                return {**mfma_useful(name), "what": what, "kernel": name, "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else "f32-acc/f16x3",
                         "foci": nf, "columns_computed": int(m.group(1)) if m else None,
                         "kernel_ms_avg": float(np.mean(km)), "kernel_launches_timed": int(len(km)), "ms_per_step": e / k2 * 1e3, "steps": k2,
                         "value": float(V) * N * nf * k2 / e / 1e6, "roofline_frac": bytes_l / (float(np.mean(km)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -818,7 +830,7 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
         nf = len(foci_run)
         k_ms = float(np.mean(km))
         bytes_l = (8.0 * V * nf + 32.0 * N * nf) if medium is None else (16.0 * V * nf)     # + 8 B / voxel of medium parameters per focus
-        ent = {"what": what, "kernel": name, "elements": N, "grid": [int(v) for v in n], "foci": nf,
+        ent = {**mfma_useful(name), "what": what, "kernel": name, "elements": N, "grid": [int(v) for v in n], "foci": nf,
                "dtype": "f32-acc/f16x2+e4m3-corr" if "fp8corr" in name else ("f32-acc/f16x3" if ("field_coset" in name or "field_toep" in name or "field_lattice" in name or "field_mfma" in name) else "f32"),
                "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(km)), "ms_per_step": e / steps * 1e3, "steps": steps,
                "value": float(V) * N * nf * steps / e / 1e6, "unit": "Mvoxel-elements/s",

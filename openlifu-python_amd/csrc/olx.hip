@@ -620,6 +620,10 @@ static int configure_variant_impl(olx_ctx* c) {
                     memcpy(c->up_blocks_key, rec_key, sizeof rec_key);
                     c->cp_nblocks = nblk;
                 }
+                // what the DENSE contraction of this launch needs, in the same units (one v_mfma_f32_16x16x32_f16 = 8192 real multiply-adds): computed
+                // voxels x elements x columns x 4 real products per complex one, times the products of the operand split -- bench.py reports
+                // dense / issued as `mfma_useful` (padding of rows, columns, K slots and the Toeplitz band all show up there)
+                const long long n_dense = (long long)((double)(P.nx - L.x_lo) * (P.ny - L.y_lo) * P.nz * (double)n * total_cols * 4.0 / 8192.0 * (c->fp8corr ? 2 : 3));
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     c->toep_nsa16 = (A.ax + 15) / 16;
                     for (int q = 0; q < 4; ++q) c->toep_targets[q] = tiles[0][0].tgt[q];
@@ -651,8 +655,8 @@ static int configure_variant_impl(olx_ctx* c) {
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", c->fp8corr ? ",fp8corr" : "",
-                             total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", c->fp8corr ? ",fp8corr" : "",
+                             total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
@@ -666,8 +670,8 @@ static int configure_variant_impl(olx_ctx* c) {
                     n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                         c->fp8corr ? ",fp8corr" : "", "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma);
+                         "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
+                         c->fp8corr ? ",fp8corr" : "", "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
                 }
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;

@@ -98,6 +98,16 @@ time.sleep(0.3 * (world - 1 - rank))
 sf.step("allgather")
 eng.ctx.field_scale(np.full(eng.ctx.n_foci, 2.0))
 res["big_after_scale"] = sf.fetch_all()
+# BASELINE configs[4]'s split: a heterogeneous medium (skull slab, marched ray sums), x-slabs per rank, the medium volumes replicated --
+# every rank marches the running ray sums over the WHOLE lateral grid and evaluates its slab; two steps through both output buffers
+from openlifu_amd.seg.seg_methods import skull_slab_volumes   # noqa: E402
+axes = [origin[a] + np.arange(n[a]) * spacing[a] for a in range(3)]
+skull = skull_slab_volumes(*axes)
+skull["model"] = "marched"
+res["hetero_slabs"] = sf.sweep_slabs(arr, d, a, origin, spacing, n, F0, C, RHO, P0, medium=skull)
+assert "field_hmarch_k" in eng.ctx.field_variant(), eng.ctx.field_variant()
+sf.step("allgather")
+res["hetero_slabs_again"] = sf.fetch_all()
 np.savez(os.path.join(tmp, f"out_{rank}.npz"), **res)
 sf.close()
 print(f"rank {rank}: ok", flush=True)

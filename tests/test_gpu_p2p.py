@@ -86,6 +86,19 @@ def test_ranks_on_one_gpu_exchange_through_p2p_transport(world, n_foci):
         sf.plan_slab_sweep(arr, d, a, origin2, spacing, n2, F0, C, RHO, P0)
         blocks.append(local_blocks())
     exp_big = od.assemble_slabs(np.stack(blocks), n2[0])
+    # configs[4]'s split: skull-slab medium, marched ray sums, x-slabs per rank (medium replicated) = the same voxels of ONE whole-grid launch,
+    # bit for bit (every rank marches the ray sums over the whole lateral grid: DESIGN.md section 6)
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    axes = [origin[a_] + np.arange(n[a_]) * spacing[a_] for a_ in range(3)]
+    skull = skull_slab_volumes(*axes)
+    skull["model"] = "marched"
+    one = od.ShardedField(eng, 1, 0)
+    exp_het = one.sweep_slabs(arr, d, a, origin, spacing, n, F0, C, RHO, P0, medium=skull)
+    assert "field_hmarch_k" in ctx.field_variant() and exp_het.shape == ref.shape and exp_het.max() > 0
+    assert np.abs(exp_het - ref).max() > 0.05 * ref.max()            # (the medium matters: this is not the homogeneous field)
+    for r in range(world):
+        assert np.array_equal(got[r]["hetero_slabs"], exp_het), (r, float(np.abs(got[r]["hetero_slabs"] - exp_het).max()))
+        assert np.array_equal(got[r]["hetero_slabs_again"], exp_het), r
     for r in range(world):
         assert np.array_equal(got[r]["slabs_skewed"], exp_slabs), r
         assert np.array_equal(got[r]["big"], exp_big), (r, float(np.abs(got[r]["big"] - exp_big).max()))
