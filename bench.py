@@ -929,6 +929,7 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
 
     class FakeXarray:
         DataArray, Dataset, Coordinates = EagerDataArray, EagerDataset, ds.Coordinates
+    mainlobe = [float(v) for v in an.mainlobe_pnp_MPa[:2]]
     sol = agg = an = None
     saved = ds.HAVE_XARRAY, ds._xa
     eager = []
@@ -953,7 +954,7 @@ def end_to_end(ol, arr, setup, target, sweep, idx, args):
             "aggregate_fetch_what": "first .data access of the aggregate Dataset's p_min, p_max and intensity (three fresh NumPy arrays)",
             "fetch_ms": (t2 - ta) * 1e3, "fetch_bytes": int(nbytes), "fetch_GBps": nbytes / max(t2 - ta, 1e-9) / 1e9,
             "fetch_what": "first .data access of simulation_result['p_min'] and ['intensity'] (device -> fresh NumPy arrays)",
-            "mainlobe_pnp_MPa": [float(v) for v in an.mainlobe_pnp_MPa[:2]]}
+            "mainlobe_pnp_MPa": mainlobe}
 
 
 def _ListPattern(ol, foci):

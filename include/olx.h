@@ -294,12 +294,15 @@ int olx_offset_grid(olx_ctx *ctx, const double *xs, int nx, const double *ys, in
 int olx_tof_spread(olx_ctx *ctx, const double *xs, int nx, const double *ys, int ny, const double *zs, int nz,
                    const double *delays_s, double c0, double *max_dtof_s);
 
-/* out[v] = sum_f weights[f] * intensity_f[v] kept on the device as the "time-average" volume
- * (Solution.get_ita, plan/solution.py:365-388); olx_field_masked_peak(which = 2) then scans THAT single
- * volume with every focus' mask. */
+/* out[v] = max_f weights[f] * intensity_f[v] kept on the device as the "time-average" volume of Solution.analyze.
+ * Why a maximum: the reference's get_ita (plan/solution.py:365-388) multiplies its [focal_point_index, x, y, z] intensity,
+ * expanded on the LAST axis, with pulse counts shaped [1, 1, 1, F] -- the counts cancel, every focus volume is its own
+ * intensity times the two duty cycles -- and analyze takes `.where(mask).max()` / `(ita * z_mask).max()` over that whole
+ * stack (plan/solution.py:243, 274), i.e. the maximum over foci AND voxels.  olx_field_masked_peak(which = 2) scans THIS
+ * single volume with every focus' mask and so returns the reference's numbers.  (Rounds 1-4 formed sum_f here.) */
 int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci);
 /* Blocking copy of that volume ([slab voxels] floats) into a caller-owned array: what Solution.get_ita returns
- * (plan/solution.py:365-388) when somebody reads it.  The volume is the one the last olx_field_weighted_intensity or
+ * (the analysis' view of plan/solution.py:365-388).  The volume is the one the last olx_field_weighted_intensity or
  * olx_solution_analyze left on the device. */
 int olx_field_weighted_fetch(olx_ctx *ctx, float *out);
 

@@ -414,14 +414,42 @@ static int configure_variant_impl(olx_ctx* c) {
             const long long t16 = coset_tiles16(wx, wy, c->lat.mx, c->lat.my, nt);
             return t16 > 0 ? (double)COS_P * wx * wy / (16.0 * (double)t16) : 0.0;
         };
+        // e4m3 correction products (kernels 2e / 2f / 2g, NT <= 2) are the default wherever their error bound is a bound on the planned volume
+        // (include/olx.h, olx_field_plan): the foci are known (olx_bf_solve in the element frame, or external delays that infer_foci
+        // recognises as geometric), every focus lies inside the planned SLAB and has N_eff = (sum w)^2 / sum w^2 >= 256; the plan flag
+        // OLX_FIELD_FP16_CORRECTION opts out.  Decided here, before the columns are packed: it also decides the tile width below.
+        auto fp8_eligible = [&]() {
+            if ((c->flags & (OLX_FIELD_FP16_CORRECTION | OLX_OUT_COMPLEX)) || c->modifier() || !c->lat.ok) return false;
+            bool ok = c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
+            if (!ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
+                c->foci_version = c->steer_version;
+                ok = true;
+            }
+            for (int f = 0; ok && f < F; ++f) {
+                for (int a = 0; a < 3; ++a) {
+                    const int b0 = a == 0 ? c->slab.x_begin : 0, cnt = a == 0 ? c->slab.x_count : c->grid.n[a];
+                    const double lo = c->grid.origin[a] + (b0 - 0.5) * c->grid.spacing[a];
+                    const double hi = c->grid.origin[a] + (b0 + cnt - 0.5) * c->grid.spacing[a];
+                    if (!(c->h_foci[3 * (size_t)f + a] >= lo && c->h_foci[3 * (size_t)f + a] <= hi)) ok = false;
+                }
+                double sw1 = 0, sw2 = 0;
+                for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
+                if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
+            }
+            return ok;
+        };
+        const char* f8env = getenv("OLX_FP8_CORRECTION");      // 0 / 1 pins either arithmetic for A/B runs and fuzz tests
+        const bool fp8_want = lat_ok && (f8env ? strcmp(f8env, "0") != 0 && !c->modifier() : fp8_eligible());
         olxplan::Tiles tiles = pack(MAXC);
         int total_cols = 0;
         // A sweep that needs SEVERAL launch tiles anyway is cut into tiles of 16 columns instead of 32: kernel 2g (NT = 2) then takes every
         // tile -- 8 x 0.43 ms against 2e's 4 x 0.92 ms on the 64-focus sweep (127 columns).  One tile of 17 - 32 columns stays with 2e's
-        // NT = 4 shape (0.82 against 2 x 0.43 ms).  OLX_FIELD_VARIANT=lattice keeps the 32-column tiles for A/B runs.
+        // NT = 4 shape when the fp16 corrections run (0.82 against 2 x 0.45 ms) and is cut in two when the e4m3 corrections apply, which
+        // the NT = 4 shape has no registers for (2 x 0.39 against 0.86 ms).  OLX_FIELD_VARIANT=lattice keeps the 32-column tiles for A/B runs.
         {
             const char* fv = getenv("OLX_FIELD_VARIANT");
-            if (tiles.size() > 1 && c->use_lattice && !(c->flags & OLX_OUT_COMPLEX) && !fv && coset_fill(2) >= 0.6) {
+            const bool wide = tiles.size() == 1 && (int)tiles[0].size() > MFMA_COLS * 2;
+            if ((tiles.size() > 1 || (wide && fp8_want)) && c->use_lattice && !(c->flags & OLX_OUT_COMPLEX) && !fv && coset_fill(2) >= 0.6) {
                 tiles = pack(MFMA_COLS * 2);
             }
         }
@@ -537,37 +565,7 @@ static int configure_variant_impl(olx_ctx* c) {
             L.vox = P.vox; L.flags = P.flags;
             const char* fv = getenv("OLX_FIELD_VARIANT");
             const long long tiles16 = coset_tiles16(P.nx - L.x_lo, P.ny - L.y_lo, A.mx, A.my, c->nt);
-            // e4m3 correction products (kernels 2e / 2g, NT <= 2), the DEFAULT since round 5 wherever their error bound is a bound on the
-            // planned volume; OLX_FIELD_FP16_CORRECTION in the plan flags opts out.  The e4m3 rounding of the two hi x lo terms adds
-            // ~2^-16 |w_e G| per element and term with random signs -- an absolute error that falls off only slowly with depth and,
-            // against the coherent focal peak sum |w_e G|, is ~ 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2 over the focus' drive
-            // weights: 4.1e-6 ... 6.2e-6 of the peak at N_eff = 256, measured on full 256^3 volumes (gate: 1e-5 of the volume's
-            // maximum).  So they run only if the planned SLAB is known to contain that peak: the foci are known (olx_bf_solve in the
-            // element frame, or external delays that infer_foci recognises as geometric), every focus lies inside the slab and has
-            // N_eff >= 256.  Otherwise the fp16 corrections (0.8e-6) run.  OLX_FP8_CORRECTION=0 / 1 (environment) pins either for
-            // A/B runs and fuzz tests.
-            {
-                const char* f8 = getenv("OLX_FP8_CORRECTION");
-                const bool asked8 = !(c->flags & OLX_FIELD_FP16_CORRECTION) && c->use_coset && cos_fp8(c->nt) && !c->modifier();
-                const bool asked = asked8;
-                bool ok = asked && c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
-                if (asked && !ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
-                    c->foci_version = c->steer_version;
-                    ok = true;
-                }
-                for (int f = 0; ok && f < F; ++f) {
-                    for (int a = 0; a < 3; ++a) {
-                        const int b0 = a == 0 ? c->slab.x_begin : 0, cnt = a == 0 ? c->slab.x_count : c->grid.n[a];
-                        const double lo = c->grid.origin[a] + (b0 - 0.5) * c->grid.spacing[a];
-                        const double hi = c->grid.origin[a] + (b0 + cnt - 0.5) * c->grid.spacing[a];
-                        if (!(c->h_foci[3 * (size_t)f + a] >= lo && c->h_foci[3 * (size_t)f + a] <= hi)) ok = false;
-                    }
-                    double sw1 = 0, sw2 = 0;
-                    for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
-                    if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
-                }
-                c->fp8corr = c->use_coset && cos_fp8(c->nt) && !c->modifier() && (f8 ? strcmp(f8, "0") != 0 : (asked8 && ok));
-            }
+            c->fp8corr = fp8_want && c->use_coset && cos_fp8(c->nt) && !c->modifier();      // (decided above, before the columns were packed)
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;

@@ -27,6 +27,9 @@ def _axis_rotation(dim: str, angle_rad: float) -> np.ndarray:
     return m
 
 
+_FROZEN: dict = {}      # id(transducer) -> gather cache of an open Transducer.frozen() block
+
+
 @dataclass
 class Transducer:
     id: str = "transducer"
@@ -61,29 +64,25 @@ class Transducer:
         """Context manager: while it is open, the gathers over the element list (``element_table``, ``element_areas``, ``get_positions``
         without a transform, the engine's table key) are evaluated once and remembered -- ``Protocol.calc_solution`` looks at the same
         256 Python objects five times per call otherwise.  The elements must not be edited inside (the hot path does not); results handed
-        out are the cached arrays themselves and must not be modified in place."""
+        out are the cached arrays themselves and must not be modified in place.  The cache lives OUTSIDE the instance (keyed by its id for
+        as long as the block is open), so ``__dict__``-based copies, ``to_dict`` and pickles never see it."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
-            outer = self.__dict__.get("_frozen_cache")
-            if outer is None:
-                self.__dict__["_frozen_cache"] = {}
+            key = id(self)
+            opened = key not in _FROZEN
+            if opened:
+                _FROZEN[key] = {}
             try:
                 yield self
             finally:
-                if outer is None:
-                    self.__dict__["_frozen_cache"] = None
+                if opened:
+                    _FROZEN.pop(key, None)
         return cm()
 
-    def __getstate__(self):
-        """Copies and pickles never carry the gather cache of an open ``frozen()`` block (it belongs to that call)."""
-        state = dict(self.__dict__)
-        state.pop("_frozen_cache", None)
-        return state
-
     def _cached(self, key, fn):
-        cache = self.__dict__.get("_frozen_cache")
+        cache = _FROZEN.get(id(self))
         if cache is None:
             return fn()
         if key not in cache:
