@@ -41,7 +41,7 @@ struct MarchSeg {
 };
 
 typedef float float4u_t __attribute__((ext_vector_type(4), aligned(8)));
-typedef float float2u_t __attribute__((ext_vector_type(2)));
+typedef float float2u_t __attribute__((ext_vector_type(2), aligned(4)));      // (also a 4-byte-aligned 8-byte load: a stencil row of the one-sum form)
 
 // ES = 1: 4 waves = 4 consecutive planes, every wave walks all elements.  ES = 16: 16 waves = 16 element subsets of ONE plane.
 template <int ES> constexpr int hm_waves() { return ES == 1 ? 4 : ES; }
@@ -53,10 +53,15 @@ template <int ES> constexpr int hm_waves() { return ES == 1 ? 4 : ES; }
 #endif
 constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 voxels -- 16 consecutive y = whole 128-byte lines of a U row
 
+// ONE (round 5): media whose absorption is PROPORTIONAL to their slowness perturbation -- a' = kappa sig in every voxel: every two-material
+// segmentation over a lossless reference medium (water + skull: UniformWater's alpha is 0), the shape of BASELINE configs[4] -- carry ONE running
+// sum.  U is then [i][element][j] float {sum sig}, a look-up two 8-byte loads instead of two 16-byte ones, the bilinear step plain fp32 instead
+// of packed pairs, and sum a' = kappa sum sig: half the bytes of the HBM-bound writer launches and of the look-up launches' L1 traffic.  The host
+// detects the property from the stencil values (olx_field_set_medium); OLX_MARCH_SUMS=2 pins the general form for A/B runs and tests.
 // SRC: the launch reads running sums (k_src >= 0).  Every element lies strictly below the first non-trivial plane (host-checked), so
 // with SRC every ray of the launch crosses the source plane upwards (0 < tt < 1) and without it no ray sees anything: the look-up is
 // compiled in or out as a whole -- no per-element branch, no zero fill of the gather registers.
-template <int NF, int ES, bool CLAMP, bool SRC>
+template <int NF, int ES, bool CLAMP, bool SRC, bool ONE>
 __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_of_k,
     const float2* __restrict__ U_src, float2* __restrict__ U_dst, const float* __restrict__ inv2z,
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const bool writer = ES > 1 && S.write && ftile == 0 && in_grid;        // (ES = 1 launches never write)
     const unsigned own = (unsigned)ig * row_cells + (unsigned)j;           // this voxel's cell in element 0's rows
     const float sv2 = 2.f * sv, av2 = 2.f * av;
+    const float kappa = H.kappa;                           // ONE: a' = kappa sig
     if (live_k) {
         const int n_mine = (P.n_el - es + ES - 1) / ES;     // elements es, es + ES, ...
         for (int c0 = 0; c0 < n_mine; c0 += ECH) {
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
             // wave waits out each L1 round trip); a ragged tail goes element by element
             auto group = [&](const int q0, auto count) {
                 constexpr int E = decltype(count)::value;
-                float4u_t lo[E], hi[E];
+                typedef typename std::conditional<ONE, float2u_t, float4u_t>::type Row;      // a stencil row: {s00, s01} | {s00, a00, s01, a01}
+                Row lo[E], hi[E];
                 float fu[E], fv[E];
                 if constexpr (SRC) {
 #pragma unroll
@@ -152,11 +159,12 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                         const unsigned i0 = (unsigned)(int)u, j0 = (unsigned)(int)v;
                         fu[s] = __builtin_amdgcn_fractf(u); fv[s] = __builtin_amdgcn_fractf(v);
                         // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
-                        const char* Ue = reinterpret_cast<const char*>(U_src + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg);
-                        const unsigned off = (__umul24(i0, row_cells) + j0) << 3;
-                        if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * 8 + off + (long long)row_cells * 8 + 15, (long long)H.nxg * row_cells * 8, 6)) { lo[s] = float4u_t{0.f, 0.f, 0.f, 0.f}; hi[s] = lo[s]; continue; }
-                        lo[s] = *reinterpret_cast<const float4u_t*>(Ue + off);                       // {s00, a00, s01, a01}
-                        hi[s] = *reinterpret_cast<const float4u_t*>(Ue + (size_t)row_cells * 8 + off);   // {s10, a10, s11, a11}
+                        constexpr int CB = ONE ? 4 : 8;      // bytes per cell of U
+                        const char* Ue = reinterpret_cast<const char*>(U_src) + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg * CB;
+                        const unsigned off = (__umul24(i0, row_cells) + j0) * CB;
+                        if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * CB + off + (long long)row_cells * CB + 2 * CB - 1, (long long)H.nxg * row_cells * CB, 6)) { lo[s] = Row{}; hi[s] = lo[s]; continue; }
+                        lo[s] = *reinterpret_cast<const Row*>(Ue + off);                             // {s00, a00, s01, a01} | {s00, s01}
+                        hi[s] = *reinterpret_cast<const Row*>(Ue + (size_t)row_cells * CB + off);     // {s10, a10, s11, a11} | {s10, s11}
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -167,18 +175,27 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                     const float dx = x - r1.y, dy = y - r1.z;
                     float2u_t sa = {0.f, 0.f};               // { sum sig, sum a' } at the crossing: (s, a) pairs in packed fp32
                     if constexpr (SRC) {
-                        const float2u_t l0 = {lo[s].x, lo[s].y}, l1 = {lo[s].z, lo[s].w}, h0 = {hi[s].x, hi[s].y}, h1 = {hi[s].z, hi[s].w};
-                        const float2u_t c0v = fv[s] * (l1 - l0) + l0, c1v = fv[s] * (h1 - h0) + h0;
-                        sa = fu[s] * (c1v - c0v) + c0v;
+                        if constexpr (ONE) {
+                            const float c0v = fmaf(fv[s], lo[s].y - lo[s].x, lo[s].x), c1v = fmaf(fv[s], hi[s].y - hi[s].x, hi[s].x);
+                            sa.x = fmaf(fu[s], c1v - c0v, c0v);
+                        } else {
+                            const float2u_t l0 = {lo[s].x, lo[s].y}, l1 = {lo[s].z, lo[s].w}, h0 = {hi[s].x, hi[s].y}, h1 = {hi[s].z, hi[s].w};
+                            const float2u_t c0v = fv[s] * (l1 - l0) + l0, c1v = fv[s] * (h1 - h0) + h0;
+                            sa = fu[s] * (c1v - c0v) + c0v;
+                        }
                     }
-                    if (writer && OLX_IN((long long)e * H.nyg + own, (long long)H.nxg * row_cells, 7)) (U_dst + (size_t)e * H.nyg)[own] = make_float2(sa.x + sv2, sa.y + av2);
+                    if (writer && OLX_IN((long long)e * H.nyg + own, (long long)H.nxg * row_cells, 7)) {
+                        if constexpr (ONE) (reinterpret_cast<float*>(U_dst) + (size_t)e * H.nyg)[own] = sa.x + sv2;
+                        else (U_dst + (size_t)e * H.nyg)[own] = make_float2(sa.x + sv2, sa.y + av2);
+                    }
                     float d2 = fmaf(dy, dy, fmaf(dx, dx, r1.x));
                     if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                     const float ri = __builtin_amdgcn_rsqf(d2);
                     const float d = d2 * ri;
                     const float l = d * r0.w;                // path per layer [wavelengths]; 0 level with the element
-                    const float ph0 = fmaf(l, sa.x + sv, d);
-                    const float amp = ri * __expf(-l * (sa.y + av));
+                    const float ssum = sa.x + sv;
+                    const float ph0 = fmaf(l, ssum, d);
+                    const float amp = ri * __expf(-l * (ONE ? kappa * ssum : sa.y + av));
                     float wf[2 * NF];                         // { w_f, phi_f }: from the ray table (ES = 1) or the steering table
                     if constexpr (RW > 0) {
 #pragma unroll
@@ -259,15 +276,17 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
         const float2* src = p_src >= 0 ? c->d_U[p_src & 1] : nullptr;
         float2* dst = write ? c->d_U[(p_src + 1) & 1] : nullptr;
         const long long tiles = (long long)((S.ni + HM_TI - 1) / HM_TI) * ((P.ny + HM_TJ - 1) / HM_TJ);
-#define OLX_HM_(ES_, CL, SR) S.nblocks = (unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)); \
-                             hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL, SR>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), \
+#define OLX_HM__(ES_, CL, SR, ON) S.nblocks = (unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)); \
+                             hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL, SR, ON>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), \
                                            dim3(64 * hm_waves<ES_>()), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
                                            c->d_inten, c->d_cplx, P, c->hp, S)
+#define OLX_HM_(ES_, CL, SR) do { if (c->march_one) { OLX_HM__(ES_, CL, SR, true); } else { OLX_HM__(ES_, CL, SR, false); } } while (0)
 #define OLX_HM(ES_, CL) do { if (p_src >= 0) { OLX_HM_(ES_, CL, true); } else { OLX_HM_(ES_, CL, false); } } while (0)
         if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }   // (4 or 8 element subsets per block: same time, measured)
         else       { if (c->clamp) OLX_HM(1, true); else OLX_HM(1, false); }
 #undef OLX_HM
 #undef OLX_HM_
+#undef OLX_HM__
     };
     if (np == 0) { go(0, nz - 1, -1, false); return; }
     go(0, c->h_plane_k[0] - 1, -1, false);                   // below the first non-trivial plane: homogeneous rays

@@ -356,8 +356,8 @@ static int configure_variant_impl(olx_ctx* c) {
         c->hp.n_foci = F;
         char hb[160];
         if (c->marched)
-            snprintf(hb, sizeof hb, "field_hmarch_k<nf%d,%s> (%d non-trivial planes, marched ray sums, %d launches)", c->nf,
-                     c->clamp ? "clamp" : "noclamp", c->hp.n_planes, 2 * c->hp.n_planes + 1);
+            snprintf(hb, sizeof hb, "field_hmarch_k<nf%d,%s%s> (%d non-trivial planes, marched ray sums, %d launches)", c->nf,
+                     c->clamp ? "clamp" : "noclamp", c->march_one ? ",one-sum" : "", c->hp.n_planes, 2 * c->hp.n_planes + 1);
         else if (c->hp.n_layers > 0)
             snprintf(hb, sizeof hb, "field_hetero_k<4,nf%d,%s,layers> (%d non-trivial planes in %d layers of <= %d)", c->nf,
                      c->clamp ? "clamp" : "noclamp", c->hp.n_planes, c->hp.n_layers, c->planes_per_layer);
@@ -1235,6 +1235,22 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         return fail(c, OLX_EINVAL, "olx_field_set_medium: OLX_MEDIUM_MARCHED needs every element strictly below the first non-trivial "
                                     "plane, >= 2 voxels along x and y and planes_per_layer = 1");
     c->marched = march_ok && c->medium_model != OLX_MEDIUM_SAMPLED;
+    // kernel 2m's one-sum form: every voxel's stencil values {sig, a'} lie on ONE line through the origin (a two-material medium over a lossless
+    // reference: water + skull).  Compared as products of the stored floats in fp64 -- exact for the handful of distinct pairs a segmentation has.
+    c->march_one = false; c->hp.kappa = 0.f;
+    if (c->marched && np > 0) {
+        double s_ref = 0, a_ref = 0;
+        bool one = true;
+        for (int p = 0; p < np && one; ++p)
+            for (size_t ij = 0; ij < (size_t)nx * ny && one; ++ij) {
+                const double sg = med[((size_t)p * nx * ny + ij) * 8], ab = med[((size_t)p * nx * ny + ij) * 8 + 1];
+                if (sg == 0.0 && ab == 0.0) continue;
+                if (s_ref == 0.0 && a_ref == 0.0) { s_ref = sg; a_ref = ab; if (s_ref == 0.0) one = false; continue; }
+                if (sg * a_ref != ab * s_ref) one = false;
+            }
+        const char* pin = getenv("OLX_MARCH_SUMS");
+        if (one && s_ref != 0.0 && !(pin && !strcmp(pin, "2"))) { c->march_one = true; c->hp.kappa = (float)(a_ref / s_ref); }
+    }
     c->h_plane_k = plane_k;
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,
                      (void**)&c->d_med_layer, (void**)&c->d_layer_lo, (void**)&c->d_layer_hi})

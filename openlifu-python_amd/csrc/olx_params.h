@@ -131,6 +131,7 @@ struct HeteroParams {
     float inv_hx, inv_hy;  // 1 / spacing [1/wavelengths]
     int nxg, nyg;          // whole-grid lateral size of the medium planes
     int xg_begin;          // slab start (voxel i of the slab is grid column i + xg_begin)
+    float kappa;           // kernel 2m's one-sum form: a' = kappa sig in every voxel (0 otherwise)
 };
 
 struct PeakParams {

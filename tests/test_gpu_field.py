@@ -382,21 +382,31 @@ def _skull_medium(xs, ys, zs, c_skull=2800.0, a_skull=6.0):
     return cvol, avol, rvol
 
 
-@pytest.mark.parametrize("model", ["sampled", "auto"])
-def test_heterogeneous_medium_layered_ray_model(ctx, model):
+@pytest.mark.parametrize("model", ["sampled", "auto", "auto_two_sums", "auto_three_materials"])
+def test_heterogeneous_medium_layered_ray_model(ctx, model, monkeypatch):
     """BASELINE config 5 shape (skull-slab mask, attenuated propagation) at a size the fp64 oracle finishes:
     kernel 2h (one sample per plane) and kernel 2m (marched ray sums, what "auto" picks here) each against its own
     definition in oracle/field_oracle.c, plus the analytic slab KAT through the C-ABI (laterally uniform slab: both
-    models reduce to it exactly)."""
+    models reduce to it exactly).  Kernel 2m carries ONE running sum when the absorption is proportional to the slowness
+    perturbation in every voxel (two materials over a lossless reference: this phantom); OLX_MARCH_SUMS=2 pins the general
+    two-sum form on the same medium, and a third material (a lossy soft layer) is not proportional and selects it by itself."""
+    want_one = model == "auto"
+    if model == "auto_two_sums":
+        monkeypatch.setenv("OLX_MARCH_SUMS", "2")
+    three = model == "auto_three_materials"
+    model = "auto" if model.startswith("auto") else model
     pos, ori, size = synthetic_array(8, 8, 4.0, jitter=True)
     foci = np.array([[0, 0, 30e-3], [3e-3, -2e-3, 28e-3]])
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 50.0, 0.0))
     xs = np.linspace(-12e-3, 12e-3, 25); ys = np.linspace(-10e-3, 10e-3, 21); zs = 5e-3 + np.arange(36) * 1e-3
     cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    if three:       # a lossy soft layer on top of the skull: (sig, a') no longer on one line through the origin
+        cvol[:, :, 14:17] = 1560.0; avol[:, :, 14:17] = 0.9; rvol[:, :, 14:17] = 1050.0
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
     ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 36), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.OUT_COMPLEX)
     ctx.field_set_medium(cvol, avol, rvol, model=model)
     assert ("field_hetero_k" if model == "sampled" else "field_hmarch_k") in ctx.field_variant(), ctx.field_variant()
+    assert ("one-sum" in ctx.field_variant()) == want_one, ctx.field_variant()
     ctx.field_launch()
     sig, ab = co.medium_terms(cvol, avol, C, F0)
     homog = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], a[0], F0, C, P0))
@@ -510,7 +520,7 @@ def test_marched_medium_foci_tiles_slabs_and_fallback(ctx):
     cvol, avol, rvol = _skull_medium(xs, ys, zs)
     sig, ab = co.medium_terms(cvol, avol, C, F0)
     h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
-    for nfoci, expect in ((1, "nf1,noclamp>"), (2, "nf2"), (5, "nf4"), (11, "nf8")):
+    for nfoci, expect in ((1, "nf1,noclamp,one-sum>"), (2, "nf2"), (5, "nf4"), (11, "nf8")):
         pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci[:nfoci], apod=("maxangle", 55.0, 0.0))
         ctx.field_plan((xs[0], ys[0], zs[0]), h, (25, 21, 44), F0, C, RHO, P0)
         ctx.field_set_medium(cvol, avol, rvol)
@@ -558,7 +568,7 @@ def test_c5_skull_slab_256cubed_marched(ctx):
     hh = (xs[1] - xs[0],) * 3
     ctx.field_plan((xs[0], ys[0], zs[0]), hh, (256,) * 3, F0, C, RHO, P0, flags=nat.OUT_PMAG)
     ctx.field_set_medium(vol["sound_speed"], vol["attenuation"], vol["density"])
-    assert "field_hmarch_k<nf4,noclamp>" in ctx.field_variant(), ctx.field_variant()
+    assert "field_hmarch_k<nf4,noclamp,one-sum>" in ctx.field_variant(), ctx.field_variant()
     ctx.field_launch()
     got = [ctx.field_fetch(f, want=("pmag",))["pmag"] for f in (0, 3)]
     rng = np.random.default_rng(147)
