@@ -20,6 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libolx.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
+# per-unit additions.  k_hmarch.hip: the SLP vectoriser pairs the scalar lerps of the one-sum look-up into v_pk_* with three v_mov shuffles per
+# look-up (its explicit float2 arithmetic of the two-sum form stays packed either way)
+UNIT_FLAGS = {"k_hmarch.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -43,7 +46,7 @@ def build(force: bool = False, defines=(), out: str = OUT) -> str:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
             host_only = s.endswith(".cpp")
-            jobs.append([cc] + [f for f in FLAGS if not (host_only and f.startswith("--offload-arch"))] + list(defines) + ["-c", s, "-o", o])
+            jobs.append([cc] + [f for f in FLAGS if not (host_only and f.startswith("--offload-arch"))] + list(defines) + UNIT_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for rc, cmd in zip(ex.map(lambda c: subprocess.run(c).returncode, jobs), jobs):

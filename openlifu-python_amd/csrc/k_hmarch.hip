@@ -51,7 +51,8 @@ template <int ES> constexpr int hm_waves() { return ES == 1 ? 4 : ES; }
 #ifndef HM_EUW
 #define HM_EUW 4
 #endif
-constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 voxels -- 16 consecutive y = whole 128-byte lines of a U row
+constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 voxels -- 16 consecutive y = whole 128-byte lines of a U row of {sum sig, sum a'} pairs
+                                           // (one-sum form: 64 bytes; a 2 x 32 tile for its writers measured the same 42 us per launch)
 
 // ONE (round 5): media whose absorption is PROPORTIONAL to their slowness perturbation -- a' = kappa sig in every voxel: every two-material
 // segmentation over a lossless reference medium (water + skull: UniformWater's alpha is 0), the shape of BASELINE configs[4] -- carry ONE running
@@ -61,7 +62,13 @@ constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 vox
 // SRC: the launch reads running sums (k_src >= 0).  Every element lies strictly below the first non-trivial plane (host-checked), so
 // with SRC every ray of the launch crosses the source plane upwards (0 < tt < 1) and without it no ray sees anything: the look-up is
 // compiled in or out as a whole -- no per-element branch, no zero fill of the gather registers.
-template <int NF, int ES, bool CLAMP, bool SRC, bool ONE>
+// INSIDE (round 5): every element lies at least half a cell inside the lateral grid, so every crossing point -- a convex combination of
+// an element and a voxel with 0 < tt < 1 -- does too: the two clamps of the look-up coordinates are compiled out (host-checked, olx_launch_hmarch).
+// TEX (round 5; ONE, look-up launches): the source sums come as TEXELS -- cell (i, e, j) holds its whole 2 x 2 stencil {U(i,j), U(i,j+1), U(i+1,j),
+// U(i+1,j+1)} (u_texel_k below, once per launch sequence for the last non-trivial plane) -- so a look-up is ONE aligned 16-byte load instead of
+// two 8-byte ones.  The long run of planes above the medium is bound by the vector-memory instruction rate (a wave's load occupies the CU's
+// address unit ~14-16 cycles whatever its width: 2 loads x 4 SIMDs per CU > the ~100 issue cycles a SIMD needs per pair), not by bytes.
+template <int NF, int ES, bool CLAMP, bool SRC, bool ONE, bool INSIDE, bool TEX = false>
 __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const float* __restrict__ tab, const float4* __restrict__ med, const int* __restrict__ plane_of_k,
     const float2* __restrict__ U_src, float2* __restrict__ U_dst, const float* __restrict__ inv2z,
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const float x = igf * P.hx, y = jgf * P.hy, z = (float)kc * P.hz;
     // the voxel's own half layer
     float sv = 0.f, av = 0.f;
-    {
+    if constexpr (ES > 1) {                                 // (look-up launches, ES = 1, cover trivial planes only: no own term -- the host's segments)
         const int pq = plane_of_k[kc];                      // wave-uniform
         if (pq >= 0) {
             const float4 m = med[(((size_t)pq * H.nxg + ic) * H.nyg + jc) * 2];
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     const bool writer = ES > 1 && S.write && ftile == 0 && in_grid;        // (ES = 1 launches never write)
     const unsigned own = (unsigned)ig * row_cells + (unsigned)j;           // this voxel's cell in element 0's rows
     const float sv2 = 2.f * sv, av2 = 2.f * av;
-    const float kappa = H.kappa;                           // ONE: a' = kappa sig
+    const float k2 = -1.4426950408889634f * H.kappa;       // ONE: a' = kappa sig -> exp(-l sum a') = exp2(k2 l sum sig)
     if (live_k) {
         const int n_mine = (P.n_el - es + ES - 1) / ES;     // elements es, es + ES, ...
         for (int c0 = 0; c0 < n_mine; c0 += ECH) {
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     const bool two = 2 * r + 1 < NF;
-                    s_ray[wave][q][2 + r] = make_float4(te[HET_TAB_HEAD + 4 * r], te[HET_TAB_HEAD + 4 * r + 1],
+                    float w0 = te[HET_TAB_HEAD + 4 * r];
+                    if constexpr (ONE && NF == 1) w0 = __builtin_amdgcn_logf(w0);      // (log2; the single focus' weight rides in the exponent: v_log_f32(0) = -inf)
+                    s_ray[wave][q][2 + r] = make_float4(w0, te[HET_TAB_HEAD + 4 * r + 1],
                                                         two ? te[HET_TAB_HEAD + 4 * r + 2] : 0.f, two ? te[HET_TAB_HEAD + 4 * r + 3] : 0.f);
                 }
             }
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
             // wave waits out each L1 round trip); a ragged tail goes element by element
             auto group = [&](const int q0, auto count) {
                 constexpr int E = decltype(count)::value;
+                static_assert(!TEX || (ONE && SRC && ES == 1), "texel look-ups: one-sum look-up launches only");
                 typedef typename std::conditional<ONE, float2u_t, float4u_t>::type Row;      // a stencil row: {s00, s01} | {s00, a00, s01, a01}
                 Row lo[E], hi[E];
                 float fu[E], fv[E];
@@ -154,11 +164,19 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
 #pragma unroll
                     for (int s = 0; s < E; ++s) {            // phase 1: addresses and gathers
                         const float4 r0 = s_ray[wave][q0 + s][0];     // same address in every lane: an LDS broadcast
-                        const float u = __builtin_amdgcn_fmed3f(fmaf(r0.x, igf, r0.y), 0.f, umax);
-                        const float v = __builtin_amdgcn_fmed3f(fmaf(r0.x, jgf, r0.z), 0.f, vmax);
+                        float u = fmaf(r0.x, igf, r0.y), v = fmaf(r0.x, jgf, r0.z);
+                        if constexpr (!INSIDE) { u = __builtin_amdgcn_fmed3f(u, 0.f, umax); v = __builtin_amdgcn_fmed3f(v, 0.f, vmax); }
                         const unsigned i0 = (unsigned)(int)u, j0 = (unsigned)(int)v;
                         fu[s] = __builtin_amdgcn_fractf(u); fv[s] = __builtin_amdgcn_fractf(v);
                         // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
+                        if constexpr (TEX) {
+                            const char* Te = reinterpret_cast<const char*>(U_src) + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg * 16;
+                            const unsigned offt = (__umul24(i0, row_cells) + j0) * 16u;
+                            if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * 16 + offt + 15, (long long)H.nxg * row_cells * 16, 6)) { lo[s] = Row{}; hi[s] = lo[s]; continue; }
+                            const float4 t4 = *reinterpret_cast<const float4*>(Te + offt);
+                            lo[s] = Row{t4.x, t4.y}; hi[s] = Row{t4.z, t4.w};
+                            continue;
+                        }
                         constexpr int CB = ONE ? 4 : 8;      // bytes per cell of U
                         const char* Ue = reinterpret_cast<const char*>(U_src) + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg * CB;
                         const unsigned off = (__umul24(i0, row_cells) + j0) * CB;
@@ -193,9 +211,15 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                     const float ri = __builtin_amdgcn_rsqf(d2);
                     const float d = d2 * ri;
                     const float l = d * r0.w;                // path per layer [wavelengths]; 0 level with the element
-                    const float ssum = sa.x + sv;
-                    const float ph0 = fmaf(l, ssum, d);
-                    const float amp = ri * __expf(-l * (ONE ? kappa * ssum : sa.y + av));
+                    const float ssum = ES > 1 ? sa.x + sv : sa.x;
+                    const float q = l * ssum;                // extra acoustic path of the ray [wavelengths]
+                    const float ph0 = d + q;
+                    // exp(-l (sum a' + a'(v) / 2)) as one exp2: ONE: a' = kappa sig -> exp2(k2 q), k2 = -kappa log2(e); with a single focus per
+                    // tile its weight rides in the exponent too (log2 w from the ray table; w = 0 -> -inf -> 0)
+                    constexpr bool WEXP = ONE && NF == 1 && RW > 0;
+                    float amp;
+                    if constexpr (ONE) amp = ri * __builtin_amdgcn_exp2f(WEXP ? fmaf(k2, q, s_ray[wave][q0 + s][2].x) : k2 * q);
+                    else amp = ri * __builtin_amdgcn_exp2f(-1.4426950408889634f * l * (ES > 1 ? sa.y + av : sa.y));
                     float wf[2 * NF];                         // { w_f, phi_f }: from the ray table (ES = 1) or the steering table
                     if constexpr (RW > 0) {
 #pragma unroll
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {           // the ray sums above serve every focus of the tile
                         const float ph = ph0 + wf[2 * f + 1];
-                        const float a = amp * wf[2 * f];
+                        const float a = WEXP ? amp : amp * wf[2 * f];
                         re[f] = fmaf(a, __builtin_amdgcn_cosf(ph), re[f]);
                         im[f] = fmaf(a, __builtin_amdgcn_sinf(ph), im[f]);
                     }
@@ -257,6 +281,20 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     }
 }
 
+// U [i][element][j] float  ->  T [i][element][j] float4 = {U(i,j), U(i,j+1), U(i+1,j), U(i+1,j+1)}, the last row / column repeated (the look-ups
+// clamp their coordinates just inside the last cell, so the repeated values carry weight ~0).  One thread per cell, 16-byte stores.
+__global__ __launch_bounds__(256) void u_texel_k(const float* __restrict__ U, float4* __restrict__ T, int nxg, int n_el, int nyg) {
+    const long long cells = (long long)nxg * n_el * nyg;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= cells) return;
+    const int j = (int)(q % nyg);
+    const long long r = q / nyg;            // i * n_el + e
+    const int i = (int)(r / n_el);
+    const long long up = i + 1 < nxg ? (long long)n_el * nyg : 0;
+    const int rj = j + 1 < nyg ? 1 : 0;
+    T[q] = make_float4(U[q], U[q + rj], U[q + up], U[q + up + rj]);
+}
+
 }  // namespace olx
 
 using namespace olx;
@@ -267,26 +305,43 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
     const FieldParams& P = c->fp;
     const int nz = P.nz, np = (int)c->h_plane_k.size();
     const int ftiles = (c->plan_foci + NF - 1) / NF;
-    auto go = [&](int k_lo, int k_hi, int p_src, bool write) {
+    // every element at least half a cell inside the lateral grid -> no crossing point needs a clamp (the look-up coordinates are convex
+    // combinations of element and voxel positions; half a cell dwarfs their fp32 rounding)
+    bool inside = true;
+    for (int e = 0; e < c->n_el && inside; ++e) {
+        const double eu = (c->h_pos[e] - c->grid.origin[0]) / c->grid.spacing[0], ev = (c->h_pos[(size_t)c->n_el + e] - c->grid.origin[1]) / c->grid.spacing[1];
+        inside = eu >= 0.5 && eu <= c->hp.nxg - 1.5 && ev >= 0.5 && ev <= c->hp.nyg - 1.5;
+    }
+    auto go = [&](int k_lo, int k_hi, int p_src, bool write, bool tex = false) {
         if (k_hi < k_lo) return;
         MarchSeg S;
         S.k_lo = k_lo; S.k_hi = k_hi; S.k_src = p_src >= 0 ? c->h_plane_k[p_src] : -1; S.write = write ? 1 : 0;
         S.i0 = write ? 0 : c->slab.x_begin; S.ni = write ? c->hp.nxg : P.nx;
         S.reverse = write && (p_src & 1);
-        const float2* src = p_src >= 0 ? c->d_U[p_src & 1] : nullptr;
+        const float2* src = tex ? reinterpret_cast<const float2*>(c->d_Utex) : (p_src >= 0 ? c->d_U[p_src & 1] : nullptr);
         float2* dst = write ? c->d_U[(p_src + 1) & 1] : nullptr;
         const long long tiles = (long long)((S.ni + HM_TI - 1) / HM_TI) * ((P.ny + HM_TJ - 1) / HM_TJ);
-#define OLX_HM__(ES_, CL, SR, ON) S.nblocks = (unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)); \
-                             hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL, SR, ON>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), \
+#define OLX_HM___(ES_, CL, SR, ON, IN) S.nblocks = (unsigned)(tiles * ((ES_ == 1) ? (k_hi - k_lo + 4) / 4 : 1)); \
+                             hipLaunchKernelGGL((field_hmarch_k<NF, ES_, CL, SR, ON, IN>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), \
                                            dim3(64 * hm_waves<ES_>()), 0, c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, \
                                            c->d_inten, c->d_cplx, P, c->hp, S)
+#define OLX_HM__(ES_, CL, SR, ON) do { if (inside) { OLX_HM___(ES_, CL, SR, ON, true); } else { OLX_HM___(ES_, CL, SR, ON, false); } } while (0)
 #define OLX_HM_(ES_, CL, SR) do { if (c->march_one) { OLX_HM__(ES_, CL, SR, true); } else { OLX_HM__(ES_, CL, SR, false); } } while (0)
 #define OLX_HM(ES_, CL) do { if (p_src >= 0) { OLX_HM_(ES_, CL, true); } else { OLX_HM_(ES_, CL, false); } } while (0)
         if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }   // (4 or 8 element subsets per block: same time, measured)
+        else if (tex) {   // one-sum look-ups out of the texel form of the last running sums
+#define OLX_HMT(CL, IN) hipLaunchKernelGGL((field_hmarch_k<NF, 1, CL, true, true, IN, true>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), dim3(64 * hm_waves<1>()), 0, \
+                                           c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp, S)
+            S.nblocks = (unsigned)(tiles * ((k_hi - k_lo + 4) / 4));
+            if (c->clamp) { if (inside) OLX_HMT(true, true); else OLX_HMT(true, false); }
+            else          { if (inside) OLX_HMT(false, true); else OLX_HMT(false, false); }
+#undef OLX_HMT
+        }
         else       { if (c->clamp) OLX_HM(1, true); else OLX_HM(1, false); }
 #undef OLX_HM
 #undef OLX_HM_
 #undef OLX_HM__
+#undef OLX_HM___
     };
     if (np == 0) { go(0, nz - 1, -1, false); return; }
     go(0, c->h_plane_k[0] - 1, -1, false);                   // below the first non-trivial plane: homogeneous rays
@@ -295,7 +350,16 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
         go(c->h_plane_k[p] + 1, c->h_plane_k[p + 1] - 1, p, false);
         go(c->h_plane_k[p + 1], c->h_plane_k[p + 1], p, true);
     }
-    go(c->h_plane_k[np - 1] + 1, nz - 1, np - 1, false);
+    // the run of planes above the medium: with the one-sum form and enough planes to pay for it, the last running sums are first spread into
+    // texels (268 MB at 256 elements x 256^2: ~0.1 ms) so that every look-up is one load
+    const int top_lo = c->h_plane_k[np - 1] + 1;
+    const bool tex = c->march_one && c->d_Utex && nz - top_lo >= 16 && !getenv("OLX_MARCH_NO_TEXELS");
+    if (tex) {
+        const long long cells = (long long)c->hp.nxg * c->n_el * c->hp.nyg;
+        hipLaunchKernelGGL(u_texel_k, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const float*>(c->d_U[(np - 1) & 1]), c->d_Utex,
+                           c->hp.nxg, c->n_el, c->hp.nyg);
+    }
+    go(top_lo, nz - 1, np - 1, false, tex);
 }
 
 void olx_launch_hmarch(olx_ctx* c, float* pm) {

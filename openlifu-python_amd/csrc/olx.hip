@@ -62,7 +62,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
+                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_Utex, c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1250,6 +1250,17 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
             }
         const char* pin = getenv("OLX_MARCH_SUMS");
         if (one && s_ref != 0.0 && !(pin && !strcmp(pin, "2"))) { c->march_one = true; c->hp.kappa = (float)(a_ref / s_ref); }
+    }
+    if (c->march_one) {     // texel form of the last running sums (k_hmarch.hip TEX): 16 bytes per cell, 32-bit byte offsets like U
+        const size_t need = (size_t)n * nx * ny;
+        if (need * sizeof(float4) < ((size_t)1 << 32)) {
+            if (c->Utex_cap < need) {
+                if (c->d_Utex) hipFree(c->d_Utex);
+                c->d_Utex = nullptr; c->Utex_cap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_Utex, sizeof(float4) * need));
+                c->Utex_cap = need;
+            }
+        } else if (c->d_Utex) { hipFree(c->d_Utex); c->d_Utex = nullptr; c->Utex_cap = 0; }
     }
     c->h_plane_k = plane_k;
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,
