@@ -64,9 +64,10 @@ constexpr int HM_TJ = 16, HM_TI = 4;       // lateral tile of a wave: 4 x 16 vox
 // compiled in or out as a whole -- no per-element branch, no zero fill of the gather registers.
 // INSIDE (round 5): every element lies at least half a cell inside the lateral grid, so every crossing point -- a convex combination of
 // an element and a voxel with 0 < tt < 1 -- does too: the two clamps of the look-up coordinates are compiled out (host-checked, olx_launch_hmarch).
-// TEX (round 5; ONE, look-up launches): the source sums come as TEXELS -- cell (i, e, j) holds its whole 2 x 2 stencil {U(i,j), U(i,j+1), U(i+1,j),
-// U(i+1,j+1)} (u_texel_k below, once per launch sequence for the last non-trivial plane) -- so a look-up is ONE aligned 16-byte load instead of
-// two 8-byte ones.  The long run of planes above the medium is bound by the vector-memory instruction rate (a wave's load occupies the CU's
+// TEX (round 5; ONE, look-up launches): the source sums come as ROW PAIRS -- cell (i, e, j) holds {U(i,j), U(i+1,j)} (u_texel_k below, once per
+// launch sequence for the last non-trivial plane), so the cells j0 and j0 + 1 are the whole 2 x 2 stencil in 16 contiguous, 8-byte-aligned
+// bytes: a look-up is ONE 16-byte load instead of two 8-byte ones.  (Whole 2 x 2 texels per cell -- 16 bytes, aligned -- measured the same
+// time and twice the HBM traffic: 4.4 GB per launch, every cell's bytes being its own.)  The long run of planes above the medium is bound by the vector-memory instruction rate (a wave's load occupies the CU's
 // address unit ~14-16 cycles whatever its width: 2 loads x 4 SIMDs per CU > the ~100 issue cycles a SIMD needs per pair), not by bytes.
 template <int NF, int ES, bool CLAMP, bool SRC, bool ONE, bool INSIDE, bool TEX = false>
 __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
@@ -170,11 +171,11 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                         fu[s] = __builtin_amdgcn_fractf(u); fv[s] = __builtin_amdgcn_fractf(v);
                         // wave-uniform 64-bit bases (scalar registers) + one 32-bit byte offset per lane (a U plane is < 4 GiB)
                         if constexpr (TEX) {
-                            const char* Te = reinterpret_cast<const char*>(U_src) + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg * 16;
-                            const unsigned offt = (__umul24(i0, row_cells) + j0) * 16u;
-                            if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * 16 + offt + 15, (long long)H.nxg * row_cells * 16, 6)) { lo[s] = Row{}; hi[s] = lo[s]; continue; }
-                            const float4 t4 = *reinterpret_cast<const float4*>(Te + offt);
-                            lo[s] = Row{t4.x, t4.y}; hi[s] = Row{t4.z, t4.w};
+                            const char* Te = reinterpret_cast<const char*>(U_src) + (size_t)(es + ES * (c0 + q0 + s)) * H.nyg * 8;
+                            const unsigned offt = (__umul24(i0, row_cells) + j0) * 8u;
+                            if (!OLX_IN((long long)(es + ES * (c0 + q0 + s)) * H.nyg * 8 + offt + 15, (long long)H.nxg * row_cells * 8 + 8, 6)) { lo[s] = Row{}; hi[s] = lo[s]; continue; }
+                            const float4u_t t4 = *reinterpret_cast<const float4u_t*>(Te + offt);      // {U(i0,j0), U(i0+1,j0), U(i0,j0+1), U(i0+1,j0+1)}
+                            lo[s] = Row{t4.x, t4.z}; hi[s] = Row{t4.y, t4.w};
                             continue;
                         }
                         constexpr int CB = ONE ? 4 : 8;      // bytes per cell of U
@@ -281,18 +282,17 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
     }
 }
 
-// U [i][element][j] float  ->  T [i][element][j] float4 = {U(i,j), U(i,j+1), U(i+1,j), U(i+1,j+1)}, the last row / column repeated (the look-ups
-// clamp their coordinates just inside the last cell, so the repeated values carry weight ~0).  One thread per cell, 16-byte stores.
-__global__ __launch_bounds__(256) void u_texel_k(const float* __restrict__ U, float4* __restrict__ T, int nxg, int n_el, int nyg) {
+// U [i][element][j] float  ->  T [i][element][j] float2 = {U(i,j), U(i+1,j)}, the last row repeated (the look-ups stay just inside the last cell, so
+// the repeated value carries weight ~0).  One thread per cell, 8-byte stores; one cell of padding behind the array (the 16-byte load of the last cell).
+__global__ __launch_bounds__(256) void u_texel_k(const float* __restrict__ U, float2* __restrict__ T, int nxg, int n_el, int nyg) {
     const long long cells = (long long)nxg * n_el * nyg;
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= cells) return;
-    const int j = (int)(q % nyg);
+    if (q > cells) return;
+    if (q == cells) { T[q] = make_float2(0.f, 0.f); return; }
     const long long r = q / nyg;            // i * n_el + e
     const int i = (int)(r / n_el);
     const long long up = i + 1 < nxg ? (long long)n_el * nyg : 0;
-    const int rj = j + 1 < nyg ? 1 : 0;
-    T[q] = make_float4(U[q], U[q + rj], U[q + up], U[q + up + rj]);
+    T[q] = make_float2(U[q], U[q + up]);
 }
 
 }  // namespace olx
@@ -351,13 +351,13 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
         go(c->h_plane_k[p + 1], c->h_plane_k[p + 1], p, true);
     }
     // the run of planes above the medium: with the one-sum form and enough planes to pay for it, the last running sums are first spread into
-    // texels (268 MB at 256 elements x 256^2: ~0.1 ms) so that every look-up is one load
+    // row pairs (134 MB at 256 elements x 256^2: ~0.06 ms) so that every look-up is one load
     const int top_lo = c->h_plane_k[np - 1] + 1;
     const bool tex = c->march_one && c->d_Utex && nz - top_lo >= 16 && !getenv("OLX_MARCH_NO_TEXELS");
     if (tex) {
         const long long cells = (long long)c->hp.nxg * c->n_el * c->hp.nyg;
-        hipLaunchKernelGGL(u_texel_k, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const float*>(c->d_U[(np - 1) & 1]), c->d_Utex,
-                           c->hp.nxg, c->n_el, c->hp.nyg);
+        hipLaunchKernelGGL(u_texel_k, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const float*>(c->d_U[(np - 1) & 1]),
+                           reinterpret_cast<float2*>(c->d_Utex), c->hp.nxg, c->n_el, c->hp.nyg);
     }
     go(top_lo, nz - 1, np - 1, false, tex);
 }

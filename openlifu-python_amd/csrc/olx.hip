@@ -1251,16 +1251,14 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
         const char* pin = getenv("OLX_MARCH_SUMS");
         if (one && s_ref != 0.0 && !(pin && !strcmp(pin, "2"))) { c->march_one = true; c->hp.kappa = (float)(a_ref / s_ref); }
     }
-    if (c->march_one) {     // texel form of the last running sums (k_hmarch.hip TEX): 16 bytes per cell, 32-bit byte offsets like U
-        const size_t need = (size_t)n * nx * ny;
-        if (need * sizeof(float4) < ((size_t)1 << 32)) {
-            if (c->Utex_cap < need) {
-                if (c->d_Utex) hipFree(c->d_Utex);
-                c->d_Utex = nullptr; c->Utex_cap = 0;
-                HIPCHK(c, hipMalloc((void**)&c->d_Utex, sizeof(float4) * need));
-                c->Utex_cap = need;
-            }
-        } else if (c->d_Utex) { hipFree(c->d_Utex); c->d_Utex = nullptr; c->Utex_cap = 0; }
+    if (c->march_one) {     // row-pair form of the last running sums (k_hmarch.hip TEX): 8 bytes per cell + one cell of padding, 32-bit byte offsets like U
+        const size_t need = (size_t)n * nx * ny + 1;
+        if (c->Utex_cap < need) {
+            if (c->d_Utex) hipFree(c->d_Utex);
+            c->d_Utex = nullptr; c->Utex_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_Utex, sizeof(float2) * need));
+            c->Utex_cap = need;
+        }
     }
     c->h_plane_k = plane_k;
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,

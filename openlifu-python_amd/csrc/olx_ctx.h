@@ -102,7 +102,7 @@ struct olx_ctx {
     // marched ray sums (kernel 2m): model requested for the next olx_field_set_medium, decision, double-buffered U[element][i][j]
     int medium_model = 0;                      // OLX_MEDIUM_AUTO / _SAMPLED / _MARCHED
     bool march_one = false;                    // kernel 2m: a' = kappa sig everywhere -> ONE running sum per ray (hp.kappa)
-    float4* d_Utex = nullptr; size_t Utex_cap = 0;   // kernel 2m, one-sum form: the last running sums as 2 x 2 texels (one 16-byte load per look-up above the medium)
+    float2* d_Utex = nullptr; size_t Utex_cap = 0;   // kernel 2m, one-sum form: the last running sums as row pairs {U(i,j), U(i+1,j)} (one 16-byte load per look-up above the medium)
     bool marched = false; float2* d_U[2] = {nullptr, nullptr}; size_t U_cap = 0; std::vector<int> h_plane_k;
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
