@@ -58,7 +58,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     if (BK.npos <= 0) return;                           // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
-    const int NC = 15 + 2 * (KX - 1) + 1;               // table columns in use: ud' = 0 .. 15 + 2 (KX - 1)
+    const int SAW = T.sa_w;                             // elements of a super-block along x
+    const int NC = SAW + P.xs * (KX - 1);               // table columns in use: ud' = xs kx - al + (SAW - 1) in [0, NC)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
     // columns NC .. 31 of the rows in use are never generated, and their Toeplitz weights are zero -- 0 x garbage must stay 0
     for (int idx = tid; idx < TOEP_ROWS * (TOEP_TW - NC); idx += TOEP_WAVES * 64) {   // (every physical row: the rows rotate, below)
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     floatx4_t acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-    const int n_sb = T.nsa16 * P.nsb;
+    const int n_sb = T.nsa * P.nsb;
     const float inv_nc = 1.0f / (float)NC;
     OLX_STAMP(0);
     for (int sb = 0; sb < n_sb; ++sb) {
         const int sa = sb / P.nsb, sbb = sb - sa * P.nsb;
         // Toeplitz weights of the super-block's 8 element rows (this wave's K-step: hi + lo = 2 x 16 bytes per lane and row),
         // requested before the table is generated so that they arrive from L2 behind it
-        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa16 + sa) * T.ay_pad + TOEP_SB * sbb + (FP8 ? 4 * ks : 0)) * 4 * 64 + (FP8 ? 0 : ks * 64) + lane;
+        const uint4* ab = afrag + ((size_t)(blockIdx.y * T.nsa + sa) * T.ay_pad + TOEP_SB * sbb + (FP8 ? 4 * ks : 0)) * 4 * 64 + (FP8 ? 0 : ks * 64) + lane;
         constexpr int NB = FP8 ? TOEP_SB / 2 : TOEP_SB, NA = FP8 ? 4 : 2;      // element rows per wave and super-block; 16-byte weight pieces per row
         uint4 afr[NB][NA];
         __syncthreads();                                // table free (previous super-block consumed)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         const int rot = (TOEP_ROWS * 64 - TOEP_SB * sbb) % TOEP_ROWS;         // phys(r) = (r + rot) mod 18
         for (int idx = tid; idx < n_new * NC; idx += TOEP_WAVES * 64) {
             const int row = (int)(((float)idx + 0.5f) * inv_nc), col = idx - row * NC;      // exact for these small integers
-            const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - 15) - TOEP_SA * P.mx * sa);
+            const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - (SAW - 1)) - SAW * P.mx * sa);
             const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
             const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
             const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         __syncthreads();
         if (sb == 0) OLX_STAMP(3);
         // ---- contraction: element rows b of the super-block, this wave's y positions and K-step
+        const unsigned ksm = (T.ks_mask >> (2 * sa)) & 3u;      // K-steps of this column of super-blocks that carry weights (wave-uniform)
+        if (!FP8 && !((ksm >> ks) & 1u)) continue;              // (fp16 corrections: this wave's K-step is all zeros here; the barriers sit above)
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int bl = FP8 ? 4 * ks + bi : bi;      // element row of the super-block (FP8: wave-uniform)
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                     intx8_t b8;
                     b8[0] = (int)q0.x; b8[1] = (int)q0.y; b8[2] = (int)q0.z; b8[3] = (int)q0.w;
                     b8[4] = (int)q1.x; b8[5] = (int)q1.y; b8[6] = (int)q1.z; b8[7] = (int)q1.w;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[t], 0, 0, 0);
+                    if (ksm & 1u) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
+                    if (ksm & 2u) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[t], 0, 0, 0);
                     // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
                     acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[t], 0, 0, 0, 128, 0, 127);
                 } else {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const bool want = (P.flags & (out ? 2u : 1u)) != 0 && kx < KX && kz < P.nz;
     // store addresses: the targets (focus, mirror image) are block-uniform, so per lane only the two x forms of the voxel
     // offset are formed once; per (y position, target) the y term is scalar: one add + one 64-bit add per 16-byte store
-    const int i = ibase + 2 * P.mx * kx;
+    const int i = ibase + P.xs * P.mx * kx;
     const int sxz = P.ny * P.nz;
     const unsigned ox0 = (unsigned)(i * sxz + kz), ox1 = (unsigned)((P.nx - 1 - i) * sxz + kz);
     // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
@@ -257,13 +260,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     OLX_STAMP(6);
 }
 
-// Toeplitz weights of kernel 2f in MFMA lane order: afrag[(((tile nsa16 + sa) ay_pad + b) 4 + {hi s0, hi s1, lo s0, lo s1}) 64 + lane].
+// Toeplitz weights of kernel 2f in MFMA lane order: afrag[(((tile nsa + sa) ay_pad + b) 4 + {hi s0, hi s1, lo s0, lo s1}) 64 + lane].
 // Lane (m = lane & 15 -> kx = m >> 1, o = m & 1; k-group g): k = 32 s + 8 g + jj -> offset ud' = k >> 1, part c = k & 1,
-// element column a = 16 sa + 2 kx - (ud' - 15).  grid (nsa16 * ay_pad, tiles), block 64.
+// element column a = sa_w sa + xs kx - (ud' - (sa_w - 1)).  grid (nsa * ay_pad, tiles), block 64.
 __global__ void toep_pack_k(const double* __restrict__ area, int n, const double* __restrict__ delays, const double* __restrict__ apod,
                             const int* __restrict__ perm, double freq, double w_scale, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]*/, const int* __restrict__ cell /*[ax][ay] -> element*/,
-                            int ax, int ay, int ay_pad, int fp8corr /*1: the two lo pieces hold the row's e4m3 bytes instead*/, uint4* __restrict__ afrag) {
+                            int ax, int ay, int ay_pad, int fp8corr /*1: the two lo pieces hold the row's e4m3 bytes instead*/, int sa_w, int xs, uint4* __restrict__ afrag) {
     const int lane = threadIdx.x, tile = blockIdx.y;
     const int sa = blockIdx.x / ay_pad, b = blockIdx.x - sa * ay_pad;
     const int m = lane & 15, g = lane >> 4, kx = m >> 1, o = m & 1;
@@ -274,9 +277,9 @@ __global__ void toep_pack_k(const double* __restrict__ area, int n, const double
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int k = 32 * s + 8 * g + jj, udp = k >> 1, c = k & 1;
-            const int al = 2 * kx - (udp - 15), a = TOEP_SA * sa + al;
+            const int al = xs * kx - (udp - (sa_w - 1)), a = sa_w * sa + al;
             double val = 0.0;
-            if (al >= 0 && al < TOEP_SA && a < ax && b < ay && f >= 0 && f < n_foci) {
+            if (al >= 0 && al < sa_w && a < ax && b < ay && f >= 0 && f < n_foci) {
                 const int e = cell[(size_t)a * ay + b];
                 if (e >= 0) {
                     const int es = perm[mirror * n + e];
@@ -321,18 +324,18 @@ extern "C" int olx_exp_read_stamps_toep(unsigned long long* out) {
 
 void olx_pack_toep(olx_ctx* c) {
     const olx_ctx::Lattice& A = c->lat;
-    dim3 g(c->toep_nsa16 * 8 * A.nsb, c->mp.n_tiles);
+    dim3 g(c->toep_nsa * 8 * A.nsb, c->mp.n_tiles);
     hipLaunchKernelGGL(toep_pack_k, g, dim3(64), 0, c->stream, c->d_area, c->n_el, c->d_delays, c->d_apod, c->d_perm, c->freq,
-                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->fp8corr ? 1 : 0, c->d_afrag);
+                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->fp8corr ? 1 : 0, c->toep_saw, c->cp.xs, c->d_afrag);
 }
 
 template <int MX, int MY>
 static void launch_toep(olx_ctx* c, float* pm) {
     ToepParams T;
-    T.q = c->cp; T.nsa16 = c->toep_nsa16; T.ay_pad = 8 * c->lat.nsb;
+    T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
     for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
     const CosetParams& Q = T.q;
-    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
+    const long long blocks = (long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
     dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);
     if (c->dir_lattice) {   // piston directivity folded into the geometry tables
         if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);

@@ -7,7 +7,7 @@ namespace olx {
 
 constexpr int TOEP_KXW = 8, TOEP_KYW = 11;         // positions per block along x / y
 constexpr int TOEP_ZB = 16;                        // planes per block (the MFMA N dimension)
-constexpr int TOEP_SA = 16, TOEP_SB = 8;           // element super-block
+constexpr int TOEP_SA_MAX = 24, TOEP_SB = 8;       // element super-block: sa_w (<= 24, ToepParams) x 8; table columns = (KXW - 1) + sa_w <= 31
 constexpr int TOEP_ROWS = TOEP_SB + TOEP_KYW - 1;  // 18 table rows: wd = ky - b in [-7, 10]
 constexpr int TOEP_TW = 32;                        // words per table row: ud' = ud + 15 in [0, 30), padded to two K-steps
 constexpr int TOEP_PSZ = TOEP_ROWS * TOEP_TW + 8;  // 584 = 8 (mod 64): conflict-free ds_read_b128 (see above)
@@ -16,7 +16,9 @@ constexpr int TOEP_XS = 20;                        // floats per row of the exch
 
 struct ToepParams {
     CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
-    int nsa16;                 // element super-block columns of 16
+    int nsa;                   // element super-block columns
+    int sa_w;                  // elements of a super-block along x (<= TOEP_SA_MAX): the whole row for arrays up to 24 wide, else 24 + the rest
+    unsigned ks_mask;          // bit (2 sa + s): K-step s of super-block column sa carries non-zero weights (a narrow last column fills K-step 1 only)
     int ay_pad;                // 8 nsb
     int targets[4];            // store targets of the column: focus * 4 + mirror image, -1 = none
 };

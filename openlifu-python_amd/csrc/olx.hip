@@ -571,6 +571,9 @@ static int configure_variant_impl(olx_ctx* c) {
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
                 const int zb = COS_ZB;      // planes per block
+                // positions of a coset along x: two pitches apart for kernels 2e / 2g (their fragment reads are 8-byte aligned that way), ONE for kernel 2f
+                // (round 5: its 8-position row tiles then fill 7 - 8 of 8 slots on BASELINE's grids instead of 5 - 6, and its tables are shared by more rows)
+                Q.xs = c->use_toep ? 1 : 2;
                 olxplan::coset_partition(Q, kxw, zb, COS_KYW);
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
@@ -596,7 +599,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
                     // (the records depend on the partition only, not on the steering table: a call that changes nothing but the foci finds the
                     // records it uploaded last time still valid -- 9 216 of them on the headline grid, 0.1 ms to derive and compare)
-                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, 2, c->use_cosetp ? 40 : 0};
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, 2, c->use_cosetp ? 40 : 0, Q.xs};
                     std::vector<CosetBlock> blk;
                     if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
@@ -623,7 +626,23 @@ static int configure_variant_impl(olx_ctx* c) {
                 // dense / issued as `mfma_useful` (padding of rows, columns, K slots and the Toeplitz band all show up there)
                 const long long n_dense = (long long)((double)(P.nx - L.x_lo) * (P.ny - L.y_lo) * P.nz * (double)n * total_cols * 4.0 / 8192.0 * (c->fp8corr ? 2 : 3));
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
-                    c->toep_nsa16 = (A.ax + 15) / 16;
+                    // element super-blocks of kernel 2f along x: the whole row for arrays up to 24 wide, else columns of 24 and the rest -- the table then has
+                    // (KXW - 1) + 24 = 31 <= 32 columns = two K-steps, and a last column of <= 8 elements fills K-step 1 only (ks_mask)
+                    c->toep_saw = std::min(A.ax, 24);
+                    c->toep_nsa = (A.ax + c->toep_saw - 1) / c->toep_saw;
+                    c->toep_ksmask = 0;
+                    int ksteps_total = 0;       // non-zero K-steps over the super-block columns
+                    for (int sa = 0; sa < c->toep_nsa; ++sa) {
+                        const int wdt = std::min(c->toep_saw, A.ax - sa * c->toep_saw);      // elements of this column
+                        // table columns with weights: ud' = xs kx - al + (saw - 1), al < wdt, kx < KXW  ->  [saw - wdt, saw - 1 + xs (KXW - 1)]
+                        const int lo_c = c->toep_saw - wdt, hi_c = c->toep_saw - 1 + Q.xs * (8 - 1);
+                        unsigned m = 0;
+                        if (lo_c <= 15) m |= 1u;
+                        if (hi_c >= 16) m |= 2u;
+                        c->toep_ksmask |= m << (2 * sa);
+                        ksteps_total += (int)(m & 1u) + (int)(m >> 1);
+                    }
+                    if (c->toep_nsa > 16) return fail(c, OLX_ESTATE, "kernel 2f: more than 16 super-block columns");
                     for (int q = 0; q < 4; ++q) c->toep_targets[q] = tiles[0][0].tgt[q];
                     if (c->cell_cap < A.cell.size()) {
                         if (c->d_cell) hipFree(c->d_cell);
@@ -632,7 +651,7 @@ static int configure_variant_impl(olx_ctx* c) {
                         c->cell_cap = A.cell.size();
                     }
                     HIPCHK(c, hipMemcpy(c->d_cell, A.cell.data(), sizeof(int) * A.cell.size(), hipMemcpyHostToDevice));
-                    const size_t need = (size_t)ntiles * c->toep_nsa16 * 8 * A.nsb * 4 * 64;
+                    const size_t need = (size_t)ntiles * c->toep_nsa * 8 * A.nsb * 4 * 64;
                     if (c->afrag_cap < need) {
                         if (c->d_afrag) hipFree(c->d_afrag);
                         c->d_afrag = nullptr; c->afrag_cap = 0;
@@ -643,13 +662,15 @@ static int configure_variant_impl(olx_ctx* c) {
                     // products -- or, with e4m3 corrections, 2 fp16 products + one K = 128 e4m3 instruction (2 units)
                     long long n_mfma = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
-                    for (int rx = 0; rx < 2 * A.mx; ++rx)
+                    // per element row and y position: 3 fp16 products per non-zero K-step, or 1 per non-zero K-step + one e4m3 instruction (2 units) per column
+                    const long long per_row = c->fp8corr ? (long long)ksteps_total + 2LL * c->toep_nsa : 3LL * ksteps_total;
+                    for (int rx = 0; rx < Q.xs * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry) {
-                            const int kxa = rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
+                            const int kxa = rx < wx ? (wx - 1 - rx) / (Q.xs * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
                             for (int sx = 0; sx < Q.nsx; ++sx)
                                 for (int sy = 0; sy < Q.nsy; ++sy) {
                                     const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * (c->fp8corr ? 4 : 6) * c->toep_nsa16 * 8 * A.nsb * Q.kblocks;
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * per_row * 8 * A.nsb * Q.kblocks;
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "

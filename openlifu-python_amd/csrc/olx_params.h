@@ -78,6 +78,7 @@ struct CosetParams {
     int x_lo, y_lo, x_begin;
     int mx, my;
     int nsx, nsy;              // parts the coset's positions are cut into along x / y
+    int xs;                    // pitches between two positions of a coset along x: 2 (kernels 2e / 2g: aligned 8-byte fragment reads), 1 (kernel 2f)
     int kblocks;               // plane blocks of COS_ZB planes
     int nsa, nsb;
     int nsbp;                  // rows of the K-slot map: nsb, padded to an even count for the NT = 2 shape (shared pair tables)

@@ -146,7 +146,8 @@ void balance_store_targets(Tiles& tiles, int max_cols) {
 }
 
 void coset_partition(CosetParams& Q, int kxw, int zb, int kyw) {
-    const int kx_max = (Q.nx - Q.x_lo + 2 * Q.mx - 1) / (2 * Q.mx), ky_max = (Q.ny - Q.y_lo + Q.my - 1) / Q.my;
+    const int px = Q.xs * Q.mx;      // voxels between two positions of a coset along x
+    const int kx_max = (Q.nx - Q.x_lo + px - 1) / px, ky_max = (Q.ny - Q.y_lo + Q.my - 1) / Q.my;
     Q.nsx = (kx_max + kxw - 1) / kxw; Q.nsy = (ky_max + kyw - 1) / kyw;
     Q.kblocks = (Q.nz + zb - 1) / zb;
 }
@@ -155,7 +156,8 @@ void coset_partition(CosetParams& Q, int kxw, int zb, int kyw) {
 // same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
 bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, int max_pos,
                         std::vector<CosetBlock>& blk, std::string& msg) {
-    const unsigned nblk = (unsigned)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks);
+    const int px = Q.xs * Q.mx;
+    const unsigned nblk = (unsigned)(px * Q.my * Q.nsx * Q.nsy * Q.kblocks);
     blk.assign(nblk, CosetBlock{});
     const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
     for (unsigned id = 0; id < nblk; ++id) {
@@ -168,11 +170,11 @@ bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, int max_pos,
         const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
         const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
         const int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
-        const int kx_all = rx < wx ? (wx - 1 - rx) / (2 * Q.mx) + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
+        const int kx_all = rx < wx ? (wx - 1 - rx) / px + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
         const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;
         CosetBlock& B = blk[id];
-        B.ibase = Q.x_lo + rx + 2 * Q.mx * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
+        B.ibase = Q.x_lo + rx + px * kx0; B.jbase = Q.y_lo + ry + Q.my * ky0; B.k0 = kblock * zb;
         B.npos = (KX > 0 && KY > 0) ? KX * KY : 0; B.KY = KY > 0 ? KY : 1; B.ky_magic = 65536 / B.KY + 1; B.KX = KX > 0 ? KX : 0; B.pad_ = 0;
         if (max_pos > 0 && B.npos > max_pos) { msg = "a block part holds more than " + std::to_string(max_pos) + " positions"; return false; }
     }

@@ -181,14 +181,14 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         CHECK(!infer_foci(true, n, F, pos.data(), bad.data(), c0, origin[2], got), "scrambled delays accepted");
     }
     // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8, 16, 2, 0)
-    struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; };
-    const Form forms[] = {{"2g", 3, 16, 2, 40}, {"2e nt1", 6, 16, 2, 0}, {"2e nt4", 2, 16, 2, 0}, {"2f", 8, 16, 2, 0}};
+    struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; int xs; };
+    const Form forms[] = {{"2g", 3, 16, 2, 40, 2}, {"2e nt1", 6, 16, 2, 0, 2}, {"2e nt4", 2, 16, 2, 0, 2}, {"2f", 8, 16, 2, 0, 1}};
     for (const Form& fm : forms) {
         if (nt_force && fm.kxw != nt_force) continue;
         CosetParams Q{};
         Q.nx = S.x_count; Q.ny = S.n[1]; Q.nz = S.n[2]; Q.x_begin = S.x_begin;
         Q.x_lo = mxf == 2 ? Q.nx / 2 : 0; Q.y_lo = myf == 2 ? Q.ny / 2 : 0;
-        Q.mx = L.mx; Q.my = L.my; Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = (L.nsb + 1) & ~1;
+        Q.mx = L.mx; Q.my = L.my; Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = (L.nsb + 1) & ~1; Q.xs = fm.xs;
         Q.ux0 = (int)std::llround((origin[0] - L.x0) / S.h); Q.uy0 = (int)std::llround((origin[1] - L.y0) / S.h);
         coset_partition(Q, fm.kxw, fm.zb);
         std::vector<CosetBlock> blk;
@@ -197,7 +197,7 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
             const bool ok = build_coset_blocks(Q, fm.zb, fm.grp, fm.max_pos, blk, why);
             CHECK(ok, "%s: %s", fm.name, why.c_str());
             if (!ok) continue;
-            CHECK(blk.size() == (size_t)(2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks), "record count");
+            CHECK(blk.size() == (size_t)(Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks), "record count");
             const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
             std::vector<unsigned char> cover((size_t)wx * wy * Q.kblocks, 0);
             for (const CosetBlock& B : blk) {
@@ -208,7 +208,7 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
                 for (int pq = 0; pq < B.npos; ++pq) CHECK(((pq * B.ky_magic) >> 16) == pq / B.KY, "magic division %d / %d", pq, B.KY);
                 for (int kx = 0; kx < B.KX; ++kx)
                     for (int ky = 0; ky < B.KY; ++ky) {
-                        const int i = B.ibase + 2 * Q.mx * kx, j = B.jbase + Q.my * ky;
+                        const int i = B.ibase + Q.xs * Q.mx * kx, j = B.jbase + Q.my * ky;
                         CHECK(i >= Q.x_lo && i < Q.nx && j >= Q.y_lo && j < Q.ny, "position (%d, %d) outside the computed region", i, j);
                         if (i >= Q.x_lo && i < Q.nx && j >= Q.y_lo && j < Q.ny) cover[((size_t)(i - Q.x_lo) * wy + (j - Q.y_lo)) * Q.kblocks + B.k0 / fm.zb]++;
                     }
