@@ -81,7 +81,6 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int n_sb = T.nsa * P.nsb;
-    const float inv_nc = 1.0f / (float)NC;
     OLX_STAMP(0);
     for (int sb = 0; sb < n_sb; ++sb) {
         const int sa = sb / P.nsb, sbb = sb - sa * P.nsb;
@@ -107,8 +106,12 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         // 8 rows the previous super-block no longer needs) -- 18 + 8 (nsb - 1) instead of 18 nsb rows per column of super-blocks.
         const int n_new = sbb == 0 ? NR : min(NR, TOEP_SB);
         const int rot = (TOEP_ROWS * 64 - TOEP_SB * sbb) % TOEP_ROWS;         // phys(r) = (r + rot) mod 18
-        for (int idx = tid; idx < n_new * NC; idx += TOEP_WAVES * 64) {
-            const int row = (int)(((float)idx + 0.5f) * inv_nc), col = idx - row * NC;      // exact for these small integers
+        // columns that meet a weight in this column of super-blocks: ud' = xs kx - al + (SAW - 1) with al < (elements of the column) -- a narrow LAST
+        // column (32 elements = 24 + 8) uses the upper ones only; the others keep the previous column's entries (finite: 0 x them stays 0)
+        const int c_lo = SAW - min(SAW, T.ax - SAW * sa), ncol = NC - c_lo;
+        const float inv_ncol = 1.0f / (float)ncol;
+        for (int idx = tid; idx < n_new * ncol; idx += TOEP_WAVES * 64) {
+            const int row = (int)(((float)idx + 0.5f) * inv_ncol), col = c_lo + idx - row * ncol;      // exact for these small integers
             const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - (SAW - 1)) - SAW * P.mx * sa);
             const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
             const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
@@ -332,7 +335,7 @@ void olx_pack_toep(olx_ctx* c) {
 template <int MX, int MY>
 static void launch_toep(olx_ctx* c, float* pm) {
     ToepParams T;
-    T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
+    T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ax = c->lat.ax; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
     for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
     const CosetParams& Q = T.q;
     const long long blocks = (long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;

@@ -17,6 +17,7 @@ constexpr int TOEP_XS = 20;                        // floats per row of the exch
 struct ToepParams {
     CosetParams q;             // grid / coset geometry as kernel 2e (nsx, nsy for TOEP_KXW / TOEP_KYW, kblocks of TOEP_ZB planes)
     int nsa;                   // element super-block columns
+    int ax;                    // elements of the lattice along x
     int sa_w;                  // elements of a super-block along x (<= TOEP_SA_MAX): the whole row for arrays up to 24 wide, else 24 + the rest
     unsigned ks_mask;          // bit (2 sa + s): K-step s of super-block column sa carries non-zero weights (a narrow last column fills K-step 1 only)
     int ay_pad;                // 8 nsb
