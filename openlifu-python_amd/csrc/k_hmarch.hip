@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                     // tile its weight rides in the exponent too (log2 w from the ray table; w = 0 -> -inf -> 0)
                     constexpr bool WEXP = ONE && NF == 1 && RW > 0;
                     float amp;
-                    if constexpr (ONE) amp = ri * __builtin_amdgcn_exp2f(WEXP ? fmaf(k2, q, s_ray[wave][q0 + s][2].x) : k2 * q);
+                    if constexpr (WEXP) amp = ri * __builtin_amdgcn_exp2f(fmaf(k2, q, s_ray[wave][q0 + s][2].x));
+                    else if constexpr (ONE) amp = ri * __builtin_amdgcn_exp2f(k2 * q);
                     else amp = ri * __builtin_amdgcn_exp2f(-1.4426950408889634f * l * (ES > 1 ? sa.y + av : sa.y));
                     float wf[2 * NF];                         // { w_f, phi_f }: from the ray table (ES = 1) or the steering table
                     if constexpr (RW > 0) {

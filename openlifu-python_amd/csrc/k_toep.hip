@@ -40,7 +40,13 @@ namespace olx {
 // 16 + 4 g .. 16 + 4 g + 3 of the table row -- the two 16-byte pieces the hi fragments of the two K-steps sit at, so the e4m3 reads hit
 // the same conflict-free slots.  The instruction spans both K-steps, so the block's two wave groups split the ELEMENT ROWS of a
 // super-block (b = 0 .. 3 | 4 .. 7) instead of the K-steps; their partial sums meet in LDS as before.
-template <int MX, int MY, bool CLAMP, bool DIR = false, bool FP8 = false>
+// M2 (round 5; arrays up to 17 elements wide, i.e. every 16 x 16 array): TWO row tiles per block -- positions kx = 0 .. 7 and 8 .. 15 of the coset, the
+// whole half axis on BASELINE's grids -- that share the block's tables AND its Toeplitz weights: A[(kx + 8, o), ud'] = A[(kx, o), ud' - 8], so the
+// second tile is the same A fragment against the table row read 8 columns further on (32 bytes: the fragment reads stay aligned and
+// conflict-free; what they overrun -- the first columns of the next row, the plane's pad -- meets zero weights and is finite because the whole
+// arena is cleared at block entry).  Same matrix instructions as two blocks of <= 8 positions; one table of <= 31 columns instead of two of
+// <= 23, half the block prologues, barriers and weight loads per position.
+template <int MX, int MY, bool CLAMP, bool DIR = false, bool FP8 = false, bool M2 = false>
 __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
                                                                     float* __restrict__ inten, const CosetBlock* __restrict__ blocks /*[gridDim.x]*/,
                                                                     const ToepParams T) {
@@ -61,12 +67,9 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int SAW = T.sa_w;                             // elements of a super-block along x
     const int NC = SAW + P.xs * (KX - 1);               // table columns in use: ud' = xs kx - al + (SAW - 1) in [0, NC)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
-    // columns NC .. 31 of the rows in use are never generated, and their Toeplitz weights are zero -- 0 x garbage must stay 0
-    for (int idx = tid; idx < TOEP_ROWS * (TOEP_TW - NC); idx += TOEP_WAVES * 64) {   // (every physical row: the rows rotate, below)
-        const int row = idx / (TOEP_TW - NC), col = NC + idx - row * (TOEP_TW - NC);
-#pragma unroll
-        for (int z = 0; z < TOEP_ZB; ++z) { s_hi[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; s_lo[z * TOEP_PSZ + row * TOEP_TW + col] = 0u; }
-    }
+    // what is never generated -- columns NC .. 31, rows beyond NR, the pads -- meets zero Toeplitz weights: 0 x garbage must stay 0, so the
+    // whole arena is cleared once (16-byte stores; M2's second row tile also reads 8 columns past its row)
+    for (int idx = tid; idx < 2 * TOEP_ZB * TOEP_PSZ / 4; idx += TOEP_WAVES * 64) reinterpret_cast<uint4*>(s_T)[idx] = make_uint4(0u, 0u, 0u, 0u);
     // dz^2 of the block's 16 planes: wave-uniform, held in scalar registers (one v_add per evaluation instead of two fmas)
     float dz2[TOEP_ZB];
 #pragma unroll
@@ -77,9 +80,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4), this wave's K-step
     const int n16 = lane & 15, g = lane >> 4;
     const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + (FP8 ? 0 : 16 * ks));
-    floatx4_t acc[3];
+    constexpr int NM = M2 ? 2 : 1;                      // row tiles: positions 8 m .. 8 m + 7
+    const bool two = M2 && KX > 8;                      // (block-uniform)
+    floatx4_t acc[NM][3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[m][t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int n_sb = T.nsa * P.nsb;
     OLX_STAMP(0);
     for (int sb = 0; sb < n_sb; ++sb) {
@@ -172,23 +179,28 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 int prow = ky + 7 - bl + rot;
                 prow = prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow;
                 const unsigned w0 = bbase + (unsigned)(prow * TOEP_TW);
-                Half8Bits bh, bw;
-                bh.u = *reinterpret_cast<const uint4*>(s_hi + w0);
-                if constexpr (FP8) {
-                    bw.u = *reinterpret_cast<const uint4*>(s_hi + w0 + 16);                      // hi, K-step 1
-                    const uint4 q0 = *reinterpret_cast<const uint4*>(s_lo + w0), q1 = *reinterpret_cast<const uint4*>(s_lo + w0 + 16);
-                    intx8_t b8;
-                    b8[0] = (int)q0.x; b8[1] = (int)q0.y; b8[2] = (int)q0.z; b8[3] = (int)q0.w;
-                    b8[4] = (int)q1.x; b8[5] = (int)q1.y; b8[6] = (int)q1.z; b8[7] = (int)q1.w;
-                    if (ksm & 1u) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
-                    if (ksm & 2u) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[t], 0, 0, 0);
-                    // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
-                    acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[t], 0, 0, 0, 128, 0, 127);
-                } else {
-                    bw.u = *reinterpret_cast<const uint4*>(s_lo + w0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    if (m == 1 && !two) continue;                                                    // block-uniform
+                    const unsigned wm = w0 + 8u * (unsigned)m;                                       // second row tile: the same weights, 8 columns on
+                    Half8Bits bh, bw;
+                    bh.u = *reinterpret_cast<const uint4*>(s_hi + wm);
+                    if constexpr (FP8) {
+                        bw.u = *reinterpret_cast<const uint4*>(s_hi + wm + 16);                      // hi, K-step 1
+                        const uint4 q0 = *reinterpret_cast<const uint4*>(s_lo + wm), q1 = *reinterpret_cast<const uint4*>(s_lo + wm + 16);
+                        intx8_t b8;
+                        b8[0] = (int)q0.x; b8[1] = (int)q0.y; b8[2] = (int)q0.z; b8[3] = (int)q0.w;
+                        b8[4] = (int)q1.x; b8[5] = (int)q1.y; b8[6] = (int)q1.z; b8[7] = (int)q1.w;
+                        if (ksm & 1u) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
+                        if (ksm & 2u) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[m][t], 0, 0, 0);
+                        // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
+                        acc[m][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[m][t], 0, 0, 0, 128, 0, 127);
+                    } else {
+                        bw.u = *reinterpret_cast<const uint4*>(s_lo + wm);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[m][t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -200,11 +212,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     __syncthreads();
     float* const s_x = reinterpret_cast<float*>(s_T);
     {
-        float* xo = s_x + (wave * 3) * 16 * TOEP_XS + n16;
+        float* xo = s_x + (wave * 3 * NM) * 16 * TOEP_XS + n16;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xo[(t * 16 + 4 * g + r) * TOEP_XS] = acc[t][r];
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[((t * NM + m) * 16 + 4 * g + r) * TOEP_XS] = acc[m][t][r];
     }
     __syncthreads();
     // read-out: K-step 0 waves finish tiles t = 0, 2, K-step 1 waves tile t = 1.  Lane = (output, kx, plane quad): four
@@ -213,24 +227,28 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int kz = k0 + 4 * pq;
     const float sc = out ? P.out_scale * P.out_scale * P.inten_scale : P.out_scale;
     float* const vol = out ? inten : pmag;
-    const bool want = (P.flags & (out ? 2u : 1u)) != 0 && kx < KX && kz < P.nz;
+    const bool want0 = (P.flags & (out ? 2u : 1u)) != 0 && kz < P.nz;
     // store addresses: the targets (focus, mirror image) are block-uniform, so per lane only the two x forms of the voxel
     // offset are formed once; per (y position, target) the y term is scalar: one add + one 64-bit add per 16-byte store
-    const int i = ibase + P.xs * P.mx * kx;
     const int sxz = P.ny * P.nz;
-    const unsigned ox0 = (unsigned)(i * sxz + kz), ox1 = (unsigned)((P.nx - 1 - i) * sxz + kz);
     // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
     // splits every 16-byte store into a 12-byte and a 4-byte instruction)
     auto readout = [&](auto full_c) {
         constexpr bool FULL4 = decltype(full_c)::value != 0;
 #pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int t = ks ? 1 : 2 * tt;
             if (ks && tt) break;
             const int ky = kyg + 4 * t;
+            const int kxg = 8 * m + kx;                      // position of the coset along x
+            const bool want = want0 && kxg < KX;
             if (ky >= KY || !want) continue;
-            const float* xa = s_x + ((kyg * 3 + t) * 16 + 2 * kx) * TOEP_XS + 4 * pq;            // K-step 0 partial
-            const float* xb = xa + 4 * 3 * 16 * TOEP_XS;                                         // K-step 1 partial (wave + 4)
+            const int i = ibase + P.xs * P.mx * kxg;
+            const unsigned ox0 = (unsigned)(i * sxz + kz), ox1 = (unsigned)((P.nx - 1 - i) * sxz + kz);
+            const float* xa = s_x + (((kyg * 3 + t) * NM + m) * 16 + 2 * kx) * TOEP_XS + 4 * pq;   // first wave group's partial
+            const float* xb = xa + 4 * 3 * NM * 16 * TOEP_XS;                                    // second wave group's partial (wave + 4)
             const float4 ra = *reinterpret_cast<const float4*>(xa), ia = *reinterpret_cast<const float4*>(xa + TOEP_XS);
             const float4 rb = *reinterpret_cast<const float4*>(xb), ib = *reinterpret_cast<const float4*>(xb + TOEP_XS);
             const float re[4] = {ra.x + rb.x, ra.y + rb.y, ra.z + rb.z, ra.w + rb.w};
@@ -345,13 +363,16 @@ static void launch_toep(olx_ctx* c, float* pm) {
         else hipLaunchKernelGGL((field_toep_k<MX, MY, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         return;
     }
+#define OLX_TP(CL, F8, M2_) hipLaunchKernelGGL((field_toep_k<MX, MY, CL, false, F8, M2_>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T)
+    const bool cl = c->clamp || c->lat.clamp;
     if (c->fp8corr) {       // e4m3 correction products (the planner's gated default)
-        if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
-        else hipLaunchKernelGGL((field_toep_k<MX, MY, false, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
-        return;
+        if (c->toep_m2) { if (cl) OLX_TP(true, true, true); else OLX_TP(false, true, true); }
+        else            { if (cl) OLX_TP(true, true, false); else OLX_TP(false, true, false); }
+    } else {
+        if (c->toep_m2) { if (cl) OLX_TP(true, false, true); else OLX_TP(false, false, true); }
+        else            { if (cl) OLX_TP(true, false, false); else OLX_TP(false, false, false); }
     }
-    if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
-    else hipLaunchKernelGGL((field_toep_k<MX, MY, false>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
+#undef OLX_TP
 }
 
 void olx_launch_toep(olx_ctx* c, float* pm) {

@@ -569,7 +569,10 @@ static int configure_variant_impl(olx_ctx* c) {
             if (c->use_coset) {
                 CosetParams& Q = c->cp;
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
-                const int kxw = c->use_toep ? 8 : cos_kxw(c->nt);   // (kernel 2f: TOEP_KXW positions along x per block)
+                // kernel 2f: 8 positions along x per row tile; arrays up to 17 elements wide take TWO row tiles per block (<= 16 positions: the tiles share
+                // tables and Toeplitz weights, k_toep.hip M2; wider arrays need the table's 32 columns for one tile: (8 - 1) + 24 = 31)
+                c->toep_m2 = c->use_toep && A.ax + 15 <= 32;
+                const int kxw = c->use_toep ? (c->toep_m2 ? 16 : 8) : cos_kxw(c->nt);
                 const int zb = COS_ZB;      // planes per block
                 // positions of a coset along x: two pitches apart for kernels 2e / 2g (their fragment reads are 8-byte aligned that way), ONE for kernel 2f
                 // (round 5: its 8-position row tiles then fill 7 - 8 of 8 slots on BASELINE's grids instead of 5 - 6, and its tables are shared by more rows)
@@ -635,7 +638,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     for (int sa = 0; sa < c->toep_nsa; ++sa) {
                         const int wdt = std::min(c->toep_saw, A.ax - sa * c->toep_saw);      // elements of this column
                         // table columns with weights: ud' = xs kx - al + (saw - 1), al < wdt, kx < KXW  ->  [saw - wdt, saw - 1 + xs (KXW - 1)]
-                        const int lo_c = c->toep_saw - wdt, hi_c = c->toep_saw - 1 + Q.xs * (8 - 1);
+                        const int lo_c = c->toep_saw - wdt, hi_c = c->toep_saw - 1 + Q.xs * (8 - 1);      // (of ONE row tile: the second tile of M2 reads the same fragments)
                         unsigned m = 0;
                         if (lo_c <= 15) m |= 1u;
                         if (hi_c >= 16) m |= 2u;
@@ -670,7 +673,7 @@ static int configure_variant_impl(olx_ctx* c) {
                             for (int sx = 0; sx < Q.nsx; ++sx)
                                 for (int sy = 0; sy < Q.nsy; ++sy) {
                                     const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * per_row * 8 * A.nsb * Q.kblocks;
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * per_row * ((KX + 7) / 8) * 8 * A.nsb * Q.kblocks;      // (row tiles of 8 positions)
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "

@@ -180,9 +180,9 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         for (int e = 0; e < n; e += 3) bad[e] += 1e-7 * (1 + e % 5);
         CHECK(!infer_foci(true, n, F, pos.data(), bad.data(), c0, origin[2], got), "scrambled delays accepted");
     }
-    // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8, 16, 2, 0)
+    // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8 | 16, 16, 2, 0; positions one pitch apart)
     struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; int xs; };
-    const Form forms[] = {{"2g", 3, 16, 2, 40, 2}, {"2e nt1", 6, 16, 2, 0, 2}, {"2e nt4", 2, 16, 2, 0, 2}, {"2f", 8, 16, 2, 0, 1}};
+    const Form forms[] = {{"2g", 3, 16, 2, 40, 2}, {"2e nt1", 6, 16, 2, 0, 2}, {"2e nt4", 2, 16, 2, 0, 2}, {"2f", 8, 16, 2, 0, 1}, {"2f m2", 16, 16, 2, 0, 1}};
     for (const Form& fm : forms) {
         if (nt_force && fm.kxw != nt_force) continue;
         CosetParams Q{};
