@@ -571,7 +571,9 @@ static int configure_variant_impl(olx_ctx* c) {
                 Q.nx = L.nx; Q.ny = L.ny; Q.nz = L.nz; Q.x_lo = L.x_lo; Q.y_lo = L.y_lo; Q.x_begin = L.x_begin; Q.mx = L.mx; Q.my = L.my;
                 // kernel 2f: 8 positions along x per row tile; arrays up to 17 elements wide take TWO row tiles per block (<= 16 positions: the tiles share
                 // tables and Toeplitz weights, k_toep.hip M2; wider arrays need the table's 32 columns for one tile: (8 - 1) + 24 = 31)
-                c->toep_m2 = c->use_toep && A.ax + 15 <= 32;
+                int saw_plan = std::min(A.ax, 24);       // element super-block width of kernel 2f (see below)
+                if (const char* e = getenv("OLX_EXP_TOEP_SAW")) { const int v = atoi(e); if (v >= 8 && v <= 24) saw_plan = std::min(A.ax, v); }   // (A/B)
+                c->toep_m2 = c->use_toep && saw_plan + 15 <= 32;
                 const int kxw = c->use_toep ? (c->toep_m2 ? 16 : 8) : cos_kxw(c->nt);
                 const int zb = COS_ZB;      // planes per block
                 // positions of a coset along x: two pitches apart for kernels 2e / 2g (their fragment reads are 8-byte aligned that way), ONE for kernel 2f
@@ -631,7 +633,7 @@ static int configure_variant_impl(olx_ctx* c) {
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     // element super-blocks of kernel 2f along x: the whole row for arrays up to 24 wide, else columns of 24 and the rest -- the table then has
                     // (KXW - 1) + 24 = 31 <= 32 columns = two K-steps, and a last column of <= 8 elements fills K-step 1 only (ks_mask)
-                    c->toep_saw = std::min(A.ax, 24);
+                    c->toep_saw = saw_plan;
                     c->toep_nsa = (A.ax + c->toep_saw - 1) / c->toep_saw;
                     c->toep_ksmask = 0;
                     int ksteps_total = 0;       // non-zero K-steps over the super-block columns
