@@ -35,6 +35,15 @@ from .target_constraints import TargetConstraints
 
 OnPulseMismatchAction = Enum("OnPulseMismatchAction", ["ERROR", "ROUND", "ROUNDUP", "ROUNDDOWN"])
 
+def _standin_coords(coords):
+    """The coordinate vectors of ``coords`` (whatever the Dataset factories made them of) as this package's own stand-in DataArrays, attrs kept:
+    what the lazy Datasets of ``calc_solution`` are labelled with while real xarray objects are only built at the end."""
+    from collections import OrderedDict
+    dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
+    return OrderedDict((d, ds.DataArray(np.asarray(coords[d].data if hasattr(coords[d], "data") else coords[d]), dims=(d,), name=d,
+                                        attrs=dict(getattr(coords[d], "attrs", {})))) for d in dims)
+
+
 def aggregate_dataset_eager(agg, coords, dims):
     """Dataset{p_min, p_max, intensity} of an ``AggregateResult`` read to the host NOW (three fresh arrays), built through
     ``ds.make_dataarray`` -- the form that also works when ``ds`` hands out real xarray objects."""
@@ -178,7 +187,16 @@ class Protocol:
         sim_options = self.sim_setup if sim_options is None else sim_options
         analysis_options = self.analysis_options if analysis_options is None else analysis_options
         self.check_target(target)
-        params = sim_options.setup_sim_scene(self.seg_method, volume=volume)
+        custom_seam = run_simulation is not sim.run_simulation  # patched seam (reference tests mock it)
+        # `params` never leaves this call on the built-in path.  With xarray installed the Dataset factories hand out real xarray objects, which
+        # cannot defer: the uniform reference medium would cost five full volumes (0.3 s at 256^3) nobody reads -- the call then works on the
+        # package's own lazy stand-ins and labels what it RETURNS with the factories' coordinates (`out_coords`)
+        if ds.HAVE_XARRAY and simulate and not custom_seam and volume is None and hasattr(self.seg_method, "ref_params"):
+            out_coords = sim_options.get_coords()
+            params = self.seg_method.ref_params(_standin_coords(out_coords), _internal=True)
+        else:
+            params = sim_options.setup_sim_scene(self.seg_method, volume=volume)
+            out_coords = params.coords
         foci = self.focal_pattern.get_targets(target)
         if self.sequence.pulse_count % len(foci) != 0:
             self.fix_pulse_mismatch(on_pulse_mismatch, foci)
@@ -187,26 +205,20 @@ class Protocol:
         delays, apod, resident = self.beamform_foci(transducer, foci, params)
         stacked = ds.make_dataset()
         fields = None
-        custom_seam = run_simulation is not sim.run_simulation  # patched seam (reference tests mock it)
         if simulate and not custom_seam:
             self.logger.info(f"Simulate for {len(foci)} foci...")
             # precision option, SimSetup.options["fp8_correction"] = "0" (sim_setup.py:51 "Additional simulation options"): keeps three fp16
             # products where the lattice kernels would use their e4m3 correction products (the default; <= 6.5e-6 of the focal peak)
             fp8 = False if str(getattr(sim_options, "options", {}).get("fp8_correction", "auto")).lower() in ("0", "false", "no") else None
-            # the per-focus volumes stay in HBM (scale / aggregate / analyze below run there); the Dataset hands them to
-            # the host on first access.  Real xarray objects cannot defer, so with xarray installed they are fetched now.
+            # the per-focus volumes stay in HBM (scale / aggregate / analyze below run there); the Dataset hands them to the host on first
+            # access.  Real xarray objects cannot defer: with xarray installed the call works on the SAME lazy stand-ins and converts at
+            # the end (`eager_out` below) -- one fetch of the final, scaled volumes instead of fetch, host-side scaling and re-upload
             fields = simulate_foci(transducer, params, delays, apod, self.pulse.frequency,
-                                   self.pulse.amplitude * voltage, steering_resident=resident, fp8_correction=fp8,
-                                   lazy=not ds.HAVE_XARRAY,
+                                   self.pulse.amplitude * voltage, steering_resident=resident, fp8_correction=fp8, lazy=True,
                                    hetero_planes_per_layer=int(getattr(sim_options, "options", {}).get("hetero_planes_per_layer", 1)),
                                    directivity=str(getattr(sim_options, "options", {}).get("directivity", "0")).lower() in ("1", "true", "yes"))
             coords = params.coords
-            if not ds.HAVE_XARRAY:
-                stacked = lazy_stack(fields, coords)
-            else:  # pragma: no cover - xarray is absent in the build image
-                pm = fields["pmag"]
-                stacked = ds.stack_foci({"p_max": (pm, coords, _ATTRS["p_max"]), "p_min": (pm.copy(), coords, _ATTRS["p_min"]),
-                                         "intensity": (fields["intensity"], coords, _ATTRS["intensity"])})
+            stacked = lazy_stack(fields, _standin_coords(coords) if ds.HAVE_XARRAY else coords, internal=ds.HAVE_XARRAY)
         elif simulate:
             cycles = np.min([np.round(self.pulse.duration * self.pulse.frequency), 20])
             outs = [run_simulation(arr=transducer, params=params, delays=delays[i], apod=apod[i],
@@ -248,18 +260,25 @@ class Protocol:
             agg = eng.adopt_aggregate()
         else:
             agg = fused_agg if fused_agg is not None else eng.aggregate_lazy(want_intensity=True)
-        coords = params.coords
+        coords = out_coords
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         shape = agg.shape
-        if ds.HAVE_XARRAY:
-            # real xarray objects cannot defer (xa.Dataset would turn a LazyDataArray into an unnamed-dims ndarray and raise
-            # MissingDimensionsError): fetch now, like the per-focus volumes above
+        eager_out = ds.HAVE_XARRAY and fields is not None
+        if ds.HAVE_XARRAY and not eager_out:
+            # (a patched run_simulation seam: its Datasets are whatever it returned) real xarray objects cannot defer: fetch now
             aggregated = aggregate_dataset_eager(agg, coords, dims)
-        else:
+        elif not eager_out:
             def lazy(name, key):
                 return agg.lazy_array(key, lambda fetch: ds.LazyDataArray(shape, np.float32, fetch, coords=coords, dims=dims, name=name,
                                                                           attrs=_ATTRS[name]))
             aggregated = ds.make_dataset({"p_min": lazy("p_min", "pmag"), "p_max": lazy("p_max", "pmag"), "intensity": lazy("intensity", "intensity")})
         if analysis is None:
             analysis = solution.analyze(options=analysis_options, param_constraints=self.param_constraints, _host_unchanged=True)
+        if eager_out:
+            # everything above ran on the device against the lazy stand-ins; now hand out what the Dataset factories make (real xarray objects
+            # when xarray is installed): ONE fetch of the final per-focus volumes and of the aggregate (xa.Dataset cannot hold a
+            # LazyDataArray: MissingDimensionsError)
+            res = solution.simulation_result
+            solution.simulation_result = ds.stack_foci({k: (np.asarray(res[k].data), coords, _ATTRS[k]) for k in ("p_max", "p_min", "intensity")})
+            aggregated = aggregate_dataset_eager(agg, coords, dims)
         return solution, aggregated, analysis

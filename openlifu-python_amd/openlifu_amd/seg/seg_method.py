@@ -85,11 +85,11 @@ class SegmentationMethod(ABC):
     def seg_params(self, volume, materials: dict | None = None):
         return self._map_params(self._segment(volume), materials=self.materials if materials is None else materials)
 
-    def ref_params(self, coords):
+    def ref_params(self, coords, _internal: bool = False):
         """Uniform reference medium on ``coords`` (seg_method.py:104-107).  Every voxel of every parameter volume holds the
         reference material's value, so the volumes are declared constant and only allocated if somebody reads them
         (same values, shapes, dims and attrs as ``_map_params(_ref_segment(coords))``)."""
-        if ds.HAVE_XARRAY:  # pragma: no cover - real xarray objects cannot defer
+        if ds.HAVE_XARRAY and not _internal:  # pragma: no cover - real xarray objects cannot defer
             return self._map_params(self._ref_segment(coords))
         dims = list(coords.dims) if hasattr(coords, "dims") else list(coords.keys())
         shape = [len(coords[d]) for d in dims]
@@ -99,7 +99,8 @@ class SegmentationMethod(ABC):
                                                  attrs={"units": info["units"], "long_name": info["name"],
                                                         "ref_value": reference.get_param(pid)})
                    for pid, info in PARAM_INFO.items()}
-        params = ds.make_dataset(volumes)
+        # (_internal: calc_solution's working copy -- the stand-in Dataset whatever the factories hand out)
+        params = ds.Dataset(volumes) if _internal else ds.make_dataset(volumes)
         params.attrs["ref_material"] = reference
         return params
 

@@ -74,7 +74,7 @@ def simulate_foci(arr, params, delays, apod, freq, amplitude, want=("pmag", "int
                               fp8_correction=fp8_correction, lazy=lazy, directivity=directivity, absorption=absorption)
 
 
-def lazy_stack(result, coords, dim="focal_point_index"):
+def lazy_stack(result, coords, dim="focal_point_index", internal=False):
     """Dataset{p_max, p_min, intensity}[focal_point_index, x, y, z] (plan/protocol.py:341-347) over a DeviceResult:
     three independent LazyDataArrays (p_max and p_min are separate host arrays once read, as callers scale them
     independently, plan/solution.py:333-334)."""
@@ -86,7 +86,8 @@ def lazy_stack(result, coords, dim="focal_point_index"):
     for name, key in (("p_max", "pmag"), ("p_min", "pmag"), ("intensity", "intensity")):
         out[name] = result.lazy_array(key, lambda fetch, name=name: ds.LazyDataArray(
             result.shape, np.float32, fetch, coords=c, dims=dims, name=name, attrs=_ATTRS[name]))
-    return ds.make_dataset(out)
+    # (internal: the stand-in Dataset whatever the factories hand out -- calc_solution's working copy when xarray is installed)
+    return ds.Dataset(out) if internal else ds.make_dataset(out)
 
 
 def dataset_from_fields(fields, coords, focus=None):

@@ -791,7 +791,7 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
                   slab=(13, 14), expect="field_coset")
 
 
-@pytest.mark.parametrize("case", ["16x16", "16x16_e4m3", "32x32_e4m3_opted_out", "padded20x12", "32x32_parts", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
+@pytest.mark.parametrize("case", ["16x16", "16x16_e4m3", "32x32_e4m3_opted_out", "padded20x12", "32x32_parts", "widths_18_28_40", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
 def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
     """Kernel 2f (one steering column: an on-axis focus on a mirror-symmetric lattice array; Toeplitz weights stationary, 16
     planes per MFMA tile) against the fp64 oracle, full volume: element counts that pad the 16 x 8 super-blocks, arrays of
@@ -811,6 +811,11 @@ def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
         _lattice_case(ctx, 20, 12, (2.4, 1.8), (50, 46, 37), (0.6, 0.6, 0.5), expect="field_toep")
     elif case == "32x32_parts":       # 4 x 4 super-blocks of 8 x 8 -> 2 x 4 of 16 x 8; 11 positions per coset along x, 22 along y: parts
         _lattice_case(ctx, 32, 32, (1.5, 1.5), (132, 132, 20), (0.25, 0.25, 0.5), foci=[[0, 0, 12e-3]], expect="field_toep")
+    elif case == "widths_18_28_40":   # element super-blocks along x: 18 = one column without the second row tile; 28 = 24 + 4 and 40 = 24 + 16 (the last column
+        # fills one / both K-steps); with e4m3 corrections (foci inside, N_eff >= 256 where the array is large enough) and opted out
+        for nax, nay, grid, zf in ((18, 16, (72, 48, 40), 14e-3), (28, 10, (90, 40, 24), 12e-3), (40, 8, (124, 36, 24), 12e-3)):
+            for opt in (None, False):
+                _lattice_case(ctx, nax, nay, (1.5, 1.5), grid, (0.5, 0.5, 0.5), foci=[[0, 0, zf]], expect="field_toep_k<mx2,my2,flat,noclamp", solve=True, fp8=opt)
     elif case == "ragged_planes":
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 44, 21), (1.0, 1.0, 1.0), z0=3e-3, expect="field_toep")
     elif case == "y_slab_fold_only":
