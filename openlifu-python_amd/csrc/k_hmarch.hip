@@ -329,7 +329,13 @@ static void launch_hmarch_nf(olx_ctx* c, float* pm) {
 #define OLX_HM__(ES_, CL, SR, ON) do { if (inside) { OLX_HM___(ES_, CL, SR, ON, true); } else { OLX_HM___(ES_, CL, SR, ON, false); } } while (0)
 #define OLX_HM_(ES_, CL, SR) do { if (c->march_one) { OLX_HM__(ES_, CL, SR, true); } else { OLX_HM__(ES_, CL, SR, false); } } while (0)
 #define OLX_HM(ES_, CL) do { if (p_src >= 0) { OLX_HM_(ES_, CL, true); } else { OLX_HM_(ES_, CL, false); } } while (0)
-        if (write) { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }   // (4 or 8 element subsets per block: same time, measured)
+        // element subsets per writer block: 16 for the two-sum form (4, 8, 16 measured the same in round 3: HBM-bound on U), 4 for the one-sum form
+        // (round 5, same box, alternating: 4.18 / 3.99 / 3.87 / 4.38 ms per focus with 16 / 8 / 4 / 2 subsets -- with half the bytes the launch
+        // is no longer bandwidth-bound and 256-thread blocks of 64 elements per wave keep more independent work per CU)
+        if (write) {
+            if (c->march_one) { if (c->clamp) OLX_HM(4, true); else OLX_HM(4, false); }
+            else              { if (c->clamp) OLX_HM(16, true); else OLX_HM(16, false); }
+        }
         else if (tex) {   // one-sum look-ups out of the texel form of the last running sums
 #define OLX_HMT(CL, IN) hipLaunchKernelGGL((field_hmarch_k<NF, 1, CL, true, true, IN, true>), dim3((S.nblocks + 7u) / 8u * 8u, ftiles), dim3(64 * hm_waves<1>()), 0, \
                                            c->stream, c->d_tab, c->d_med, c->d_plane_of_k, src, dst, c->d_inv2z, pm, c->d_inten, c->d_cplx, P, c->hp, S)
