@@ -342,6 +342,13 @@ typedef struct olx_focus_report {
 int olx_solution_analyze(olx_ctx *ctx, const double *A, const double *ita_weights, const double *line_pts,
                          const olx_analysis_opts *opts, const double *scale_per_focus, olx_focus_report *reports,
                          float *ita_global);
+/* The same in two halves, for callers that have host work of their own to do meanwhile (Solution.analyze evaluates the emitted pressure / power /
+ * thermal index beside it): _begin copies its arguments, enqueues every kernel and the copy of the report on the context's stream and returns;
+ * _finish waits for the stream and unpacks the report.  Between the two the context must not be used for anything else (one caller thread per
+ * context; every other entry point that touches the stream would order itself behind the analysis anyway).  olx_solution_analyze = both. */
+int olx_solution_analyze_begin(olx_ctx *ctx, const double *A, const double *ita_weights, const double *line_pts,
+                               const olx_analysis_opts *opts, const double *scale_per_focus);
+int olx_solution_analyze_finish(olx_ctx *ctx, olx_focus_report *reports, float *ita_global);
 
 /* ---- multi-GPU reassembly (RCCL over xGMI) -------------------------------------------
  * One context per rank.  id_bytes = the 128-byte ncclUniqueId made by rank 0

@@ -1929,11 +1929,12 @@ int olx_field_weighted_fetch(olx_ctx* c, float* out) {
 // synchronisation: 7.6 of calc_solution's 11 ms.  Here the same kernels are enqueued back to back; the numbers that feed later
 // steps (mainlobe peak -> -3 dB centroid cut-off, beam-width cut-offs) stay on the device; one pinned block goes in, one
 // comes out, one synchronisation.  Scratch is owned by the context and reused.
-int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
-                         const olx_analysis_opts* o, const double* scale_per_focus, olx_focus_report* reports, float* ita_global) {
+int olx_solution_analyze_begin(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
+                               const olx_analysis_opts* o, const double* scale_per_focus) {
     if (!c) return OLX_EINVAL;
+    c->an_pending = false;
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_solution_analyze: nothing planned");
-    if (!A || !ita_weights || !o || !reports || !ita_global) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
+    if (!A || !ita_weights || !o) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
     if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_solution_analyze: intensity not planned");
     const int F = c->plan_foci;
     if (F > 4096) return fail(c, OLX_EINVAL, "olx_solution_analyze: too many foci");
@@ -2018,7 +2019,21 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h + out_pk, d + out_pk, out_end - out_pk, hipMemcpyDeviceToHost, c->stream));
+    // everything is enqueued; the report sits in the pinned block once the stream has drained (olx_solution_analyze_finish)
+    c->an_pending = true; c->an_F = F; c->an_npts = npts; c->an_out_pk = out_pk; c->an_out_ita = out_ita; c->an_out_bd = out_bd; c->an_out_mom = out_mom;
+    return OLX_OK;
+}
+
+int olx_solution_analyze_finish(olx_ctx* c, olx_focus_report* reports, float* ita_global) {
+    if (!c) return OLX_EINVAL;
+    if (!reports || !ita_global) return fail(c, OLX_EINVAL, "olx_solution_analyze_finish: null argument");
+    if (!c->an_pending) return fail(c, OLX_ESTATE, "olx_solution_analyze_finish: no analysis in flight (olx_solution_analyze_begin first)");
+    c->an_pending = false;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned char* h = static_cast<const unsigned char*>(c->h_an);
+    const int F = c->an_F, npts = c->an_npts;
+    const size_t out_pk = c->an_out_pk, out_ita = c->an_out_ita, out_bd = c->an_out_bd, out_mom = c->an_out_mom;
     const float* pk = reinterpret_cast<const float*>(h + out_pk);
     const float* ita = reinterpret_cast<const float*>(h + out_ita);
     const int* bd = reinterpret_cast<const int*>(h + out_bd);
@@ -2032,6 +2047,13 @@ int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights,
     }
     *ita_global = ita[F];
     return OLX_OK;
+}
+
+int olx_solution_analyze(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
+                         const olx_analysis_opts* o, const double* scale_per_focus, olx_focus_report* reports, float* ita_global) {
+    if (c && (!reports || !ita_global)) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
+    const int rc = olx_solution_analyze_begin(c, A, ita_weights, line_pts, o, scale_per_focus);
+    return rc ? rc : olx_solution_analyze_finish(c, reports, ita_global);
 }
 
 // RCCL prints a version banner through C stdio on stdout; callers (bench.py) own stdout for their

@@ -94,6 +94,7 @@ struct olx_ctx {
     double* d_peakA = nullptr; unsigned* d_peak = nullptr; size_t peak_cap = 0;
     float* d_wint = nullptr; size_t wint_cap = 0;  // weighted-intensity (time-average) volume
     void* d_an = nullptr; void* h_an = nullptr; size_t an_dev_cap = 0, an_host_cap = 0;   // olx_solution_analyze: device scratch, pinned staging
+    bool an_pending = false; int an_F = 0, an_npts = 0; size_t an_out_pk = 0, an_out_ita = 0, an_out_bd = 0, an_out_mom = 0;   // an analysis enqueued by olx_solution_analyze_begin
     // heterogeneous medium (kernel 2h)
     bool hetero = false; HeteroParams hp{}; float4* d_med = nullptr; int *d_plane_k = nullptr, *d_plane_of_k = nullptr;
     float* d_inv2z = nullptr; int *d_kfirst = nullptr, *d_klast = nullptr;

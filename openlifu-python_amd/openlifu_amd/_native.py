@@ -32,7 +32,7 @@ SYMBOLS = [
     "olx_sync", "olx_set_elements", "olx_bf_solve", "olx_set_steering", "olx_bf_quantize", "olx_field_plan",
     "olx_field_launch", "olx_field_fetch", "olx_field", "olx_field_upload", "olx_field_set_medium", "olx_field_time", "olx_profile_begin", "olx_profile_end", "olx_field_variant",
     "olx_field_aggregate", "olx_field_scale", "olx_field_masked_peak", "olx_field_masked_moments", "olx_field_sample", "olx_offset_grid", "olx_tof_spread",
-    "olx_field_weighted_intensity", "olx_field_weighted_fetch", "olx_comm_unique_id", "olx_comm_init",
+    "olx_field_weighted_intensity", "olx_field_weighted_fetch", "olx_solution_analyze_begin", "olx_solution_analyze_finish", "olx_comm_unique_id", "olx_comm_init",
     "olx_comm_destroy", "olx_field_allgather", "olx_allgather_fetch", "olx_field_allreduce_aggregate", "olx_field_reduce_scatter_aggregate",
     "olx_aggregate_fetch", "olx_field_aggregate_device", "olx_field_analysis_peaks", "olx_field_aggregate_counts", "olx_rccl_path", "olx_bf_time", "olx_field_fetch_all", "olx_field_medium_layering", "olx_field_medium_model", "olx_set_element_apertures",
     "olx_solution_analyze", "olx_scan_time", "olx_comm_export", "olx_comm_import", "olx_comm_transport",
@@ -131,6 +131,8 @@ def load(require_gpu: bool = True):
         lib.olx_comm_ranks_seen.argtypes = [vp]
         lib.olx_scan_time.argtypes = [vp, c_int, c_int, fp, dp]
         lib.olx_solution_analyze.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), dp, POINTER(OlxFocusReport), fp]
+        lib.olx_solution_analyze_begin.argtypes = [vp, dp, dp, dp, POINTER(OlxAnalysisOpts), dp]
+        lib.olx_solution_analyze_finish.argtypes = [vp, POINTER(OlxFocusReport), POINTER(c_float)]
         _lib = lib
     if require_gpu and device_count() < 1:
         raise NativeError("no HIP device visible: the openlifu_amd field/beamforming path needs an MI355X "
@@ -456,11 +458,11 @@ class Context:
 
     def solution_analyze_begin(self, A, ita_weights, aspect, r_main_m, r_side_m, zmin_m, line_pts=None, line_offsets=None,
                                beam_db=(3, 6), scale=None, overlap=False):
-        """Everything ``Solution.analyze`` reads off the resident volumes in one crossing (``olx_solution_analyze``).
-        Marshals the arguments HERE and returns ``finish() -> report``.  ``overlap=True`` starts the C call (it releases the GIL and
-        blocks for the device's scans) on a helper thread at once, so that the caller's own host arithmetic runs beside it; ``finish()``
-        joins it and ``finish.abandon()`` joins it WITHOUT reading the report -- the context is not thread-safe, so a caller whose host
-        arithmetic raises must call one of the two before it touches the context again (``Solution.analyze`` does, try / except).
+        """Everything ``Solution.analyze`` reads off the resident volumes in one analysis (``olx_solution_analyze_begin`` / ``_finish``).
+        Marshals the arguments HERE and returns ``finish() -> report``.  ``overlap=True`` enqueues the device work at once
+        (``olx_solution_analyze_begin`` returns as soon as everything is on the stream), so that the caller's own host arithmetic runs
+        beside it; ``finish()`` waits for the report and ``finish.abandon()`` waits WITHOUT reading it -- a caller whose host arithmetic
+        raises must call one of the two before it touches the context again (``Solution.analyze`` does, try / except).
         ``line_offsets`` = the three offset vectors [m] of the focal-axis lines, ``line_pts`` [F, n0 + n1 + n2, 3] their
         positions.  Returns a dict of arrays: peaks [F, 6], ita_main [F], moments [F, 4], bounds [F, 3, 2, 2] (indices into
         the axis lines, -1 = none) and the scalar ita_global.  ``scale`` [F]: ``field_scale_aggregate`` happens first (one pass with the
@@ -490,32 +492,21 @@ class Context:
             pts = _f64(line_pts, (F, sum(len(v) for v in line_offsets), 3))
         rep = (OlxFocusReport * F)()
         glob = c_float(0)
-        argv = (self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc), rep, ctypes.byref(glob))
+        argv = (self._h, _dptr(A), _dptr(w), _dptr(pts), ctypes.byref(o), _dptr(sc))
         keep = (A, w, pts, o, sc)          # (the arrays behind the pointers live as long as the closure)
-        box = {}                           # "rc": the C call's return code, "exc": what the helper thread raised instead
+        state = {"begun": False, "done": False}
 
-        def call():
-            try:
-                box["rc"] = self._lib.olx_solution_analyze(*argv)
-            except BaseException as e:     # (a ctypes argument error, a KeyboardInterrupt delivered to the helper, ...)
-                box["exc"] = e
-        helper = None
+        def begin():
+            state["begun"] = True
+            self._chk(self._lib.olx_solution_analyze_begin(*argv))
         if overlap:
-            import threading
-            helper = threading.Thread(target=call)
-            helper.start()
-
-        def join():
-            if helper is not None:
-                helper.join()
-            elif not box:
-                call()
+            begin()
 
         def finish():
-            join()
-            if "exc" in box:
-                raise box["exc"]
-            self._chk(box["rc"])
+            if not state["begun"]:
+                begin()
+            state["done"] = True
+            self._chk(self._lib.olx_solution_analyze_finish(self._h, rep, ctypes.byref(glob)))
             assert keep is not None
             raw = np.frombuffer(rep, dtype=np.dtype([("peaks", np.float32, 6), ("ita_main", np.float32), ("reserved", np.float32),
                                                      ("moments", np.float64, 4), ("bounds", np.int32, (3, 2, 2))]))
@@ -523,9 +514,10 @@ class Context:
                     "bounds": raw["bounds"].copy(), "ita_global": float(glob.value)}
 
         def abandon():
-            """The caller failed on its side: wait for the crossing to leave the context, drop whatever it reported."""
-            if helper is not None:
-                helper.join()
+            """The caller failed on its side: let the enqueued analysis drain, drop whatever it reports."""
+            if state["begun"] and not state["done"]:
+                state["done"] = True
+                self._lib.olx_solution_analyze_finish(self._h, rep, ctypes.byref(glob))
         finish.abandon = abandon
         return finish
 

@@ -35,7 +35,7 @@ def begin(self, *a, **k):
         t1 = time.perf_counter(); r = fin(); events.append(("analyze_finish(wait)", t1, time.perf_counter())); return r
     finish.abandon = fin.abandon
     return finish
-nat.Context.solution_analyze_begin = begin
+nat.Context.solution_analyze_begin = begin   # (since round 5 the device work is enqueued by olx_solution_analyze_begin: no helper thread)
 for _ in range(3):
     proto.calc_solution(target, arr, simulate=True, scale=True)
 rows = []
