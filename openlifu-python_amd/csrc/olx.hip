@@ -819,8 +819,8 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     {   // Re-planning the SAME launch (same grid, slab, foci count, medium constants, flags, element table, family pins): everything
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
-        const char* e1 = getenv("OLX_FIELD_VARIANT"); const char* e2 = getenv("OLX_FP8_CORRECTION"); const char* e3 = getenv("OLX_GTABLE"); const char* e4 = getenv("OLX_MIXED_CORRECTION"); const char* e5 = getenv("OLX_COSETP_SHAPE");
-        const std::string env = std::string(e1 ? e1 : "") + "|" + (e2 ? e2 : "") + "|" + (e3 ? e3 : "") + "|" + (e4 ? e4 : "") + "|" + (e5 ? e5 : "");
+        std::string env;   // the developer switches the plan below reads
+        for (const char* name : {"OLX_FIELD_VARIANT", "OLX_FP8_CORRECTION", "OLX_EXP_TOEP_SAW"}) { const char* e = getenv(name); env += e ? e : ""; env += '|'; }
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;
