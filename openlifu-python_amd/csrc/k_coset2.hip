@@ -45,7 +45,7 @@ static __device__ unsigned long long g_cutrace[16384][8][5];
 #define OLX_CUTRACE(k, v)
 #endif
 
-template <int MX, int MY, bool CLAMP, bool FP8, bool DIR = false>
+template <int MX, int MY, bool CLAMP, bool FP8, bool DIR = false, bool BOTH = true /*|p| and intensity both wanted (the product's case): no flag tests between the stores*/>
 __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     const uint4* __restrict__ bfrag, float* __restrict__ pmag, float* __restrict__ inten,
     const int* __restrict__ targets /*[tiles][32 columns][4]: focus * 4 + mirror image, -1 = none*/,
@@ -287,42 +287,36 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
         if (sb0 == 0) OLX_STAMP(4);
     }
     OLX_STAMP(5);
-    // ---- epilogue, straight from the accumulators.  Lane (g, c16): rows 4 g .. 4 g + 3 = planes k0 + 4 g .. + 3 of the tile's
-    // position, column c16 = (o, re | im).  The |p| lane (part 0) and its partner (part 1, the intensity lane) hold the same
-    // (S re)^2 + (S im)^2 after one quad swap; per pair of rows the |p| lane takes the root of the first and the partner lane of
-    // the second (handed back through the swap): one quarter-rate instruction per two rows.
-    // Two passes, both counted in vector instructions (the kernel's scarce resource: the VALU port is busy ~2/3 of its time):
-    //   A  |p| / intensity over the accumulators, in place;
-    //   B  per store-target slot of the lane's column (outer) the 64-bit base of its focus volume and its mirror masks once, then
-    //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU) -- 4 vector
-    //      instructions per 16-byte store (the former tile-outer loop formed every address from scratch: 17).
-    int lane_e = lane;                                   // (opaque: the epilogue's per-lane constants -- targets, bases, scales -- are formed here,
+    // ---- epilogue, straight from the accumulators.  The steering fragments carry Re of column c in column tile 0 and Im of the same column
+    // in column tile 1 (mfma_pack_k, split_reim), so lane (g, c16) holds BOTH parts of column c16 for rows 4 g .. 4 g + 3 = planes
+    // k0 + 4 g .. + 3 of the tile's position: |p| and intensity in place without a lane exchange, two 16-byte stores per store target.
+    // (Rounds 2 - 4 kept (Re, Im) in adjacent matrix columns as kernels 2c / 2e do: a quad swap per square, selects between the |p| lane
+    // and the intensity lane, and every address formed once per lane pair -- 48 instead of 12 - 20 vector instructions per position here,
+    // 5 instead of 3.5 per store; the vector issue port is this kernel's scarce resource.)
+    //   A  |p| / intensity over the accumulators, in place (two rows per packed fp32 instruction);
+    //   B  per store-target slot of the lane's column (outer) the 64-bit bases of its focus volumes and its mirror masks once, then
+    //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU), shared by both stores.
+    int lane_e = lane;                                   // (opaque: the epilogue's per-lane constants -- targets, bases -- are formed here,
     asm volatile("" : "+v"(lane_e));                     // not kept in registers across the K-steps)
-    const int c16 = lane_e & 15, part = c16 & 1;
+    const int c16 = lane_e & 15;
     const int kz = k0 + 4 * (lane_e >> 4);
     if (kz < P.nz) {
-    const float s_lane = part == 0 ? P.out_scale : P.out_scale * P.out_scale * P.inten_scale;
-    float* const vol = part ? inten : pmag;
-    const bool want = (P.flags & (part ? 2u : 1u)) != 0;
-    int4 tq[NT];                                         // store targets of this lane's column: focus * 4 + mirror image, -1 = none
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        tq[nt] = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (c16 >> 1)) * 4);
+    const float s_p = P.out_scale, s_i = P.out_scale * P.out_scale * P.inten_scale;
+    const bool want_p = (P.flags & 1u) != 0, want_i = (P.flags & 2u) != 0;      // (uniform)
+    // store targets of this lane's column: focus * 4 + mirror image, -1 = none
+    const int4 tq = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + c16) * 4);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         if (t >= ntile) continue;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const float a0 = acc[t][nt][r], a1 = acc[t][nt][r + 1];
-                const float sq0 = a0 * a0, sq1 = a1 * a1;
-                const float m0 = __builtin_fmaf(a0, a0, quad_swap1(sq0)), m1 = __builtin_fmaf(a1, a1, quad_swap1(sq1));   // (pinned: own square unrounded, partner's rounded)
-                const float y = __builtin_amdgcn_sqrtf(part == 0 ? m0 : m1);
-                const float ys = quad_swap1(y);
-                acc[t][nt][r] = (part == 0 ? y : m0) * s_lane;
-                acc[t][nt][r + 1] = (part == 0 ? ys : m1) * s_lane;
-            }
+        for (int r = 0; r < 4; r += 2) {
+            const float2_t re = {acc[t][0][r], acc[t][0][r + 1]}, im = {acc[t][1][r], acc[t][1][r + 1]};
+            const float2_t m = __builtin_elementwise_fma(re, re, im * im);
+            acc[t][0][r] = __builtin_amdgcn_sqrtf(m.x) * s_p;
+            acc[t][0][r + 1] = __builtin_amdgcn_sqrtf(m.y) * s_p;
+            const float2_t in = m * float2_t{s_i, s_i};
+            acc[t][1][r] = in.x;
+            acc[t][1][r + 1] = in.y;
         }
     }
     const int xm = P.nx - 1, ym = P.ny - 1;
@@ -332,40 +326,36 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     auto readout = [&](auto full_c) {
         constexpr bool FULL4 = decltype(full_c)::value != 0;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int q = 0; q < 4; ++q) {
+            const int code = q == 0 ? tq.x : q == 1 ? tq.y : q == 2 ? tq.z : tq.w;
+            if (code < 0) continue;
+            const unsigned m = (unsigned)code & 3u;
+            const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
+            unsigned fxm = fx ? 0xFFFFFFFFu : 0u, fym = fy ? 0xFFFFFFFFu : 0u;
+            asm volatile("" : "+v"(fxm), "+v"(fym));      // (opaque: kept as masks -- one v_and per term instead of a move and a select)
+            const long long fb = (long long)(code >> 2) * P.vox + kz;
+            float* const base_p = pmag + fb;
+            float* const base_i = inten + fb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int code = want ? (q == 0 ? tq[nt].x : q == 1 ? tq[nt].y : q == 2 ? tq[nt].z : tq[nt].w) : -1;
-                if (code < 0) continue;
-                const unsigned m = (unsigned)code & 3u;
-                const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
-                unsigned fxm = fx ? 0xFFFFFFFFu : 0u, fym = fy ? 0xFFFFFFFFu : 0u;
-                asm volatile("" : "+v"(fxm), "+v"(fym));      // (opaque: kept as masks -- one v_and per term instead of a move and a select)
-#ifdef OLX_EXP_L2STORE
-                float* const base = vol;
-#else
-                float* const base = vol + (long long)(code >> 2) * P.vox + kz;
-#endif
+            for (int t = 0; t < MT; ++t) {
+                if (t >= ntile) continue;
+                const int pos = wave + COS_NW * t;
+                const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;
+                const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform (scalar ALU)
+                const unsigned o00 = (unsigned)(i * sxz + j * P.nz);
+                const unsigned DX = (unsigned)((xm - 2 * i) * sxz), DY = (unsigned)((ym - 2 * j) * P.nz);
+                const unsigned off = o00 + (fxm & DX) + (fym & DY);
+                if (!OLX_IN(fb + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
+                if constexpr (FULL4) {
+                    if (BOTH || want_p) *reinterpret_cast<float4*>(base_p + off) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+                    if (BOTH || want_i) *reinterpret_cast<float4*>(base_i + off) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+                } else {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    if (t >= ntile) continue;
-                    const int pos = wave + COS_NW * t;
-                    const int kx = (pos * ky_magic) >> 16, ky = pos - kx * KY;
-                    const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform (scalar ALU)
-                    const unsigned o00 = (unsigned)(i * sxz + j * P.nz);
-                    const unsigned DX = (unsigned)((xm - 2 * i) * sxz), DY = (unsigned)((ym - 2 * j) * P.nz);
-                    const unsigned off = o00 + (fxm & DX) + (fym & DY);
-#ifdef OLX_EXP_L2STORE
-                    float* dst = base + ((off + (unsigned)kz) & 0xFFFFFu);           // A/B: stores stay cache resident
-#else
-                    float* dst = base + off;
-#endif
-                    if (!OLX_IN((long long)(code >> 2) * P.vox + kz + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
-                    if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = acc[t][nt][e];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (kz + e < P.nz) {
+                            if (BOTH || want_p) base_p[off + e] = acc[t][0][e];
+                            if (BOTH || want_i) base_i[off + e] = acc[t][1][e];
+                        }
                 }
             }
         }
@@ -407,7 +397,9 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
 #endif
     const bool clamp = c->clamp || c->lat.clamp;
     dim3 grid((unsigned)c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);
-#define OLX_CP(CL, F8, DR) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q)
+    const bool both = (Q.flags & 3u) == 3u;
+#define OLX_CP(CL, F8, DR) do { if (both) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q); \
+                                else hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q); } while (0)
     if (c->dir_lattice) {   // piston directivity / uniform absorption folded into the geometry tables (fp16 corrections only)
         if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true);
     } else if (c->fp8corr) {

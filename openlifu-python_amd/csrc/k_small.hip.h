@@ -199,9 +199,9 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                             double w_scale /* P0/lambda * rev * S_W */, double rev, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]: representative focus, mirror image (-1 = unused)*/,
                             const int* __restrict__ slot_elem /*kernel 2d: element of K slot s (-1 = virtual), NULL = identity*/,
-                            int fp8corr /*1 = kernel 2e / 2g, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element;
-                                          2 = kernel 2g's mixed corrections: hi and lo fp16 fragments followed by 8 e4m3 bytes per lane [hi(k0), hi(k1)] x 4 elements
-                                          (* 2^-6), 160 instead of 128 uint4 per K-step and column tile*/,
+                            int fp8corr /*1 = kernel 2e / 2g, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element*/,
+                            int split_reim /*1 = kernel 2g (NT = 2): matrix column c of column tile 0 is Re, of column tile 1 Im of steering column c --
+                                             a lane's accumulators then hold both parts of its voxels; 0 = (Re, Im) in adjacent matrix columns*/,
                             float4* __restrict__ coords, uint4* __restrict__ bfrag) {
     const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
     if (!slot_elem && tile == 0 && nt == 0 && lane < 16) {
@@ -210,7 +210,7 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                                           (float)((pos[2 * n + e] - oz) * rev), 0.f)
                             : make_float4(1.0e4f, 1.0e4f, 1.0e4f, 0.f);  // padding: far away, zero weight
     }
-    const int g = lane >> 4, c = lane & 15, o = nt * 8 + (c >> 1), part_c = c & 1;
+    const int g = lane >> 4, c = lane & 15, o = split_reim ? c : nt * 8 + (c >> 1), part_c = split_reim ? nt : c & 1;
     const int col_focus = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2];
     const int col_mirror = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2 + 1];
     Half8Bits hi, lo;
@@ -233,19 +233,6 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
         const _Float16 l = (_Float16)(float)(val - (double)(float)h);
         hi.h[jj] = h;
         lo.h[jj] = l;
-    }
-    if (fp8corr == 2) {
-        uint4* dst2 = bfrag + (((size_t)tile * (n_pad / 16) + ks) * NT + nt) * 160;
-        dst2[lane] = hi.u;
-        dst2[64 + lane] = lo.u;
-        uint2 q8;
-        int w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[0] * COS_F8_HI, (float)hi.h[1] * COS_F8_HI, 0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[2] * COS_F8_HI, (float)hi.h[3] * COS_F8_HI, w0, true);
-        int w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[4] * COS_F8_HI, (float)hi.h[5] * COS_F8_HI, 0, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi.h[6] * COS_F8_HI, (float)hi.h[7] * COS_F8_HI, w1, true);
-        q8.x = (unsigned)w0; q8.y = (unsigned)w1;
-        reinterpret_cast<uint2*>(dst2 + 128)[lane] = q8;
-        return;
     }
     if (fp8corr) {
         Half8Bits q;

@@ -757,7 +757,7 @@ static int pack_if_needed(olx_ctx* c) {
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
-                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, c->d_coords, c->d_bfrag);
+                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, (c->use_lattice && c->use_cosetp) ? 1 : 0, c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
