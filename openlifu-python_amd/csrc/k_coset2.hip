@@ -16,8 +16,8 @@ namespace olx {
 //   * MFMA tile = ONE position x the block's 16 planes (row = plane).  Wave w takes the positions w, w + 8, ... of the
 //     block's position grid (<= 5 tiles).  A lane then holds, for its column, rows 4 g .. 4 g + 3 = FOUR CONSECUTIVE PLANES
 //     of one voxel column: |p| / intensity in place, one 16-byte store per store target straight from the accumulators
-//     (the four lanes g = 0 .. 3 of a column write the same 64 contiguous bytes as kernel 2e's read-out).  No staging
-//     arena, no epilogue barriers, no job-list pass.
+//     (after one lane transpose four CONSECUTIVE lanes write 64 contiguous bytes, as kernel 2e's read-out does).
+//     No staging arena, no epilogue barriers, no job-list pass.
 //   * The geometry tables of the 16 planes are shared by the block: wave w still evaluates planes 2 w, 2 w + 1 (same
 //     26-row pair tables, same arithmetic), behind the block barriers that the steering-fragment staging needs anyway.
 //   * A fragment of row p (plane), k-group g: table of plane p, row ky - g + ROW0 - 4 kb - 8 sl, entries UW - 8 - 2 kx + 4 ka ..:
@@ -78,7 +78,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     if (npos <= 0) return;                              // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
+#ifdef OLX_EXP_SKIP33   // timing experiment only (WRONG results): no wave takes a fifth tile -- what a balanced 33rd position could gain at most
+    const int ntile = min(4, __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW));
+#else
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= MT)
+#endif
     // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl.
     // (Its per-lane constants are formed inside the pair loop from an opaque copy of the lane index: hoisted, they would be live
     // across the K-steps, where the fp8 shape has no register to spare -- 5 spilled registers cost 190 MB of scratch traffic.)
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int nsbp = P.nsbp;                    // even: chunks = table pairs never straddle sa
+#ifdef OLX_EXP_STOREONLY   // timing experiment only (WRONG results): no tables, no K-steps -- the launch's store pattern alone
+    const int n_sb = 0;
+#else
     const int n_sb = P.nsa * nsbp;
+#endif
     constexpr int CHUNK_U4 = PAIR * 4 * NT * B_KS_U4, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
@@ -291,34 +299,49 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     // in column tile 1 (mfma_pack_k, split_reim), so lane (g, c16) holds BOTH parts of column c16 for rows 4 g .. 4 g + 3 = planes
     // k0 + 4 g .. + 3 of the tile's position: |p| and intensity in place without a lane exchange, two 16-byte stores per store target.
     // (Rounds 2 - 4 kept (Re, Im) in adjacent matrix columns as kernels 2c / 2e do: a quad swap per square, selects between the |p| lane
-    // and the intensity lane, and every address formed once per lane pair -- 48 instead of 12 - 20 vector instructions per position here,
-    // 5 instead of 3.5 per store; the vector issue port is this kernel's scarce resource.)
-    //   A  |p| / intensity over the accumulators, in place (two rows per packed fp32 instruction);
+    // and the intensity lane, every address formed once per lane pair -- 48 instead of 12 vector instructions per position, 5 instead
+    // of 3.5 per store: 939 -> 734 vector instructions per wave.  That alone changed the launch time by nothing -- profiles/r05_store_path.txt.)
+    //   A  |p| / intensity over the accumulators (two rows per packed fp32 instruction), then the lane transpose below;
     //   B  per store-target slot of the lane's column (outer) the 64-bit bases of its focus volumes and its mirror masks once, then
     //      per tile (inner) offset = o00 + (fx & DX) + (fy & DY) with the three terms wave-uniform (scalar ALU), shared by both stores.
     int lane_e = lane;                                   // (opaque: the epilogue's per-lane constants -- targets, bases -- are formed here,
     asm volatile("" : "+v"(lane_e));                     // not kept in registers across the K-steps)
-    const int c16 = lane_e & 15;
-    const int kz = k0 + 4 * (lane_e >> 4);
-    if (kz < P.nz) {
+    // The accumulators put the four plane quads of a column 16 lanes apart; the vector memory unit takes a 16-byte store four LANES at a
+    // time, so from there every 64-byte run goes out as four separate 16-byte requests.  One lane transpose first (ds_bpermute: the LDS
+    // crossbar, no vector-ALU work): lane 4 c + g takes over column c, planes 4 g .. 4 g + 3 -- four consecutive lanes now write 64
+    // contiguous bytes: -7 % on the launch (profiles/r05_store_path.txt).
+    const int c16 = lane_e >> 2;
+    const int kz = k0 + 4 * (lane_e & 3);
+    const int src_lane4 = (16 * (lane_e & 3) + (lane_e >> 2)) * 4;      // byte index of the lane that computed this lane's values
     const float s_p = P.out_scale, s_i = P.out_scale * P.out_scale * P.inten_scale;
     const bool want_p = (P.flags & 1u) != 0, want_i = (P.flags & 2u) != 0;      // (uniform)
-    // store targets of this lane's column: focus * 4 + mirror image, -1 = none
-    const int4 tq = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + c16) * 4);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         if (t >= ntile) continue;
+        float o[NT][4];
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
             const float2_t re = {acc[t][0][r], acc[t][0][r + 1]}, im = {acc[t][1][r], acc[t][1][r + 1]};
             const float2_t m = __builtin_elementwise_fma(re, re, im * im);
-            acc[t][0][r] = __builtin_amdgcn_sqrtf(m.x) * s_p;
-            acc[t][0][r + 1] = __builtin_amdgcn_sqrtf(m.y) * s_p;
+            o[0][r] = __builtin_amdgcn_sqrtf(m.x) * s_p;
+            o[0][r + 1] = __builtin_amdgcn_sqrtf(m.y) * s_p;
             const float2_t in = m * float2_t{s_i, s_i};
-            acc[t][1][r] = in.x;
-            acc[t][1][r + 1] = in.y;
+            o[1][r] = in.x;
+            o[1][r + 1] = in.y;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            floatx4_t v;
+            v[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, o[nt][0])));
+            v[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, o[nt][1])));
+            v[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, o[nt][2])));
+            v[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, o[nt][3])));
+            acc[t][nt] = v;
         }
     }
+    if (kz < P.nz) {
+    // store targets of this lane's column: focus * 4 + mirror image, -1 = none
+    const int4 tq = *reinterpret_cast<const int4*>(targets + ((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + c16) * 4);
     const int xm = P.nx - 1, ym = P.ny - 1;
     const int sxz = P.ny * P.nz;
     // (the ragged-nz variant is a separate copy of the loop: with both store forms in one body the compiler merges them and
@@ -333,7 +356,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
             unsigned fxm = fx ? 0xFFFFFFFFu : 0u, fym = fy ? 0xFFFFFFFFu : 0u;
             asm volatile("" : "+v"(fxm), "+v"(fym));      // (opaque: kept as masks -- one v_and per term instead of a move and a select)
+#ifdef OLX_EXP_L2STORE   // timing experiment only (WRONG results): every store lands in a cache-resident 4 MB window of its volume -- what the HBM write path costs
+            const long long fb = 0;
+#else
             const long long fb = (long long)(code >> 2) * P.vox + kz;
+#endif
             float* const base_p = pmag + fb;
             float* const base_i = inten + fb;
 #pragma unroll
@@ -344,11 +371,20 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform (scalar ALU)
                 const unsigned o00 = (unsigned)(i * sxz + j * P.nz);
                 const unsigned DX = (unsigned)((xm - 2 * i) * sxz), DY = (unsigned)((ym - 2 * j) * P.nz);
+#ifdef OLX_EXP_L2STORE
+                const unsigned off = (o00 + (fxm & DX) + (fym & DY) + (unsigned)kz + ((unsigned)code >> 2) * 4096u) & 0xFFFFCu;
+#else
                 const unsigned off = o00 + (fxm & DX) + (fym & DY);
+#endif
                 if (!OLX_IN(fb + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
                 if constexpr (FULL4) {
+#ifdef OLX_EXP_NTSTORE   // A/B: non-temporal output stores
+                    if (BOTH || want_p) __builtin_nontemporal_store(acc[t][0], reinterpret_cast<floatx4_t*>(base_p + off));
+                    if (BOTH || want_i) __builtin_nontemporal_store(acc[t][1], reinterpret_cast<floatx4_t*>(base_i + off));
+#else
                     if (BOTH || want_p) *reinterpret_cast<float4*>(base_p + off) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
                     if (BOTH || want_i) *reinterpret_cast<float4*>(base_i + off) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+#endif
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -389,17 +425,19 @@ extern "C" int olx_exp_read_stamps_cosetp(unsigned long long* out) {
 
 template <int MX, int MY>
 static void launch_cosetp(olx_ctx* c, float* pm) {
-#ifdef OLX_DEBUG_BOUNDS   // self-test of the debug build: pretend the output arrays hold one focus less -- the last focus' stores must be reported (and skipped)
     CosetParams Q = c->cp;
+#ifdef OLX_DEBUG_BOUNDS   // self-test of the debug build: pretend the output arrays hold one focus less -- the last focus' stores must be reported (and skipped)
     if (getenv("OLX_DEBUG_BOUNDS_SELFTEST")) Q.n_foci -= 1;
-#else
-    const CosetParams& Q = c->cp;
 #endif
+    float* inten_exp = c->d_inten;
+    // timing experiments only (WRONG results: the volumes overlap): focus stride shortened by OLX_EXP_FPAD floats, intensity base moved by OLX_EXP_IPAD floats
+    if (const char* e = getenv("OLX_EXP_FPAD")) Q.vox -= atoll(e);
+    if (const char* e = getenv("OLX_EXP_IPAD")) inten_exp += atoll(e);
     const bool clamp = c->clamp || c->lat.clamp;
     dim3 grid((unsigned)c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);
     const bool both = (Q.flags & 3u) == 3u;
-#define OLX_CP(CL, F8, DR) do { if (both) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q); \
-                                else hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_targets, c->d_cpblocks, Q); } while (0)
+#define OLX_CP(CL, F8, DR) do { if (both) hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, inten_exp, c->d_targets, c->d_cpblocks, Q); \
+                                else hipLaunchKernelGGL((field_cosetp_k<MX, MY, CL, F8, DR, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, inten_exp, c->d_targets, c->d_cpblocks, Q); } while (0)
     if (c->dir_lattice) {   // piston directivity / uniform absorption folded into the geometry tables (fp16 corrections only)
         if (clamp) OLX_CP(true, false, true); else OLX_CP(false, false, true);
     } else if (c->fp8corr) {

@@ -601,15 +601,24 @@ static int configure_variant_impl(olx_ctx* c) {
                     }
                 }
                 {   // kernel 2e / 2g / 2f / 2q block records: blockIdx.x -> (coset, part, plane block), in the kernels' former decode order
-                    // (the two blocks that write the two 64-byte halves of the same 128-byte lines get ids 8 apart = same XCD under round-robin dispatch)
                     // (the records depend on the partition only, not on the steering table: a call that changes nothing but the foci finds the
                     // records it uploaded last time still valid -- 9 216 of them on the headline grid, 0.1 ms to derive and compare)
-                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, 2, c->use_cosetp ? 40 : 0, Q.xs};
+                    // Plane blocks of one position set that follow each other on ONE XCD (round-robin dispatch: ids 8 apart): all 16 of them where the
+                    // counts divide -- that XCD's L2 then collects whole 1 KB z lines of every voxel column before it writes them back.  Measured on the
+                    // headline shard, alternating runs on one box: 1 / 2 / 4 / 8 / 16 in a row = 0.406 / 0.392 / 0.392 / 0.390 / 0.383 ms; y cosets
+                    // grouped on top (48 - 192 in a row) 0.384 - 0.388 (profiles/r05_store_path.txt).  A/B: OLX_EXP_KGRP.
+                    unsigned kgrp = 1u;
+                    {
+                        const unsigned long long nb = (unsigned long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
+                        for (unsigned g2 = 16u; g2 >= 2u; g2 >>= 1) if (Q.kblocks % (int)g2 == 0 && nb % (8ull * g2) == 0) { kgrp = g2; break; }
+                    }
+                    if (const char* e = getenv("OLX_EXP_KGRP")) kgrp = (unsigned)std::max(1, atoi(e));
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs};
                     std::vector<CosetBlock> blk;
                     if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
                         std::string why;
-                        if (!olxplan::build_coset_blocks(Q, zb, 2u, c->use_cosetp ? 40 : 0, blk, why))
+                        if (!olxplan::build_coset_blocks(Q, zb, kgrp, c->use_cosetp ? 40 : 0, blk, why))
                             return fail(c, OLX_ESTATE, "kernel 2g: %s", why.c_str());
                     }
                     const unsigned nblk = (unsigned)blk.size();
@@ -820,7 +829,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
         std::string env;   // the developer switches the plan below reads
-        for (const char* name : {"OLX_FIELD_VARIANT", "OLX_FP8_CORRECTION", "OLX_EXP_TOEP_SAW"}) { const char* e = getenv(name); env += e ? e : ""; env += '|'; }
+        for (const char* name : {"OLX_FIELD_VARIANT", "OLX_FP8_CORRECTION", "OLX_EXP_TOEP_SAW", "OLX_EXP_KGRP"}) { const char* e = getenv(name); env += e ? e : ""; env += '|'; }
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;

@@ -162,14 +162,21 @@ bool build_coset_blocks(const CosetParams& Q, int zb, unsigned grp, int max_pos,
     const int wx = Q.nx - Q.x_lo, wy = Q.ny - Q.y_lo;
     for (unsigned id = 0; id < nblk; ++id) {
         unsigned b = id;
-        int kblock;
-        if ((Q.kblocks % grp) == 0 && nblk % (8 * grp) == 0) {
+        int kblock, ry_lo = 0;
+        unsigned gy = 1;      // y cosets that follow each other on an XCD (grp > kblocks: grp = kblocks * gy)
+        if (grp > (unsigned)Q.kblocks && grp % (unsigned)Q.kblocks == 0 && (unsigned)Q.my % (grp / (unsigned)Q.kblocks) == 0 && nblk % (8 * grp) == 0) {
+            gy = grp / (unsigned)Q.kblocks;
+            const unsigned xcd = b % 8, sft = b / 8, inner = sft % grp;
+            kblock = (int)(inner % (unsigned)Q.kblocks); ry_lo = (int)(inner / (unsigned)Q.kblocks);
+            b = (sft / grp) * 8 + xcd;
+        } else if (grp <= (unsigned)Q.kblocks && (Q.kblocks % grp) == 0 && nblk % (8 * grp) == 0) {
             const unsigned xcd = b % 8, sft = b / 8, kb_lo = sft % grp, u = (sft / grp) * 8 + xcd, part = (unsigned)Q.kblocks / grp;
             kblock = (int)(grp * (u % part) + kb_lo); b = u / part;
         } else { kblock = (int)(b % (unsigned)Q.kblocks); b /= (unsigned)Q.kblocks; }
         const int sy_part = (int)(b % (unsigned)Q.nsy); b /= (unsigned)Q.nsy;
         const int sx_part = (int)(b % (unsigned)Q.nsx); b /= (unsigned)Q.nsx;
-        const int ry = (int)(b % (unsigned)Q.my), rx = (int)(b / (unsigned)Q.my);
+        const unsigned myh = (unsigned)Q.my / gy;
+        const int ry = (int)(b % myh) * (int)gy + ry_lo, rx = (int)(b / myh);
         const int kx_all = rx < wx ? (wx - 1 - rx) / px + 1 : 0, ky_all = ry < wy ? (wy - 1 - ry) / Q.my + 1 : 0;
         const int kx0 = sx_part * kx_all / Q.nsx, KX = (sx_part + 1) * kx_all / Q.nsx - kx0;
         const int ky0 = sy_part * ky_all / Q.nsy, KY = (sy_part + 1) * ky_all / Q.nsy - ky0;

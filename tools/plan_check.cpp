@@ -180,9 +180,14 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         for (int e = 0; e < n; e += 3) bad[e] += 1e-7 * (1 + e % 5);
         CHECK(!infer_foci(true, n, F, pos.data(), bad.data(), c0, origin[2], got), "scrambled delays accepted");
     }
-    // ---- block records of every shape the kernels use: (kxw, zb, grp, limit) = 2g / 2e NT = 2 (3, 16, 2, 40), 2e NT = 1 (6, 16, 2, 0), 2e NT = 4 (2, 16, 2, 0), 2f (8 | 16, 16, 2, 0; positions one pitch apart)
+    // ---- block records of every shape the kernels use: (kxw, zb, limit) = 2g / 2e NT = 2 (3, 16, 40), 2e NT = 1 (6, 16, 0), 2e NT = 4 (2, 16, 0), 2f (8 | 16, 16, 0; positions one pitch apart),
+    // each in every order of the records over the XCDs the host may choose (grp plane blocks -- or plane blocks x y cosets -- in a row on one XCD)
     struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; int xs; };
-    const Form forms[] = {{"2g", 3, 16, 2, 40, 2}, {"2e nt1", 6, 16, 2, 0, 2}, {"2e nt4", 2, 16, 2, 0, 2}, {"2f", 8, 16, 2, 0, 1}, {"2f m2", 16, 16, 2, 0, 1}};
+    std::vector<Form> forms;
+    for (unsigned grp : {1u, 2u, 4u, 16u, 48u, 192u})
+        for (const Form& f0 : {Form{"2g", 3, 16, 2, 40, 2}, Form{"2e nt1", 6, 16, 2, 0, 2}, Form{"2e nt4", 2, 16, 2, 0, 2}, Form{"2f", 8, 16, 2, 0, 1}, Form{"2f m2", 16, 16, 2, 0, 1}}) {
+            Form f = f0; f.grp = grp; forms.push_back(f);
+        }
     for (const Form& fm : forms) {
         if (nt_force && fm.kxw != nt_force) continue;
         CosetParams Q{};
@@ -217,10 +222,10 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
             for (unsigned char v : cover) bad += v != 1;
             CHECK(bad == 0, "%s: %zu (voxel column, plane block) cells not covered exactly once (grid %dx%dx%d pitch %dx%d fold %d%d slab %d+%d)", fm.name, bad, S.n[0], S.n[1], S.n[2],
                   S.mxv, S.myv, mxf, myf, S.x_begin, S.x_count);
-            // the two records that share 128-byte lines (plane blocks 2 j, 2 j + 1 of one part) sit 8 ids apart = one XCD (when the id space allows it)
-            if ((Q.kblocks % fm.grp) == 0 && blk.size() % (8 * fm.grp) == 0)
+            // the records that share z lines (plane blocks j, j + 1, ... of one part) sit 8 ids apart = one XCD (when the id space allows it)
+            if (fm.grp >= 2 && fm.grp <= (unsigned)Q.kblocks && (Q.kblocks % fm.grp) == 0 && blk.size() % (8 * fm.grp) == 0)
                 for (size_t id = 0; id + 8 < blk.size(); ++id)
-                    if ((id / 8) % fm.grp == 0 && blk[id].npos > 0)
+                    if ((id / 8) % fm.grp != fm.grp - 1 && blk[id].npos > 0)
                         CHECK(blk[id + 8].ibase == blk[id].ibase && blk[id + 8].jbase == blk[id].jbase && blk[id + 8].k0 == blk[id].k0 + fm.zb, "line partners not 8 ids apart");
         }
     }

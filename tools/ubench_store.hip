@@ -46,6 +46,10 @@ int main() {
     time([&] { hipMemsetAsync(d, 0, bytes, 0); }, "hipMemsetAsync", gb);
     // runs: total runs = bytes / R; each block writes 8 rows x nv volumes
     {
+        const int R4 = 4; const size_t rows = vox * 4 / (R4 * 16); const unsigned blocks = (unsigned)(rows / 8);
+        time([&] { hipLaunchKernelGGL(runs_k<4>, dim3(blocks), dim3(512), 0, 0, d, vox / 4, (int)nv, (int)rows); }, "64-B runs, 16 volumes", gb);
+    }
+    {
         const int R4 = 8; const size_t rows = vox * 4 / (R4 * 16); const unsigned blocks = (unsigned)(rows / 8);
         time([&] { hipLaunchKernelGGL(runs_k<8>, dim3(blocks), dim3(512), 0, 0, d, vox / 4, (int)nv, (int)rows); }, "128-B runs, 16 volumes", gb);
     }
