@@ -319,6 +319,8 @@ def live_traffic(kernel_name: str, argv_workload):
 
 N_CU = 256
 STORE_DRAIN_GBS = 6300.0     # sustained write / stream-copy rate of this part (tools/ubench_store.hip: 5.1 - 6.6 TB/s; DESIGN.md 5.3: 6.3 TB/s)
+STORE_RUN64_GBS = 4300.0     # ... and what it absorbs in scattered runs of 64 contiguous bytes, the lattice kernels' store pattern (one block = 16 planes of a
+                             # voxel column; profiles/ubench_store_r05.txt: 64 B 4.3, 128 B 5.4, 1 KiB 7.7 TB/s)
 
 
 def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
@@ -339,13 +341,19 @@ def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
     matrix_cyc, other_cyc = 16.0 * units, 4.0 * n_other + 4.0 * n_trans
     matrix_ms = matrix_cyc / (N_SIMD * clk * 1e9) * 1e3
     port_ms = (matrix_cyc + other_cyc) / (N_SIMD * clk * 1e9) * 1e3
-    store_ms = alg_bytes / (STORE_DRAIN_GBS * 1e9) * 1e3
+    runs64 = kernel_name.startswith(("field_cosetp_k", "field_coset_k", "field_toep_k"))
+    store_rate = STORE_RUN64_GBS if runs64 else STORE_DRAIN_GBS
+    store_ms = alg_bytes / (store_rate * 1e9) * 1e3
     floor_ms = max(port_ms, store_ms)
     return {"what": "floors of this formulation at the clock measured under this load: vector issue port of the SIMDs (matrix + other vector "
-                    "instructions share it) and the HBM write drain of the result; `floor_ms` = the larger one (perfect overlap of the two)",
+                    "instructions share it) and the HBM write drain of the result in the kernel's store pattern; `floor_ms` = the larger one "
+                    "(perfect overlap of the two).  Lower bounds, not a model of the launch: round 5's A/B runs (profiles/r05_store_path.txt) "
+                    "show the headline launch bound by neither alone -- 22 % fewer vector instructions left it as long as before, cache-resident "
+                    "stores make it 0.305 ms; a block is a chain of barrier-separated phases on different units with two blocks per CU",
+            "store_pattern": "runs of 64 contiguous bytes (16 planes of a voxel column per block)" if runs64 else "streaming",
             "clock_ghz": clk, "clock_source": "SQ_BUSY_CU_CYCLES / 256 CUs / dispatch duration, child pass of this run",
             "matrix_instructions": n_mfma, "matrix_units_of_16_cycles": units, "other_vector_instructions": n_other, "transcendentals": n_trans,
-            "matrix_only_ms": matrix_ms, "issue_port_ms": port_ms, "store_drain_ms": store_ms, "store_drain_rate_GBps": STORE_DRAIN_GBS,
+            "matrix_only_ms": matrix_ms, "issue_port_ms": port_ms, "store_drain_ms": store_ms, "store_drain_rate_GBps": store_rate,
             "floor_ms": floor_ms, "roofline_frac_at_floor": alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_ms": k_ms, "measured_over_floor": k_ms / floor_ms,
             "matrix_only_ms_at_2p4ghz": matrix_cyc / (N_SIMD * CLK_GHZ * 1e9) * 1e3}
