@@ -356,6 +356,11 @@ def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
             "matrix_only_ms": matrix_ms, "issue_port_ms": port_ms, "store_drain_ms": store_ms, "store_drain_rate_GBps": store_rate,
             "floor_ms": floor_ms, "roofline_frac_at_floor": alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_ms": k_ms, "measured_over_floor": k_ms / floor_ms,
+            "busy_cycles_per_cu": v["SQ_BUSY_CU_CYCLES"] / N_CU,
+            "ms_at_2p4ghz": v["SQ_BUSY_CU_CYCLES"] / N_CU / (CLK_GHZ * 1e9) * 1e3,
+            "clock_note": "the chip holds `clock_ghz` under this load (power cap; 2.4 GHz nominal): the launch is `busy_cycles_per_cu` cycles long, `ms_at_2p4ghz` "
+                          "is what those cycles would take at the nominal clock -- with cache-resident stores the same kernel runs 7 % fewer cycles at an 8 % higher clock "
+                          "(profiles/r05_store_path.txt, 15)",
             "matrix_only_ms_at_2p4ghz": matrix_cyc / (N_SIMD * CLK_GHZ * 1e9) * 1e3}
 
 
