@@ -841,6 +841,34 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
     _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
 
 
+@pytest.mark.parametrize("case", ["2g_nt2", "2g_ragged_nz", "2e_nt1", "2f"])
+def test_one_output_only_equals_the_two_output_launch(ctx, case):
+    """|p| alone and intensity alone (OLX_OUT_PMAG / OLX_OUT_INTENSITY) give the bits of the launch that writes both: kernel 2g has its own
+    instantiation for the two-output case (no flag tests between its stores), the single-output launches run the other one; its ragged-nz
+    store form (nz not a multiple of 4) is a third copy of the read-out."""
+    foci = {"2g_nt2": [[1e-3, 2e-3, 30e-3], [-3e-3, 1e-3, 26e-3], [2e-3, -4e-3, 22e-3]], "2g_ragged_nz": [[1e-3, 2e-3, 24e-3], [-3e-3, 1e-3, 20e-3], [2e-3, -4e-3, 22e-3]],
+            "2e_nt1": [[1e-3, 2e-3, 30e-3]], "2f": [[0, 0, 30e-3]]}[case]
+    nz = 23 if case == "2g_ragged_nz" else 32
+    expect = {"2g_nt2": "field_cosetp_k<nt2", "2g_ragged_nz": "field_cosetp_k<nt2", "2e_nt1": "field_coset_k<nt1", "2f": "field_toep_k"}[case]
+    a, b = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    pos = np.stack([(a.ravel() - 7.5) * 3.0, (b.ravel() - 7.5) * 3.0, np.zeros(256)], axis=1)
+    pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), np.tile([2.7, 2.7], (256, 1)), np.asarray(foci), solve=True)
+    n = (40, 44, nz)
+    origin = (-(n[0] - 1) / 2 * 1e-3, -(n[1] - 1) / 2 * 1e-3, 5e-3)
+    got = {}
+    for name, flags in (("both", nat.OUT_PMAG | nat.OUT_INTENSITY), ("p", nat.OUT_PMAG), ("i", nat.OUT_INTENSITY)):
+        ctx.field_plan(origin, (1e-3,) * 3, n, F0, C, RHO, P0, flags=flags)
+        assert expect in ctx.field_variant(), ctx.field_variant()
+        ctx.field_launch()
+        want = ("pmag", "intensity") if name == "both" else (("pmag",) if name == "p" else ("intensity",))
+        got[name] = [ctx.field_fetch(f, want=want) for f in range(len(foci))]
+    for f in range(len(foci)):
+        assert np.array_equal(got["p"][f]["pmag"], got["both"][f]["pmag"]) and np.array_equal(got["i"][f]["intensity"], got["both"][f]["intensity"])
+        ref = np.abs(co.field_on_grid(origin[0] + np.arange(n[0]) * 1e-3, origin[1] + np.arange(n[1]) * 1e-3, origin[2] + np.arange(n[2]) * 1e-3,
+                                      pos_m, area, d[f], ap[f], F0, C, P0, dmin=0.5e-3))
+        assert np.abs(got["both"][f]["pmag"] - ref).max() / ref.max() <= TOL_P
+
+
 def test_fp8_correction_products_are_the_gated_default(ctx, monkeypatch):
     """Kernel 2e / 2g's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
     grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  They are the DEFAULT (round 5) -- on the olx_bf_solve path and at the
