@@ -147,49 +147,58 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             const float dx = fmaf(U, P.hx_hi, fmaf(U, P.hx_lo, P.fx0));
             const float dx2 = dx * dx;
             const int Wsb = Wlane - 8 * P.my * sbb0;
+            // one table entry: G of squared lateral distance r2 on a plane dz2v above the elements -> hi / lo words at table offset o
+            auto entry = [&](const float r2, const float dz2v, const float dy, const int o, const bool ok) __attribute__((always_inline)) {
+                float d2 = r2 + dz2v;
+                if (CLAMP) d2 = fmaxf(d2, P.dmin2);
+                const float ri = __builtin_amdgcn_rsqf(d2);
+                const float ph = d2 * ri;
+                float rs = ri * P.g_scale;
+                if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
+                const float2_t gg = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * float2_t{rs, rs};      // (one packed multiply)
+                const float gr = gg.x, gi = gg.y;
+                half2_t hi;
+                if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
+                else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
+                // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
+                float lr, li;
+                const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
+                unsigned lo_word;
+                if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
+                    // (v_cvt_scalef32_pk_fp8_f32 DIVIDES by its power-of-two scale operand -- tools/probe/cvt_scale_probe.hip --
+                    // and rounds / saturates as the unscaled convert: the four operand scalings cost no instruction)
+                    short2_t w;                  // (both halves are written below)
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
+                    lo_word = __builtin_bit_cast(unsigned, w);
+                } else {
+                    lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
+                }
+                if (ok && OLX_IN(o, T_WORDS, 0)) {
+                    s_hi[o] = __builtin_bit_cast(unsigned, hi);
+                    s_lo[o] = lo_word;
+                }
+            };
+            // rows 0 .. TROWS - 2 in whole rounds of RPR rows x the wave's two planes; the LAST row once for both planes (row group wl takes
+            // plane wl): 11 instead of 12 evaluations per lane and pair
+            static_assert((TROWS - 1) % RPR == 0 && COS_P <= RPR, "the last table row is shared by the planes of a wave");
 #pragma unroll 2
-            for (int r = 0; r < NROUND; ++r) {
-                const bool row_ok = gen_lane && RPR * r + wl < TROWS;  // the last round may run past the table
+            for (int r = 0; r < NROUND - 1; ++r) {
                 const float W = (float)(Wsb + RPR * P.my * r);
                 const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
                 const float r2 = fmaf(dy, dy, dx2);
 #pragma unroll
-                for (int z = 0; z < COS_P; ++z) {
-                    float d2 = r2 + dz2[z];
-                    if (CLAMP) d2 = fmaxf(d2, P.dmin2);
-                    const float ri = __builtin_amdgcn_rsqf(d2);
-                    const float ph = d2 * ri;
-                    float rs = ri * P.g_scale;
-                    if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
-                    const float gr = rs * __builtin_amdgcn_cosf(ph);
-                    const float gi = rs * __builtin_amdgcn_sinf(ph);
-                    half2_t hi;
-                    if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
-                    else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
-                    // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract)
-                    float lr, li;
-                    const unsigned hw = __builtin_bit_cast(unsigned, hi);
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
-                    unsigned lo_word;
-                    if constexpr (FP8) {             // e4m3 bytes [lo re, lo im | hi re, hi im], |.| <= 256 (448 overflows to NaN)
-                        // (v_cvt_scalef32_pk_fp8_f32 DIVIDES by its power-of-two scale operand -- tools/probe/cvt_scale_probe.hip --
-                        // and rounds / saturates as the unscaled convert: the four operand scalings cost no instruction)
-                        short2_t w;                  // (both halves are written below)
-                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lr, li, 1.0f / COS_F8_LO, false);
-                        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, gr, gi, 1.0f / COS_F8_HI, true);
-                        lo_word = __builtin_bit_cast(unsigned, w);
-                    } else {
-                        lo_word = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
-                    }
-                    if (row_ok) {
-                        const int o = z * PSZ + tw_off + RPR * r * CP_TW;
-                        if (OLX_IN(o, T_WORDS, 0)) {
-                            s_hi[o] = __builtin_bit_cast(unsigned, hi);
-                            s_lo[o] = lo_word;
-                        }
-                    }
-                }
+                for (int z = 0; z < COS_P; ++z) entry(r2, dz2[z], dy, z * PSZ + tw_off + RPR * r * CP_TW, gen_lane);
+            }
+            if (KY + 14 >= TROWS - 1) {      // (block-uniform: the fragments of KY positions reach table rows 0 .. KY + 14)
+                const float W = (float)(Wsb - P.my * wl + (TROWS - 1) * P.my);
+                const float dy = fmaf(W, P.hy_hi, fmaf(W, P.hy_lo, P.fy0));
+                float dzl = dz2[0];
+#pragma unroll
+                for (int z = 1; z < COS_P; ++z) dzl = wl == z ? dz2[z] : dzl;
+                entry(fmaf(dy, dy, dx2), dzl, dy, (wave * COS_P + wl) * PSZ + (TROWS - 1) * CP_TW + (CP_UW - 1 - ui), wl < COS_P);
             }
         }
         if constexpr (FP8) __builtin_amdgcn_s_setprio(0);
