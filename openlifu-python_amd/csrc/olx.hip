@@ -489,17 +489,27 @@ static int configure_variant_impl(olx_ctx* c) {
                 colinfo[((size_t)t * MAXC + o) * 2 + 1] = tiles[t][o].m;
                 for (int q = 0; q < 4; ++q) targets[((size_t)t * MAXC + o) * 4 + q] = tiles[t][o].tgt[q];
             }
-        HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+        // (uploaded tables are remembered: an interactive caller re-plans per target, and a new target of the same focal pattern leaves the mirror
+        // permutations, the columns' representatives and their store targets as they were -- no copies, no wait for the stream)
+        bool sent = false;
+        if (c->up_perm != perm) {
+            HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+            c->up_perm = perm; sent = true;
+        }
         if (c->colinfo_cap < colinfo.size() + targets.size()) {
             if (c->d_colinfo) hipFree(c->d_colinfo);
-            c->d_colinfo = nullptr; c->colinfo_cap = 0;
+            c->d_colinfo = nullptr; c->colinfo_cap = 0; c->up_colinfo.clear(); c->up_targets.clear();
             HIPCHK(c, hipMalloc((void**)&c->d_colinfo, sizeof(int) * (colinfo.size() + targets.size())));
             c->colinfo_cap = colinfo.size() + targets.size();
         }
-        c->d_targets = c->d_colinfo + colinfo.size();
-        HIPCHK(c, hipMemcpyAsync(c->d_colinfo, colinfo.data(), sizeof(int) * colinfo.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_targets, targets.data(), sizeof(int) * targets.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // perm / colinfo / targets live on this stack frame
+        int* const d_targets_new = c->d_colinfo + colinfo.size();
+        if (c->up_colinfo != colinfo || c->up_targets != targets || c->d_targets != d_targets_new) {
+            c->d_targets = d_targets_new;
+            HIPCHK(c, hipMemcpyAsync(c->d_colinfo, colinfo.data(), sizeof(int) * colinfo.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_targets, targets.data(), sizeof(int) * targets.size(), hipMemcpyHostToDevice, c->stream));
+            c->up_colinfo = colinfo; c->up_targets = targets; sent = true;
+        }
+        if (sent) HIPCHK(c, hipStreamSynchronize(c->stream));  // perm / colinfo / targets live on this stack frame
         if (c->coords_cap < (size_t)n_pad) {
             if (c->d_coords) hipFree(c->d_coords);
             c->d_coords = nullptr; c->coords_cap = 0;
@@ -733,6 +743,7 @@ static int configure_variant_impl(olx_ctx* c) {
             }
         HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // perm is a stack vector
+        c->up_perm.clear();                          // (the lattice / matrix path's remembered copy no longer describes d_perm)
         const size_t need = (size_t)((F + c->nf - 1) / c->nf) * n * (4 + 2 * nm * c->nf);  // never trust the plan-time bound
         if (c->tab_cap < need) {
             if (c->d_tab) hipFree(c->d_tab);
@@ -959,7 +970,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         }
         if (c->perm_cap < (size_t)4 * n) {
             if (c->d_perm) hipFree(c->d_perm);
-            c->d_perm = nullptr; c->perm_cap = 0;
+            c->d_perm = nullptr; c->perm_cap = 0; c->up_perm.clear();
             HIPCHK(c, hipMalloc((void**)&c->d_perm, sizeof(int) * 4 * n));
             c->perm_cap = (size_t)4 * n;
         }
