@@ -707,8 +707,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms_avg": k_ms, "kernel_launches_timed": int(len(kern_ms)),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the accumulate is issue bound (matrix pipe + VALU), not HBM bound "
-                                 "(SURVEY 8(d), DESIGN.md 5); see issue_ceiling"},
+                         "note": "the accumulate is bound on the compute side (a block's chain of vector-ALU, matrix pipe + LDS and store phases "
+                                 "at the clock the chip holds under its power cap), not by HBM bandwidth: SURVEY 8(d), DESIGN.md 5.5; see "
+                                 "`achievable` and `issue_ceiling`"},
             **mfma_useful(kernel_name),
             "issue_ceiling": {"achieved_Mpairs_s": float(vox_launch) * N * F / (k_ms * 1e-3) / 1e6, "peak_Mpairs_s": ceil_pairs / 1e6,
                               "frac": float(vox_launch) * N * F / (k_ms * 1e-3) / ceil_pairs, "model": model},
