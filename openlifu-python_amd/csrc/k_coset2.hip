@@ -439,9 +439,10 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (getenv("OLX_DEBUG_BOUNDS_SELFTEST")) Q.n_foci -= 1;
 #endif
     float* inten_exp = c->d_inten;
-    // timing experiments only (WRONG results: the volumes overlap): focus stride shortened by OLX_EXP_FPAD floats, intensity base moved by OLX_EXP_IPAD floats
+#ifdef OLX_EXP_PADS   // timing builds only (WRONG results: the volumes overlap): focus stride shortened by OLX_EXP_FPAD floats, intensity base moved by OLX_EXP_IPAD floats
     if (const char* e = getenv("OLX_EXP_FPAD")) Q.vox -= atoll(e);
     if (const char* e = getenv("OLX_EXP_IPAD")) inten_exp += atoll(e);
+#endif
     const bool clamp = c->clamp || c->lat.clamp;
     dim3 grid((unsigned)c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);
     const bool both = (Q.flags & 3u) == 3u;
