@@ -869,6 +869,30 @@ def test_one_output_only_equals_the_two_output_launch(ctx, case):
         assert np.abs(got["both"][f]["pmag"] - ref).max() / ref.max() <= TOL_P
 
 
+def test_block_record_order_does_not_change_results(ctx, monkeypatch):
+    """The host chooses in which order the block records of kernels 2e / 2f / 2g meet the XCDs (all 16 plane blocks of a position set in a row
+    on one XCD; OLX_EXP_KGRP pins 1, 2, 4 ... for A/B runs): a performance choice only -- every order gives the same bits."""
+    a, b = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    pos = np.stack([(a.ravel() - 7.5) * 3.0, (b.ravel() - 7.5) * 3.0, np.zeros(256)], axis=1)
+    n = (48, 48, 64)
+    origin = (-(n[0] - 1) / 2 * 1e-3, -(n[1] - 1) / 2 * 1e-3, 5e-3)
+    for foci, expect in (([[1e-3, 2e-3, 30e-3], [-3e-3, 1e-3, 26e-3], [2e-3, -4e-3, 22e-3]], "field_cosetp_k<nt2"), ([[0, 0, 30e-3]], "field_toep_k")):
+        setup_ctx(ctx, pos, np.zeros_like(pos), np.tile([2.7, 2.7], (256, 1)), np.asarray(foci), solve=True)
+        got = {}
+        for grp in (None, "1", "2", "4"):
+            if grp is None:
+                monkeypatch.delenv("OLX_EXP_KGRP", raising=False)
+            else:
+                monkeypatch.setenv("OLX_EXP_KGRP", grp)
+            ctx.field_plan(origin, (1e-3,) * 3, n, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+            assert expect in ctx.field_variant(), ctx.field_variant()
+            ctx.field_launch()
+            got[grp] = ctx.field_fetch_all()
+        for grp in ("1", "2", "4"):
+            assert np.array_equal(got[grp]["pmag"], got[None]["pmag"]) and np.array_equal(got[grp]["intensity"], got[None]["intensity"]), grp
+    monkeypatch.delenv("OLX_EXP_KGRP", raising=False)
+
+
 def test_fp8_correction_products_are_the_gated_default(ctx, monkeypatch):
     """Kernel 2e / 2g's e4m3 correction products (NT <= 2) cost ~5.8e-6 of the focal peak at 256 equally driven elements and
     grow as 1 / sqrt(N_eff), N_eff = (sum w)^2 / sum w^2.  They are the DEFAULT (round 5) -- on the olx_bf_solve path and at the
