@@ -155,8 +155,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 const float ph = d2 * ri;
                 float rs = ri * P.g_scale;
                 if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
-                const float2_t gg = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * float2_t{rs, rs};      // (one packed multiply)
-                const float gr = gg.x, gi = gg.y;
+                float gr = rs * __builtin_amdgcn_cosf(ph), gi = rs * __builtin_amdgcn_sinf(ph);
+                asm volatile("" : "+v"(gr), "+v"(gi));      // (two plain multiplies: packed fp32 beside the partner block's matrix instructions measured slower)
                 half2_t hi;
                 if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
                 else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
