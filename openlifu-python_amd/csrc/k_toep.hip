@@ -135,8 +135,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const float ph = d2 * ri;
                 float rs = ri * P.g_scale;
                 if constexpr (DIR) rs *= table_mod(dx, dy, ph, ri, P.dir_wx, P.dir_wy, P.absorb_l2);      // (own instantiations: the default path never sees this)
-                const float2_t gv = float2_t{__builtin_amdgcn_cosf(ph), __builtin_amdgcn_sinf(ph)} * rs;      // (one v_pk_mul_f32)
-                const float gr = gv[0], gi = gv[1];
+                float gr = rs * __builtin_amdgcn_cosf(ph), gi = rs * __builtin_amdgcn_sinf(ph);
+                asm volatile("" : "+v"(gr), "+v"(gi));      // (two plain multiplies: a packed one measured slower in kernel 2g's fill)
                 half2_t hi;
                 if constexpr (FP8) hi = __builtin_convertvector(float2_t{gr, gi}, half2_t);      // to nearest: |lo| <= half an ulp
                 else hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(gr, gi));
