@@ -326,8 +326,9 @@ STORE_RUN64_GBS = 4300.0     # ... and what it absorbs in scattered runs of 64 c
 def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
     """What THIS FORMULATION permits, from counters measured in this run (one more child pass: SQ_BUSY_CU_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA,
     SQ_INSTS_VALU_TRANS_F32): a SIMD has ONE vector issue port that its matrix and its other vector instructions share, so
-    the launch cannot be shorter than (16 cycles per matrix instruction + 4 per other vector instruction [+ 4 more per transcendental])
-    / 1024 SIMDs at the clock the chip holds under this load (power cap), nor than the HBM write drain of its result."""
+    the launch cannot be shorter than (16 cycles per matrix unit + 2.45 per other vector instruction, 8.17 per transcendental -- the issue costs
+    tools/ubench_valu.hip measures) / 1024 SIMDs at the clock the chip holds under this load (power cap), nor than the HBM write drain of its
+    result in the kernel's store pattern."""
     try:
         v, dur_us = pmc_pass(kernel_name, argv_workload, ["SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32"])
     except Exception as e:  # noqa: BLE001
@@ -338,7 +339,9 @@ def achievable(kernel_name: str, argv_workload, alg_bytes: float, k_ms: float):
     # planner states the launch's units (lattice kernels) they are used instead of the instruction count
     mu = re.search(r"(\d+) MFMA/launch", kernel_name)
     units = float(mu.group(1)) if mu else n_mfma
-    matrix_cyc, other_cyc = 16.0 * units, 4.0 * n_other + 4.0 * n_trans
+    # (issue costs measured by tools/ubench_valu.hip at four waves per SIMD: a plain fp32 instruction 2.45 cycles, a transcendental 8.17; conversions
+    # and mixed-precision instructions cost up to 4.2 -- the cheapest figure keeps this a floor)
+    matrix_cyc, other_cyc = 16.0 * units, CYC_PLAIN * (n_other - n_trans) + CYC_TRANS * n_trans
     matrix_ms = matrix_cyc / (N_SIMD * clk * 1e9) * 1e3
     port_ms = (matrix_cyc + other_cyc) / (N_SIMD * clk * 1e9) * 1e3
     runs64 = kernel_name.startswith(("field_cosetp_k", "field_coset_k", "field_toep_k"))
