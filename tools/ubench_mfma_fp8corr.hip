@@ -21,7 +21,7 @@ __device__ inline intx8_t rnd_fp8(unsigned& s) {   // random e4m3 bytes with the
     return v;
 }
 
-template <int MODE>   // 0: 6 fp16 MFMAs per step; 1: 2 fp16 + 1 fp8 (K = 128); 2: 2 fp16 only (the hi*hi floor)
+template <int MODE>   // 0: 6 fp16 MFMAs per step; 1: 2 fp16 + 1 fp8 (K = 128); 2: 2 fp16 only (the hi*hi floor); 3 / 4: 2 fp16 + 1 fp6 / fp4 (K = 128)
 __global__ __launch_bounds__(256) void burn(float* out, int iters) {
     unsigned s = threadIdx.x * 747796405u + blockIdx.x * 2891336453u + 1u;
     half8_t ah[2], al[2], bh[2], bl[2];
@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void burn(float* out, int iters) {
                 }
             }
             if (MODE == 1) acc[q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[q], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            // MODE 3 / 4: the correction product with FP6 (E2M3, format 2) / FP4 (E2M1, format 4) operands -- the same instruction at the rate of the
+            // narrower formats (only the TIMING is of interest here: the operand bytes are the e4m3 ones, reinterpreted)
+            if (MODE == 3) acc[q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[q], 2, 2, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            if (MODE == 4) acc[q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[q], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         }
     }
     float sum = 0.f;
@@ -67,6 +71,8 @@ int main() {
         run(burn<0>, "6 x f16 16x16x32 (today)", 100000);
         run(burn<1>, "2 x f16 16x16x32 + 1 x fp8 16x16x128", 100000);
         run(burn<2>, "2 x f16 16x16x32 (hi*hi only)", 100000);
+        run(burn<3>, "2 x f16 16x16x32 + 1 x fp6 (E2M3) 16x16x128", 100000);
+        run(burn<4>, "2 x f16 16x16x32 + 1 x fp4 (E2M1) 16x16x128", 100000);
     }
     return 0;
 }
