@@ -20,7 +20,7 @@ torch is used only for the rendezvous / barrier (gloo); the product path is ctyp
 
 Arithmetic: fp32 accumulate of fp16 hi/lo operands on the matrix cores.  `value` is measured in the LIBRARY DEFAULT mode
 (`--corrections auto`): what Protocol.calc_solution runs unless told otherwise -- on this shard the two hi x lo correction products
-go through e4m3 (<= 6.5e-6 of the focal peak; north_star's gate is 1e-5).  `--corrections fp16` times the opted-out mode (plan flag
+go through e4m3 (<= 7.5e-6 of the volume maximum, include/olx.h; north_star's gate is 1e-5).  `--corrections fp16` times the opted-out mode (plan flag
 OLX_FIELD_FP16_CORRECTION / SimSetup.options["fp8_correction"] = "0": three fp16 products, <= 2e-6) as the headline instead.  At
 N = 1 the line carries the other mode beside it (`precision_safe` / `library_default`), a `parity` block measured in this run against the fp64 C oracle, and the other
 shapes of the path (`legs`: single focus on / off axis, off-axis shard, 64-focus sweep), each planned, clock-ramped and timed
@@ -382,7 +382,7 @@ def main():
                          "(DESIGN.md 6); north_star's all-gather of every per-focus volume and the compute without exchange are timed beside it.  N = 1: none")
     ap.add_argument("--corrections", choices=["auto", "fp8", "fp16"], default="auto",
                     help="hi x lo correction products of the fp16 operand split: auto (= fp8) = the library default, e4m3 products where their "
-                         "bound (<= 6.5e-6 of the focal peak) is a bound on the planned volume; fp16 = opted out (plan flag "
+                         "bound (<= 7.5e-6 of the volume maximum, include/olx.h) is a bound on the planned volume; fp16 = opted out (plan flag "
                          "OLX_FIELD_FP16_CORRECTION, <= 2e-6); the other one is timed beside it at N = 1")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--spacing-mm", type=float, default=0.25)

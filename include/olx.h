@@ -143,13 +143,22 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  *   pointer may be NULL.
  * accuracy: fp32 results within 1e-5 of the volume's maximum |p| against the fp64 definition (north_star's gate; the
  *   per-pair and fp16-split kernels measure 0.8e-6 ... 1.9e-6).  Matrix arrays on a commensurate grid (the lattice
- *   kernels 2e / 2g) compute the two small correction products of their fp16 hi/lo operand split in fp8 (e4m3)
- *   BY DEFAULT -- ~14 % faster, error <= 6.5e-6 of the FOCAL PEAK (measured 4.1e-6 ... 6.2e-6 on full 256^3 volumes) --
- *   but only when that bound is a bound on the planned volume: every focus of the steering table is known (it came
- *   from olx_bf_solve in the element frame, or its external delays are recognised as geometric), lies inside the
- *   planned slab, and drives >= 256 elements effectively ((sum w)^2 / sum w^2).  Everything else -- small or
- *   strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, the single-column kernel 2f, complex
- *   output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION in `flags` opts out everywhere.
+ *   kernels 2e / 2g and the single-column kernel 2f) compute the two small correction products of their fp16 hi/lo
+ *   operand split in fp8 (e4m3) BY DEFAULT -- ~20 % faster, error <= 7.5e-6 of the VOLUME MAXIMUM (measured 4.1e-6 ...
+ *   6.2e-6 on full 256^3 volumes) -- but only where the planner can bound it (olx_plan.h, FP8_ERR_K / FP8_ERR_BOUND):
+ *   the scheme's error is relative to each element's own term, 6.2e-6 |w_e| / d(v, e) rms with random sign, so it asks for
+ *     (i)   every focus of the steering table known (it came from olx_bf_solve in the element frame, or its external
+ *           delays are recognised as geometric) and inside the planned slab -- the slab then holds the coherent focal
+ *           peak P_f = sum_e w_ef / d(focus_f, e);
+ *     (ii)  >= 256 effectively driven elements, (sum w)^2 / sum w^2;
+ *     (iii) 3.75e-5 max_e(w_ef) sqrt(max_v sum_e 1 / d'(v, e)^2) <= 7.5e-6 P_f for every focus: six sigma of the error of the
+ *           planned slab's WORST voxel (the one next to an element; d' = the clamped distance).  On BASELINE's 16 x 16 array
+ *           this admits grids that start >= ~4.5 mm above the element plane and refuses every grid that reaches or crosses
+ *           it -- the reference's default SimSetup (z_extent from -4 mm, sim/sim_setup.py:36) runs three fp16 products.
+ *   Everything else -- small or strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, near-field
+ *   grids, 17-32 columns in one tile, complex output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION
+ *   in `flags` (or OLX_FP8_CORRECTION=0 in the environment) opts out everywhere; nothing can opt IN past the rule in the
+ *   product library (OLX_FP8_CORRECTION=1 is honoured by developer builds only).
  *   olx_field_variant() names the kernel in use ("fp8corr" when the e4m3 products are active). */
 int olx_field_plan(olx_ctx *ctx, const olx_grid *grid, const olx_slab *slab /*NULL = whole grid*/,
                    int n_foci, double freq, double c, double rho, double p0_pa, unsigned flags);

@@ -36,6 +36,8 @@ def build(force: bool = False, defines=(), out: str = OUT) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))     # (*.cpp: host-only units, e.g. olx_plan.cpp)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "olx.h")]
     tag = "" if not defines else "_" + "_".join(d.lstrip("-D").replace("=", "") for d in defines)
+    if defines:     # every non-product build (debug library, timing / tracing builds) also honours the developer pins the product ignores:
+        defines = list(defines) + ["-DOLX_DEV_PINS"]      # OLX_FP8_CORRECTION=1 (forces e4m3 past its error rule), OLX_EXP_KGRP, OLX_EXP_TOEP_SAW
     objdir = os.path.join(HERE, "build" + tag)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)

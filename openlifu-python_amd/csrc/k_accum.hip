@@ -224,9 +224,6 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
         for (int k = 0; k < NOUT; ++k) { re[q][k] = 0.f; im[q][k] = 0.f; }
     }
     const float* t = tab + (size_t)tile * P.n_el * STRIDE;
-#ifdef OLX_EXP_UNROLL
-#pragma unroll OLX_EXP_UNROLL
-#endif
     for (int e = 0; e < P.n_el; ++e) {
         const float* te = t + (size_t)e * STRIDE;
         const float dx = x - te[0], dy = y - te[1];

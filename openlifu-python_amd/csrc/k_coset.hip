@@ -112,12 +112,6 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     const int nsbp = P.nsbp;                    // SHARE: nsb padded to an even count, so chunks = table pairs never straddle sa
     const int n_sb = P.nsa * nsbp;
     OLX_STAMP(0);
-#ifdef OLX_EXP_STAGGER
-    if (blockIdx.y == 0 && blockIdx.x < 768) {   // first-round blocks start staggered (A/B: do store bursts of lock-stepped blocks add up?)
-        const long long t0 = __builtin_readcyclecounter(), wait = (long long)((blockIdx.x * 7) % 16) * (OLX_EXP_STAGGER);
-        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
     constexpr int CHUNK_U4 = SB_PER_CHUNK * 4 * NT * 128, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
@@ -383,11 +377,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                         kx += skx; ky += sky;
                         if (ky >= KY) { ky -= KY; ++kx; }
                         const int io = fx ? (P.nx - 1 - i) : i, jo = fy ? (P.ny - 1 - j) : j;
-#ifdef OLX_EXP_L2STORE
-                        dst[u] = qu < npos ? base + ((long long)(io * P.ny + jo) * P.nz & 0xFFFFF) - (long long)(job >> 6) * P.vox : nullptr;  // A/B: stores stay cache resident
-#else
                         dst[u] = qu < npos ? base + (long long)(io * P.ny + jo) * P.nz : nullptr;
-#endif
                         if (dst[u] && !OLX_IN((long long)(job >> 6) * P.vox + kz + (long long)(io * P.ny + jo) * P.nz + (FAST ? 3 : 0), (long long)P.n_foci * P.vox, 3)) dst[u] = nullptr;
                         const float* v = sv + (qu < npos ? qu : q) * RS;
                         val[u] = make_float4(v[0], v[1], v[2], v[3]);
@@ -409,16 +399,6 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
             }
             }
     };
-#ifdef OLX_EXP_NOEPILOGUE
-    {   // A/B build: keep every accumulator live, skip staging + stores
-        float live = 0.f;
-#pragma unroll
-        for (int t = 0; t < COS_MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) live += acc[t][nt][0] + acc[t][nt][1] + acc[t][nt][2] + acc[t][nt][3];
-        if (live != 123.456f) return;
-    }
-#endif
     stage_and_store(IntC<0>{});
     if constexpr (NT > GROUP) stage_and_store(IntC<GROUP>{});
     OLX_STAMP(7);

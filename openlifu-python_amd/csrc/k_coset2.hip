@@ -78,11 +78,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
     if (npos <= 0) return;                              // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
-#ifdef OLX_EXP_SKIP33   // timing experiment only (WRONG results): no wave takes a fifth tile -- what a balanced 33rd position could gain at most
-    const int ntile = min(4, __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW));
-#else
     const int ntile = __builtin_amdgcn_readfirstlane((npos - wave + COS_NW - 1) / COS_NW);      // this wave's positions: wave, wave + 8, ... (wave-uniform, <= MT)
-#endif
     // table generation role (planes 2 wave, 2 wave + 1): lane -> (wl = lane / UW < RPR, ui = lane % UW); round r: rows RPR r + wl.
     // (Its per-lane constants are formed inside the pair loop from an opaque copy of the lane index: hoisted, they would be live
     // across the K-steps, where the fp8 shape has no register to spare -- 5 spilled registers cost 190 MB of scratch traffic.)
@@ -102,11 +98,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int nsbp = P.nsbp;                    // even: chunks = table pairs never straddle sa
-#ifdef OLX_EXP_STOREONLY   // timing experiment only (WRONG results): no tables, no K-steps -- the launch's store pattern alone
-    const int n_sb = 0;
-#else
     const int n_sb = P.nsa * nsbp;
-#endif
     constexpr int CHUNK_U4 = PAIR * 4 * NT * B_KS_U4, PRE = CHUNK_U4 / THREADS;
     static_assert(CHUNK_U4 % THREADS == 0, "chunk must split evenly over the block");
     uint4 pre[PRE];
@@ -365,11 +357,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             const bool fx = (MX == 2) && (m & 1u), fy = (MY == 2) && ((MX == 2) ? (m >> 1) : (m & 1u));
             unsigned fxm = fx ? 0xFFFFFFFFu : 0u, fym = fy ? 0xFFFFFFFFu : 0u;
             asm volatile("" : "+v"(fxm), "+v"(fym));      // (opaque: kept as masks -- one v_and per term instead of a move and a select)
-#ifdef OLX_EXP_L2STORE   // timing experiment only (WRONG results): every store lands in a cache-resident 4 MB window of its volume -- what the HBM write path costs
-            const long long fb = 0;
-#else
             const long long fb = (long long)(code >> 2) * P.vox + kz;
-#endif
             float* const base_p = pmag + fb;
             float* const base_i = inten + fb;
 #pragma unroll
@@ -380,20 +368,11 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 const int i = ibase + 2 * P.mx * kx, j = jbase + P.my * ky;      // wave-uniform (scalar ALU)
                 const unsigned o00 = (unsigned)(i * sxz + j * P.nz);
                 const unsigned DX = (unsigned)((xm - 2 * i) * sxz), DY = (unsigned)((ym - 2 * j) * P.nz);
-#ifdef OLX_EXP_L2STORE
-                const unsigned off = (o00 + (fxm & DX) + (fym & DY) + (unsigned)kz + ((unsigned)code >> 2) * 4096u) & 0xFFFFCu;
-#else
                 const unsigned off = o00 + (fxm & DX) + (fym & DY);
-#endif
                 if (!OLX_IN(fb + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
                 if constexpr (FULL4) {
-#ifdef OLX_EXP_NTSTORE   // A/B: non-temporal output stores
-                    if (BOTH || want_p) __builtin_nontemporal_store(acc[t][0], reinterpret_cast<floatx4_t*>(base_p + off));
-                    if (BOTH || want_i) __builtin_nontemporal_store(acc[t][1], reinterpret_cast<floatx4_t*>(base_i + off));
-#else
                     if (BOTH || want_p) *reinterpret_cast<float4*>(base_p + off) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
                     if (BOTH || want_i) *reinterpret_cast<float4*>(base_i + off) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
-#endif
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -439,10 +418,6 @@ static void launch_cosetp(olx_ctx* c, float* pm) {
     if (getenv("OLX_DEBUG_BOUNDS_SELFTEST")) Q.n_foci -= 1;
 #endif
     float* inten_exp = c->d_inten;
-#ifdef OLX_EXP_PADS   // timing builds only (WRONG results: the volumes overlap): focus stride shortened by OLX_EXP_FPAD floats, intensity base moved by OLX_EXP_IPAD floats
-    if (const char* e = getenv("OLX_EXP_FPAD")) Q.vox -= atoll(e);
-    if (const char* e = getenv("OLX_EXP_IPAD")) inten_exp += atoll(e);
-#endif
     const bool clamp = c->clamp || c->lat.clamp;
     dim3 grid((unsigned)c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);
     const bool both = (Q.flags & 3u) == 3u;

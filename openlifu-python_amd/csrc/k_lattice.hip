@@ -127,7 +127,6 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
             const int sb = sb0 + sbl;
             const int sa = sb / nsbp, sbb = sb - sa * nsbp;      // sa-major order (host slot map)
             // ---- G table of this super-block: 110 offsets x ZW planes (2 rounds of 64 lanes per plane)
-#ifndef OLX_EXP_NOTGEN
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float U = (float)(Ur[r] - 8 * P.mx * sa), W = (float)(Wr[r] - 8 * P.my * sbb);
@@ -149,7 +148,6 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
                     Tlo[z * LAT_PSZ + toff[r]] = __builtin_bit_cast(unsigned, lo);
                 }
             }
-#endif
             // the table is wave-private: DS operations of one wave execute in order, only the compiler must not
             // move the fragment reads above the table writes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -169,10 +167,6 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     Half8Bits ah, al;
-#ifdef OLX_EXP_NOAREAD
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ah.w[q] = 0x3c003c00u + t + q + ks; al.w[q] = 0x1c001c00u + t + q; }
-#else
                     // four separate ds_read_b64 (2 LDS cycles each, 64-bank mode).  Relaxed atomic loads keep the
                     // compiler from fusing them into ds_read2_b64, which runs at a quarter of that rate.
                     const unsigned long long* ph2 = reinterpret_cast<const unsigned long long*>(Thi + t * LAT_PSZ + roff);
@@ -183,14 +177,6 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
                     const unsigned long long l1 = __hip_atomic_load(pl2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     ah.w[0] = (unsigned)h0; ah.w[1] = (unsigned)(h0 >> 32); ah.w[2] = (unsigned)h1; ah.w[3] = (unsigned)(h1 >> 32);
                     al.w[0] = (unsigned)l0; al.w[1] = (unsigned)(l0 >> 32); al.w[2] = (unsigned)l1; al.w[3] = (unsigned)(l1 >> 32);
-#endif
-#ifdef OLX_EXP_NOMFMA
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[t][nt][0] += (float)bh[nt].h[0] + (float)bl[nt].h[0];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(ah.w[q]), "v"(al.w[q]));
-                    continue;
-#endif
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
 #pragma unroll
@@ -257,9 +243,6 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
             const int4 tg = reinterpret_cast<const int4*>(targets)[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (col >> 1)];
             const int tgs[4] = {tg.x, tg.y, tg.z, tg.w};
             const float* src = s_out + col * CS + 4 * piece;
-#ifdef OLX_EXP_NOSTORE
-            if (kz == 123456)
-#endif
             if (want && fast) {
                 float* tb[4]; bool tfx[4], tfy[4];   // per store target: volume base, mirror flags (hoisted out of the rows)
 #pragma unroll

@@ -117,19 +117,12 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
                     ah.w[q] = __builtin_bit_cast(unsigned, hi);
                     al.w[q] = __builtin_bit_cast(unsigned, lo);
                 }
-#ifdef OLX_EXP_NOMFMA
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[t][nt][0] += (float)bh[nt].h[0] + (float)bl[nt].h[0];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(ah.w[q]), "v"(al.w[q]));
-#else
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh[nt].h, acc[t][nt], 0, 0, 0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh[nt].h, acc[t][nt], 0, 0, 0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl[nt].h, acc[t][nt], 0, 0, 0);
-#endif
             }
         }
     }

@@ -432,14 +432,35 @@ static int configure_variant_impl(olx_ctx* c) {
                     const double hi = c->grid.origin[a] + (b0 + cnt - 0.5) * c->grid.spacing[a];
                     if (!(c->h_foci[3 * (size_t)f + a] >= lo && c->h_foci[3 * (size_t)f + a] <= hi)) ok = false;
                 }
-                double sw1 = 0, sw2 = 0;
-                for (int e = 0; e < n; ++e) { const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]); sw1 += w; sw2 += w * w; }
+                double sw1 = 0, sw2 = 0, wmx = 0, peak = 0;
+                const double* fo = &c->h_foci[3 * (size_t)f];
+                for (int e = 0; e < n; ++e) {
+                    const double w = std::fabs(c->h_apod[(size_t)f * n + e] * c->h_area[e]);
+                    sw1 += w; sw2 += w * w; wmx = std::max(wmx, w);
+                    const double ddx = fo[0] - c->h_pos[e], ddy = fo[1] - c->h_pos[(size_t)n + e], ddz = fo[2] - c->h_pos[2 * (size_t)n + e];
+                    peak += w / std::sqrt(std::max(ddx * ddx + ddy * ddy + ddz * ddz, 1e-30));
+                }
                 if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
+                // the near field: the error next to an element is relative to that element's own term (olx_plan.h, FP8_ERR_K): the bound on
+                // the worst voxel of the planned slab must stay below FP8_ERR_BOUND of this focus' coherent peak
+                if (ok) {
+                    if (c->nf_s2 < 0) {   // once per (element table, planned slab): olx_field_plan resets it
+                        const int b0[3] = {c->slab.x_begin, 0, 0}, cnt[3] = {c->slab.x_count, c->grid.n[1], c->grid.n[2]};
+                        c->nf_s2 = olxplan::nearfield_s2(n, c->h_pos.data(), c->grid.origin, c->grid.spacing, b0, cnt,
+                                                         0.5 * std::min({c->grid.spacing[0], c->grid.spacing[1], c->grid.spacing[2]}));
+                    }
+                    if (!(olxplan::FP8_ERR_K * wmx * std::sqrt(c->nf_s2) <= olxplan::FP8_ERR_BOUND * peak)) ok = false;
+                }
             }
             return ok;
         };
-        const char* f8env = getenv("OLX_FP8_CORRECTION");      // 0 / 1 pins either arithmetic for A/B runs and fuzz tests
-        const bool fp8_want = lat_ok && (f8env ? strcmp(f8env, "0") != 0 && !c->modifier() : fp8_eligible());
+        // OLX_FP8_CORRECTION=0 (environment) opts out like the plan flag.  "1" FORCES the e4m3 products past the eligibility rule -- results may
+        // then miss the 1e-5 gate, so only developer builds (OLX_DEV_PINS: the debug library, A/B timing builds) honour it; the product ignores it.
+        const char* f8env = getenv("OLX_FP8_CORRECTION");
+        bool fp8_want = lat_ok && !(f8env && !strcmp(f8env, "0")) && fp8_eligible();
+#ifdef OLX_DEV_PINS
+        if (f8env && strcmp(f8env, "0") != 0) fp8_want = lat_ok && !c->modifier();
+#endif
         olxplan::Tiles tiles = pack(MAXC);
         int total_cols = 0;
         // A sweep that needs SEVERAL launch tiles anyway is cut into tiles of 16 columns instead of 32: kernel 2g (NT = 2) then takes every
@@ -582,7 +603,9 @@ static int configure_variant_impl(olx_ctx* c) {
                 // kernel 2f: 8 positions along x per row tile; arrays up to 17 elements wide take TWO row tiles per block (<= 16 positions: the tiles share
                 // tables and Toeplitz weights, k_toep.hip M2; wider arrays need the table's 32 columns for one tile: (8 - 1) + 24 = 31)
                 int saw_plan = std::min(A.ax, 24);       // element super-block width of kernel 2f (see below)
+#ifdef OLX_DEV_PINS
                 if (const char* e = getenv("OLX_EXP_TOEP_SAW")) { const int v = atoi(e); if (v >= 8 && v <= 24) saw_plan = std::min(A.ax, v); }   // (A/B)
+#endif
                 c->toep_m2 = c->use_toep && saw_plan + 15 <= 32;
                 const int kxw = c->use_toep ? (c->toep_m2 ? 16 : 8) : cos_kxw(c->nt);
                 const int zb = COS_ZB;      // planes per block
@@ -622,7 +645,9 @@ static int configure_variant_impl(olx_ctx* c) {
                         const unsigned long long nb = (unsigned long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
                         for (unsigned g2 = 16u; g2 >= 2u; g2 >>= 1) if (Q.kblocks % (int)g2 == 0 && nb % (8ull * g2) == 0) { kgrp = g2; break; }
                     }
+#ifdef OLX_DEV_PINS
                     if (const char* e = getenv("OLX_EXP_KGRP")) kgrp = (unsigned)std::max(1, atoi(e));
+#endif
                     const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs};
                     std::vector<CosetBlock> blk;
                     if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
@@ -654,6 +679,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     // (KXW - 1) + 24 = 31 <= 32 columns = two K-steps, and a last column of <= 8 elements fills K-step 1 only (ks_mask)
                     c->toep_saw = saw_plan;
                     c->toep_nsa = (A.ax + c->toep_saw - 1) / c->toep_saw;
+                    if (c->toep_nsa > 16) return fail(c, OLX_ESTATE, "kernel 2f: more than 16 super-block columns");      // (ks_mask holds 2 bits per column)
                     c->toep_ksmask = 0;
                     int ksteps_total = 0;       // non-zero K-steps over the super-block columns
                     for (int sa = 0; sa < c->toep_nsa; ++sa) {
@@ -666,7 +692,6 @@ static int configure_variant_impl(olx_ctx* c) {
                         c->toep_ksmask |= m << (2 * sa);
                         ksteps_total += (int)(m & 1u) + (int)(m >> 1);
                     }
-                    if (c->toep_nsa > 16) return fail(c, OLX_ESTATE, "kernel 2f: more than 16 super-block columns");
                     for (int q = 0; q < 4; ++q) c->toep_targets[q] = tiles[0][0].tgt[q];
                     if (c->cell_cap < A.cell.size()) {
                         if (c->d_cell) hipFree(c->d_cell);
@@ -918,6 +943,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     }
     c->min_dist = c->clamp ? dmin : std::sqrt(min_d2);  // lower bound of any voxel-element distance [m]
     detect_lattice(c, lo, hi, dmin);
+    c->nf_s2 = -1.0;      // near-field sum of the e4m3 error bound: derived lazily by configure_variant (fp8_eligible)
     // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
     auto mirror_perm = [&](int axis, std::vector<int>& perm) -> bool {
         const double ctr = g->origin[axis] + 0.5 * (g->n[axis] - 1) * g->spacing[axis];
@@ -1952,7 +1978,10 @@ int olx_field_weighted_fetch(olx_ctx* c, float* out) {
 int olx_solution_analyze_begin(olx_ctx* c, const double* A, const double* ita_weights, const double* line_pts,
                                const olx_analysis_opts* o, const double* scale_per_focus) {
     if (!c) return OLX_EINVAL;
-    c->an_pending = false;
+    if (c->an_pending) {   // a begin without its finish: the earlier analysis' copies may still be reading / writing the pinned block this call rewrites
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->an_pending = false;
+    }
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_solution_analyze: nothing planned");
     if (!A || !ita_weights || !o) return fail(c, OLX_EINVAL, "olx_solution_analyze: null argument");
     if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_solution_analyze: intensity not planned");

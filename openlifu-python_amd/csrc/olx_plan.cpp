@@ -259,4 +259,42 @@ bool infer_foci(bool flat, int n, int F, const double* pos, const double* delays
     return true;
 }
 
+double nearfield_s2(int n, const double* pos, const double origin[3], const double spacing[3], const int begin[3], const int count[3], double dclamp) {
+    if (n <= 0) return 0.0;
+    const double* P[3] = {pos, pos + n, pos + 2 * (size_t)n};
+    const double dc2 = dclamp * dclamp;
+    // candidates: every element for n <= 1024, else every stride-th one and the element nearest to the array's centroid
+    // (regular arrays: the sum peaks next to the innermost elements, which have the most neighbours)
+    const int stride = n <= 1024 ? 1 : (n + 1023) / 1024;
+    int centre = 0;
+    {
+        double m[3] = {0, 0, 0}, best = 1e300;
+        for (int a = 0; a < 3; ++a) { for (int e = 0; e < n; ++e) m[a] += P[a][e]; m[a] /= n; }
+        for (int e = 0; e < n; ++e) {
+            double d2 = 0;
+            for (int a = 0; a < 3; ++a) d2 += (P[a][e] - m[a]) * (P[a][e] - m[a]);
+            if (d2 < best) { best = d2; centre = e; }
+        }
+    }
+    std::vector<int> cand;
+    for (int e = 0; e < n; e += stride) cand.push_back(e);
+    cand.push_back(centre);
+    double s2max = 0.0;
+    for (const int e0 : cand) {
+        double v[3];
+        for (int a = 0; a < 3; ++a) {
+            long long i = std::llround((P[a][e0] - origin[a]) / spacing[a]);
+            i = std::max<long long>(begin[a], std::min<long long>(i, (long long)begin[a] + count[a] - 1));
+            v[a] = origin[a] + (double)i * spacing[a];
+        }
+        double s2 = 0.0;
+        for (int e = 0; e < n; ++e) {
+            const double dx = v[0] - P[0][e], dy = v[1] - P[1][e], dz = v[2] - P[2][e];
+            s2 += 1.0 / std::max(dx * dx + dy * dy + dz * dz, dc2);
+        }
+        s2max = std::max(s2max, s2);
+    }
+    return s2max;
+}
+
 }  // namespace olxplan

@@ -70,4 +70,20 @@ std::vector<int> build_store_jobs(const Tiles& tiles, int max_nt, int cols_per_n
 bool infer_foci(bool flat, int n, int F, const double* pos /*[3][n]*/, const double* delays /*[F][n]*/, double c, double grid_z_mid,
                 std::vector<double>& foci);
 
+// ---- error bound of the e4m3 correction products (kernels 2e / 2f / 2g; calibration: tools/emul_fp8_bound.py) ----
+// The scheme's error is RELATIVE TO EACH TERM w_e G(v, e): sigma_1 = 6.2e-6 |w_e| / d'(v, e) per element with random sign (<= 2^-13 worst case),
+// so a voxel v carries  err(v) <= FP8_ERR_K sqrt(S2(v)),  S2(v) = sum_e (w_e / d'(v, e))^2, with FP8_ERR_K = 6 sigma_1 (the largest
+// normalised error over 3.4 M emulated voxels x 8 foci of every scenario was 5.7 - 6.4 sigma_1).  Far from the array that is the
+// 1 / sqrt(N_eff) of the focal peak of round 5's argument; NEXT to an element the single nearest term dominates S2 and the error
+// can exceed the focal peak's share (grids through / close above the element plane: VERDICT round 5).  The planner therefore asks for
+//     FP8_ERR_K * wmax_f * sqrt(max_v sum_e 1 / d'(v, e)^2) <= FP8_ERR_BOUND * sum_e w_ef / d(focus_f, e)      for every focus f
+// (right side: the coherent focal peak, a lower bound of the volume maximum when the focus lies inside the planned volume) and keeps
+// three fp16 products otherwise.
+constexpr double FP8_ERR_K = 3.75e-5;        // 6 sigma_1
+constexpr double FP8_ERR_BOUND = 7.5e-6;     // stated in include/olx.h (olx_field_plan); north_star's gate is 1e-5
+// max over the candidate voxels (the voxel of the planned slab nearest to each element: S2 peaks next to an element) of
+// sum_e 1 / max(d(v, e), dclamp)^2 [1/m^2].  pos = [3][n] (SoA) [m]; voxel i of axis a sits at origin[a] + i spacing[a], i in [begin[a], begin[a] + count[a]).
+// O(n * min(n, 1024)): evaluated once per (element table, planned slab) by the caller.
+double nearfield_s2(int n, const double* pos, const double origin[3], const double spacing[3], const int begin[3], const int count[3], double dclamp);
+
 }  // namespace olxplan

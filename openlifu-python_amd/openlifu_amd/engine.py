@@ -243,7 +243,7 @@ class Engine:
         """Pressure field for F foci -> dict of float32 arrays [F, nx, ny, nz] (fresh, writable,
         caller-owned).  ``steering_resident`` reuses the table the last ``beamform`` left on the
         device instead of uploading ``delays`` / ``apod``.  ``fp8_correction=False`` opts OUT of the e4m3
-        correction products the lattice kernels use by default where their bound (<= 6.5e-6 of the focal peak) is a bound on the
+        correction products the lattice kernels use by default where their bound (<= 7.5e-6 of the volume maximum, include/olx.h) is a bound on the
         planned volume (include/olx.h OLX_FIELD_FP16_CORRECTION: three fp16 products everywhere, <= 2e-6).  ``directivity`` opts in to the far-field piston factor of the elements
         (OLX_FIELD_DIRECTIVITY; folded into the lattice kernels' tables for flat arrays of equal axis-aligned elements, else the exact
         per-pair kernel; homogeneous media).  ``absorption`` [Np/m] > 0: uniform absorbing medium, every term carries exp(-a d)

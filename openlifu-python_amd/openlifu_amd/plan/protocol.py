@@ -208,7 +208,7 @@ class Protocol:
         if simulate and not custom_seam:
             self.logger.info(f"Simulate for {len(foci)} foci...")
             # precision option, SimSetup.options["fp8_correction"] = "0" (sim_setup.py:51 "Additional simulation options"): keeps three fp16
-            # products where the lattice kernels would use their e4m3 correction products (the default; <= 6.5e-6 of the focal peak)
+            # products where the lattice kernels would use their e4m3 correction products (the default; <= 7.5e-6 of the volume maximum, include/olx.h)
             fp8 = False if str(getattr(sim_options, "options", {}).get("fp8_correction", "auto")).lower() in ("0", "false", "no") else None
             # the per-focus volumes stay in HBM (scale / aggregate / analyze below run there); the Dataset hands them to the host on first
             # access.  Real xarray objects cannot defer: with xarray installed the call works on the SAME lazy stand-ins and converts at

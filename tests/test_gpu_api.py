@@ -103,6 +103,29 @@ def test_calc_solution_wheel_scale_and_aggregate():
     assert not np.array_equal(agg["p_max"].data, agg2["p_max"].data)
 
 
+@pytest.mark.parametrize("pattern", ["single", "wheel"])
+def test_calc_solution_on_the_untouched_default_simsetup(pattern):
+    """The reference's DEFAULT SimSetup (spacing 1.0, x / y +-30 mm, z_extent (-4, 60): sim/sim_setup.py:24-36) passes through the element
+    plane; with a 256-element lattice array the planner must NOT take the e4m3 correction products there (their error next to an element
+    is relative to that element's own term: include/olx.h, olx_field_plan) -- full-volume parity of every focus at north_star's 1e-5."""
+    arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup()
+    assert setup.spacing == 1.0 and tuple(setup.z_extent) == (-4, 60)
+    fp = ol.focal_patterns.SinglePoint(target_pressure=1.0e6) if pattern == "single" else \
+        ol.focal_patterns.Wheel(center=True, num_spokes=7, spoke_radius=5.0, target_pressure=1.0e6)
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sequence=ol.Sequence(pulse_count=8, pulse_train_interval=0),
+                        focal_pattern=fp, sim_setup=setup)
+    target = ol.Point(position=(0, 0, 40), units="mm", id="t")
+    sol, agg, an = proto.calc_solution(target, arr, simulate=True, scale=False)
+    name = ol.get_engine().ctx.field_variant()
+    assert ("field_toep_k" in name or "field_coset" in name) and "clamp" in name and "fp8corr" not in name, name
+    xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
+    assert (len(xs), len(ys), len(zs)) == (61, 61, 65) and zs[0] == -4e-3
+    ref = _oracle_solution(arr, sol.foci, xs, ys, zs, 400e3, ("uniform", 1.0, 0.0), 1e5)
+    for i, (d, a, p) in enumerate(ref):
+        assert np.abs(sol.simulation_result["p_min"].data[i] - p).max() / p.max() <= 1e-5, (i, name)
+
+
 def test_calc_solution_without_simulation_and_scale_guard():
     arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
     proto = ol.Protocol()
@@ -288,8 +311,22 @@ def test_run_simulation_with_segmented_medium():
     iref = 1e-4 * ref ** 2 / (2 * params["density"].data * params["sound_speed"].data)
     assert np.abs(dset["intensity"].data - iref).max() / iref.max() <= 4e-5
     uni = setup.setup_sim_scene(segm)
-    ol.sim.run_simulation(arr, uni, delays, apod, freq=400e3, amplitude=1.0)
+    dset_u, _ = ol.sim.run_simulation(arr, uni, delays, apod, freq=400e3, amplitude=1.0)
     assert "field_h" not in ol.get_engine().ctx.field_variant()
+    # ref_values_only=True (sim/kwave_if.py:49-56, 113): the reference then simulates its homogeneous reference medium whatever the
+    # volumes hold -- the SAME bits as the uniform run for the pressures; the intensity still divides by the volumes' own impedance (:140-141)
+    dset_r, _ = ol.sim.run_simulation(arr, params, delays, apod, freq=400e3, amplitude=1.0, ref_values_only=True)
+    assert "field_h" not in ol.get_engine().ctx.field_variant()
+    assert np.array_equal(dset_r["p_min"].data, dset_u["p_min"].data) and np.array_equal(dset_r["p_max"].data, dset_u["p_max"].data)
+    Z = params["density"].data * params["sound_speed"].data
+    assert np.allclose(dset_r["intensity"].data, 1e-4 * dset_u["p_min"].data.astype(np.float64) ** 2 / (2 * Z), rtol=1e-6)
+    assert not np.array_equal(dset_r["intensity"].data, dset_u["intensity"].data)
+    # ... including the reference medium's absorption: a lossy reference material is applied, a lossy VOLUME over a lossless reference is not
+    tissue = ol.seg_methods.UniformTissue()
+    lossy = setup.setup_sim_scene(tissue)       # uniform tissue: ref_value of the attenuation = tissue's 0.3 dB/cm/MHz
+    d_l, _ = ol.sim.run_simulation(arr, lossy, delays, apod, freq=400e3, amplitude=1.0)
+    d_lr, _ = ol.sim.run_simulation(arr, lossy, delays, apod, freq=400e3, amplitude=1.0, ref_values_only=True)
+    assert np.array_equal(d_l["p_min"].data, d_lr["p_min"].data) and "absorption" in ol.get_engine().ctx.field_variant()
 
 
 def test_run_simulation_with_piston_directivity():

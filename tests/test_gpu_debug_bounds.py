@@ -24,7 +24,7 @@ def test_bounds_checks_exist_only_in_the_debug_library():
 def test_kernels_stay_inside_their_extents_in_the_debug_library():
     env = dict(os.environ, OLX_LIB_PATH=os.path.join(LIB, "libolx_dbg.so"))
     env.pop("OLX_FIELD_VARIANT", None)
-    sel = ("fuzz or ragged or lattice_without_mirror_folds or padded_array or element_plane or single_column_toeplitz or pair_tables or "
+    sel = ("fuzz or block_record_order or gated_default or ragged or lattice_without_mirror_folds or padded_array or element_plane or single_column_toeplitz or pair_tables or "
            "marched_medium or heterogeneous_medium or mirror_partner or large_element_counts")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_field.py"), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)

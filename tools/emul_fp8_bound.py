@@ -1,0 +1,131 @@
+"""Developer tool (NumPy only, no GPU, no oracle): emulate the operand scheme of the e4m3 correction products of kernels 2e / 2f / 2g
+(k_coset2.hip `entry`, k_small.hip.h `mfma_pack_k`) and calibrate the planner's error bound (olx_plan.cpp `fp8_error_bound`).
+
+Scheme emulated, per real component:  G sg = hi + lo with hi = fp16 RN; lo8 = e4m3(lo * 32), hi8 = e4m3(G sg / 64);
+W sw = Wh + Wl (both fp16 RN), Wh8 = e4m3(Wh / 64), Wl8 = e4m3(Wl * 32);  P = hi Wh + lo8 Wh8 + hi8 Wl8 (E8M0 block scales undo the 2^-1),
+sg / sw = the power-of-two operand scales of olx.hip (|G sg| <= 2^14 at the clamp distance, |W sw| <= 2^14).
+
+What it prints per scenario: the max error over the emulated voxels relative to the volume maximum, the same with three fp16 products,
+and the planner's predictor  K * max_v sqrt(sum_e (w_e / d'_ve)^2) / min_f peak_f  next to it.
+    python tools/emul_fp8_bound.py            # the scenarios of VERDICT round 5 + BASELINE's grids
+"""
+import sys
+import numpy as np
+
+
+def q_e4m3(x):
+    x = np.asarray(x, dtype=np.float64)
+    s = np.sign(x)
+    a = np.minimum(np.abs(x), 448.0)
+    e = np.floor(np.log2(np.maximum(a, 1e-300)))
+    e = np.maximum(e, -6)            # subnormals share the exponent of the smallest normal
+    step = 2.0 ** (e - 3)
+    return s * np.round(a / step) * step
+
+
+def f16(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float16).astype(np.float64)
+
+
+def array16(nx=16, ny=16, pitch=3e-3):
+    xe = (np.arange(nx) - (nx - 1) / 2) * pitch
+    ye = (np.arange(ny) - (ny - 1) / 2) * pitch
+    ex, ey = np.meshgrid(xe, ye, indexing="ij")
+    return np.stack([ex.ravel(), ey.ravel(), np.zeros(nx * ny)], 1)
+
+
+def wheel8(z=40e-3, r=5e-3):
+    return np.array([[r * np.cos(t), r * np.sin(t), z] for t in 2 * np.pi * np.arange(7) / 63] + [[0, 0, z]])
+
+
+def emulate(vox, epos, foci, w_e, f0=400e3, c=1500.0, dclamp=None, chunk=4096):
+    """Returns |P| exact, |P| e4m3 scheme, |P| fp16x3 scheme, S2[v] = sum_e (w_e/d')^2 (d' in metres), per focus peaks."""
+    lam = c / f0
+    rev = 1.0 / lam
+    df = np.linalg.norm(foci[:, None, :] - epos[None, :, :], axis=2)
+    tof = df / c
+    tau = tof.max(1, keepdims=True) - tof
+    W = (w_e[None, :] * np.exp(2j * np.pi * f0 * tau)).T          # [E, F]
+    wmax = np.abs(W).max()
+    sw = 2.0 ** np.floor(np.log2(16384.0 / wmax))
+    sg = 2.0 ** np.floor(np.log2(16384.0 * dclamp * rev))
+    Ws = W * sw
+    Whr, Whi = f16(Ws.real), f16(Ws.imag)
+    Wlr, Wli = f16(Ws.real - Whr), f16(Ws.imag - Whi)
+    Wh = Whr + 1j * Whi
+    Wl = Wlr + 1j * Wli
+    Wh8 = (q_e4m3(Whr / 64) + 1j * q_e4m3(Whi / 64)) * 64
+    Wl8 = (q_e4m3(Wlr * 32) + 1j * q_e4m3(Wli * 32)) / 32
+    out = [np.empty((len(vox), len(foci))) for _ in range(3)]
+    S2 = np.empty(len(vox))
+    for a in range(0, len(vox), chunk):
+        v = vox[a:a + chunk]
+        d = np.maximum(np.linalg.norm(v[:, None, :] - epos[None, :, :], axis=2), dclamp) * rev      # wavelengths
+        G = sg / d * np.exp(2j * np.pi * d)
+        Gr, Gi = G.real.astype(np.float32).astype(np.float64), G.imag.astype(np.float32).astype(np.float64)
+        hr, hi = f16(Gr), f16(Gi)
+        lr, li = Gr - hr, Gi - hi
+        Gh = hr + 1j * hi
+        Gl8 = (q_e4m3(lr * 32) + 1j * q_e4m3(li * 32)) / 32
+        Gh8 = (q_e4m3(Gr / 64) + 1j * q_e4m3(Gi / 64)) * 64
+        Gl16 = f16(lr) + 1j * f16(li)
+        exact = (Gr + 1j * Gi) @ Ws
+        p8 = Gh @ Wh + Gl8 @ Wh8 + Gh8 @ Wl8
+        p16 = Gh @ Wh + Gl16 @ Wh + Gh @ Wl
+        out[0][a:a + chunk] = np.abs(exact)
+        out[1][a:a + chunk] = np.abs(p8)
+        out[2][a:a + chunk] = np.abs(p16)
+        S2[a:a + chunk] = ((w_e[None, :] / (d * lam)) ** 2).sum(1)
+    peaks = (w_e[None, :] / df).sum(1) * sg * rev * sw / 1.0      # coherent focal sums in the same units as |P|: w/d[m] * sg/rev.. see below
+    return out[0], out[1], out[2], S2, peaks
+
+
+def grid_axis(lo, hi, h):
+    n = int(round((hi - lo) / h)) + 1
+    return np.linspace(lo, hi, n)
+
+
+def scenario(name, h, z_lo, z_hi, xy_half, foci, epos, w_e, planes_mm=12.0, n_far=20000, seed=3, K=None):
+    """All voxels of the quadrant x, y >= 0 on the planes within planes_mm of the element plane + a random far sample."""
+    rng = np.random.default_rng(seed)
+    xs = grid_axis(-xy_half, xy_half, h)
+    zs = grid_axis(z_lo, z_hi, h)
+    xq = xs[xs >= 0]
+    znear = zs[np.abs(zs) <= planes_mm * 1e-3]
+    X, Y, Z = np.meshgrid(xq, xq, znear, indexing="ij")
+    near = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    if len(near) > 400000:
+        near = near[rng.choice(len(near), 400000, replace=False)]
+    far = np.stack([rng.choice(xs, n_far), rng.choice(xs, n_far), rng.choice(zs, n_far)], 1)
+    vox = np.vstack([near, far, foci])
+    dcl = 0.5 * h
+    ex, e8, e16, S2, _ = emulate(vox, epos, foci, w_e, dclamp=dcl)
+    vmax = ex.max(0)                                     # per focus: max over the emulated voxels (contains the focus and the near field)
+    focal = ex[-len(foci):].diagonal()
+    err8 = (np.abs(e8 - ex) / vmax).max()
+    err16 = (np.abs(e16 - ex) / vmax).max()
+    err8_focal = (np.abs(e8 - ex) / focal).max()
+    # normalised error per voxel: err / sqrt(S2) in units where |P| = sum w/d -> the per-term sigma
+    scale = ex[-len(foci):].diagonal() / (w_e[None, :] / np.linalg.norm(foci[:, None, :] - epos[None, :, :], axis=2)).sum(1)   # |P| units per (w/d[m])
+    z = np.abs(e8 - ex) / (np.sqrt(S2)[:, None] * scale[None, :])
+    pred = np.sqrt(S2.max()) / ((w_e[None, :] / np.linalg.norm(foci[:, None, :] - epos[None, :, :], axis=2)).sum(1)).min()
+    print(f"{name:38s} nearmax/focal {ex[:len(near)].max() / focal.min():5.2f}  e4m3 err/volmax {err8:.2e}  err/focal {err8_focal:.2e}  fp16x3 {err16:.1e}  "
+          f"z: rms {np.sqrt((z ** 2).mean()):.2e} max {z.max():.2e}   sqrt(maxS2)/peak {pred:.3f}" + (f"  bound {K * pred:.2e}" if K else ""))
+    return err8_focal, pred, z.max()
+
+
+if __name__ == "__main__":
+    K = float(sys.argv[1]) if len(sys.argv) > 1 else None
+    epos = array16()
+    w = np.ones(len(epos))
+    on = np.array([[0, 0, 40e-3]])
+    sh = wheel8()
+    for foci, fn in ((on, "on-axis"), (sh, "shard8")):
+        scenario(f"1 mm, z -4..60, {fn}", 1e-3, -4e-3, 60e-3, 30e-3, foci, epos, w, K=K)
+        scenario(f"0.5 mm, z -4..60, {fn}", 0.5e-3, -4e-3, 60e-3, 31.75e-3, foci, epos, w, K=K)
+        scenario(f"0.25 mm, z 0.25.., {fn}", 0.25e-3, 0.25e-3, 64e-3, 31.875e-3, foci, epos, w, K=K)
+        scenario(f"0.25 mm, z -4..60, {fn}", 0.25e-3, -4e-3, 60e-3, 31.875e-3, foci, epos, w, K=K)
+        scenario(f"0.25 mm, z 5.. (headline), {fn}", 0.25e-3, 5e-3, 68.75e-3, 31.875e-3, foci, epos, w, K=K)
+        scenario(f"0.5 mm, z 5.. (configs[1]), {fn}", 0.5e-3, 5e-3, 68.5e-3, 31.75e-3, foci, epos, w, K=K)
+        scenario(f"0.25 mm, z 2.., {fn}", 0.25e-3, 2e-3, 65.75e-3, 31.875e-3, foci, epos, w, K=K)
+        scenario(f"0.25 mm, z 1.., {fn}", 0.25e-3, 1e-3, 64.75e-3, 31.875e-3, foci, epos, w, K=K)

@@ -231,7 +231,55 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
     }
 }
 
+// ---- e4m3 error rule (olx_plan.h FP8_ERR_K / FP8_ERR_BOUND, nearfield_s2): known decisions on BASELINE's 16 x 16 @ 3 mm array, uniform drive, focus (0, 0, 40) mm
+// (ratios from tools/emul_fp8_bound.py), and nearfield_s2 against the brute-force maximum over every voxel of the grid's first planes.
+static void check_fp8_rule() {
+    const int na = 16, n = na * na;
+    std::vector<double> pos(3 * (size_t)n, 0.0);
+    for (int a = 0; a < na; ++a) for (int b = 0; b < na; ++b) { pos[(size_t)a * na + b] = (a - 7.5) * 3e-3; pos[(size_t)n + a * na + b] = (b - 7.5) * 3e-3; }
+    double peak = 0;
+    for (int e = 0; e < n; ++e) peak += 1.0 / std::sqrt(pos[e] * pos[e] + pos[(size_t)n + e] * pos[(size_t)n + e] + 40e-3 * 40e-3);
+    struct G { double h, z0; int nxy, nz; bool admit; double ratio; } grids[] = {
+        {0.25e-3, 5e-3, 256, 256, true, 0.188},       // the headline grid
+        {0.5e-3, 5e-3, 128, 128, true, 0.188},        // configs[1]
+        {1e-3, -4e-3, 61, 65, false, 0.340},          // the reference's default SimSetup: through the element plane
+        {0.5e-3, -4e-3, 121, 129, false, 0.730},      // (odd counts: a voxel sits ON every element -- the clamp distance)
+        {0.25e-3, -4e-3, 241, 257, false, 1.403},
+        {0.25e-3, 0.25e-3, 256, 256, false, 0.61},    // one voxel above the element plane
+        {0.25e-3, 1e-3, 256, 256, false, 0.285},
+    };
+    for (const G& g : grids) {
+        const double origin[3] = {-(g.nxy - 1) / 2.0 * g.h, -(g.nxy - 1) / 2.0 * g.h, g.z0}, spacing[3] = {g.h, g.h, g.h};
+        const int b0[3] = {0, 0, 0}, cnt[3] = {g.nxy, g.nxy, g.nz};
+        const double s2 = nearfield_s2(n, pos.data(), origin, spacing, b0, cnt, 0.5 * g.h);
+        const double ratio = std::sqrt(s2) / peak;
+        CHECK(std::fabs(ratio - g.ratio) <= 0.03 * g.ratio + 0.005, "fp8 rule: ratio %.4f, expected %.3f (h %.2g z0 %.2g)", ratio, g.ratio, g.h, g.z0);
+        CHECK((FP8_ERR_K * ratio <= FP8_ERR_BOUND) == g.admit, "fp8 rule: h %.2g z0 %.2g admitted = %d, expected %d", g.h, g.z0, (int)(FP8_ERR_K * ratio <= FP8_ERR_BOUND), (int)g.admit);
+        // brute force over the three planes nearest to the elements (a quadrant: the array and the grid are symmetric)
+        double brute = 0;
+        int kn = (int)std::llround((0.0 - g.z0) / g.h); kn = std::max(0, std::min(kn, g.nz - 1));
+        for (int k = std::max(0, kn - 1); k <= std::min(g.nz - 1, kn + 1); ++k)
+            for (int i = g.nxy / 2; i < g.nxy; ++i)
+                for (int j = g.nxy / 2; j < g.nxy; ++j) {
+                    const double x = origin[0] + i * g.h, y = origin[1] + j * g.h, z = origin[2] + k * g.h;
+                    double sum = 0;
+                    for (int e = 0; e < n; ++e) {
+                        const double dx = x - pos[e], dy = y - pos[(size_t)n + e];
+                        sum += 1.0 / std::max(dx * dx + dy * dy + z * z, 0.25 * g.h * g.h);
+                    }
+                    brute = std::max(brute, sum);
+                }
+        CHECK(s2 <= brute * (1 + 1e-12) && s2 >= 0.97 * brute, "nearfield_s2 %.6g vs brute-force maximum %.6g (h %.2g z0 %.2g)", s2, brute, g.h, g.z0);
+    }
+    {   // a slab beside the array sees the clamped nearest voxel, not the element's own position
+        const double origin[3] = {-31.875e-3, -31.875e-3, 5e-3}, spacing[3] = {0.25e-3, 0.25e-3, 0.25e-3};
+        const int b0[3] = {192, 0, 0}, cnt[3] = {64, 256, 256}, whole0[3] = {0, 0, 0}, whole[3] = {256, 256, 256};
+        CHECK(nearfield_s2(n, pos.data(), origin, spacing, b0, cnt, 0.125e-3) < nearfield_s2(n, pos.data(), origin, spacing, whole0, whole, 0.125e-3), "slab beside the centre must see a smaller sum");
+    }
+}
+
 int main(int argc, char** argv) {
+    check_fp8_rule();
     const int cases = argc > 1 ? atoi(argv[1]) : 200;
     const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 147;
     std::mt19937_64 rng(seed);
