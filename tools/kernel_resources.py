@@ -10,9 +10,14 @@ import sys
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-c", "-o", "/tmp/olx_dev.o",
-       os.path.join(HERE, "openlifu-python_amd", "csrc", "olx.hip"), "-I/opt/rocm/include", "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+import glob
+out = ""
+for src in sorted(glob.glob(os.path.join(HERE, "openlifu-python_amd", "csrc", "*.hip"))):      # every translation unit (one per kernel family)
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-c", "-o", "/tmp/olx_dev.o", src,
+           "-I/opt/rocm/include", "-Rpass-analysis=kernel-resource-usage"] + [a for a in sys.argv[2:] if a.startswith("-")]
+    if flt and flt not in open(src).read():
+        continue
+    out += subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], {}
 for line in out.splitlines():
     m = re.search(r"remark: +(.*?): +(\S+) \[-Rpass", line)
