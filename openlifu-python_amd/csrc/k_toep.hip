@@ -27,7 +27,7 @@ namespace olx {
 //     group on 16 distinct 16-byte slots (planes {0-3, 12-15} on the even ones, {4-11} one k-group further on the odd ones).
 //   * A fragments (the Toeplitz weights: 4 x 16 bytes per lane and element row) are packed once per steering table by
 //     toep_pack_k in lane order and arrive through L2, one element row ahead.
-//   * Wave w owns the y positions ky = w, w + 4, w + 8 (<= 3 accumulator tiles).  D layout: lane (g, n) holds rows
+//   * Wave w owns the y positions ky = 3 w, 3 w + 1, 3 w + 2 (<= 3 accumulator tiles; round 6: consecutive, so that the pairs (ky, b) of a diagonal share their table row).  D layout: lane (g, n) holds rows
 //     4 g .. 4 g + 3 = (kx = 2 g, re), (2 g, im), (2 g + 1, re), (2 g + 1, im) of plane n -- |p| and the intensity need
 //     no cross-lane step, and the 16 lanes of a k-group write 64 contiguous bytes of z per (position, target).
 // ------------------------------------------------------------------------------------
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int NC = SAW + P.xs * (KX - 1);               // table columns in use: ud' = xs kx - al + (SAW - 1) in [0, NC)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
     // what is never generated -- columns NC .. 31, rows beyond NR, the pads -- meets zero Toeplitz weights: 0 x garbage must stay 0, so the
-    // whole arena is cleared once (16-byte stores; M2's second row tile also reads 8 columns past its row)
+    // whole arena is cleared once (16-byte stores; M2's second row tile also reads 8 columns past its row).  (Round 6: clearing only the
+    // words a stored fragment can read -- 832 of 18 688 -- measured 5 - 11 % SLOWER, same box, alternating: per-row dword stores.)
     for (int idx = tid; idx < 2 * TOEP_ZB * TOEP_PSZ / 4; idx += TOEP_WAVES * 64) reinterpret_cast<uint4*>(s_T)[idx] = make_uint4(0u, 0u, 0u, 0u);
     // dz^2 of the block's 16 planes: wave-uniform, held in scalar registers (one v_add per evaluation instead of two fmas)
     float dz2[TOEP_ZB];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     const int n16 = lane & 15, g = lane >> 4;
     const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + (FP8 ? 0 : 16 * ks));
     constexpr int NM = M2 ? 2 : 1;                      // row tiles: positions 8 m .. 8 m + 7
-    const bool two = M2 && KX > 8;                      // (block-uniform)
+    (void)KX;
     floatx4_t acc[NM][3];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
@@ -98,14 +99,17 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         uint4 afr[NB][NA];
         __syncthreads();                                // table free (previous super-block consumed)
         if (sb == 0) OLX_STAMP(1);
+        auto load_weights = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int bl = 0; bl < NB; ++bl) {
+                if constexpr (FP8) {       // hi of both K-steps, then the 32 e4m3 bytes of the row
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) afr[bl][q] = ab[(bl * 4 + q) * 64];
+                } else { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
+            }
+        };
         // (requested behind the barrier: __syncthreads() drains vmcnt, the loads would be waited for right there)
-#pragma unroll
-        for (int bl = 0; bl < NB; ++bl) {
-            if constexpr (FP8) {       // hi of both K-steps, then the 32 e4m3 bytes of the row
-#pragma unroll
-                for (int q = 0; q < 4; ++q) afr[bl][q] = ab[(bl * 4 + q) * 64];
-            } else { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
-        }
+        load_weights();
         // ---- G tables of the 16 planes: (row, column) pairs across the threads
         // Sliding rows: logical row r of super-block (sa, sbb) is the offset wd = r - 7 - 8 sbb against element row 0 of the
         // column of super-blocks, so rows 8 .. NR - 1 of super-block sbb + 1 ARE rows 0 .. NR - 9 of super-block sbb.  The table is a
@@ -159,51 +163,83 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         __syncthreads();
         if (sb == 0) OLX_STAMP(3);
         // ---- contraction: element rows b of the super-block, this wave's y positions and K-step
+        // Round 6: a wave owns THREE CONSECUTIVE y positions ky = 3 kyg + t, and the (y position, element row) pairs are walked along their
+        // diagonals d = t - bi: every pair of a diagonal meets the SAME table row wd = ky - b, so its B fragments are read once and serve up to
+        // three matrix-instruction groups (48 instead of 96 ds_read_b128 per wave and super-block with two row tiles: the fragment reads had made
+        // the LDS, not the matrix pipe, the busiest unit of this kernel -- 54 % against 33 %).  The schedule is static -- no wave-uniform branch
+        // inside, the K-step mask and the second row tile are compile-time cases -- so the compiler can issue a diagonal's reads under the
+        // previous diagonal's matrix instructions instead of waiting out every read (round 5: one s_waitcnt lgkmcnt(0) per group).  A y position
+        // beyond KY reads rows that exist (the ring has 18) and its sums are never stored.
         const unsigned ksm = (T.ks_mask >> (2 * sa)) & 3u;      // K-steps of this column of super-blocks that carry weights (wave-uniform)
         if (!FP8 && !((ksm >> ks) & 1u)) continue;              // (fp16 corrections: this wave's K-step is all zeros here; the barriers sit above)
+        if (3 * kyg >= KY) continue;                            // (no y position of this wave exists: wave-uniform)
+        const int p0 = 3 * kyg + 7 - (FP8 ? 4 * ks : 0) + rot + TOEP_ROWS;      // logical table row of (t = 0, bi = 0) + 18 (>= 18 + 3 - 7)
+        auto contract = [&](auto two_c, auto ksm_c) __attribute__((always_inline)) {
+            constexpr int NMM = decltype(two_c)::value ? 2 : 1;
+            constexpr unsigned KSM = decltype(ksm_c)::value;
+            constexpr int ND = NB + 2, NSTEP = NMM * ND;      // diagonals d = -(NB - 1) .. 2 per row tile
+            // B fragments of one diagonal: hi of this wave's K-step(s) and -- FP8 -- the 32 e4m3 bytes of the table row's two pieces
+            struct BF { uint4 h0, h1, q0, q1; };
+            auto load = [&](const int step) __attribute__((always_inline)) {
+                const int m = step / ND, d = step - m * ND - (NB - 1);
+                int prow = p0 + d;                           // physical row of the ring (scalar arithmetic: wave-uniform)
+                prow = prow >= 2 * TOEP_ROWS ? prow - 2 * TOEP_ROWS : (prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow);
+                const unsigned wm = bbase + (unsigned)(prow * TOEP_TW) + 8u * (unsigned)m;       // second row tile: the same weights, 8 columns on
+                BF f;
+                f.h0 = *reinterpret_cast<const uint4*>(s_hi + wm);
+                if constexpr (FP8) {
+                    f.h1 = *reinterpret_cast<const uint4*>(s_hi + wm + 16);                      // hi, K-step 1
+                    f.q0 = *reinterpret_cast<const uint4*>(s_lo + wm); f.q1 = *reinterpret_cast<const uint4*>(s_lo + wm + 16);
+                } else { f.h1 = *reinterpret_cast<const uint4*>(s_lo + wm); f.q0 = f.h1; f.q1 = f.h1; }
+                return f;
+            };
+            // one diagonal ahead with one row tile (12 accumulator registers); with two, accumulators + weights + two sets of fragments fill all
+            // 128 registers for no gain (same box, alternating: 0.0695 either way) -- the block's other wave on the SIMD covers the read
+            constexpr bool AHEAD = !M2;
+            BF cur = load(0);
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
-            const int bl = FP8 ? 4 * ks + bi : bi;      // element row of the super-block (FP8: wave-uniform)
-            Half8Bits ah, al;
-            ah.u = afr[bi][0]; al.u = afr[bi][1];      // (FP8: hi of K-step 0 and 1)
-            intx8_t a8;
-            if constexpr (FP8) {
-                a8[0] = (int)afr[bi][2].x; a8[1] = (int)afr[bi][2].y; a8[2] = (int)afr[bi][2].z; a8[3] = (int)afr[bi][2].w;
-                a8[4] = (int)afr[bi][3].x; a8[5] = (int)afr[bi][3].y; a8[6] = (int)afr[bi][3].z; a8[7] = (int)afr[bi][3].w;
-            }
+            for (int step = 0; step < NSTEP; ++step) {
+                const int m = step / ND, d = step - m * ND - (NB - 1);
+                BF nxt = cur;
+                if constexpr (AHEAD) { if (step + 1 < NSTEP) nxt = load(step + 1); }      // the next diagonal's reads go out under this one's matrix instructions
+                if constexpr (!AHEAD) __builtin_amdgcn_sched_barrier(0);
+                Half8Bits bh, bw;
+                bh.u = cur.h0; bw.u = cur.h1;
+                intx8_t b8;
+                if constexpr (FP8) {
+                    b8[0] = (int)cur.q0.x; b8[1] = (int)cur.q0.y; b8[2] = (int)cur.q0.z; b8[3] = (int)cur.q0.w;
+                    b8[4] = (int)cur.q1.x; b8[5] = (int)cur.q1.y; b8[6] = (int)cur.q1.z; b8[7] = (int)cur.q1.w;
+                }
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int ky = kyg + 4 * t;
-                if (ky >= KY) continue;                 // wave-uniform
-                // logical table row ky - bl + 7 -> physical row of the ring (scalar arithmetic: everything here is wave-uniform)
-                int prow = ky + 7 - bl + rot;
-                prow = prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow;
-                const unsigned w0 = bbase + (unsigned)(prow * TOEP_TW);
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    if (m == 1 && !two) continue;                                                    // block-uniform
-                    const unsigned wm = w0 + 8u * (unsigned)m;                                       // second row tile: the same weights, 8 columns on
-                    Half8Bits bh, bw;
-                    bh.u = *reinterpret_cast<const uint4*>(s_hi + wm);
+                for (int t = 0; t < 3; ++t) {
+                    const int bi = t - d;                    // element row of this wave's share: (t, bi) on the diagonal d
+                    if (bi < 0 || bi >= NB) continue;        // (compile-time)
+                    Half8Bits ah, al;
+                    ah.u = afr[bi][0]; al.u = afr[bi][1];    // (FP8: hi of K-step 0 and 1)
                     if constexpr (FP8) {
-                        bw.u = *reinterpret_cast<const uint4*>(s_hi + wm + 16);                      // hi, K-step 1
-                        const uint4 q0 = *reinterpret_cast<const uint4*>(s_lo + wm), q1 = *reinterpret_cast<const uint4*>(s_lo + wm + 16);
-                        intx8_t b8;
-                        b8[0] = (int)q0.x; b8[1] = (int)q0.y; b8[2] = (int)q0.z; b8[3] = (int)q0.w;
-                        b8[4] = (int)q1.x; b8[5] = (int)q1.y; b8[6] = (int)q1.z; b8[7] = (int)q1.w;
-                        if (ksm & 1u) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
-                        if (ksm & 2u) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[m][t], 0, 0, 0);
+                        intx8_t a8;
+                        a8[0] = (int)afr[bi][2].x; a8[1] = (int)afr[bi][2].y; a8[2] = (int)afr[bi][2].z; a8[3] = (int)afr[bi][2].w;
+                        a8[4] = (int)afr[bi][3].x; a8[5] = (int)afr[bi][3].y; a8[6] = (int)afr[bi][3].z; a8[7] = (int)afr[bi][3].w;
+                        if constexpr ((KSM & 1u) != 0) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
+                        if constexpr ((KSM & 2u) != 0) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[m][t], 0, 0, 0);
                         // E8M0 scales undo the operand scaling: 2^(128 - 127) * COS_F8_LO * COS_F8_HI = 1
                         acc[m][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[m][t], 0, 0, 0, 128, 0, 127);
                     } else {
-                        bw.u = *reinterpret_cast<const uint4*>(s_lo + wm);
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[m][t], 0, 0, 0);
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[m][t], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);           // (one diagonal ahead, not more: the fragments of all of them would not fit the registers)
+                if constexpr (AHEAD) cur = nxt;
+                else if (step + 1 < NSTEP) cur = load(step + 1);
             }
-        }
+        };
+        if constexpr (M2) {     // (arrays up to 17 wide: one column of super-blocks, both K-steps carry weights)
+            contract(IntC<1>{}, IntC<3>{});      // (both row tiles always: the host picks this shape only where some part has more than 8 positions -- a second contraction body beside it costs 34 spilled registers)
+        } else if constexpr (FP8) {
+            if (ksm == 3u) contract(IntC<0>{}, IntC<3>{}); else if (ksm == 2u) contract(IntC<0>{}, IntC<2>{}); else contract(IntC<0>{}, IntC<1>{});
+        } else contract(IntC<0>{}, IntC<3>{});
         if (sb == 0) OLX_STAMP(4);
     }
     OLX_STAMP(5);
@@ -221,8 +257,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 for (int r = 0; r < 4; ++r) xo[((t * NM + m) * 16 + 4 * g + r) * TOEP_XS] = acc[m][t][r];
     }
     __syncthreads();
-    // read-out: K-step 0 waves finish tiles t = 0, 2, K-step 1 waves tile t = 1.  Lane = (output, kx, plane quad): four
-    // consecutive planes of one position -> one 16-byte store per target (64 contiguous bytes per four lanes)
+    // read-out: the (y position, row tile) pairs q = t NM + m of a y-position group are split evenly between its two waves (group 0: the first
+    // half).  Lane = (output, kx, plane quad): four consecutive planes of one position -> one 16-byte store per target (64 contiguous bytes per four lanes)
     const int out = lane >> 5, kx = (lane >> 2) & 7, pq = lane & 3;
     const int kz = k0 + 4 * pq;
     const float sc = out ? P.out_scale * P.out_scale * P.inten_scale : P.out_scale;
@@ -235,13 +271,13 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     // splits every 16-byte store into a 12-byte and a 4-byte instruction)
     auto readout = [&](auto full_c) {
         constexpr bool FULL4 = decltype(full_c)::value != 0;
+        constexpr int NQ = 3 * NM, QH = (NQ + 1) / 2;     // pairs per group; the first wave takes QH of them
 #pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int t = ks ? 1 : 2 * tt;
-            if (ks && tt) break;
-            const int ky = kyg + 4 * t;
+        for (int qq = 0; qq < QH; ++qq) {
+            const int q = ks ? QH + qq : qq;
+            if (q >= NQ) break;
+            const int t = q / NM, m = q - t * NM;
+            const int ky = 3 * kyg + t;
             const int kxg = 8 * m + kx;                      // position of the coset along x
             const bool want = want0 && kxg < KX;
             if (ky >= KY || !want) continue;

@@ -613,6 +613,13 @@ static int configure_variant_impl(olx_ctx* c) {
                 // (round 5: its 8-position row tiles then fill 7 - 8 of 8 slots on BASELINE's grids instead of 5 - 6, and its tables are shared by more rows)
                 Q.xs = c->use_toep ? 1 : 2;
                 olxplan::coset_partition(Q, kxw, zb, COS_KYW);
+                if (c->toep_m2) {   // the two-row-tile shape computes both tiles of every block: only where a part holds more than 8 positions along x
+                    const int wxh = Q.nx - Q.x_lo, kxa_max = wxh > 0 ? (wxh - 1) / (Q.xs * Q.mx) + 1 : 0;
+                    if ((kxa_max + Q.nsx - 1) / std::max(1, Q.nsx) <= 8) {
+                        c->toep_m2 = false;
+                        olxplan::coset_partition(Q, 8, zb, COS_KYW);
+                    }
+                }
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
