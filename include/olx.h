@@ -310,9 +310,12 @@ int olx_tof_spread(olx_ctx *ctx, const double *xs, int nx, const double *ys, int
  * stack (plan/solution.py:243, 274), i.e. the maximum over foci AND voxels.  olx_field_masked_peak(which = 2) scans THIS
  * single volume with every focus' mask and so returns the reference's numbers.  (Rounds 1-4 formed sum_f here.) */
 int olx_field_weighted_intensity(olx_ctx *ctx, const double *weights, int n_foci);
-/* Blocking copy of that volume ([slab voxels] floats) into a caller-owned array: what Solution.get_ita returns
- * (the analysis' view of plan/solution.py:365-388).  The volume is the one the last olx_field_weighted_intensity or
- * olx_solution_analyze left on the device. */
+/* Blocking copy of that volume ([slab voxels] floats) into a caller-owned array: max_f w_f I_f, the ONE volume analyze's masked
+ * maxima scan.  (Solution.get_ita itself returns the whole [focal_point_index, x, y, z] stack, plan/solution.py:365-388; the host
+ * mirror forms it from the per-focus intensities, not from this volume.)  The volume is the one the last
+ * olx_field_weighted_intensity or olx_solution_analyze left on the device.
+ * ABI note: with OLX_ABI_VERSION 2 the reduction over foci of olx_field_weighted_intensity changed from SUM to MAX (see above);
+ * a caller built against ABI v1 gets different numbers for F > 1 -- check olx_abi_version(). */
 int olx_field_weighted_fetch(olx_ctx *ctx, float *out);
 
 /* ---- one-call analysis (Solution.analyze, plan/solution.py:135-281) ---------------------

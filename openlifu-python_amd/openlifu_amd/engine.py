@@ -194,7 +194,9 @@ class Engine:
         return self._live_aggregate
 
     def weighted_lazy(self, weights) -> WeightedResult:
-        """sum_f weights[f] intensity_f over the resident focus volumes (``field_weighted_sum_k``), left in HBM."""
+        """max_f weights[f] intensity_f over the resident focus volumes, left in HBM: the single "time-average" volume ``Solution.analyze``'s
+        masked maxima scan (the reference takes them over the whole [focus, x, y, z] stack of ``get_ita``, plan/solution.py:243, 274).  The
+        kernels keep their round-1 names (``field_weighted_sum_k`` / ``_peak_k``); rounds 1-4 formed the count-weighted SUM here."""
         self.ctx.field_weighted_intensity(weights)                           # (retires a live one through the hook)
         self._live_weighted = WeightedResult(self, self.ctx._shape)
         return self._live_weighted

@@ -120,7 +120,31 @@ class Solution:
         coords = {d: src.coords[d] for d in src.dims if d in src.coords}
         if ds.HAVE_XARRAY:  # pragma: no cover - xarray absent in the image
             return ds.make_dataarray(values(), coords, dims=src.dims, name="intensity", attrs=attrs)
-        return ds.LazyDataArray(tuple(src.shape), np.float64, values, coords=coords, dims=src.dims, name="intensity", attrs=attrs)
+        # The reference returns a SNAPSHOT taken at call time (rescale_data_arr deep-copies, plan/solution.py:365-388).  A source that already
+        # lives on the host can be edited by the caller at any moment: evaluate now.  A source still in HBM stays lazy, but the snapshot is taken
+        # the moment anything could change it: when the source is brought to the host (its reader may edit it in place) and before
+        # ``scale`` touches the device copy.
+        if not (isinstance(src, ds.LazyDataArray) and not src.materialized):
+            return ds.DataArray(values(), coords=coords, dims=src.dims, name="intensity", attrs=attrs)
+        import weakref
+        ita = ds.LazyDataArray(tuple(src.shape), np.float64, values, coords=coords, dims=src.dims, name="intensity", attrs=attrs)
+        ref = weakref.ref(ita)
+
+        def snapshot():
+            da = ref()
+            if da is not None and not da.materialized:
+                _ = da.data
+        src._on_materialize.append(snapshot)
+        pending = self.__dict__.setdefault("_ita_pending", [])
+        pending.append(ref)
+        return ita
+
+    def _flush_ita(self):
+        """Outstanding lazy ``get_ita`` arrays take their snapshot now (called before this solution's volumes change)."""
+        for ref in self.__dict__.pop("_ita_pending", []):
+            da = ref()
+            if da is not None and not da.materialized:
+                _ = da.data
 
     # ---- device-side analysis -----------------------------------------------------------------
     def _device_is_current(self) -> bool:
@@ -291,6 +315,7 @@ class Solution:
         # only the per-focus mainlobe peak of |p| enters the factors (compute_scaling_factors reads nothing else of the
         # analysis the reference runs here, plan/solution.py:313-317): one masked scan instead of the whole report
         analysis = self._mainlobe_peaks(SolutionAnalysisOptions() if analysis_options is None else analysis_options)
+        self._flush_ita()                 # (a get_ita array handed out earlier is the PRE-scale snapshot)
         apod_factors, v0, v1 = self.compute_scaling_factors(focal_pattern, analysis)
         factors = v1 / v0 * apod_factors
         res = self.simulation_result

@@ -156,6 +156,7 @@ class LazyDataArray(DataArray):
         self._fetch = fetch
         self._host = None
         self._uniform = uniform_value
+        self._on_materialize = []      # callables run once, right after the host copy exists and before the reader can edit it (snapshots taken from this array)
         self._init_labels(len(self._shape), coords, dims, name, attrs)
 
     @property
@@ -183,6 +184,9 @@ class LazyDataArray(DataArray):
             if host.shape != self._shape:
                 raise ValueError(f"device result of shape {host.shape}, expected {self._shape}")
             self._host, self._fetch = host, None
+            hooks, self._on_materialize = self._on_materialize, []
+            for h in hooks:
+                h()
         return self._host
 
     @data.setter

@@ -453,6 +453,42 @@ def test_results_stay_on_the_device_until_read_and_host_edits_win():
     assert sol_b.analyze().mainlobe_pnp_MPa == an_b.mainlobe_pnp_MPa
 
 
+def test_get_ita_is_a_snapshot_taken_at_call_time():
+    """plan/solution.py:365-388: the reference's get_ita deep-copies at call time (rescale_data_arr), so `ita = sol.get_ita(); sol.scale(...)`
+    leaves `ita` the PRE-scale time average, and an in-place edit of the intensity after the call does not leak into it.  Here the
+    volumes stay in HBM and the array is lazy -- the snapshot is taken the moment anything could change it (before scale touches the
+    device copy; when the source is brought to the host, before its reader can edit it), and at once when the source already is a host array."""
+    from openlifu_amd.util import dataset as ds
+    arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm", sensitivity=1e5)
+    setup = ol.SimSetup(spacing=1.0, x_extent=(-10, 10), y_extent=(-10, 10), z_extent=(5, 40))
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sim_setup=setup, sequence=ol.Sequence(pulse_count=6, pulse_train_interval=0),
+                        focal_pattern=ol.focal_patterns.Wheel(center=True, num_spokes=2, spoke_radius=2.0, target_pressure=1.0, units="MPa"))
+    sol, _, _ = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=False)
+    duty = sol.get_pulsetrain_dutycycle() * sol.get_sequence_dutycycle()
+    src = sol.simulation_result["intensity"]
+    assert isinstance(src, ds.LazyDataArray) and not src.materialized
+    ita = sol.get_ita()                                  # lazy: nothing has crossed PCIe yet
+    assert isinstance(ita, ds.LazyDataArray) and not ita.materialized and not src.materialized
+    sol.scale(proto.focal_pattern)                       # scales the volumes (device and host copies)
+    post = src.data.astype(np.float64)
+    pre = ita.data
+    factors2 = post[:, 10, 10, 25] / (pre[:, 10, 10, 25] / (1e3 * duty))
+    assert not np.allclose(factors2, 1.0) and np.allclose(sol.get_ita().data, post * 1e3 * duty, rtol=1e-6)      # a new call sees the scaled volumes
+    assert np.allclose(pre * factors2[:, None, None, None], post * 1e3 * duty, rtol=2e-5)                        # the old one is the pre-scale snapshot
+    # a source that is brought to the host later: the snapshot is taken before the reader can edit it
+    sol2, _, _ = proto.calc_solution(ol.Point(position=(0, 0, 30)), arr, scale=False)
+    ita2 = sol2.get_ita()
+    host = sol2.simulation_result["intensity"].data      # materialises the source (and thereby the snapshot)
+    assert ita2.materialized
+    keep = host.copy()
+    host *= 3.0
+    assert np.allclose(ita2.data, keep.astype(np.float64) * 1e3 * duty, rtol=1e-6)
+    # a source that already lives on the host: evaluated at once
+    ita3 = sol2.get_ita()
+    host *= 0.0
+    assert np.allclose(ita3.data, 3.0 * keep.astype(np.float64) * 1e3 * duty, rtol=1e-6)
+
+
 def test_fetch_paths_agree(monkeypatch):
     """olx_field_fetch_all (pipelined pinned ring, the default) == per-focus fetches, in every OLX_FETCH_MODE."""
     from openlifu_amd import _native as nat

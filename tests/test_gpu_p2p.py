@@ -1,4 +1,4 @@
-"""Two REAL ranks exchanging shards through the product's reassembly path on ONE GPU: the direct peer-to-peer transport behind
+"""Two, three and four REAL ranks exchanging shards through the product's reassembly path on ONE GPU: the direct peer-to-peer transport behind
 olx_field_allgather (OLX_GATHER=p2p: every rank pulls its peers' blocks out of IPC-mapped output buffers, csrc/olx_p2p.hip).
 RCCL refuses two ranks on one device; HIP IPC does not, so this is the exchange the builder's single GPU can run.  The ranks
 are fresh child processes (tests/p2p_worker.py); the assembled result must equal the single-process result bit for bit --
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n_foci", [(2, 3), (3, 4)])
+@pytest.mark.parametrize("world,n_foci", [(2, 3), (3, 4), (4, 5)])      # 4 ranks: the world BASELINE configs[4] names (5 processes on the card with this one: within the box's limit of 6)
 def test_ranks_on_one_gpu_exchange_through_p2p_transport(world, n_foci):
     with tempfile.TemporaryDirectory(prefix="olx_p2p_") as tmp:
         env = dict(os.environ)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 typedef float floatx16_t __attribute__((ext_vector_type(16)));
 
@@ -25,6 +26,16 @@ __global__ __launch_bounds__(256) void burn(float* out, int iters) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q & 3], b[(q + 1) & 3], acc[q], 0, 0, 0);
+        }
+        for (int q = 0; q < 8; ++q) acc_sum += acc[q][0] + acc[q][3];
+    } else if (SHAPE == 1616) {      // the CDNA3 shape (K = 16): does gfx950 run it in half the time of 16x16x32?
+        floatx4_t acc[8];
+        for (int q = 0; q < 8; ++q) acc[q] = floatx4_t{0, 0, 0, 0};
+        half4_t a4[4], b4[4];
+        for (int i = 0; i < 4; ++i) { a4[i] = half4_t{a[i][0], a[i][1], a[i][2], a[i][3]}; b4[i] = half4_t{b[i][0], b[i][1], b[i][2], b[i][3]}; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[q & 3], b4[(q + 1) & 3], acc[q], 0, 0, 0);
         }
         for (int q = 0; q < 8; ++q) acc_sum += acc[q][0] + acc[q][3];
     } else {
@@ -56,6 +67,7 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         run(burn<16>, "16x16x32 f16 (8 acc tiles)", 400000, 8.0 * 16 * 16 * 32 * 2);
         run(burn<32>, "32x32x16 f16 (4 acc tiles)", 400000, 4.0 * 32 * 32 * 16 * 2);
+        run(burn<1616>, "16x16x16 f16 (8 acc tiles)", 400000, 8.0 * 16 * 16 * 16 * 2);
     }
     return 0;
 }
