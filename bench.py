@@ -810,7 +810,7 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
       c4_1024x512    configs[3]  1024 elements (32 x 32 @ 1.5 mm), 512^3 @ 0.125 mm, PiecewiseLinear(60, 20) apodization + Direct delays (kernel 1)
       c5_skull_f1/f8 configs[4]  256 elements, 256^3, skull-slab medium (marched ray sums), 1 and 8 foci per launch
       tilted2_*      a two-module TransducerArray on a cylinder (xdc/transducerarray.py:86-115), 2 x 128 elements: tilted normals, no common lattice
-      jitter_*       the 16 x 16 array with +-0.1 mm element jitter (seed 147): not a lattice, not mirror-symmetric"""
+      jitter_*       the 16 x 16 array with +-0.1 mm element jitter (seed 147): not a lattice, not mirror-symmetric (1 focus, the 8-focus shard, the 64-focus sweep)"""
     from oracle import bf_oracle as bo, c_oracle as co
     from openlifu_amd.engine import grid_from_coords
     from openlifu_amd.seg.seg_methods import skull_slab_volumes
@@ -895,6 +895,7 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
         el.position = np.asarray(el.position, dtype=np.float64) + rng.uniform(-0.1, 0.1, 3) * np.array([1.0, 1.0, 0.0])
     run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus, covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
+    run("jitter_sweep64", "the same array, configs[2]'s whole 64-focus sweep on one GPU (64 steering columns in two launch tiles of 32: kernel 2c's NT = 4 shape)", jit, g256, sweep, steps=20, check=(0, 17, 63), covered_by="tests/test_gpu_field.py::test_many_foci_without_symmetry_uses_wide_mfma_tiles (full volumes, smaller grids)")
     skull = skull_slab_volumes(*g256[3])
     skull["model"] = "marched"
     run("c5_skull_f1", "BASELINE configs[4] on one GPU: 256 elements, 256^3, skull-slab medium, marched ray sums (kernel 2m), one focus per launch",

@@ -55,6 +55,25 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
         const float phi = t[e * TAB_STRIDE + 4];
         const float dx = x - ex, dy = y - ey;
         const float r2 = fmaf(dy, dy, dx * dx);
+        // Two voxels per packed fp32 instruction (v_pk_add / v_pk_fma / v_pk_mul: the five plain operations of a pair; the three transcendentals
+        // stay scalar) -- same bits; jittered array, single focus, 256^3: 1.154 -> 1.080 ms (same box, alternating: round 6)
+        if constexpr (ZPL % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < ZPL; q += 2) {
+                float2_t d2;
+                if (FLAT) d2 = float2_t{r2, r2} + float2_t{z[q], z[q + 1]};
+                else { const float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez}; d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2}); }
+                if (CLAMP) { d2.x = fmaxf(d2.x, P.dmin2); d2.y = fmaxf(d2.y, P.dmin2); }
+                const float2_t ri = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+                const float2_t ph = __builtin_elementwise_fma(d2, ri, float2_t{phi, phi});
+                const float2_t s = {__builtin_amdgcn_sinf(ph.x), __builtin_amdgcn_sinf(ph.y)};
+                const float2_t c = {__builtin_amdgcn_cosf(ph.x), __builtin_amdgcn_cosf(ph.y)};
+                const float2_t a = float2_t{w, w} * ri;
+                const float2_t rr = __builtin_elementwise_fma(a, c, float2_t{re[q], re[q + 1]});
+                const float2_t ii = __builtin_elementwise_fma(a, s, float2_t{im[q], im[q + 1]});
+                re[q] = rr.x; re[q + 1] = rr.y; im[q] = ii.x; im[q + 1] = ii.y;
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
             float d2;
@@ -230,6 +249,34 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
         const float ez = te[2];
         const float r2 = fmaf(dy, dy, dx * dx);
         float gr[ZPL], gi[ZPL];
+        if constexpr (ZPL % 2 == 0) {      // two voxels per packed fp32 instruction, as kernel 2a (same bits): tilted array, single focus 0.372 -> 0.348 ms
+#pragma unroll
+            for (int q = 0; q < ZPL; q += 2) {
+                float2_t d2;
+                if (FLAT) d2 = float2_t{r2, r2} + float2_t{z[q], z[q + 1]};
+                else { const float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez}; d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2}); }
+                if (CLAMP) { d2.x = fmaxf(d2.x, P.dmin2); d2.y = fmaxf(d2.y, P.dmin2); }
+                const float2_t ri = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
+                const float2_t ph = d2 * ri;
+                const float2_t g0 = ri * float2_t{__builtin_amdgcn_cosf(ph.x), __builtin_amdgcn_cosf(ph.y)};
+                const float2_t g1 = ri * float2_t{__builtin_amdgcn_sinf(ph.x), __builtin_amdgcn_sinf(ph.y)};
+                gr[q] = g0.x; gr[q + 1] = g0.y; gi[q] = g1.x; gi[q + 1] = g1.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                const float wr = te[4 + 2 * k], wi = te[5 + 2 * k];
+#pragma unroll
+                for (int q = 0; q < ZPL; q += 2) {
+                    const float2_t g0 = {gr[q], gr[q + 1]}, g1 = {gi[q], gi[q + 1]};
+                    float2_t rr = {re[q][k], re[q + 1][k]}, ii = {im[q][k], im[q + 1][k]};
+                    rr = __builtin_elementwise_fma(g0, float2_t{wr, wr}, rr);
+                    rr = __builtin_elementwise_fma(-g1, float2_t{wi, wi}, rr);
+                    ii = __builtin_elementwise_fma(g0, float2_t{wi, wi}, ii);
+                    ii = __builtin_elementwise_fma(g1, float2_t{wr, wr}, ii);
+                    re[q][k] = rr.x; re[q + 1][k] = rr.y; im[q][k] = ii.x; im[q + 1][k] = ii.y;
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
             float d2;
@@ -255,6 +302,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
                 im[q][k] = fmaf(gr[q], wi, im[q][k]);
                 im[q][k] = fmaf(gi[q], wr, im[q][k]);
             }
+        }
         }
     }
     const bool full = (k0 + ZPL <= P.nz) && (P.nz % ZPL == 0);

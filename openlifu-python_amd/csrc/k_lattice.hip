@@ -143,7 +143,12 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
-                    const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
+                    // lo = g - (float)hi in ONE mixed-precision fma per component (the compiler's form: a convert and a subtract -- same bits)
+                    float lr, li;
+                    const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
+                    const auto lo = __builtin_amdgcn_cvt_pkrtz(lr, li);
                     Thi[z * LAT_PSZ + toff[r]] = __builtin_bit_cast(unsigned, hi);
                     Tlo[z * LAT_PSZ + toff[r]] = __builtin_bit_cast(unsigned, lo);
                 }

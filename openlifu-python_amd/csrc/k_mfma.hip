@@ -97,6 +97,8 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 Half8Bits ah, al;
+                // (the plain operations of two G values in packed fp32 instructions, as kernels 2a / 2b have them, measured +5 % here -- jittered
+                // shard 2.00 -> 2.10 ms, tilted 0.705 -> 0.750: beside matrix instructions packed fp32 loses, MI355X_MICROARCH.md)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float d2;
@@ -113,7 +115,16 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
                     const float gr = rs * __builtin_amdgcn_cosf(ph);
                     const float gi = rs * __builtin_amdgcn_sinf(ph);
                     const auto hi = __builtin_amdgcn_cvt_pkrtz(gr, gi);
-                    const auto lo = __builtin_amdgcn_cvt_pkrtz(gr - (float)hi[0], gi - (float)hi[1]);
+                    // lo = g - (float)hi: with >= 2 column tiles in ONE mixed-precision fma per component (the compiler's form is a convert and a
+                    // subtract -- same bits): tilted 8-focus shard 0.731 -> 0.711 ms, 64-focus sweeps -1.8 %; with one column tile the same change
+                    // measured +7 % (jittered shard 2.005 -> 2.146 ms, same box, alternating), so that shape keeps the compiler's form
+                    float lr, li;
+                    if constexpr (NT >= 2) {
+                        const unsigned hw = __builtin_bit_cast(unsigned, hi);
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lr) : "v"(hw), "v"(gr));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(li) : "v"(hw), "v"(gi));
+                    } else { lr = gr - (float)hi[0]; li = gi - (float)hi[1]; }
+                    const auto lo = __builtin_amdgcn_cvt_pkrtz(lr, li);
                     ah.w[q] = __builtin_bit_cast(unsigned, hi);
                     al.w[q] = __builtin_bit_cast(unsigned, lo);
                 }
