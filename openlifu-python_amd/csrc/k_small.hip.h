@@ -256,6 +256,12 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
 // The streaming scans touch every byte of the result volumes once per pass: non-temporal 16-byte loads / stores (the volumes are far larger
 // than L2 + Infinity Cache, and a line kept for them evicts one somebody will read) -- aggregate 64 -> 68 %, scale 66 -> 69 % of 8 TB/s.
 typedef float olx_f4_t __attribute__((ext_vector_type(4)));
+// Minimum waves per SIMD of the register-heavy scans (round 6, same box, alternating): field_masked_peak_k at 4 (<= 128 registers instead of 132:
+// 4 instead of 3 waves per SIMD keep more loads in flight) 126.6 -> 116 us = 53 -> 58 % of 8 TB/s; at 5 it spills (162 us).  The six-peak scan and
+// the fused post-pass LOSE with the same setting (201 -> 242 us, 470 -> 756 us: their exact-test branches spill) and keep the compiler's choice.
+#define OLX_SCAN_WPE_FIELD_MASKED_PEAK_K 4
+#define OLX_SCAN_WPE_FIELD_ANALYSIS_PEAKS4_K 1
+#define OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K 1
 __device__ __forceinline__ float4 ld4s(const float4* p) {
     const olx_f4_t v = __builtin_nontemporal_load(reinterpret_cast<const olx_f4_t*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
@@ -458,7 +464,7 @@ __device__ __forceinline__ int mask_fast_side(float d2, float rin2, float rout2)
 // so the cross-block reduction is an integer atomicMax.
 // ------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void field_masked_peak_k(const float* __restrict__ vol,
+__global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_MASKED_PEAK_K) void field_masked_peak_k(const float* __restrict__ vol,
                                                             const double* __restrict__ A,
                                                             const PeakParams P,
                                                             unsigned* __restrict__ out) {
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(256) void field_weighted_sum_k(const float* __restr
 // divisions: there is no hardware integer divide) is paid once per 32 bytes of traffic instead of once per 8.  The fp64 focal-frame
 // expression and the comparisons per voxel are the ones of field_analysis_peaks_k, so the peaks are bit-identical.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void field_analysis_peaks4_k(const float* __restrict__ pmag, const float* __restrict__ inten,
+__global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_ANALYSIS_PEAKS4_K) void field_analysis_peaks4_k(const float* __restrict__ pmag, const float* __restrict__ inten,
                                                                 const double* __restrict__ A, const PeakParams P /*radius = r_main*/,
                                                                 const double r_side, unsigned* __restrict__ out /*[F][6]*/) {
     const int f = blockIdx.y;
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
 // volumes cross HBM twice (read, write back) instead of five times.  Voxel-major: a lane owns a quad of z voxels of ALL (<= 8) foci.
 // ------------------------------------------------------------------------------------
 constexpr int SAA_MAXF = 8;
-__global__ __launch_bounds__(256) void field_scale_agg_analyze_k(float* __restrict__ pmag, float* __restrict__ inten, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void field_scale_agg_analyze_k(float* __restrict__ pmag, float* __restrict__ inten, const float* __restrict__ scale,
                                                                   const float* __restrict__ wts, const double* __restrict__ A, int n_foci,
                                                                   const PeakParams P /*radius = r_main*/, double r_side, float inv_n,
                                                                   float* __restrict__ pmax, float* __restrict__ imean, float* __restrict__ wint,
