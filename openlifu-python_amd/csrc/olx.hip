@@ -62,7 +62,7 @@ int olx_ctx_destroy(olx_ctx* c) {
     void* ptrs[] = {c->d_pos, c->d_nrm, c->d_area, c->d_delays, c->d_apod, c->d_foci, c->d_M, c->d_tab,
                     c->d_pmag[0], c->d_pmag[1], c->d_inten, c->d_cplx, c->d_agg_p, c->d_agg_i,
                     c->d_scale, c->d_gather, c->d_peakA, c->d_peak, c->d_perm, c->d_coords, c->d_bfrag, c->d_colinfo, c->d_wint, c->d_med, c->d_plane_k, c->d_plane_of_k,
-                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_Utex, c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
+                    c->d_an, c->d_inv2z, c->d_kfirst, c->d_klast, c->d_slot, c->d_jobs, c->d_med_layer, c->d_layer_lo, c->d_layer_hi, c->d_U[0], c->d_U[1], c->d_Utex, c->d_sig, c->d_cell, c->d_afrag, c->d_tab2, c->d_cpblocks};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1341,8 +1341,14 @@ int olx_field_set_medium(olx_ctx* c, const float* sound_speed, const float* atte
     }
     c->h_plane_k = plane_k;
     for (void** q : {(void**)&c->d_med, (void**)&c->d_plane_k, (void**)&c->d_plane_of_k, (void**)&c->d_inv2z, (void**)&c->d_kfirst, (void**)&c->d_klast,
-                     (void**)&c->d_med_layer, (void**)&c->d_layer_lo, (void**)&c->d_layer_hi})
+                     (void**)&c->d_med_layer, (void**)&c->d_layer_lo, (void**)&c->d_layer_hi, (void**)&c->d_sig})
         if (*q) { hipFree(*q); *q = nullptr; }
+    if (c->march_one && np > 0) {   // compact copy of the planes' own slowness terms for the fused writers (k_hmarch.hip, field_hmarch_fused_k)
+        std::vector<float> sig((size_t)np * nx * ny);
+        for (size_t q = 0; q < sig.size(); ++q) sig[q] = med[q * 8];
+        HIPCHK(c, hipMalloc((void**)&c->d_sig, sizeof(float) * sig.size()));
+        HIPCHK(c, hipMemcpy(c->d_sig, sig.data(), sizeof(float) * sig.size(), hipMemcpyHostToDevice));
+    }
     if (c->marched) {
         const size_t need = (size_t)n * nx * ny;
         if (c->U_cap < need) {

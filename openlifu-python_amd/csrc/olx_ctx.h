@@ -107,6 +107,7 @@ struct olx_ctx {
     bool march_one = false;                    // kernel 2m: a' = kappa sig everywhere -> ONE running sum per ray (hp.kappa)
     float2* d_Utex = nullptr; size_t Utex_cap = 0;   // kernel 2m, one-sum form: the last running sums as row pairs {U(i,j), U(i+1,j)} (one 16-byte load per look-up above the medium)
     bool marched = false; float2* d_U[2] = {nullptr, nullptr}; size_t U_cap = 0; std::vector<int> h_plane_k;
+    float* d_sig = nullptr;                   // kernel 2m, one-sum form: the planes' own terms as ONE float per cell, sig[plane][i][j] (the fused writers read them coalesced)
     size_t out_cap = 0; int nbuf = 1; int cur = 0;
     std::string variant;
     std::vector<hipEvent_t> prof_ev; int prof_n = 0; bool prof_on = false;

@@ -559,6 +559,67 @@ def test_marched_medium_foci_tiles_slabs_and_fallback(ctx):
         ctx.field_set_medium(cvol, avol, rvol, model="marched")
 
 
+@pytest.mark.parametrize("case", ["skull_phantom_96", "ragged_edges_clamped", "gaps_between_planes"])
+def test_marched_fused_writers_equal_single_plane_launches(ctx, case, monkeypatch):
+    """Kernel 2m's fused writers (round 6, OPT-IN -- OLX_MARCH_FUSE=2 / 3 / 4: up to four consecutive non-trivial planes per launch, the running
+    sums in between carried in LDS over the tile's hull towards each element; they cut the writers' HBM traffic by G but measured slower than
+    the single-plane writers, which stay the default) against those single-plane writers -- the SAME BITS, full volumes, |p| and intensity --
+    and against the fp64 marched oracle (runs of 31 planes end in groups of every size).  Cases: BASELINE's skull phantom on a 96 x 80 lateral grid (tiles of 16 with a ragged last
+    row / column, elements all round the tiles); a grid whose first lateral voxels lie outside the array (look-up coordinates clamped);
+    a medium whose non-trivial planes come in runs of 1, 2, 3 and 5 with trivial planes in between."""
+    from openlifu_amd.seg.seg_methods import skull_slab_volumes
+    if case == "skull_phantom_96":
+        pos, ori, size = synthetic_array(16, 16, 3.0)
+        xs = (np.arange(96) - 47.5) * 0.5e-3; ys = (np.arange(80) - 39.5) * 0.6e-3; zs = 5e-3 + np.arange(72) * 0.25e-3
+        vol = skull_slab_volumes(xs, ys, zs)
+        cvol, avol, rvol = vol["sound_speed"], vol["attenuation"], vol["density"]
+    elif case == "ragged_edges_clamped":       # the array is wider than the grid: elements outside the lateral grid -> the clamped look-ups
+        pos, ori, size = synthetic_array(16, 16, 3.0)
+        xs = (np.arange(37) - 18.0) * 1e-3; ys = (np.arange(50) - 24.5) * 0.8e-3; zs = 4e-3 + np.arange(40) * 0.5e-3
+        cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    else:
+        pos, ori, size = synthetic_array(8, 8, 4.0)
+        xs = np.linspace(-12e-3, 12e-3, 33); ys = np.linspace(-10e-3, 10e-3, 41); zs = 3e-3 + np.arange(48) * 0.5e-3
+        cvol = np.full((33, 41, 48), C, dtype=np.float32); avol = np.zeros_like(cvol); rvol = np.full_like(cvol, RHO)
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        for k in (8, 11, 12, 15, 16, 17, 20, 21, 22, 23, 24, 30):
+            m = (np.sin(300.0 * X + 0.2 * k) * np.cos(250.0 * Y) > -0.3)
+            cvol[:, :, k][m] = 2800.0; avol[:, :, k][m] = 6.0; rvol[:, :, k][m] = 1900.0
+    foci = np.array([[1e-3, -2e-3, 18e-3]])
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    n = (len(xs), len(ys), len(zs))
+    h = (xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0])
+    got = {}
+    for fuse in ("4", "0", "2", "3"):
+        monkeypatch.setenv("OLX_MARCH_FUSE", fuse)
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, n, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+        ctx.field_set_medium(cvol, avol, rvol, model="marched")
+        assert "field_hmarch_k<nf1," in ctx.field_variant() and "one-sum" in ctx.field_variant(), ctx.field_variant()
+        ctx.field_launch()
+        got[fuse] = ctx.field_fetch(0)
+        assert ("fused writers" in ctx.field_variant()) == (fuse != "0"), (fuse, ctx.field_variant())      # (named once the launch sequence has run)
+        if case == "skull_phantom_96" and fuse == "4":
+            assert "fused writers: 31 planes in 8 launches" in ctx.field_variant(), ctx.field_variant()
+    monkeypatch.delenv("OLX_MARCH_FUSE", raising=False)
+    for fuse in ("4", "2", "3"):
+        assert np.array_equal(got[fuse]["pmag"], got["0"]["pmag"]), (case, fuse, float(np.abs(got[fuse]["pmag"] - got["0"]["pmag"]).max() / got["0"]["pmag"].max()))
+        assert np.array_equal(got[fuse]["intensity"], got["0"]["intensity"]), (case, fuse)
+    sig, ab = co.medium_terms(cvol, avol, C, F0)
+    ref = np.abs(co.field_hetero_march(xs, ys, zs, sig, ab, pos_m, area, d[0], a[0], F0, C, P0))
+    assert np.abs(got["4"]["pmag"] - ref).max() / ref.max() <= HET_TOL_P
+    # x-slab launches (the multi-GPU shard unit) with fused writers: the whole lateral grid is marched, the slab's voxels are the whole-grid ones
+    monkeypatch.setenv("OLX_MARCH_FUSE", "4")
+    monkeypatch.setenv("OLX_MARCH_FUSE_TI", "4")          # (the 4 x 16 tile of the single-plane writers: the other shape of the fused kernel)
+    parts = []
+    for b, cnt in ((0, n[0] // 3), (n[0] // 3, n[0] - n[0] // 3)):
+        ctx.field_plan((xs[0], ys[0], zs[0]), h, n, F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY, slab=(b, cnt))
+        ctx.field_set_medium(cvol, avol, rvol, model="marched")
+        ctx.field_launch()
+        parts.append(ctx.field_fetch(0)["pmag"])
+    assert np.array_equal(np.concatenate(parts, axis=0), got["4"]["pmag"])
+    monkeypatch.delenv("OLX_MARCH_FUSE", raising=False); monkeypatch.delenv("OLX_MARCH_FUSE_TI", raising=False)
+
+
 def test_c5_skull_slab_256cubed_marched(ctx):
     """BASELINE config 5 at full size with the default (marched) model: 256 el, 256^3 at 0.25 mm, skull-slab phantom, 4 foci
     in one launch.  Whole z columns (through the slab and the focal region) against the fp64 marched oracle, voxels below the slab
