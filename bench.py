@@ -202,6 +202,15 @@ def mfma_useful(name: str) -> dict:
     return {"mfma_issued": issued, "mfma_dense": dense, "mfma_useful": dense / issued if issued else None}
 
 
+def _library_stamp(nat):
+    """The commit libolx.so was built from (openlifu-python_amd/build.py writes <library>.stamp; the GPU box has no .git)."""
+    try:
+        with open(nat.LIB_PATH + ".stamp") as f:
+            return f.read().strip()
+    except OSError:
+        return "unknown"
+
+
 def static_traffic(kernel_name: str, grid_n: int):
     """HBM bytes per launch from the committed PMC summaries (profiles/traffic.json), matched on the kernel variant
     string: a STATIC figure from tools/profile_round.sh's counter passes, not measured in this run; None when the
@@ -684,6 +693,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if skull is None else "strong", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
+            "library_built_from_commit": _library_stamp(nat),
             # which exchange `value` includes: the scaling claim of this line (the other modes are reported beside it in `config`)
             "scaling_claim": mode if gather else "none",
             "n_ranks_rendezvous": world, "n_ranks_seen": ranks_seen if gather else world,

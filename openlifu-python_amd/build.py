@@ -57,7 +57,21 @@ def build(force: bool = False, defines=(), out: str = OUT) -> str:
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if jobs or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs):
         subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    write_stamp(out)
     return out
+
+
+def write_stamp(out: str) -> None:
+    """<library>.stamp = the commit the library was built from (+ "-dirty" when the csrc / include tree differs from it): it travels with the
+    library to the GPU box (which has no .git), so that bench.py and tools/profile_round.sh can name the code their numbers belong to."""
+    root = os.path.join(HERE, "..")
+    try:
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+        dirty = subprocess.run(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "openlifu-python_amd/csrc", "include"]).returncode != 0
+        with open(out + ".stamp", "w") as f:
+            f.write(head + ("-dirty" if dirty else "") + "\n")
+    except Exception:  # noqa: BLE001 - no git here (the GPU box): keep the stamp that travelled with the library
+        pass
 
 
 if __name__ == "__main__":

@@ -26,8 +26,13 @@ for k, v in s.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
         v["hbm_note"] = "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section)"
+try:
+    s["library_built_from_commit"] = open("openlifu-python_amd/lib/libolx.so.stamp").read().strip()
+except OSError:
+    s["library_built_from_commit"] = "unknown"
 s["command"] = "tools/profile_round.sh: rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 50 --warmup 5 --cpu-seconds 0 " + " ".join(sys.argv[2:])
 json.dump(s, open(out + "/pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in s.items() if isinstance(v, dict)}))
 PY
+cp openlifu-python_amd/lib/libolx.so.stamp "$out/kernel_stats.commit" 2>/dev/null
 head -4 "$out/kernel_stats.csv"
