@@ -121,7 +121,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         // column (32 elements = 24 + 8) uses the upper ones only; the others keep the previous column's entries (finite: 0 x them stays 0)
         const int c_lo = SAW - min(SAW, T.ax - SAW * sa), ncol = NC - c_lo;
         const float inv_ncol = 1.0f / (float)ncol;
-        for (int idx = tid; idx < n_new * ncol; idx += TOEP_WAVES * 64) {
+        auto fill = [&](const int idx, auto z0_c, auto zn_c) __attribute__((always_inline)) {
+            constexpr int Z0 = decltype(z0_c)::value, ZN = decltype(zn_c)::value;
             const int row = (int)(((float)idx + 0.5f) * inv_ncol), col = c_lo + idx - row * ncol;      // exact for these small integers
             const float U = (float)(ibase + P.x_begin + P.ux0 + P.mx * (col - (SAW - 1)) - SAW * P.mx * sa);
             const float W = (float)(jbase + P.uy0 + P.my * (row - 7) - TOEP_SB * P.my * sbb);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
             prow = prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow;
             const int o = prow * TOEP_TW + col;
 #pragma unroll
-            for (int z = 0; z < TOEP_ZB; ++z) {
+            for (int z = Z0; z < Z0 + ZN; ++z) {
                 float d2 = r2 + dz2[z];
                 if (CLAMP) d2 = fmaxf(d2, P.dmin2);
                 const float ri = __builtin_amdgcn_rsqf(d2);
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                     s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, w);
                 } else s_lo[z * TOEP_PSZ + o] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lr, li));
             }
-        }
+        };
+        // (where one round leaves half of the block idle -- <= 256 pairs: every super-block after the first -- splitting a pair's 16 planes over the
+        // two wave groups measured +1.5 % on configs[3], as in round 5: idle waves cost nothing, the partner block's waves take the SIMDs)
+        for (int idx = tid; idx < n_new * ncol; idx += TOEP_WAVES * 64) fill(idx, IntC<0>{}, IntC<TOEP_ZB>{});
         if (sb == 0) OLX_STAMP(2);
         __syncthreads();
         if (sb == 0) OLX_STAMP(3);
