@@ -413,8 +413,7 @@ OLX_BOUNDS_READER(coset)
 template <int NT, int MX, int MY>
 static void launch_coset(olx_ctx* c, float* pm, bool clamp) {
     const CosetParams& Q = c->cp;
-    const long long blocks = (long long)2 * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
-    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(COS_NW * 64);
+    dim3 grid(c->cp_nblocks, c->mp.n_tiles), blk(COS_NW * 64);      // (the block records of this launch: all of them, or one side of a launch split at fp8_kcut)
 #define OLX_COS(CL, F8) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, CL, F8, false>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q)
     if (c->dir_lattice) {   // piston directivity folded into the geometry tables (fp16 corrections only)
         if (clamp) hipLaunchKernelGGL((field_coset_k<NT, MX, MY, true, false, true>), grid, blk, 0, c->stream, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_jobs, c->d_cpblocks, Q);

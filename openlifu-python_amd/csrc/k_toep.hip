@@ -396,8 +396,7 @@ static void launch_toep(olx_ctx* c, float* pm) {
     T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ax = c->lat.ax; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
     for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
     const CosetParams& Q = T.q;
-    const long long blocks = (long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
-    dim3 grid((unsigned)blocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);
+    dim3 grid(c->cp_nblocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);      // (the block records of this launch: all of them, or one side of a launch split at fp8_kcut)
     if (c->dir_lattice) {   // piston directivity folded into the geometry tables
         if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         else hipLaunchKernelGGL((field_toep_k<MX, MY, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);

@@ -418,13 +418,19 @@ static int configure_variant_impl(olx_ctx* c) {
         // (include/olx.h, olx_field_plan): the foci are known (olx_bf_solve in the element frame, or external delays that infer_foci
         // recognises as geometric), every focus lies inside the planned SLAB and has N_eff = (sum w)^2 / sum w^2 >= 256; the plan flag
         // OLX_FIELD_FP16_CORRECTION opts out.  Decided here, before the columns are packed: it also decides the tile width below.
-        auto fp8_eligible = [&]() {
-            if ((c->flags & (OLX_FIELD_FP16_CORRECTION | OLX_OUT_COMPLEX)) || c->modifier() || !c->lat.ok) return false;
+        // Returns the first plane of the e4m3 products (0: every plane; a multiple of 16 = the plane blocks of kernels 2e / 2f / 2g: the blocks below keep
+        // three fp16 products), or -1: not eligible.  Conditions (i) and (ii) concern the whole planned slab; the near-field condition (iii) is asked
+        // of the planes from the cut on -- the error of a voxel belongs to the arithmetic its OWN plane block runs, and it is measured against the
+        // maximum of the whole volume, which holds the focal peak by (i).  The reference's default SimSetup (z from -4 mm: through the element plane)
+        // thereby loses the e4m3 products for its first plane block(s) only.
+        auto fp8_eligible = [&]() -> int {
+            if ((c->flags & (OLX_FIELD_FP16_CORRECTION | OLX_OUT_COMPLEX)) || c->modifier() || !c->lat.ok) return -1;
             bool ok = c->h_foci.size() == 3 * (size_t)F && c->foci_version == c->steer_version;
             if (!ok && infer_foci(c, c->h_foci)) {   // external delays: geometric?
                 c->foci_version = c->steer_version;
                 ok = true;
             }
+            double need = 0;        // the largest  FP8_ERR_K wmax_f / (FP8_ERR_BOUND peak_f)  over the foci: sqrt(S2) must stay below 1 / need
             for (int f = 0; ok && f < F; ++f) {
                 for (int a = 0; a < 3; ++a) {
                     const int b0 = a == 0 ? c->slab.x_begin : 0, cnt = a == 0 ? c->slab.x_count : c->grid.n[a];
@@ -440,27 +446,49 @@ static int configure_variant_impl(olx_ctx* c) {
                     const double ddx = fo[0] - c->h_pos[e], ddy = fo[1] - c->h_pos[(size_t)n + e], ddz = fo[2] - c->h_pos[2 * (size_t)n + e];
                     peak += w / std::sqrt(std::max(ddx * ddx + ddy * ddy + ddz * ddz, 1e-30));
                 }
-                if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5)) ok = false;
-                // the near field: the error next to an element is relative to that element's own term (olx_plan.h, FP8_ERR_K): the bound on
-                // the worst voxel of the planned slab must stay below FP8_ERR_BOUND of this focus' coherent peak
-                if (ok) {
-                    if (c->nf_s2 < 0) {   // once per (element table, planned slab): olx_field_plan resets it
-                        const int b0[3] = {c->slab.x_begin, 0, 0}, cnt[3] = {c->slab.x_count, c->grid.n[1], c->grid.n[2]};
-                        c->nf_s2 = olxplan::nearfield_s2(n, c->h_pos.data(), c->grid.origin, c->grid.spacing, b0, cnt,
-                                                         0.5 * std::min({c->grid.spacing[0], c->grid.spacing[1], c->grid.spacing[2]}));
-                    }
-                    if (!(olxplan::FP8_ERR_K * wmx * std::sqrt(c->nf_s2) <= olxplan::FP8_ERR_BOUND * peak)) ok = false;
-                }
+                if (!(sw2 > 0 && sw1 * sw1 / sw2 >= 255.5) || !(peak > 0)) ok = false;
+                else need = std::max(need, olxplan::FP8_ERR_K * wmx / (olxplan::FP8_ERR_BOUND * peak));
             }
-            return ok;
+            if (!ok) return -1;
+            // Voxels ON a symmetry plane of the array see its elements in pairs at exactly the same distance -- the same table entry, the same
+            // rounding error, and for a focus on that plane the same weight: the pair's errors add coherently instead of at random.  On the array's
+            // axis (both planes: grids with an odd voxel count centred on the array, e.g. the reference's default SimSetup) the emulation finds the
+            // largest normalised error 1.5 x that of a grid whose voxels straddle the planes (4.2e-5 against 2.7 - 3.0e-5; the device measured
+            // 9.2e-6 of the peak where the plain rule promised 7.5e-6): the rule's constant is raised by a quarter per plane that carries voxels.
+            {
+                int planes = 0;
+                for (int a = 0; a < 2; ++a) {
+                    const double ctr = (a == 0 ? c->lat.x0 + 0.5 * (c->lat.ax - 1) * c->lat.px : c->lat.y0 + 0.5 * (c->lat.ay - 1) * c->lat.py);
+                    const double idx = (ctr - c->grid.origin[a]) / c->grid.spacing[a];
+                    const int b0 = a == 0 ? c->slab.x_begin : 0, cnt = a == 0 ? c->slab.x_count : c->grid.n[a];
+                    if (std::fabs(idx - std::round(idx)) <= 1e-6 && idx >= b0 - 0.5 && idx <= b0 + cnt - 0.5) ++planes;
+                }
+                need *= 1.0 + 0.25 * planes;
+            }
+            // the near field: the error next to an element is relative to that element's own term (olx_plan.h, FP8_ERR_K): the bound on the worst
+            // voxel of the planes that run the e4m3 products must stay below FP8_ERR_BOUND of every focus' coherent peak.  S2 per first plane block:
+            // derived lazily, once per (element table, planned slab) -- olx_field_plan resets it
+            const int nzb = (c->grid.n[2] + COS_ZB - 1) / COS_ZB;
+            if ((int)c->nf_s2.size() != nzb) c->nf_s2.assign(nzb, -1.0);
+            for (int q = 0; q < nzb; ++q) {
+                if (c->nf_s2[q] < 0) {
+                    const int b0[3] = {c->slab.x_begin, 0, q * COS_ZB}, cnt[3] = {c->slab.x_count, c->grid.n[1], c->grid.n[2] - q * COS_ZB};
+                    c->nf_s2[q] = olxplan::nearfield_s2(n, c->h_pos.data(), c->grid.origin, c->grid.spacing, b0, cnt,
+                                                        0.5 * std::min({c->grid.spacing[0], c->grid.spacing[1], c->grid.spacing[2]}));
+                }
+                if (need * std::sqrt(c->nf_s2[q]) <= 1.0) return q * COS_ZB;
+            }
+            return -1;
         };
         // OLX_FP8_CORRECTION=0 (environment) opts out like the plan flag.  "1" FORCES the e4m3 products past the eligibility rule -- results may
         // then miss the 1e-5 gate, so only developer builds (OLX_DEV_PINS: the debug library, A/B timing builds) honour it; the product ignores it.
         const char* f8env = getenv("OLX_FP8_CORRECTION");
-        bool fp8_want = lat_ok && !(f8env && !strcmp(f8env, "0")) && fp8_eligible();
+        int fp8_cut = (lat_ok && !(f8env && !strcmp(f8env, "0"))) ? fp8_eligible() : -1;
 #ifdef OLX_DEV_PINS
-        if (f8env && strcmp(f8env, "0") != 0) fp8_want = lat_ok && !c->modifier();
+        if (f8env && strcmp(f8env, "0") != 0) fp8_cut = (lat_ok && !c->modifier()) ? 0 : -1;
 #endif
+        const bool fp8_want = fp8_cut >= 0;
+        c->fp8_kcut = fp8_want ? fp8_cut : 0;
         olxplan::Tiles tiles = pack(MAXC);
         int total_cols = 0;
         // A sweep that needs SEVERAL launch tiles anyway is cut into tiles of 16 columns instead of 32: kernel 2g (NT = 2) then takes every
@@ -537,7 +565,8 @@ static int configure_variant_impl(olx_ctx* c) {
             HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
             c->coords_cap = n_pad;
         }
-        const size_t need = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;      // uint4 per K-step and column tile: hi, lo of the 64 lanes
+        c->bfrag_half = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;      // uint4 per K-step and column tile: hi, lo of the 64 lanes
+        const size_t need = 2 * c->bfrag_half;                            // (a second set in the other arithmetic for a launch split at fp8_kcut)
         if (c->bfrag_cap < need) {
             if (c->d_bfrag) hipFree(c->d_bfrag);
             c->d_bfrag = nullptr; c->bfrag_cap = 0;
@@ -655,15 +684,19 @@ static int configure_variant_impl(olx_ctx* c) {
 #ifdef OLX_DEV_PINS
                     if (const char* e = getenv("OLX_EXP_KGRP")) kgrp = (unsigned)std::max(1, atoi(e));
 #endif
-                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs};
+                    const int kcut = c->fp8corr ? c->fp8_kcut : 0;      // records of the plane blocks from the cut on come FIRST (a launch of their own in the e4m3 arithmetic)
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs, kcut};
                     std::vector<CosetBlock> blk;
                     if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
                         std::string why;
                         if (!olxplan::build_coset_blocks(Q, zb, kgrp, c->use_cosetp ? 40 : 0, blk, why))
                             return fail(c, OLX_ESTATE, "kernel 2g: %s", why.c_str());
+                        if (kcut > 0) std::stable_partition(blk.begin(), blk.end(), [&](const CosetBlock& b) { return b.k0 >= kcut || b.npos <= 0; });
                     }
                     const unsigned nblk = (unsigned)blk.size();
+                    c->cp_nfar = nblk;
+                    if (kcut > 0) { c->cp_nfar = 0; for (const CosetBlock& b : blk) if (b.k0 >= kcut || b.npos <= 0) ++c->cp_nfar; }
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);
                         c->d_cpblocks = nullptr; c->cpblocks_cap = 0; c->up_blocks.clear();
@@ -680,7 +713,11 @@ static int configure_variant_impl(olx_ctx* c) {
                 // what the DENSE contraction of this launch needs, in the same units (one v_mfma_f32_16x16x32_f16 = 8192 real multiply-adds): computed
                 // voxels x elements x columns x 4 real products per complex one, times the products of the operand split -- bench.py reports
                 // dense / issued as `mfma_useful` (padding of rows, columns, K slots and the Toeplitz band all show up there)
-                const long long n_dense = (long long)((double)(P.nx - L.x_lo) * (P.ny - L.y_lo) * P.nz * (double)n * total_cols * 4.0 / 8192.0 * (c->fp8corr ? 2 : 3));
+                // (a launch split at fp8_kcut: the plane blocks below the cut run three fp16 products -- the matrix units of both parts are weighted by their planes)
+                const double far_frac = c->fp8corr ? (double)std::max(0, P.nz - c->fp8_kcut) / (double)P.nz : 0.0;
+                const double corr_units = 3.0 - far_frac;                                   // 2 with e4m3 corrections everywhere, 3 with fp16 x 3
+                const std::string f8tag = !c->fp8corr ? "" : (c->fp8_kcut > 0 ? ",fp8corr from plane " + std::to_string(c->fp8_kcut) : ",fp8corr");
+                const long long n_dense = (long long)((double)(P.nx - L.x_lo) * (P.ny - L.y_lo) * P.nz * (double)n * total_cols * 4.0 / 8192.0 * corr_units);
                 if (c->use_toep) {   // kernel 2f operands: lattice cell -> element map, Toeplitz weight fragments, the column's store targets
                     // element super-blocks of kernel 2f along x: the whole row for arrays up to 24 wide, else columns of 24 and the rest -- the table then has
                     // (KXW - 1) + 24 = 31 <= 32 columns = two K-steps, and a last column of <= 8 elements fills K-step 1 only (ks_mask)
@@ -707,7 +744,8 @@ static int configure_variant_impl(olx_ctx* c) {
                         c->cell_cap = A.cell.size();
                     }
                     HIPCHK(c, hipMemcpy(c->d_cell, A.cell.data(), sizeof(int) * A.cell.size(), hipMemcpyHostToDevice));
-                    const size_t need = (size_t)ntiles * c->toep_nsa * 8 * A.nsb * 4 * 64;
+                    c->afrag_half = (size_t)ntiles * c->toep_nsa * 8 * A.nsb * 4 * 64;
+                    const size_t need = 2 * c->afrag_half;      // (a second set in the other arithmetic for a launch split at fp8_kcut)
                     if (c->afrag_cap < need) {
                         if (c->d_afrag) hipFree(c->d_afrag);
                         c->d_afrag = nullptr; c->afrag_cap = 0;
@@ -719,34 +757,34 @@ static int configure_variant_impl(olx_ctx* c) {
                     long long n_mfma = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     // per element row and y position: 3 fp16 products per non-zero K-step, or 1 per non-zero K-step + one e4m3 instruction (2 units) per column
-                    const long long per_row = c->fp8corr ? (long long)ksteps_total + 2LL * c->toep_nsa : 3LL * ksteps_total;
+                    const double per_row = far_frac * ((double)ksteps_total + 2.0 * c->toep_nsa) + (1.0 - far_frac) * 3.0 * ksteps_total;
                     for (int rx = 0; rx < Q.xs * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry) {
                             const int kxa = rx < wx ? (wx - 1 - rx) / (Q.xs * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
                             for (int sx = 0; sx < Q.nsx; ++sx)
                                 for (int sy = 0; sy < Q.nsy; ++sy) {
                                     const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    if (KX > 0 && KY > 0) n_mfma += (long long)KY * per_row * ((KX + 7) / 8) * 8 * A.nsb * Q.kblocks;      // (row tiles of 8 positions)
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)((double)KY * per_row * ((KX + 7) / 8) * 8 * A.nsb * Q.kblocks);      // (row tiles of 8 positions)
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", c->fp8corr ? ",fp8corr" : "",
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", f8tag.c_str(),
                              total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
-                long long n_mfma = tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                long long n_mfma = (long long)((double)tiles16 * ((P.nz + COS_P - 1) / COS_P) * A.nsa * A.nsb * 4 * c->nt * corr_units * ntiles);
                 if (c->use_cosetp) {   // kernel 2g: one row tile per position and 16-plane block, no padded rows
                     long long npos_all = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     for (int rx = 0; rx < 2 * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry)
                             npos_all += (long long)(rx < wx ? (wx - 1 - rx) / (2 * A.mx) + 1 : 0) * (ry < wy ? (wy - 1 - ry) / A.my + 1 : 0);
-                    n_mfma = npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * (c->fp8corr ? 2 : 3) * ntiles;
+                    n_mfma = (long long)((double)npos_all * Q.kblocks * A.nsa * A.nsb * 4 * c->nt * corr_units * ntiles);
                 }
                 snprintf(nmbuf, sizeof nmbuf, "field_coset%s_k<nt%d,mx%d,my%d,flat,%s%s%s> %d columns for %d foci x %d images in %d tile(s); "
                          "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", c->use_cosetp ? "p" : "", c->nt, c->mx, c->my, lat_clamp ? "clamp" : "noclamp",
-                         c->fp8corr ? ",fp8corr" : "", "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
+                         f8tag.c_str(), "", total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
                 }
             } else {
                 const long long n_mfma = (long long)L.tiles_x * L.tiles_y * L.kgroups * A.nsa * A.nsb * 4 * c->lat_mt * c->nt * 3 * ntiles;
@@ -811,6 +849,12 @@ static int pack_if_needed(olx_ctx* c) {
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
                            (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, (c->use_lattice && c->use_cosetp) ? 1 : 0, c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
+        if (c->use_lattice && c->use_coset && c->fp8corr && c->cp_nfar < c->cp_nblocks) {   // a launch split at fp8_kcut: the fp16 operands of the plane blocks below the cut
+            hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
+                               c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
+                               c->plan_foci, c->d_colinfo, c->d_slot, 0, c->use_cosetp ? 1 : 0, c->d_coords, c->d_bfrag + c->bfrag_half);
+            if (c->use_toep) { c->fp8corr = false; c->d_afrag += c->afrag_half; olx_pack_toep(c); c->d_afrag -= c->afrag_half; c->fp8corr = true; }
+        }
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
@@ -950,7 +994,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     }
     c->min_dist = c->clamp ? dmin : std::sqrt(min_d2);  // lower bound of any voxel-element distance [m]
     detect_lattice(c, lo, hi, dmin);
-    c->nf_s2 = -1.0;      // near-field sum of the e4m3 error bound: derived lazily by configure_variant (fp8_eligible)
+    c->nf_s2.clear();     // near-field sums of the e4m3 error bound: derived lazily by configure_variant (fp8_eligible)
     // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
     auto mirror_perm = [&](int axis, std::vector<int>& perm) -> bool {
         const double ctr = g->origin[axis] + 0.5 * (g->n[axis] - 1) * g->spacing[axis];
@@ -1045,9 +1089,17 @@ int olx_field_launch(olx_ctx* c) {
     if (c->hetero) { if (c->marched) olx_launch_hmarch(c, pm); else olx_launch_hetero(c, pm); }
     else if (c->use_mfma) {
         if (!c->use_lattice) olx_launch_mfma(c, pm);
-        else if (c->use_toep) olx_launch_toep(c, pm);
-        else if (c->use_cosetp) olx_launch_cosetp(c, pm);
-        else if (c->use_coset) olx_launch_coset(c, pm);
+        else if (c->use_coset) {
+            auto go = [&]() { if (c->use_toep) olx_launch_toep(c, pm); else if (c->use_cosetp) olx_launch_cosetp(c, pm); else olx_launch_coset(c, pm); };
+            if (c->fp8corr && c->cp_nfar < c->cp_nblocks) {   // split at fp8_kcut: e4m3 corrections for the plane blocks from the cut on, three fp16 products below it
+                const unsigned nall = c->cp_nblocks;
+                c->cp_nblocks = c->cp_nfar;
+                if (c->cp_nblocks) go();
+                c->fp8corr = false; c->d_cpblocks += c->cp_nfar; c->cp_nblocks = nall - c->cp_nfar; c->d_bfrag += c->bfrag_half; c->d_afrag += c->afrag_half;
+                go();
+                c->fp8corr = true; c->d_cpblocks -= c->cp_nfar; c->cp_nblocks = nall; c->d_bfrag -= c->bfrag_half; c->d_afrag -= c->afrag_half;
+            } else go();
+        }
         else olx_launch_lattice(c, pm);
     }
     else if (c->mx * c->my * c->nf > 1) {

@@ -79,7 +79,10 @@ struct olx_ctx {
     typedef olxplan::Lattice Lattice;          // olx_plan.h: regular (a, b) lattice in one z plane, pitch = whole voxels
     Lattice lat;
     bool use_lattice = false; int lat_mt = 8; LatParams lp{}; int* d_slot = nullptr; size_t slot_cap = 0;
-    double nf_s2 = -1.0;   // max_v sum_e 1 / d'(v, e)^2 over the planned slab [1/m^2] (olxplan::nearfield_s2; < 0 = not derived yet): the e4m3 error bound's near-field term
+    std::vector<double> nf_s2;   // [plane block q]: max_v sum_e 1 / d'(v, e)^2 over the planes >= 16 q of the planned slab [1/m^2] (olxplan::nearfield_s2; < 0 = not derived yet): the e4m3 error bound's near-field term
+    int fp8_kcut = 0;            // e4m3 correction products for the plane blocks from this plane on, fp16 x 3 below (0: everywhere); meaningful while fp8corr
+    unsigned cp_nfar = 0;        // block records [0, cp_nfar): planes >= fp8_kcut; [cp_nfar, cp_nblocks): the planes below (their operands sit bfrag_half / afrag_half further on)
+    size_t bfrag_half = 0, afrag_half = 0;
     bool use_coset = false; bool fp8corr = false; CosetParams cp{}; int* d_jobs = nullptr; size_t jobs_cap = 0;   // kernel 2e (whole cosets per wave) instead of 2d's row tiles
     // kernel 2f (one steering column: Toeplitz weights stationary, 16 planes per MFMA tile)
     CosetBlock* d_cpblocks = nullptr; size_t cpblocks_cap = 0; unsigned cp_nblocks = 0;   // kernel 2g block records

@@ -78,7 +78,9 @@ bool infer_foci(bool flat, int n, int F, const double* pos /*[3][n]*/, const dou
 // can exceed the focal peak's share (grids through / close above the element plane: VERDICT round 5).  The planner therefore asks for
 //     FP8_ERR_K * wmax_f * sqrt(max_v sum_e 1 / d'(v, e)^2) <= FP8_ERR_BOUND * sum_e w_ef / d(focus_f, e)      for every focus f
 // (right side: the coherent focal peak, a lower bound of the volume maximum when the focus lies inside the planned volume) and keeps
-// three fp16 products otherwise.
+// three fp16 products otherwise -- for the whole launch, or (round 6) for the plane blocks below the first one from which the rule holds.
+// Voxels ON a symmetry plane of the array see element pairs at identical distances, whose errors add coherently: the caller raises
+// FP8_ERR_K by a quarter per symmetry plane that carries voxels (olx.hip, fp8_eligible; calibration in tools/emul_fp8_bound.py).
 constexpr double FP8_ERR_K = 3.75e-5;        // 6 sigma_1
 constexpr double FP8_ERR_BOUND = 7.5e-6;     // stated in include/olx.h (olx_field_plan); north_star's gate is 1e-5
 // max over the candidate voxels (the voxel of the planned slab nearest to each element: S2 peaks next to an element) of

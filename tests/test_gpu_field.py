@@ -1045,7 +1045,7 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, monkeypatch):
 
 
 @pytest.mark.parametrize("spacing,z_lo,shard", [(1.0, -4.0, False), (1.0, -4.0, True), (0.5, -4.0, False), (0.5, -4.0, True), (0.25, -4.0, False), (0.25, -4.0, True),
-                                                 (0.25, 0.25, True), (0.5, 0.5, False), (0.25, 1.0, True), (0.25, 2.0, False)])
+                                                 (0.25, 0.25, True), (0.5, 0.5, False), (0.25, 1.0, True), (0.25, 2.0, False), (0.5, -4.0, "offaxis")])
 def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
     """the e4m3 correction products' error is relative to EACH element's own term, so a voxel next to a
     single element carries an error that the 1 / sqrt(N_eff) argument does not cover.  BASELINE's 16 x 16 @ 3 mm array, uniform drive,
@@ -1053,9 +1053,11 @@ def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
     the grid passes THROUGH the element plane, sim/sim_setup.py:24-36) at 1.0 / 0.5 / 0.25 mm, and on grids that start one or a few
     voxels above the plane.  FULL-volume parity against the fp64 oracle in whatever arithmetic the planner picks: <= 1e-5 of the
     volume maximum always, <= the stated 7.5e-6 wherever the plan names the e4m3 products -- and the planner's rule (olx_plan.h: FP8_ERR_K
-    sqrt(max_v sum_e (w_e / d')^2) <= FP8_ERR_BOUND x focal peak) must refuse them on every grid that reaches the plane."""
+    sqrt(max_v sum_e (w_e / d')^2) <= FP8_ERR_BOUND x focal peak) must refuse them for the plane blocks next to the array: such a launch is
+    SPLIT ("fp8corr from plane K": three fp16 products in the blocks below the cut -- the same bits as the opted-out plan -- e4m3 above it)."""
     pos, ori, size = synthetic_array(16, 16, 3.0)
-    foci = _wheel_shard(8) if shard else np.array([[0, 0, 40e-3]])
+    foci = np.array([[1.3e-3, 0.7e-3, 40e-3]]) if shard == "offaxis" else (_wheel_shard(8) if shard else np.array([[0, 0, 40e-3]]))      # (off the axis: 4 columns, kernel 2e)
+    shard = shard is True
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
     if z_lo < 0:      # SimSetup's default extents
         nxy, nz = int(round(60.0 / spacing)) + 1, int(round(64.0 / spacing)) + 1
@@ -1067,19 +1069,34 @@ def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
     ctx.field_plan((xs[0], xs[0], zs[0]), h, (nxy, nxy, nz), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
     name = ctx.field_variant()
     assert "field_toep_k" in name or "field_coset" in name, name
-    if z_lo <= 1.0:
-        assert "fp8corr" not in name, name          # every one of these grids has voxels within 1 mm of an element
+    kcut = 0
+    if z_lo <= 1.0:       # every one of these grids has voxels within 1 mm of an element: e4m3 products at most from a later plane block on
+        assert ",fp8corr>" not in name, name
+        if "fp8corr" in name:
+            kcut = int(name.split("fp8corr from plane ")[1].split(">")[0])
+            assert kcut % 16 == 0 and 0 < kcut < nz and (z_lo + kcut * spacing) >= 4.0, (name, kcut)
     ctx.field_launch()
     worst = 0.0
+    got = {}
     for f in ((0, 1, 4) if shard else (0,)):
         out = ctx.field_fetch(f)
+        got[f] = out["pmag"]
         ref = np.abs(co.field_on_grid(xs, xs, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.5 * h[0]))
         err = np.abs(out["pmag"] - ref).max() / ref.max()
         worst = max(worst, err)
         assert err <= (FP8_BOUND if "fp8corr" in name else 2e-6), (name, f, err)
         iref = fo.intensity_wcm2(ref, RHO, C)
         assert np.abs(out["intensity"] - iref).max() / iref.max() <= TOL_I
-    print(f"{spacing} mm from z = {z_lo} mm, {'shard' if shard else 'on-axis'}: {name.split(' ')[0]}  max error {worst:.2e} of the volume maximum")
+    print(f"{spacing} mm from z = {z_lo} mm, {'shard' if shard else 'on-axis'}: {name.split('> ')[0]}>  max error {worst:.2e} of the volume maximum")
+    if kcut:      # a launch split at the cut: the plane blocks below it are the fp16 plan's bit for bit, the ones above it ran the other arithmetic
+        ctx.field_plan((xs[0], xs[0], zs[0]), h, (nxy, nxy, nz), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | nat.FIELD_FP16_CORRECTION)
+        assert "fp8corr" not in ctx.field_variant()
+        ctx.field_launch()
+        for f, mine in got.items():
+            ref16 = ctx.field_fetch(f)["pmag"]
+            assert np.array_equal(mine[:, :, :kcut], ref16[:, :, :kcut]), (name, f)
+            assert not np.array_equal(mine[:, :, kcut:], ref16[:, :, kcut:]), (name, f)
+            assert np.abs(mine - ref16).max() / ref16.max() <= FP8_BOUND
 
 
 @pytest.mark.parametrize("n_foci,rank,expect", [(8, 0, "nt2,mx2,my2,flat,noclamp,fp8corr> 15 columns"), (8, 5, "nt2,mx2,my2,flat,noclamp,fp8corr> 16 columns"),
