@@ -151,12 +151,17 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  *           delays are recognised as geometric) and inside the planned slab -- the slab then holds the coherent focal
  *           peak P_f = sum_e w_ef / d(focus_f, e);
  *     (ii)  >= 256 effectively driven elements, (sum w)^2 / sum w^2;
- *     (iii) 3.75e-5 max_e(w_ef) sqrt(max_v sum_e 1 / d'(v, e)^2) <= 7.5e-6 P_f for every focus: six sigma of the error of the
- *           planned slab's WORST voxel (the one next to an element; d' = the clamped distance).  On BASELINE's 16 x 16 array
- *           this admits grids that start >= ~4.5 mm above the element plane and refuses every grid that reaches or crosses
- *           it -- the reference's default SimSetup (z_extent from -4 mm, sim/sim_setup.py:36) runs three fp16 products.
- *   Everything else -- small or strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, near-field
- *   grids, 17-32 columns in one tile, complex output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION
+ *     (iii) 3.75e-5 s max_e(w_ef) sqrt(max_v sum_e 1 / d'(v, e)^2) <= 7.5e-6 P_f for every focus: six sigma of the error of the
+ *           WORST voxel (the one next to an element; d' = the clamped distance), the maximum taken over the planes that run
+ *           the e4m3 products; s = 1, 1.25 or 1.5 with voxels on none, one or both symmetry planes of the array (element
+ *           pairs at identical distances: their errors add coherently).  The kernels work in blocks of 16 planes, and the
+ *           rule is asked per block: a launch is SPLIT at the first plane block from which it holds -- three fp16 products
+ *           below ("fp8corr from plane K" in olx_field_variant; those planes carry the opted-out plan's bits), e4m3 above.
+ *           On BASELINE's 16 x 16 array that is every plane for grids that start >= ~4.5 mm above the element plane; the
+ *           reference's default SimSetup (z_extent from -4 mm, through the element plane: sim/sim_setup.py:36) runs the
+ *           e4m3 products from z = 28 mm (1 mm grid), 20 mm (0.5 mm), 16 mm (0.25 mm) on.
+ *   Everything else -- small or strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, the plane
+ *   blocks next to the array, 17-32 columns in one tile, complex output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION
  *   in `flags` (or OLX_FP8_CORRECTION=0 in the environment) opts out everywhere; nothing can opt IN past the rule in the
  *   product library (OLX_FP8_CORRECTION=1 is honoured by developer builds only).
  *   olx_field_variant() names the kernel in use ("fp8corr" when the e4m3 products are active). */
