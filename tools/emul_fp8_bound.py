@@ -7,7 +7,8 @@ sg / sw = the power-of-two operand scales of olx.hip (|G sg| <= 2^14 at the clam
 
 What it prints per scenario: the max error over the emulated voxels relative to the volume maximum, the same with three fp16 products,
 and the planner's predictor  K * max_v sqrt(sum_e (w_e / d'_ve)^2) / min_f peak_f  next to it.
-    python tools/emul_fp8_bound.py            # the scenarios of VERDICT round 5 + BASELINE's grids
+    python tools/emul_fp8_bound.py              # the scenarios of VERDICT round 5 + BASELINE's grids
+    python tools/emul_fp8_bound.py --symmetric  # voxels ON the array's symmetry planes (odd voxel counts) against voxels that straddle them
 """
 import sys
 import numpy as np
@@ -114,7 +115,40 @@ def scenario(name, h, z_lo, z_hi, xy_half, foci, epos, w_e, planes_mm=12.0, n_fa
     return err8_focal, pred, z.max()
 
 
+def symmetry_scan():
+    """Grids with an odd voxel count centred on the array (voxels ON its symmetry planes: the reference's default SimSetup) against grids whose
+    voxels straddle the planes, plane ranges at 4, 12 and 28 mm: the largest normalised error (err / sqrt(S2), i.e. in units of the per-term
+    sigma) sits on the array's AXIS in the odd grids -- 4.2e-5 against 2.7 - 3.0e-5 -- because element pairs at identical distances carry
+    identical rounding errors.  The planner's rule raises its constant by a quarter per symmetry plane that carries voxels (olx.hip)."""
+    epos = array16()
+    w = np.ones(len(epos))
+    for h, odd in ((0.5e-3, True), (0.5e-3, False), (1e-3, True), (0.25e-3, True)):
+        half = 30e-3 if odd else (30e-3 - h / 2)
+        xs = grid_axis(-half, half, h)
+        xq = xs[xs >= -1e-12]
+        for z0, z1 in ((4e-3, 8e-3), (12e-3, 16e-3), (28e-3, 32e-3)):
+            zs = np.arange(z0, z1 + 1e-9, h)
+            X, Y, Z = np.meshgrid(xq, xq, zs, indexing="ij")
+            vox = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+            if len(vox) > 300000:
+                vox = vox[np.random.default_rng(1).choice(len(vox), 300000, replace=False)]
+            for foci, fn in ((np.array([[0, 0, 40e-3]]), "on-axis"), (wheel8(), "shard8")):
+                v = np.vstack([vox, foci])
+                ex, e8, _, S2, _ = emulate(v, epos, foci, w, dclamp=0.5 * h)
+                df = np.linalg.norm(foci[:, None, :] - epos[None, :, :], axis=2)
+                peakw = (w[None, :] / df).sum(1)
+                scale = ex[-len(foci):].diagonal() / peakw
+                zz = np.abs(e8 - ex) / (np.sqrt(S2)[:, None] * scale[None, :])
+                err = np.abs(e8 - ex) / ex[-len(foci):].diagonal()[None, :]
+                i = np.unravel_index(err.argmax(), err.shape)
+                print(f"h {h * 1e3:4.2f} mm  voxels on the symmetry planes: {str(odd):5s}  z {z0 * 1e3:2.0f}-{z1 * 1e3:2.0f} mm  {fn:8s}  largest normalised error {zz.max():.2e}  "
+                      f"err / focal peak {err.max():.2e} at {np.round(v[i[0]] * 1e3, 3)} mm   sqrt(max S2) / peak {np.sqrt(S2.max()) / peakw.min():.3f}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--symmetric":
+        symmetry_scan()
+        sys.exit(0)
     K = float(sys.argv[1]) if len(sys.argv) > 1 else None
     epos = array16()
     w = np.ones(len(epos))
