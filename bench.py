@@ -154,8 +154,9 @@ def sampled_parity(ctx, coords, pos_m, area, foci_m, n_samples=20000, check=(0, 
         if f >= len(foci_m):
             continue
         d, a = bo.beamform(pos_m, np.zeros_like(pos_m) if ori is None else ori, foci_m[f], C0, apod=apod)
-        ref = np.abs(co.field_at_points(pts, pos_m, area, d, a, F0, C0, SENS))
-        peak = max(np.abs(co.field_at_points([foci_m[f]], pos_m, area, d, a, F0, C0, SENS))[0], ref.max())
+        dmin = 0.5 * min(float(c[1] - c[0]) for c in coords)      # the definition's clamp (a grid through the element plane has voxels on elements)
+        ref = np.abs(co.field_at_points(pts, pos_m, area, d, a, F0, C0, SENS, dmin=dmin))
+        peak = max(np.abs(co.field_at_points([foci_m[f]], pos_m, area, d, a, F0, C0, SENS, dmin=dmin))[0], ref.max())
         got = ctx.field_fetch(f, want=("pmag",))["pmag"][idx[:, 0], idx[:, 1], idx[:, 2]]
         worst = max(worst, float(np.abs(got - ref).max() / peak))
         checked.append(int(f))
@@ -820,7 +821,8 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
       c4_1024x512    configs[3]  1024 elements (32 x 32 @ 1.5 mm), 512^3 @ 0.125 mm, PiecewiseLinear(60, 20) apodization + Direct delays (kernel 1)
       c5_skull_f1/f8 configs[4]  256 elements, 256^3, skull-slab medium (marched ray sums), 1 and 8 foci per launch
       tilted2_*      a two-module TransducerArray on a cylinder (xdc/transducerarray.py:86-115), 2 x 128 elements: tilted normals, no common lattice
-      jitter_*       the 16 x 16 array with +-0.1 mm element jitter (seed 147): not a lattice, not mirror-symmetric (1 focus, the 8-focus shard, the 64-focus sweep)"""
+      jitter_*       the 16 x 16 array with +-0.1 mm element jitter (seed 147): not a lattice, not mirror-symmetric (1 focus, the 8-focus shard, the 64-focus sweep)
+      default_extents_*  the reference's default SimSetup extents (z from -4 mm) at 0.25 mm: launches split at the e4m3 rule's plane cut"""
     from oracle import bf_oracle as bo, c_oracle as co
     from openlifu_amd.engine import grid_from_coords
     from openlifu_amd.seg.seg_methods import skull_slab_volumes
@@ -905,6 +907,14 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
         el.position = np.asarray(el.position, dtype=np.float64) + rng.uniform(-0.1, 0.1, 3) * np.array([1.0, 1.0, 0.0])
     run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus, covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
+    # the reference's DEFAULT SimSetup extents (x, y in +-30 mm, z from -4 mm: through the element plane; sim/sim_setup.py:24-36) at the headline's spacing:
+    # the planner splits the launch -- three fp16 products in the plane blocks next to the array, e4m3 corrections from the cut on (include/olx.h)
+    dsetup = ol.SimSetup(spacing=0.25)
+    dorigin, dspacing, dn = grid_from_coords(dsetup.get_coords())
+    gdef = (dorigin, dspacing, dn, [np.asarray(c.data) * 1e-3 for c in dsetup.get_coords().values()])
+    run("default_extents_f8", "the reference's default SimSetup extents at 0.25 mm (241 x 241 x 257, z from -4 mm: the grid passes through the element plane), 16 x 16 array, "
+        "the 8-focus shard", m16, gdef, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_e4m3_rule_near_the_array (full volumes)")
+    run("default_extents_f1", "the same grid, single on-axis focus", m16, gdef, focus, steps=200, covered_by="tests/test_gpu_field.py::test_e4m3_rule_near_the_array (full volumes)")
     run("jitter_sweep64", "the same array, configs[2]'s whole 64-focus sweep on one GPU (64 steering columns in two launch tiles of 32: kernel 2c's NT = 4 shape)", jit, g256, sweep, steps=20, check=(0, 17, 63), covered_by="tests/test_gpu_field.py::test_many_foci_without_symmetry_uses_wide_mfma_tiles (full volumes, smaller grids)")
     skull = skull_slab_volumes(*g256[3])
     skull["model"] = "marched"
