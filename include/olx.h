@@ -157,9 +157,11 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  *           pairs at identical distances: their errors add coherently).  The kernels work in blocks of 16 planes, and the
  *           rule is asked per block: a launch is SPLIT at the first plane block from which it holds -- three fp16 products
  *           below ("fp8corr from plane K" in olx_field_variant; those planes carry the opted-out plan's bits), e4m3 above.
- *           On BASELINE's 16 x 16 array that is every plane for grids that start >= ~4.5 mm above the element plane; the
- *           reference's default SimSetup (z_extent from -4 mm, through the element plane: sim/sim_setup.py:36) runs the
- *           e4m3 products from z = 28 mm (1 mm grid), 20 mm (0.5 mm), 16 mm (0.25 mm) on.
+ *           A split is two launches: it is taken only while >= 3/4 of the planes lie above the cut and >= 8 M (voxel, focus)
+ *           pairs do; otherwise the whole launch keeps three fp16 products.  On BASELINE's 16 x 16 array: every plane for grids
+ *           that start >= ~4.5 mm above the element plane; a 240 x 240 x 256 grid from z = -4 mm at 0.25 mm is split at plane
+ *           32 / 48 (z = 4 / 8 mm); the reference's default SimSetup (odd voxel counts centred on the array: voxels on both
+ *           symmetry planes, cut at z = 28 / 20 / 16 mm for 1 / 0.5 / 0.25 mm) runs three fp16 products throughout.
  *   Everything else -- small or strongly apodized arrays, arbitrary delay patterns, slabs beside the foci, the plane
  *   blocks next to the array, 17-32 columns in one tile, complex output -- keeps three fp16 products (<= 2e-6).  OLX_FIELD_FP16_CORRECTION
  *   in `flags` (or OLX_FP8_CORRECTION=0 in the environment) opts out everywhere; nothing can opt IN past the rule in the

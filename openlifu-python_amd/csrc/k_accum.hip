@@ -103,13 +103,13 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
         it[q] = m2 * P.inten_scale;
     }
     const bool full = (k0 + ZPL <= P.nz);
-    if (ZPL == 4 && full && (P.nz & 3) == 0) {
-        if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
-        if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+    if (ZPL == 4 && full) {      // (dword-aligned 16-byte stores: rows of odd length are fine)
+        if (P.flags & 1u) *reinterpret_cast<floatx4u_t*>(pmag + base) = floatx4u_t{pm[0], pm[1], pm[2], pm[3]};
+        if (P.flags & 2u) *reinterpret_cast<floatx4u_t*>(inten + base) = floatx4u_t{it[0], it[1], it[2], it[3]};
         if (P.flags & 4u) {
-            float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
-            c4[0] = make_float4(re[0], im[0], re[1], im[1]);
-            c4[1] = make_float4(re[2], im[2], re[3], im[3]);
+            floatx4u_t* c4 = reinterpret_cast<floatx4u_t*>(cplx + 2 * base);
+            c4[0] = floatx4u_t{re[0], im[0], re[1], im[1]};
+            c4[1] = floatx4u_t{re[2], im[2], re[3], im[3]};
         }
     } else {
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
         }
         }
     }
-    const bool full = (k0 + ZPL <= P.nz) && (P.nz % ZPL == 0);
+    const bool full = k0 + ZPL <= P.nz;      // (dword-aligned 16-byte stores: rows of odd length are fine)
 #pragma unroll
     for (int kk = 0; kk < MX * MY * NF; ++kk) {      // every stored volume slice: (focus, mirror image)
         const int f = tile * NF + kk / (MX * MY);
@@ -325,12 +325,12 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
             it[q] = m2 * P.inten_scale;
         }
         if (ZPL == 4 && full) {
-            if (P.flags & 1u) *reinterpret_cast<float4*>(pmag + base) = make_float4(pm[0], pm[1], pm[2], pm[3]);
-            if (P.flags & 2u) *reinterpret_cast<float4*>(inten + base) = make_float4(it[0], it[1], it[2], it[3]);
+            if (P.flags & 1u) *reinterpret_cast<floatx4u_t*>(pmag + base) = floatx4u_t{pm[0], pm[1], pm[2], pm[3]};
+            if (P.flags & 2u) *reinterpret_cast<floatx4u_t*>(inten + base) = floatx4u_t{it[0], it[1], it[2], it[3]};
             if (P.flags & 4u) {
-                float4* c4 = reinterpret_cast<float4*>(cplx + 2 * base);
-                c4[0] = make_float4(re[0][k], im[0][k], re[1][k], im[1][k]);
-                c4[1] = make_float4(re[2][k], im[2][k], re[3][k], im[3][k]);
+                floatx4u_t* c4 = reinterpret_cast<floatx4u_t*>(cplx + 2 * base);
+                c4[0] = floatx4u_t{re[0][k], im[0][k], re[1][k], im[1][k]};
+                c4[1] = floatx4u_t{re[2][k], im[2][k], re[3][k], im[3][k]};
             }
         } else {
 #pragma unroll

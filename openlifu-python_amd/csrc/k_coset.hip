@@ -287,7 +287,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
     // column lane & 15 = (o, part).  Staging [position][column][plane of the block], two halves of the position grid.
     const int c16 = lane & 15, part = c16 & 1, gy = lane >> 4;
     const int kb0 = BK.k0;
-    const bool fast = (P.nz % COS_ZB) == 0;
+    const bool fast = kb0 + COS_ZB <= P.nz;      // (block-uniform: only a LAST, partial plane block stores plane by plane)
     // |p| / intensity in place, then one staged pass per column tile (complex output is served by kernel 2d: the host
     // does not select this kernel when OLX_OUT_COMPLEX is planned)
     // The |p| lane (part 0) and its partner, the intensity lane (part 1), hold the same (S re)^2 + (S im)^2 for every row, and
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_coset_k(
                     for (int u = 0; u < RU; ++u) {
                         if (!dst[u]) continue;
                         if constexpr (FAST) {
-                            *reinterpret_cast<float4*>(dst[u]) = val[u];
+                            *reinterpret_cast<floatx4u_t*>(dst[u]) = floatx4u_t{val[u].x, val[u].y, val[u].z, val[u].w};
                         } else {
                             const float vv[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
 #pragma unroll

@@ -371,8 +371,8 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
                 const unsigned off = o00 + (fxm & DX) + (fym & DY);
                 if (!OLX_IN(fb + off + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 2)) continue;
                 if constexpr (FULL4) {
-                    if (BOTH || want_p) *reinterpret_cast<float4*>(base_p + off) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
-                    if (BOTH || want_i) *reinterpret_cast<float4*>(base_i + off) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+                    if (BOTH || want_p) *reinterpret_cast<floatx4u_t*>(base_p + off) = floatx4u_t{acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]};
+                    if (BOTH || want_i) *reinterpret_cast<floatx4u_t*>(base_i + off) = floatx4u_t{acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]};
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(COS_NW * 64, 4) void field_cosetp_k(
             }
         }
     };
-    if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
+    if (k0 + COS_ZB <= P.nz) readout(IntC<1>{}); else readout(IntC<0>{});      // (block-uniform: only a LAST, partial plane block stores plane by plane)
     }
     OLX_STAMP(6);
 #ifdef OLX_EXP_CUTRACE

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
     // adjacent lanes (full 128-B lines at ZB = 32).
     const int c16 = lane & 15, part = c16 & 1, gy = lane >> 4;
     const int kb0 = (int)kblock * ZB;                // first plane of the block
-    const bool fast = (P.nz % ZB) == 0;              // whole 16-B aligned runs
+    const bool fast = kb0 + ZB <= P.nz;              // every plane of the block exists (dword-aligned 16-byte stores: rows of odd length are fine)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         __syncthreads();                             // K loop / previous read-out done with the arena
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(LAT_THREADS, NT >= 4 ? 2 : 4) void field_lattice_k(
                     for (int s4 = 0; s4 < 4; ++s4) {
                         if (!tb[s4]) continue;
                         const int off = ((tfx[s4] ? aX : ai) + (tfy[s4] ? bY : j)) * P.nz;
-                        *reinterpret_cast<float4*>(tb[s4] + off) = val;
+                        *reinterpret_cast<floatx4u_t*>(tb[s4] + off) = floatx4u_t{val.x, val.y, val.z, val.w};
                     }
                 }
             } else if (want) {                       // ragged nz: guarded scalar stores (not a throughput path)

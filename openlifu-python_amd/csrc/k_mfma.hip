@@ -144,7 +144,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
     const int part = r16 & 1;
     float* const dst_arr = part == 0 ? pmag : inten;
     const bool want = part == 0 ? (P.flags & 1u) != 0 : (P.flags & 2u) != 0;
-    const bool fast = (P.nz % RUN) == 0;  // wave-uniform: every z of the run exists, 16-B aligned
+    const bool fast = zb + RUN <= P.nz;   // wave-uniform: every z of the run exists (dword-aligned 16-byte stores: rows of odd length are fine)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int4 tg = reinterpret_cast<const int4*>(targets)[(size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + nt * MFMA_COLS + (r16 >> 1)];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
                 if (want)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        *reinterpret_cast<float4*>(dst_arr + base + 16 * t) = make_float4(w[t][0], w[t][1], w[t][2], w[t][3]);
+                        *reinterpret_cast<floatx4u_t*>(dst_arr + base + 16 * t) = floatx4u_t{w[t][0], w[t][1], w[t][2], w[t][3]};
             } else if (want) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)

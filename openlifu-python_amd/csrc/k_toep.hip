@@ -309,7 +309,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 const unsigned oy = (unsigned)((fy ? (P.ny - 1 - j) : j) * P.nz);                 // scalar
                 float* dst = vol + (long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy);      // (32-bit offset within the focus volume)
                 if (!OLX_IN((long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy) + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 5)) continue;
-                if constexpr (FULL4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (FULL4) *reinterpret_cast<floatx4u_t*>(dst) = floatx4u_t{v[0], v[1], v[2], v[3]};
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
             }
         }
     };
-    if ((P.nz & 3) == 0) readout(IntC<1>{}); else readout(IntC<0>{});
+    if (k0 + TOEP_ZB <= P.nz) readout(IntC<1>{}); else readout(IntC<0>{});      // (block-uniform: only a LAST, partial plane block stores plane by plane)
     OLX_STAMP(6);
 }
 

@@ -13,6 +13,10 @@ typedef int intx8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
+// four floats at a dword-aligned address: ONE global_store_dwordx4 (the part runs in unaligned-access mode).  Rows of nz floats with nz not a
+// multiple of 4 -- every grid of the reference's SimSetup has an odd voxel count per axis (sim/sim_setup.py:152-155) -- put a voxel column's
+// four-plane pieces on dword boundaries only; until round 6 such grids took one-dword stores everywhere (2.5 x the launch time at nz = 257).
+typedef float floatx4u_t __attribute__((ext_vector_type(4), aligned(4)));
 
 union Half8Bits { half8_t h; uint4 u; unsigned w[4]; };
 

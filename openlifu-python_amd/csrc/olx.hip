@@ -487,6 +487,11 @@ static int configure_variant_impl(olx_ctx* c) {
 #ifdef OLX_DEV_PINS
         if (f8env && strcmp(f8env, "0") != 0) fp8_cut = (lat_ok && !c->modifier()) ? 0 : -1;
 #endif
+        // A split launch is two launches and two operand sets: on BASELINE's array it pays from ~8 M (voxel, focus) pairs above the cut
+        // (121 x 121 x 81 planes x 8 foci: -13 %; the same grid with one focus +27 %, 61 x 61 x 33 x 8: +60 %; profiles/r06_time_grid.txt)
+        // -- and only while the cut leaves at least three quarters of the planes above it (cut at plane 48 of 256: -3 ... -12 %; at plane 80: +-0;
+        // profiles/r06_time_grid.txt); otherwise the whole launch keeps three fp16 products
+        if (fp8_cut > 0 && ((double)c->slab.x_count * c->grid.n[1] * (c->grid.n[2] - fp8_cut) * F < 8.0e6 || 4 * fp8_cut > c->grid.n[2])) fp8_cut = -1;
         const bool fp8_want = fp8_cut >= 0;
         c->fp8_kcut = fp8_want ? fp8_cut : 0;
         olxplan::Tiles tiles = pack(MAXC);
@@ -676,27 +681,39 @@ static int configure_variant_impl(olx_ctx* c) {
                     // counts divide -- that XCD's L2 then collects whole 1 KB z lines of every voxel column before it writes them back.  Measured on the
                     // headline shard, alternating runs on one box: 1 / 2 / 4 / 8 / 16 in a row = 0.406 / 0.392 / 0.392 / 0.390 / 0.383 ms; y cosets
                     // grouped on top (48 - 192 in a row) 0.384 - 0.388 (profiles/r05_store_path.txt).  A/B: OLX_EXP_KGRP.
-                    unsigned kgrp = 1u;
-                    {
-                        const unsigned long long nb = (unsigned long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * Q.kblocks;
-                        for (unsigned g2 = 16u; g2 >= 2u; g2 >>= 1) if (Q.kblocks % (int)g2 == 0 && nb % (8ull * g2) == 0) { kgrp = g2; break; }
-                    }
-#ifdef OLX_DEV_PINS
-                    if (const char* e = getenv("OLX_EXP_KGRP")) kgrp = (unsigned)std::max(1, atoi(e));
-#endif
+                    // (round 6: any count that divides the plane blocks, not only powers of two -- the reference's SimSetup grids have odd voxel counts,
+                    // 257 planes = 17 plane blocks: without a group their 64-byte runs went to eight different L2s and the launch took 2.5 x as long)
+                    auto pick_grp = [&](int kblocks) {
+                        const unsigned long long nb = (unsigned long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * kblocks;
+                        for (int g2 = std::min(kblocks, 32); g2 >= 2; --g2) if (kblocks % g2 == 0 && nb % (8ull * g2) == 0) return (unsigned)g2;
+                        return 1u;
+                    };
                     const int kcut = c->fp8corr ? c->fp8_kcut : 0;      // records of the plane blocks from the cut on come FIRST (a launch of their own in the e4m3 arithmetic)
-                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs, kcut};
+                    const int kb_near = kcut / zb, kb_far = Q.kblocks - kb_near;
+                    unsigned kgrp = pick_grp(kb_far), kgrp_near = kb_near > 0 ? pick_grp(kb_near) : 0u;
+#ifdef OLX_DEV_PINS
+                    if (const char* e = getenv("OLX_EXP_KGRP")) { kgrp = (unsigned)std::max(1, atoi(e)); if (kb_near > 0) kgrp_near = kgrp; }
+#endif
+                    const int rec_key[16] = {Q.nx, Q.ny, Q.nz, Q.x_lo, Q.y_lo, Q.mx, Q.my, Q.nsx, Q.nsy, Q.kblocks, zb, (int)kgrp, c->use_cosetp ? 40 : 0, Q.xs, kcut, (int)kgrp_near};
                     std::vector<CosetBlock> blk;
                     if (!c->up_blocks.empty() && memcmp(c->up_blocks_key, rec_key, sizeof rec_key) == 0) blk = c->up_blocks;
                     else {
                         std::string why;
-                        if (!olxplan::build_coset_blocks(Q, zb, kgrp, c->use_cosetp ? 40 : 0, blk, why))
+                        // each side of the cut gets its own record list (plane blocks of a position set in a row per XCD within the side)
+                        CosetParams Qf = Q; Qf.kblocks = kb_far;
+                        if (!olxplan::build_coset_blocks(Qf, zb, kgrp, c->use_cosetp ? 40 : 0, blk, why))
                             return fail(c, OLX_ESTATE, "kernel 2g: %s", why.c_str());
-                        if (kcut > 0) std::stable_partition(blk.begin(), blk.end(), [&](const CosetBlock& b) { return b.k0 >= kcut || b.npos <= 0; });
+                        for (CosetBlock& b : blk) b.k0 += kcut;
+                        if (kb_near > 0) {
+                            std::vector<CosetBlock> near;
+                            CosetParams Qn = Q; Qn.kblocks = kb_near;
+                            if (!olxplan::build_coset_blocks(Qn, zb, kgrp_near, c->use_cosetp ? 40 : 0, near, why))
+                                return fail(c, OLX_ESTATE, "kernel 2g: %s", why.c_str());
+                            blk.insert(blk.end(), near.begin(), near.end());
+                        }
                     }
                     const unsigned nblk = (unsigned)blk.size();
-                    c->cp_nfar = nblk;
-                    if (kcut > 0) { c->cp_nfar = 0; for (const CosetBlock& b : blk) if (b.k0 >= kcut || b.npos <= 0) ++c->cp_nfar; }
+                    c->cp_nfar = nblk - (unsigned)((unsigned long long)Q.xs * Q.mx * Q.my * Q.nsx * Q.nsy * kb_near);
                     if (c->cpblocks_cap < nblk) {
                         if (c->d_cpblocks) hipFree(c->d_cpblocks);
                         c->d_cpblocks = nullptr; c->cpblocks_cap = 0; c->up_blocks.clear();

@@ -1045,7 +1045,7 @@ def test_headline_shard_256cubed_full_volume_parity(ctx, fp8, monkeypatch):
 
 
 @pytest.mark.parametrize("spacing,z_lo,shard", [(1.0, -4.0, False), (1.0, -4.0, True), (0.5, -4.0, False), (0.5, -4.0, True), (0.25, -4.0, False), (0.25, -4.0, True),
-                                                 (0.25, 0.25, True), (0.5, 0.5, False), (0.25, 1.0, True), (0.25, 2.0, False), (0.5, -4.0, "offaxis")])
+                                                 (0.25, 0.25, True), (0.5, 0.5, False), (0.25, 1.0, True), (0.25, 2.0, False), (0.5, -4.0, "offaxis"), (0.25, -4.0, "even8"), (0.25, -4.0, "even1")])
 def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
     """the e4m3 correction products' error is relative to EACH element's own term, so a voxel next to a
     single element carries an error that the 1 / sqrt(N_eff) argument does not cover.  BASELINE's 16 x 16 @ 3 mm array, uniform drive,
@@ -1056,11 +1056,12 @@ def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
     sqrt(max_v sum_e (w_e / d')^2) <= FP8_ERR_BOUND x focal peak) must refuse them for the plane blocks next to the array: such a launch is
     SPLIT ("fp8corr from plane K": three fp16 products in the blocks below the cut -- the same bits as the opted-out plan -- e4m3 above it)."""
     pos, ori, size = synthetic_array(16, 16, 3.0)
-    foci = np.array([[1.3e-3, 0.7e-3, 40e-3]]) if shard == "offaxis" else (_wheel_shard(8) if shard else np.array([[0, 0, 40e-3]]))      # (off the axis: 4 columns, kernel 2e)
-    shard = shard is True
+    even = shard in ("even8", "even1")      # an even voxel count: no voxel on the array's symmetry planes, the cut comes early enough for a SPLIT launch
+    foci = np.array([[1.3e-3, 0.7e-3, 40e-3]]) if shard == "offaxis" else (_wheel_shard(8) if shard in (True, "even8") else np.array([[0, 0, 40e-3]]))      # (off the axis: 4 columns, kernel 2e)
+    shard = shard in (True, "even8")
     pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
     if z_lo < 0:      # SimSetup's default extents
-        nxy, nz = int(round(60.0 / spacing)) + 1, int(round(64.0 / spacing)) + 1
+        nxy, nz = int(round(60.0 / spacing)) + 1 - (1 if even else 0), int(round(64.0 / spacing)) + 1 - (1 if even else 0)
     else:             # the benchmark's cube moved down to z_lo
         nxy = nz = int(round(64.0 / spacing))
     xs = (np.arange(nxy) - (nxy - 1) / 2) * spacing * 1e-3
@@ -1074,7 +1075,11 @@ def test_e4m3_rule_near_the_array(ctx, spacing, z_lo, shard):
         assert ",fp8corr>" not in name, name
         if "fp8corr" in name:
             kcut = int(name.split("fp8corr from plane ")[1].split(">")[0])
-            assert kcut % 16 == 0 and 0 < kcut < nz and (z_lo + kcut * spacing) >= 4.0, (name, kcut)
+            assert kcut % 16 == 0 and 0 < kcut <= nz // 4 and (z_lo + kcut * spacing) >= 4.0, (name, kcut)
+        if even:
+            assert kcut in (32, 48), name                      # (z = 4 / 8 mm: >= 81 % of the planes above the cut -- a SPLIT launch)
+        elif z_lo < 0:
+            assert "fp8corr" not in name, name                 # (odd counts: voxels on the symmetry planes move the cut to plane 80 of 257, too late to pay for two launches)
     ctx.field_launch()
     worst = 0.0
     got = {}
