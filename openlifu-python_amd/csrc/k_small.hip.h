@@ -272,6 +272,21 @@ __device__ __forceinline__ void st4s(float4* p, const float4 v) {
 // (the one-pass scale + aggregate + analyze kernel: non-temporal LOADS only -- 62.4 -> 64.4 %; with non-temporal stores it drops to 30 %)
 #define OLX_SAA_LD(p) ld4s(p)
 #define OLX_SAA_ST(p, v) (*(p) = (v))
+// row quads: four consecutive z voxels of ONE row starting at a dword-aligned address, the last quad of a row possibly partial (nz % 4 != 0: every grid of
+// the reference's SimSetup has odd voxel counts) -- the 16-byte form wherever the quad is whole, element by element (zero-filled) at a row's end
+__device__ __forceinline__ float4 ld4u(const float* p, const int cnt) {
+    if (cnt == 4) { const olx::floatx4u_t v = __builtin_nontemporal_load(reinterpret_cast<const olx::floatx4u_t*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    float4 r = make_float4(p[0], 0.f, 0.f, 0.f);
+    if (cnt > 1) r.y = p[1];
+    if (cnt > 2) r.z = p[2];
+    return r;
+}
+__device__ __forceinline__ void st4u(float* p, const float4 v, const int cnt) {
+    if (cnt == 4) { *reinterpret_cast<olx::floatx4u_t*>(p) = olx::floatx4u_t{v.x, v.y, v.z, v.w}; return; }
+    p[0] = v.x;
+    if (cnt > 1) p[1] = v.y;
+    if (cnt > 2) p[2] = v.z;
+}
 #define OLX_LD4(p) __builtin_nontemporal_load(p)
 #define OLX_ST4(p, v) __builtin_nontemporal_store(v, p)
 __global__ __launch_bounds__(256) void field_aggregate_k(const float* __restrict__ pmag, const float* __restrict__ inten,
@@ -1002,9 +1017,12 @@ __global__ __launch_bounds__(256) void field_weighted_sum_peak_k(const float* __
 // aggregation over foci (max |p|, mean intensity), the time-average intensity volume sum_f w_f I_f with its global peak above zmin,
 // and the six masked peaks per focus of Solution.analyze -- each the arithmetic of its own kernel (field_scale_aggregate_k,
 // field_weighted_sum_peak_k, field_analysis_peaks4_k: same products, same order over f, same mask decisions), but the 1.07 GB of
-// volumes cross HBM twice (read, write back) instead of five times.  Voxel-major: a lane owns a quad of z voxels of ALL (<= 8) foci.
+// volumes cross HBM twice (read, write back) instead of five times.  Voxel-major: a lane owns a quad of z voxels of ALL (<= 8) foci -- round 6:
+// a ROW quad (ld4u / st4u), so rows of any length take this pass (every grid of the reference's SimSetup has odd voxel counts; until then such grids
+// fell back to five scalar passes: calc_solution 2.9 instead of 1.7 ms at 241 x 241 x 257 x 8 foci).
 // ------------------------------------------------------------------------------------
 constexpr int SAA_MAXF = 8;
+template <bool ROWQ /*rows of any length: row quads with a partial last quad (the 16-byte aligned form measured 470 us against 790 us with the general one)*/>
 __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void field_scale_agg_analyze_k(float* __restrict__ pmag, float* __restrict__ inten, const float* __restrict__ scale,
                                                                   const float* __restrict__ wts, const double* __restrict__ A, int n_foci,
                                                                   const PeakParams P /*radius = r_main*/, double r_side, float inv_n,
@@ -1017,7 +1035,7 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
     __syncthreads();
     if ((int)threadIdx.x < n_foci) mask_fast_prepare(sM[threadIdx.x], sA[threadIdx.x], P, P.radius, r_side, true);
     __syncthreads();
-    const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = (int)(P.vox >> 2);
+    const int nzq = (P.nz + 3) >> 2, nyzq = P.ny * nzq, nq = P.nx * nyzq;      // row quads (host: nq < 2^31)
     const float inv_nyzq = 1.0f / (float)nyzq, inv_nzq = 1.0f / (float)nzq;
     const double rm2 = P.radius * P.radius, rm2lo = rm2 * (1.0 - 1e-12), rm2hi = rm2 * (1.0 + 1e-12);
     const double rs2 = r_side * r_side, rs2lo = rs2 * (1.0 - 1e-12), rs2hi = rs2 * (1.0 + 1e-12);
@@ -1033,6 +1051,8 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
     for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
         int ix, iy, iz0;
         quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
+        const int cnt = ROWQ ? min(4, P.nz - iz0) : 4;                        // < 4 only in a row's last quad when nz % 4 != 0
+        const long long vo = ((long long)ix * P.ny + iy) * P.nz + iz0;        // first voxel of the quad (= 4 iq when nz % 4 == 0)
         const float fx = fmaf((float)ix, hx, ox), fy = fmaf((float)iy, hy, oy);
         float fz[4];
 #pragma unroll
@@ -1045,12 +1065,14 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
             float4 p4, w4;
             {
 #pragma clang fp contract(off)      // sums of the ROUNDED scaled values (the stored ones), as the separate kernels form them
-            float4* pp = reinterpret_cast<float4*>(pmag + (long long)f * P.vox) + iq;
-            float4* ip = reinterpret_cast<float4*>(inten + (long long)f * P.vox) + iq;
-            p4 = OLX_SAA_LD(pp); w4 = OLX_SAA_LD(ip);
+            float* const pp = pmag + (long long)f * P.vox + vo;
+            float* const ip = inten + (long long)f * P.vox + vo;
+            if constexpr (ROWQ) { p4 = ld4u(pp, cnt); w4 = ld4u(ip, cnt); }
+            else { p4 = OLX_SAA_LD(reinterpret_cast<const float4*>(pp)); w4 = OLX_SAA_LD(reinterpret_cast<const float4*>(ip)); }
             p4.x *= s; p4.y *= s; p4.z *= s; p4.w *= s;
             w4.x *= s2; w4.y *= s2; w4.z *= s2; w4.w *= s2;
-            OLX_SAA_ST(pp, p4); OLX_SAA_ST(ip, w4);
+            if constexpr (ROWQ) { st4u(pp, p4, cnt); st4u(ip, w4, cnt); }
+            else { OLX_SAA_ST(reinterpret_cast<float4*>(pp), p4); OLX_SAA_ST(reinterpret_cast<float4*>(ip), w4); }
             m.x = fmaxf(m.x, p4.x); m.y = fmaxf(m.y, p4.y); m.z = fmaxf(m.z, p4.z); m.w = fmaxf(m.w, p4.w);
             sm.x += w4.x; sm.y += w4.y; sm.z += w4.z; sm.w += w4.w;
             }
@@ -1091,9 +1113,9 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
                 if (zok) { pk[f][4] = fmaxf(pk[f][4], pv[e]); pk[f][5] = fmaxf(pk[f][5], wv[e]); }
             }
         }
-        OLX_SAA_ST(reinterpret_cast<float4*>(pmax) + iq, m);
-        OLX_SAA_ST(reinterpret_cast<float4*>(imean) + iq, make_float4(sm.x * inv_n, sm.y * inv_n, sm.z * inv_n, sm.w * inv_n));
-        OLX_SAA_ST(reinterpret_cast<float4*>(wint) + iq, ws);
+        const float4 mean4 = make_float4(sm.x * inv_n, sm.y * inv_n, sm.z * inv_n, sm.w * inv_n);
+        if constexpr (ROWQ) { st4u(pmax + vo, m, cnt); st4u(imean + vo, mean4, cnt); st4u(wint + vo, ws, cnt); }
+        else { OLX_SAA_ST(reinterpret_cast<float4*>(pmax + vo), m); OLX_SAA_ST(reinterpret_cast<float4*>(imean + vo), mean4); OLX_SAA_ST(reinterpret_cast<float4*>(wint + vo), ws); }
         const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) if ((iz0 + e) >= iz_first) wmax = fmaxf(wmax, wsv[e]);

@@ -1599,7 +1599,7 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
     if (iters < 1 || !ms_each || !bytes_per_launch) return fail(c, OLX_EINVAL, "olx_scan_time: iters < 1 or null output");
     if (!c->planned) return fail(c, OLX_ESTATE, "olx_scan_time: nothing planned");
     if (kernel < 0 || kernel > OLX_SCAN_FUSED_POST) return fail(c, OLX_EINVAL, "olx_scan_time: unknown kernel %d", kernel);
-    if (kernel == OLX_SCAN_FUSED_POST && (c->plan_foci > SAA_MAXF || (c->fp.nz & 3) || c->fp.vox >= (1ll << 33))) return fail(c, OLX_ESTATE, "olx_scan_time: the fused pass needs <= 8 foci and nz %% 4 == 0");
+    if (kernel == OLX_SCAN_FUSED_POST && (c->plan_foci > SAA_MAXF || (long long)c->fp.nx * c->fp.ny * ((c->fp.nz + 3) / 4) >= (1ll << 31))) return fail(c, OLX_ESTATE, "olx_scan_time: the fused pass needs <= 8 foci and < 2^31 row quads");
     if (!(c->flags & OLX_OUT_INTENSITY)) return fail(c, OLX_ESTATE, "olx_scan_time: intensity not planned");
     HIPCHK(c, hipSetDevice(c->device));
     if (kernel == OLX_SCAN_SCALE || kernel == OLX_SCAN_FUSED_POST) { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }
@@ -1681,7 +1681,7 @@ int olx_scan_time(olx_ctx* c, int kernel, int iters, float* ms_each, double* byt
             *bytes_per_launch = vox * 32.0; break;
         case OLX_SCAN_FUSED_POST:          // scale (by 1.0) + aggregate + six peaks + time-average volume in one pass
             P.op = 0;
-            hipLaunchKernelGGL(field_scale_agg_analyze_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, c->d_scale, d_w, d_A, F, P, 5e-3,
+            hipLaunchKernelGGL((c->fp.nz & 3) ? field_scale_agg_analyze_k<true> : field_scale_agg_analyze_k<false>, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, c->d_scale, d_w, d_A, F, P, 5e-3,
                                1.0f / (float)F, c->d_agg_p, c->d_agg_i, c->d_wint, d_pk, d_pk + 6 * (size_t)F - 1);
             *bytes_per_launch = vox * (16.0 * F + 12.0); break;
         default:
@@ -2107,7 +2107,8 @@ int olx_solution_analyze_begin(olx_ctx* c, const double* A, const double* ita_we
     // scale_per_focus given: Solution.scale and the aggregation over foci happen first -- fused with the peak scan and the
     // time-average volume into ONE pass over the volumes when the shape allows (<= 8 foci, z rows of whole quads, no complex output),
     // otherwise as the separate olx_field_scale_aggregate pass
-    const bool fused = scale_per_focus && quad && F <= SAA_MAXF && !(c->flags & OLX_OUT_COMPLEX);
+    const bool rowquads = (long long)c->fp.nx * c->fp.ny * ((c->fp.nz + 3) / 4) < (1ll << 31);      // (the fused pass walks ROW quads: rows of any length)
+    const bool fused = scale_per_focus && rowquads && F <= SAA_MAXF && !(c->flags & OLX_OUT_COMPLEX);
     if (scale_per_focus && !fused) { int rc = olx_field_scale_aggregate(c, scale_per_focus, F); if (rc) return rc; }
     if (fused) {
         { int rc_ = exported_buffers_quiesce(c, c->cur); if (rc_) return rc_; }   // (p2p: the fused pass scales the volumes in place)
@@ -2129,7 +2130,7 @@ int olx_solution_analyze_begin(olx_ctx* c, const double* A, const double* ita_we
     P.radius = o->r_main_m; P.op = 0; P.use_zmin = 1; P.zmin = o->zmin_m;
     const long long want = (P.vox + 255) / 256;
     if (fused)      // scale + aggregate + peaks + time-average volume (with its global peak) in one pass
-        hipLaunchKernelGGL(field_scale_agg_analyze_k, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, reinterpret_cast<const float*>(d + in_sc),
+        hipLaunchKernelGGL((c->fp.nz & 3) ? field_scale_agg_analyze_k<true> : field_scale_agg_analyze_k<false>, dim3(2048), dim3(256), 0, c->stream, c->d_pmag[c->cur], c->d_inten, reinterpret_cast<const float*>(d + in_sc),
                            reinterpret_cast<const float*>(d + in_w), d_A, F, P, o->r_side_m, 1.0f / (float)F, c->d_agg_p, c->d_agg_i, c->d_wint, d_pk, d_ita + F);
     else if (quad) hipLaunchKernelGGL(field_analysis_peaks4_k, dim3(scan_blocks(want, F), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);
     else hipLaunchKernelGGL(field_analysis_peaks_k, dim3((unsigned)std::min<long long>(want, 2048), F), dim3(256), 0, c->stream, pm, c->d_inten, d_A, P, o->r_side_m, d_pk);

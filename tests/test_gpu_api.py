@@ -601,8 +601,9 @@ def test_reference_example_files_through_calc_solution_against_g1(golden):
 def test_fused_scale_aggregate_analyze_equals_the_separate_steps(spokes, z_hi):
     """calc_solution(scale=True) scales the volumes, aggregates them and runs the whole analysis in ONE crossing and ONE pass over the
     volumes (olx_solution_analyze with scale factors).  Same numbers as the separate public steps -- Solution.scale (device scaling),
-    the aggregation, Solution.analyze -- bit for bit: volumes, aggregate, every analysis entry.  The one-pass kernel serves <= 8 foci on
-    z rows of whole quads; 11 foci and a 79-plane grid take the same entry point through the separate passes."""
+    the aggregation, Solution.analyze -- bit for bit: volumes, aggregate, every analysis entry.  The one-pass kernel serves <= 8 foci; on a
+    79-plane grid (rows that are not whole quads: every grid of the reference's SimSetup has odd counts) it runs in its ROW-quad form
+    (round 6); 11 foci take the same entry point through the separate passes."""
     from dataclasses import asdict
     arr = ol.Transducer.gen_matrix_array(nx=16, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
     setup = ol.SimSetup(spacing=0.5, x_extent=(-16, 15.5), y_extent=(-16, 15.5), z_extent=(5, z_hi))      # 64 x 64 x 80 (79)
