@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
     __syncthreads();
     if ((int)threadIdx.x < n_foci) mask_fast_prepare(sM[threadIdx.x], sA[threadIdx.x], P, P.radius, r_side, true);
     __syncthreads();
-    const int nzq = (P.nz + 3) >> 2, nyzq = P.ny * nzq, nq = P.nx * nyzq;      // row quads (host: nq < 2^31)
+    const int nzq = P.nz >> 2, nyzq = P.ny * nzq, nq = P.nx * nyzq;            // WHOLE quads of the rows (host: nx ny ceil(nz / 4) < 2^31)
     const float inv_nyzq = 1.0f / (float)nyzq, inv_nzq = 1.0f / (float)nzq;
     const double rm2 = P.radius * P.radius, rm2lo = rm2 * (1.0 - 1e-12), rm2hi = rm2 * (1.0 + 1e-12);
     const double rs2 = r_side * r_side, rs2lo = rs2 * (1.0 - 1e-12), rs2hi = rs2 * (1.0 + 1e-12);
@@ -1048,10 +1048,10 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
         for (int k = 0; k < 6; ++k) pk[f][k] = 0.f;
     float wmax = 0.f;
     const int stride = gridDim.x * blockDim.x;
-    for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
-        int ix, iy, iz0;
-        quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
-        const int cnt = ROWQ ? min(4, P.nz - iz0) : 4;                        // < 4 only in a row's last quad when nz % 4 != 0
+    // one quad of z voxels of every focus; WHOLE: four voxels (the 16-byte forms), else the 1 - 3 voxels behind a row's last whole quad
+    auto quad = [&](const int ix, const int iy, const int iz0, auto whole_c) __attribute__((always_inline)) {
+        constexpr bool WHOLE = decltype(whole_c)::value != 0;
+        const int cnt = WHOLE ? 4 : P.nz - iz0;                               // < 4 only behind a row's last whole quad (nz % 4 != 0)
         const long long vo = ((long long)ix * P.ny + iy) * P.nz + iz0;        // first voxel of the quad (= 4 iq when nz % 4 == 0)
         const float fx = fmaf((float)ix, hx, ox), fy = fmaf((float)iy, hy, oy);
         float fz[4];
@@ -1067,7 +1067,8 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
 #pragma clang fp contract(off)      // sums of the ROUNDED scaled values (the stored ones), as the separate kernels form them
             float* const pp = pmag + (long long)f * P.vox + vo;
             float* const ip = inten + (long long)f * P.vox + vo;
-            if constexpr (ROWQ) { p4 = ld4u(pp, cnt); w4 = ld4u(ip, cnt); }
+            if constexpr (ROWQ && WHOLE) { p4 = ld4u(pp, 4); w4 = ld4u(ip, 4); }
+            else if constexpr (ROWQ) { p4 = ld4u(pp, cnt); w4 = ld4u(ip, cnt); }
             else { p4 = OLX_SAA_LD(reinterpret_cast<const float4*>(pp)); w4 = OLX_SAA_LD(reinterpret_cast<const float4*>(ip)); }
             p4.x *= s; p4.y *= s; p4.z *= s; p4.w *= s;
             w4.x *= s2; w4.y *= s2; w4.z *= s2; w4.w *= s2;
@@ -1119,6 +1120,21 @@ __global__ __launch_bounds__(256, OLX_SCAN_WPE_FIELD_SCALE_AGG_ANALYZE_K) void f
         const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) if ((iz0 + e) >= iz_first) wmax = fmaxf(wmax, wsv[e]);
+    };
+    for (int iq = blockIdx.x * blockDim.x + threadIdx.x; iq < nq; iq += stride) {
+        int ix, iy, iz0;
+        quad_decode(iq, nzq, nyzq, inv_nyzq, inv_nzq, ix, iy, iz0);
+        quad(ix, iy, iz0, IntC<1>{});
+    }
+    if constexpr (ROWQ) {
+        if (P.nz & 3) {      // the rows' tails: one thread per row
+            const float inv_ny = 1.0f / (float)P.ny;
+            for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P.nx * P.ny; r += stride) {
+                int ix = (int)((float)r * inv_ny), iy = r - ix * P.ny;
+                if (iy < 0) { --ix; iy += P.ny; } else if (iy >= P.ny) { ++ix; iy -= P.ny; }
+                quad(ix, iy, P.nz & ~3, IntC<0>{});
+            }
+        }
     }
     // block reduction: 6 F + 1 maxima
 #pragma unroll
