@@ -620,6 +620,47 @@ def test_marched_fused_writers_equal_single_plane_launches(ctx, case, monkeypatc
     monkeypatch.delenv("OLX_MARCH_FUSE", raising=False); monkeypatch.delenv("OLX_MARCH_FUSE_TI", raising=False)
 
 
+def test_split_launch_with_several_column_tiles_and_in_a_slab(ctx):
+    """A launch split at the e4m3 rule's plane cut (include/olx.h) where the sweep needs SEVERAL launch tiles (16 foci -> two tiles of 16 columns: the
+    block records of both sides are walked once per tile, both operand sets are packed per tile) and in an x-slab (the multi-GPU shard unit: the
+    slab that holds the foci may split, its neighbour keeps three fp16 products): planes below the cut = the opted-out plan's bits, every focus
+    within the stated bound of the fp64 oracle."""
+    pos, ori, size = synthetic_array(16, 16, 3.0)
+    foci = bo.wheel_targets([0, 0, 40.0], True, 15, 5.0) * 1e-3
+    pos_m, area, d, a = setup_ctx(ctx, pos, ori, size, foci, solve=True)
+    n = 128
+    xs = (np.arange(n) - (n - 1) / 2) * 0.5e-3
+    zs = (-4.0 + np.arange(n) * 0.5) * 1e-3
+    h = (0.5e-3,) * 3
+    for slab in (None, (32, 64), (0, 32)):
+        res = {}
+        for flags in (0, nat.FIELD_FP16_CORRECTION):
+            ctx.field_plan((xs[0], xs[0], zs[0]), h, (n, n, n), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | flags, slab=slab)
+            name = ctx.field_variant()
+            ctx.field_launch()
+            res[flags] = (name, [ctx.field_fetch(f)["pmag"] for f in (0, 7, 15)])
+        name = res[0][0]
+        assert "in 2 tile(s)" in name or slab is not None, name
+        if slab == (0, 32):           # the foci lie outside this slab: three fp16 products
+            assert "fp8corr" not in name, name
+            for g, r16 in zip(res[0][1], res[nat.FIELD_FP16_CORRECTION][1]):
+                assert np.array_equal(g, r16)
+            continue
+        assert "fp8corr from plane " in name, name
+        kcut = int(name.split("fp8corr from plane ")[1].split(">")[0])
+        assert kcut in (16, 32), name
+        sl = slice(None) if slab is None else slice(slab[0], slab[0] + slab[1])
+        # (the opted-out plan packs 17 - 32 columns into ONE tile of kernel 2e's NT = 4 shape; the split plan runs kernel 2g on two tiles of 16 on both
+        # sides of the cut: the same bits only where both plans run the same kernel)
+        same_kernel = name.split(",flat")[0] == res[nat.FIELD_FP16_CORRECTION][0].split(",flat")[0] and name.split(" columns")[1] == res[nat.FIELD_FP16_CORRECTION][0].split(" columns")[1]
+        for f, g, r16 in zip((0, 7, 15), res[0][1], res[nat.FIELD_FP16_CORRECTION][1]):
+            if same_kernel:
+                assert np.array_equal(g[:, :, :kcut], r16[:, :, :kcut]), (slab, f)
+            assert np.abs(g[:, :, :kcut] - r16[:, :, :kcut]).max() <= 3e-6 * r16.max() and not np.array_equal(g[:, :, kcut:], r16[:, :, kcut:]), (slab, f)
+            ref = np.abs(co.field_on_grid(xs[sl], xs, zs, pos_m, area, d[f], a[f], F0, C, P0, dmin=0.25e-3))
+            assert np.abs(g - ref).max() / ref.max() <= FP8_BOUND, (slab, f)
+
+
 def test_c5_skull_slab_256cubed_marched(ctx):
     """BASELINE config 5 at full size with the default (marched) model: 256 el, 256^3 at 0.25 mm, skull-slab phantom, 4 foci
     in one launch.  Whole z columns (through the slab and the focal region) against the fp64 marched oracle, voxels below the slab
