@@ -908,7 +908,8 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
     run("jitter_f1", "16 x 16 array with +-0.1 mm lateral element jitter (seed 147), single focus, 256^3", jit, g256, focus, covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     run("jitter_f8", "the same array, the 8-focus shard", jit, g256, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_jittered_tilted_elements_general_variant, test_kernel_families_agree_with_oracle (full volumes, smaller grids)")
     # the reference's DEFAULT SimSetup extents (x, y in +-30 mm, z from -4 mm: through the element plane; sim/sim_setup.py:24-36) at the headline's spacing:
-    # the planner splits the launch -- three fp16 products in the plane blocks next to the array, e4m3 corrections from the cut on (include/olx.h)
+    # the e4m3 rule (include/olx.h) fails in the plane blocks next to the array and the cut comes too late to pay for a second launch, so the planner
+    # keeps three fp16 products throughout; the plane count is odd, so the stores are dword-aligned x4 and the XCD group is 17 blocks
     dsetup = ol.SimSetup(spacing=0.25)
     dorigin, dspacing, dn = grid_from_coords(dsetup.get_coords())
     gdef = (dorigin, dspacing, dn, [np.asarray(c.data) * 1e-3 for c in dsetup.get_coords().values()])
