@@ -46,31 +46,53 @@ namespace olx {
 // conflict-free; what they overrun -- the first columns of the next row, the plane's pad -- meets zero weights and is finite because the whole
 // arena is cleared at block entry).  Same matrix instructions as two blocks of <= 8 positions; one table of <= 31 columns instead of two of
 // <= 23, half the block prologues, barriers and weight loads per position.
-template <int MX, int MY, bool CLAMP, bool DIR = false, bool FP8 = false, bool M2 = false>
-__global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
+// NM = 3 (round 6; arrays wider than 17 elements, e.g. BASELINE configs[3]): THREE row tiles -- 24 positions along x -- on 48-word table rows, one block per CU
+// (ToepShape<3>, k_toep.hip.h): a table entry then serves 2.1 positions along x instead of one in four.
+template <int MX, int MY, bool CLAMP, bool DIR = false, bool FP8 = false, int NM = 1>
+__global__ __launch_bounds__(ToepShape<NM>::WAVES * 64, ToepShape<NM>::MINW) void field_toep_k(const uint4* __restrict__ afrag, float* __restrict__ pmag,
                                                                     float* __restrict__ inten, const CosetBlock* __restrict__ blocks /*[gridDim.x]*/,
                                                                     const ToepParams T) {
+    using S = ToepShape<NM>;
+    constexpr int TOEP_PSZ = S::PSZ, TOEP_TW = S::TW, TOEP_ROWS = S::ROWS, TOEP_WAVES = S::WAVES, NKY = S::NKY, KYG = S::KYG;
+    constexpr bool M2 = NM >= 2;                         // more than one row tile: all of them are always computed
     const CosetParams& P = T.q;
     __shared__ __attribute__((aligned(16))) unsigned s_T[2 * TOEP_ZB * TOEP_PSZ];     // [hi | lo][plane][row][ud']
     unsigned* const s_hi = s_T;
     unsigned* const s_lo = s_T + TOEP_ZB * TOEP_PSZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kyg = wave & 3, ks = wave >> 2;              // ks: this wave's K-step -- FP8: its half of the super-block's element rows
+    const int kyg = wave % KYG, ks = wave / KYG;              // ks: this wave's K-step -- FP8: its half of the super-block's element rows
     // the block's share of the coset decomposition: one scalar load of the host's record (olx.hip, as kernel 2g; the two blocks
     // that write the two 64-byte halves of the same 128-byte lines have ids 8 apart -- the same XCD, i.e. the same L2, under
     // round-robin dispatch).  Decoded here, the chain of integer divisions was ~160 vector and ~400 scalar instructions per wave.
-    const CosetBlock BK = blocks[blockIdx.x];
+    // NM = 3 (one block per CU: nobody covers a block's store drain, launch and first loads): the grid is one block per CU and a block WALKS the records
+    // blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: a block keeps to the records of its XCD, in the host's order) -- the stores of a record
+    // drain under the next record's table generation.
+    constexpr bool WALK = NM == 3;
+    unsigned rec = blockIdx.x;
+    do {                                                // (one pass where WALK is false: the loop form alone costs the 128-register shapes 15 - 22 spills)
+    if (WALK && rec != blockIdx.x) lds_barrier();       // the previous record's exchange tiles are read: the arena is free (LDS only: its stores drain under this record's tables)
+    const CosetBlock BK = blocks[rec];
     const int KX = BK.KX, KY = BK.KY;
-    if (BK.npos <= 0) return;                           // block-uniform
+    if (BK.npos <= 0) { if constexpr (WALK) continue; else return; }      // block-uniform
     const int ibase = BK.ibase, jbase = BK.jbase;
     const int k0 = BK.k0;
     const int SAW = T.sa_w;                             // elements of a super-block along x
     const int NC = SAW + P.xs * (KX - 1);               // table columns in use: ud' = xs kx - al + (SAW - 1) in [0, NC)
     const int NR = KY + TOEP_SB - 1;                    // table rows in use: wd = -7 .. KY - 1
-    // what is never generated -- columns NC .. 31, rows beyond NR, the pads -- meets zero Toeplitz weights: 0 x garbage must stay 0, so the
-    // whole arena is cleared once (16-byte stores; M2's second row tile also reads 8 columns past its row).  (Round 6: clearing only the
-    // words a stored fragment can read -- 832 of 18 688 -- measured 5 - 11 % SLOWER, same box, alternating: per-row dword stores.)
-    for (int idx = tid; idx < 2 * TOEP_ZB * TOEP_PSZ / 4; idx += TOEP_WAVES * 64) reinterpret_cast<uint4*>(s_T)[idx] = make_uint4(0u, 0u, 0u, 0u);
+    // What no generation round writes and the fragment reads of a STORED position meet must be finite (it meets zero Toeplitz weights: 0 x garbage must stay 0; the
+    // arena holds the previous block's exchange tiles): the columns NC .. TW - 1 of every row, the rows NR .. ROWS - 1 (a second row tile reads 8 columns past its
+    // row into the next one; the ring of rows later rotates generated rows over them) and the plane's pad.  16-byte stores over (half, plane) x row items --
+    // 1.3 k of them on BASELINE's 16 x 16 shapes instead of the whole arena's 4.7 k (profiles/r06_toep_phases.txt: the whole-arena clear was 7 % of the launch).
+    // (Rows of y positions beyond KY -- computed by a wave that also holds stored ones, never stored -- may read anything.)
+    {
+        const int nc4 = NC & ~3;
+        for (int idx = tid; idx < 32 * (TOEP_ROWS + 1); idx += TOEP_WAVES * 64) {
+            const int hz = idx & 31, row = idx >> 5;            // (hi | lo half, plane), table row -- row ROWS = the pad behind the last row
+            unsigned* const p = s_T + hz * TOEP_PSZ + row * TOEP_TW;
+            const int c1 = row == TOEP_ROWS ? TOEP_PSZ - TOEP_ROWS * TOEP_TW : TOEP_TW;
+            for (int c = row < NR ? nc4 : 0; c < c1; c += 4) *reinterpret_cast<uint4*>(p + c) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     // dz^2 of the block's 16 planes: wave-uniform, held in scalar registers (one v_add per evaluation instead of two fmas)
     float dz2[TOEP_ZB];
 #pragma unroll
@@ -81,13 +103,12 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     // B fragment base of this lane [words]: plane (lane & 15), k-group (lane >> 4), this wave's K-step
     const int n16 = lane & 15, g = lane >> 4;
     const unsigned bbase = (unsigned)(n16 * TOEP_PSZ + 4 * g + (FP8 ? 0 : 16 * ks));
-    constexpr int NM = M2 ? 2 : 1;                      // row tiles: positions 8 m .. 8 m + 7
-    (void)KX;
-    floatx4_t acc[NM][3];
+    (void)KX;                                           // (row tiles: positions 8 m .. 8 m + 7)
+    floatx4_t acc[NM][NKY];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[m][t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NKY; ++t) acc[m][t] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     const int n_sb = T.nsa * P.nsb;
     OLX_STAMP(0);
     for (int sb = 0; sb < n_sb; ++sb) {
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 } else { afr[bl][0] = ab[bl * 4 * 64]; afr[bl][1] = ab[(bl * 4 + 2) * 64]; }
             }
         };
-        // (requested behind the barrier: __syncthreads() drains vmcnt, the loads would be waited for right there)
+        // (requested behind the barrier: __syncthreads() drains vmcnt, the loads would be waited for right there; LDS-only barriers here and behind the fill: +- 0)
         load_weights();
         // ---- G tables of the 16 planes: (row, column) pairs across the threads
         // Sliding rows: logical row r of super-block (sa, sbb) is the offset wd = r - 7 - 8 sbb against element row 0 of the
@@ -162,6 +183,8 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         };
         // (where one round leaves half of the block idle -- <= 256 pairs: every super-block after the first -- splitting a pair's 16 planes over the
         // two wave groups measured +1.5 % on configs[3], as in round 5: idle waves cost nothing, the partner block's waves take the SIMDs)
+        // (a wave taking four of the 16 planes of its entries, so that a super-block's 248 - 376 new entries fill whole rounds of 128 threads: +4 ... +8 % on every
+        // shape -- the index and dx^2 + dy^2 arithmetic repeats per quarter, and what counts is the instructions issued, not the idle lanes: profiles/r06_toep_phases.txt)
         for (int idx = tid; idx < n_new * ncol; idx += TOEP_WAVES * 64) fill(idx, IntC<0>{}, IntC<TOEP_ZB>{});
         if (sb == 0) OLX_STAMP(2);
         __syncthreads();
@@ -176,12 +199,73 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
         // beyond KY reads rows that exist (the ring has 18) and its sums are never stored.
         const unsigned ksm = (T.ks_mask >> (2 * sa)) & 3u;      // K-steps of this column of super-blocks that carry weights (wave-uniform)
         if (!FP8 && !((ksm >> ks) & 1u)) continue;              // (fp16 corrections: this wave's K-step is all zeros here; the barriers sit above)
-        if (3 * kyg >= KY) continue;                            // (no y position of this wave exists: wave-uniform)
-        const int p0 = 3 * kyg + 7 - (FP8 ? 4 * ks : 0) + rot + TOEP_ROWS;      // logical table row of (t = 0, bi = 0) + 18 (>= 18 + 3 - 7)
+        if (NKY * kyg >= KY) continue;                            // (no y position of this wave exists: wave-uniform)
+        const int p0 = NKY * kyg + 7 - (FP8 ? 4 * ks : 0) + rot + TOEP_ROWS;      // logical table row of (t = 0, bi = 0) + ROWS (p0 + d stays in [0, 3 ROWS))
         auto contract = [&](auto two_c, auto ksm_c) __attribute__((always_inline)) {
-            constexpr int NMM = decltype(two_c)::value ? 2 : 1;
+            constexpr int NMM = decltype(two_c)::value;
             constexpr unsigned KSM = decltype(ksm_c)::value;
-            constexpr int ND = NB + 2, NSTEP = NMM * ND;      // diagonals d = -(NB - 1) .. 2 per row tile
+            constexpr int ND = NB + NKY - 1, NSTEP = NMM * ND;      // diagonals d = -(NB - 1) .. NKY - 1 per row tile
+            if constexpr (NMM == 3) {
+                // three row tiles: a diagonal's fragments for ALL tiles in one step -- 3 - 6 independent accumulators per step (a tile alone has one or two: the
+                // matrix instructions of an accumulator are a dependent chain), and tile m's K-step s sits 8 m + 16 s words into the row, so tile 2's
+                // K-step 0 IS tile 0's K-step 1: 5 pieces x (hi, e4m3) = 10 ds_read_b128 per diagonal instead of 12
+                constexpr int NP = FP8 ? 5 : 3;
+                struct BF3 { uint4 h[NP], q[NP]; };          // FP8: piece j = words 8 j .. of the row (hi fp16 | e4m3 bytes); fp16 x 3: tile j, this wave's K-step (hi | lo)
+                auto load3 = [&](const int di) __attribute__((always_inline)) {
+                    int prow = p0 + di - (NB - 1);           // physical row of the ring (scalar arithmetic: wave-uniform)
+                    prow = prow >= 2 * TOEP_ROWS ? prow - 2 * TOEP_ROWS : (prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow);
+                    const unsigned wm = bbase + (unsigned)(prow * TOEP_TW);
+                    BF3 f;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        if (FP8 && KSM == 2u && j < 2) f.h[j] = make_uint4(0u, 0u, 0u, 0u);      // (K-step 0 carries no weights here: its hi pieces are not read)
+                        else f.h[j] = *reinterpret_cast<const uint4*>(s_hi + wm + 8 * j);
+                        f.q[j] = *reinterpret_cast<const uint4*>(s_lo + wm + 8 * j);
+                    }
+                    return f;
+                };
+                BF3 cur3 = load3(0);
+#pragma unroll
+                for (int di = 0; di < ND; ++di) {
+                    const int d = di - (NB - 1);
+                    BF3 nxt3 = cur3;
+                    if (di + 1 < ND) nxt3 = load3(di + 1);   // one diagonal ahead (256 registers per lane in this shape)
+                    const uint4* fh = cur3.h; const uint4* fq = cur3.q;
+#pragma unroll
+                    for (int pass = 0; pass < 3; ++pass)     // the three products of a group one after the other ACROSS the groups
+#pragma unroll
+                        for (int t = 0; t < NKY; ++t) {
+                            const int bi = t - d;
+                            if (bi < 0 || bi >= NB) continue;    // (compile-time)
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) {
+                                Half8Bits ah, al, bh, bw;
+                                ah.u = afr[bi][0]; al.u = afr[bi][1];
+                                if constexpr (FP8) {
+                                    bh.u = fh[m]; bw.u = fh[m + 2];
+                                    if (pass == 0) { if constexpr ((KSM & 1u) != 0) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0); }
+                                    else if (pass == 1) { if constexpr ((KSM & 2u) != 0) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bw.h, acc[m][t], 0, 0, 0); }
+                                    else {
+                                        intx8_t a8, b8;
+                                        a8[0] = (int)afr[bi][2].x; a8[1] = (int)afr[bi][2].y; a8[2] = (int)afr[bi][2].z; a8[3] = (int)afr[bi][2].w;
+                                        a8[4] = (int)afr[bi][3].x; a8[5] = (int)afr[bi][3].y; a8[6] = (int)afr[bi][3].z; a8[7] = (int)afr[bi][3].w;
+                                        b8[0] = (int)fq[m].x; b8[1] = (int)fq[m].y; b8[2] = (int)fq[m].z; b8[3] = (int)fq[m].w;
+                                        b8[4] = (int)fq[m + 2].x; b8[5] = (int)fq[m + 2].y; b8[6] = (int)fq[m + 2].z; b8[7] = (int)fq[m + 2].w;
+                                        acc[m][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[m][t], 0, 0, 0, 128, 0, 127);
+                                    }
+                                } else {
+                                    bh.u = fh[m]; bw.u = fq[m];
+                                    if (pass == 0) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc[m][t], 0, 0, 0);
+                                    else if (pass == 1) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc[m][t], 0, 0, 0);
+                                    else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bw.h, acc[m][t], 0, 0, 0);
+                                }
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);       // (one diagonal ahead, not more)
+                    cur3 = nxt3;
+                }
+                return;
+            }
             // B fragments of one diagonal: hi of this wave's K-step(s) and -- FP8 -- the 32 e4m3 bytes of the table row's two pieces
             struct BF { uint4 h0, h1, q0, q1; };
             auto load = [&](const int step) __attribute__((always_inline)) {
@@ -215,7 +299,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                     b8[4] = (int)cur.q1.x; b8[5] = (int)cur.q1.y; b8[6] = (int)cur.q1.z; b8[7] = (int)cur.q1.w;
                 }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NKY; ++t) {
                     const int bi = t - d;                    // element row of this wave's share: (t, bi) on the diagonal d
                     if (bi < 0 || bi >= NB) continue;        // (compile-time)
                     Half8Bits ah, al;
@@ -239,11 +323,11 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
                 else if (step + 1 < NSTEP) cur = load(step + 1);
             }
         };
-        if constexpr (M2) {     // (arrays up to 17 wide: one column of super-blocks, both K-steps carry weights)
-            contract(IntC<1>{}, IntC<3>{});      // (both row tiles always: the host picks this shape only where some part has more than 8 positions -- a second contraction body beside it costs 34 spilled registers)
+        if constexpr (NM == 2) {     // (arrays up to 17 wide: one column of super-blocks, both K-steps carry weights)
+            contract(IntC<2>{}, IntC<3>{});      // (both row tiles always: the host picks this shape only where some part has more than 8 positions -- a second contraction body beside it costs 34 spilled registers)
         } else if constexpr (FP8) {
-            if (ksm == 3u) contract(IntC<0>{}, IntC<3>{}); else if (ksm == 2u) contract(IntC<0>{}, IntC<2>{}); else contract(IntC<0>{}, IntC<1>{});
-        } else contract(IntC<0>{}, IntC<3>{});
+            if (ksm == 3u) contract(IntC<NM>{}, IntC<3>{}); else if (ksm == 2u) contract(IntC<NM>{}, IntC<2>{}); else contract(IntC<NM>{}, IntC<1>{});
+        } else contract(IntC<NM>{}, IntC<3>{});
         if (sb == 0) OLX_STAMP(4);
     }
     OLX_STAMP(5);
@@ -252,9 +336,9 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     __syncthreads();
     float* const s_x = reinterpret_cast<float*>(s_T);
     {
-        float* xo = s_x + (wave * 3 * NM) * 16 * TOEP_XS + n16;
+        float* xo = s_x + (wave * NKY * NM) * 16 * TOEP_XS + n16;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NKY; ++t)
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -275,20 +359,20 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     // splits every 16-byte store into a 12-byte and a 4-byte instruction)
     auto readout = [&](auto full_c) {
         constexpr bool FULL4 = decltype(full_c)::value != 0;
-        constexpr int NQ = 3 * NM, QH = (NQ + 1) / 2;     // pairs per group; the first wave takes QH of them
+        constexpr int NQ = NKY * NM, QH = (NQ + 1) / 2;     // pairs per group; the first wave takes QH of them
 #pragma unroll
         for (int qq = 0; qq < QH; ++qq) {
             const int q = ks ? QH + qq : qq;
             if (q >= NQ) break;
             const int t = q / NM, m = q - t * NM;
-            const int ky = 3 * kyg + t;
+            const int ky = NKY * kyg + t;
             const int kxg = 8 * m + kx;                      // position of the coset along x
             const bool want = want0 && kxg < KX;
             if (ky >= KY || !want) continue;
             const int i = ibase + P.xs * P.mx * kxg;
             const unsigned ox0 = (unsigned)(i * sxz + kz), ox1 = (unsigned)((P.nx - 1 - i) * sxz + kz);
-            const float* xa = s_x + (((kyg * 3 + t) * NM + m) * 16 + 2 * kx) * TOEP_XS + 4 * pq;   // first wave group's partial
-            const float* xb = xa + 4 * 3 * NM * 16 * TOEP_XS;                                    // second wave group's partial (wave + 4)
+            const float* xa = s_x + (((kyg * NKY + t) * NM + m) * 16 + 2 * kx) * TOEP_XS + 4 * pq;   // first wave group's partial
+            const float* xb = xa + KYG * NKY * NM * 16 * TOEP_XS;                                // second wave group's partial (wave + KYG)
             const float4 ra = *reinterpret_cast<const float4*>(xa), ia = *reinterpret_cast<const float4*>(xa + TOEP_XS);
             const float4 rb = *reinterpret_cast<const float4*>(xb), ib = *reinterpret_cast<const float4*>(xb + TOEP_XS);
             const float re[4] = {ra.x + rb.x, ra.y + rb.y, ra.z + rb.z, ra.w + rb.w};
@@ -319,6 +403,7 @@ __global__ __launch_bounds__(TOEP_WAVES * 64, 4) void field_toep_k(const uint4* 
     };
     if (k0 + TOEP_ZB <= P.nz) readout(IntC<1>{}); else readout(IntC<0>{});      // (block-uniform: only a LAST, partial plane block stores plane by plane)
     OLX_STAMP(6);
+    } while (WALK && (rec += gridDim.x) < T.n_rec);      // records
 }
 
 // Toeplitz weights of kernel 2f in MFMA lane order: afrag[(((tile nsa + sa) ay_pad + b) 4 + {hi s0, hi s1, lo s0, lo s1}) 64 + lane].
@@ -396,21 +481,22 @@ static void launch_toep(olx_ctx* c, float* pm) {
     T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ax = c->lat.ax; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
     for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
     const CosetParams& Q = T.q;
-    dim3 grid(c->cp_nblocks, c->mp.n_tiles), blk(TOEP_WAVES * 64);      // (the block records of this launch: all of them, or one side of a launch split at fp8_kcut)
-    if (c->dir_lattice) {   // piston directivity folded into the geometry tables
+    const int nm = c->toep_nm;                          // row tiles per block (the planner's choice: olx.hip)
+    T.n_rec = c->cp_nblocks;
+    // (three row tiles: one block per CU walks the records; a multiple of 8 blocks so that a block's records stay on its XCD)
+    const unsigned walkers = (unsigned)std::max(8, c->n_cu / 8 * 8);
+    dim3 grid(nm == 3 ? std::min(c->cp_nblocks, walkers) : c->cp_nblocks, c->mp.n_tiles), blk((nm == 3 ? ToepShape<3>::WAVES : ToepShape<1>::WAVES) * 64);      // (the block records of this launch: all of them, or one side of a launch split at fp8_kcut)
+    if (c->dir_lattice) {   // piston directivity folded into the geometry tables (one row tile: the planner keeps nm = 1 here)
         if (c->clamp || c->lat.clamp) hipLaunchKernelGGL((field_toep_k<MX, MY, true, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         else hipLaunchKernelGGL((field_toep_k<MX, MY, false, true>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T);
         return;
     }
-#define OLX_TP(CL, F8, M2_) hipLaunchKernelGGL((field_toep_k<MX, MY, CL, false, F8, M2_>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T)
+#define OLX_TP(CL, F8, NM_) hipLaunchKernelGGL((field_toep_k<MX, MY, CL, false, F8, NM_>), grid, blk, 0, c->stream, c->d_afrag, pm, c->d_inten, c->d_cpblocks, T)
+#define OLX_TPN(CL, F8) do { if (nm == 3) OLX_TP(CL, F8, 3); else if (nm == 2) OLX_TP(CL, F8, 2); else OLX_TP(CL, F8, 1); } while (0)
     const bool cl = c->clamp || c->lat.clamp;
-    if (c->fp8corr) {       // e4m3 correction products (the planner's gated default)
-        if (c->toep_m2) { if (cl) OLX_TP(true, true, true); else OLX_TP(false, true, true); }
-        else            { if (cl) OLX_TP(true, true, false); else OLX_TP(false, true, false); }
-    } else {
-        if (c->toep_m2) { if (cl) OLX_TP(true, false, true); else OLX_TP(false, false, true); }
-        else            { if (cl) OLX_TP(true, false, false); else OLX_TP(false, false, false); }
-    }
+    if (c->fp8corr) { if (cl) OLX_TPN(true, true); else OLX_TPN(false, true); }      // e4m3 correction products (the planner's gated default)
+    else            { if (cl) OLX_TPN(true, false); else OLX_TPN(false, false); }
+#undef OLX_TPN
 #undef OLX_TP
 }
 

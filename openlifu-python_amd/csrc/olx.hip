@@ -15,6 +15,7 @@
 #include "k_small.hip.h"
 #include "olx_launch.h"
 #include "olx_plan.h"
+#include "k_toep.hip.h"
 
 extern "C" {
 
@@ -640,20 +641,39 @@ static int configure_variant_impl(olx_ctx* c) {
 #ifdef OLX_DEV_PINS
                 if (const char* e = getenv("OLX_EXP_TOEP_SAW")) { const int v = atoi(e); if (v >= 8 && v <= 24) saw_plan = std::min(A.ax, v); }   // (A/B)
 #endif
-                c->toep_m2 = c->use_toep && saw_plan + 15 <= 32;
-                const int kxw = c->use_toep ? (c->toep_m2 ? 16 : 8) : cos_kxw(c->nt);
+                // (NM = 2 reads the second tile's fragments 8 columns on in the same 32-word rows: arrays up to 17 wide; wider arrays take THREE tiles on 48-word rows
+                // -- ToepShape<3>, k_toep.hip.h: one block per CU -- where that does not add padded position slots: BASELINE configs[3])
+                c->toep_nm = !c->use_toep ? 1 : (saw_plan + 15 <= 32 ? 2 : 1);
                 const int zb = COS_ZB;      // planes per block
                 // positions of a coset along x: two pitches apart for kernels 2e / 2g (their fragment reads are 8-byte aligned that way), ONE for kernel 2f
                 // (round 5: its 8-position row tiles then fill 7 - 8 of 8 slots on BASELINE's grids instead of 5 - 6, and its tables are shared by more rows)
                 Q.xs = c->use_toep ? 1 : 2;
-                olxplan::coset_partition(Q, kxw, zb, COS_KYW);
-                if (c->toep_m2) {   // the two-row-tile shape computes both tiles of every block: only where a part holds more than 8 positions along x
-                    const int wxh = Q.nx - Q.x_lo, kxa_max = wxh > 0 ? (wxh - 1) / (Q.xs * Q.mx) + 1 : 0;
-                    if ((kxa_max + Q.nsx - 1) / std::max(1, Q.nsx) <= 8) {
-                        c->toep_m2 = false;
-                        olxplan::coset_partition(Q, 8, zb, COS_KYW);
+                int kyw = COS_KYW;
+                if (c->use_toep) {
+                    const int wxh = Q.nx - Q.x_lo, wyh = Q.ny - Q.y_lo;
+                    const int kxa_max = wxh > 0 ? (wxh - 1) / (Q.xs * Q.mx) + 1 : 0, kya_max = wyh > 0 ? (wyh - 1) / Q.my + 1 : 0;
+                    auto parts = [](int k, int w) { return std::max(1, (k + w - 1) / w); };
+                    if (c->toep_nm == 2) {      // the two-row-tile shape computes both tiles of every block: only where a part holds more than 8 positions along x
+                        if ((kxa_max + parts(kxa_max, 16) - 1) / parts(kxa_max, 16) <= 8) c->toep_nm = 1;
+                    } else if (!c->dir_lattice) {
+                        // position slots the matrix pipe works through, per coset and plane block: x parts x 8 NM, y parts x the wave groups that hold a position
+                        auto slots = [&](int nm, int kyw_, int nky) {
+                            const int px_ = parts(kxa_max, 8 * nm), py_ = parts(kya_max, kyw_);
+                            const int ky_part = (kya_max + py_ - 1) / py_;
+                            return (long long)px_ * 8 * nm * py_ * ((ky_part + nky - 1) / nky) * nky;
+                        };
+                        const char* pin = nullptr;
+#ifdef OLX_DEV_PINS
+                        pin = getenv("OLX_EXP_TOEP_NM");      // (A/B: 1 or 3)
+#endif
+                        // (one block per CU in that shape: only where the launch still has a block for every CU)
+                        const long long nblk3 = (long long)Q.xs * Q.mx * Q.my * parts(kxa_max, 24) * parts(kya_max, ToepShape<3>::KYW) * ((Q.nz + zb - 1) / zb);
+                        const bool want3 = pin ? atoi(pin) == 3 : (kxa_max > 8 && nblk3 >= 256 && 20 * slots(3, ToepShape<3>::KYW, ToepShape<3>::NKY) <= 21 * slots(1, ToepShape<1>::KYW, ToepShape<1>::NKY));
+                        if (want3) { c->toep_nm = 3; kyw = ToepShape<3>::KYW; }
                     }
                 }
+                const int kxw = c->use_toep ? 8 * c->toep_nm : cos_kxw(c->nt);
+                olxplan::coset_partition(Q, kxw, zb, kyw);
                 Q.nsa = L.nsa; Q.nsb = L.nsb; Q.nsbp = L.nsbp; Q.ux0 = L.ux0; Q.uy0 = L.uy0; Q.fx0 = L.fx0; Q.fy0 = L.fy0;
                 Q.hx_hi = L.hx_hi; Q.hx_lo = L.hx_lo; Q.hy_hi = L.hy_hi; Q.hy_lo = L.hy_lo; Q.hz = L.hz;
                 Q.dmin2 = L.dmin2; Q.flat_ez = L.flat_ez; Q.g_scale = L.g_scale; Q.out_scale = L.out_scale; Q.inten_scale = L.inten_scale;
@@ -781,12 +801,12 @@ static int configure_variant_impl(olx_ctx* c) {
                             for (int sx = 0; sx < Q.nsx; ++sx)
                                 for (int sy = 0; sy < Q.nsy; ++sy) {
                                     const int KX = (sx + 1) * kxa / Q.nsx - sx * kxa / Q.nsx, KY = (sy + 1) * kya / Q.nsy - sy * kya / Q.nsy;
-                                    if (KX > 0 && KY > 0) n_mfma += (long long)((double)KY * per_row * ((KX + 7) / 8) * 8 * A.nsb * Q.kblocks);      // (row tiles of 8 positions)
+                                    if (KX > 0 && KY > 0) n_mfma += (long long)((double)KY * per_row * (c->toep_nm > 1 ? 8 * c->toep_nm : 8) * A.nsb * Q.kblocks);      // (row tiles of 8 positions: every tile of the block's shape is computed)
                                 }
                         }
                     snprintf(nmbuf, sizeof nmbuf, "field_toep%s_k<mx%d,my%d,flat,%s%s> %d columns for %d foci x %d images in %d tile(s); "
-                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense)", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", f8tag.c_str(),
-                             total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense);
+                             "%dx%d lattice, pitch %dx%d voxels, %lld MFMA/launch (%lld dense), %d row tile(s) x %d y positions per block", "", c->mx, c->my, lat_clamp ? "clamp" : "noclamp", f8tag.c_str(),
+                             total_cols, F, n_img, ntiles, A.ax, A.ay, A.mx, A.my, n_mfma, n_dense, c->toep_nm, kyw);
                 } else {
                 // matrix-pipe time in units of one v_mfma_f32_16x16x32_f16 (16 cycles): 3 fp16 products per K-step, or with fp8
                 // corrections 1 fp16 product per K-step + one K = 128 e4m3 instruction (2 units) per two K-steps
@@ -933,7 +953,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         // derived below is still valid -- an interactive caller re-plans per target while only the steering changes.  The steering-
         // dependent part (configure_variant + packing) is redone at the next launch anyway when the table changed.
         std::string env;   // the developer switches the plan below reads
-        for (const char* name : {"OLX_FIELD_VARIANT", "OLX_FP8_CORRECTION", "OLX_EXP_TOEP_SAW", "OLX_EXP_KGRP"}) { const char* e = getenv(name); env += e ? e : ""; env += '|'; }
+        for (const char* name : {"OLX_FIELD_VARIANT", "OLX_FP8_CORRECTION", "OLX_EXP_TOEP_SAW", "OLX_EXP_TOEP_NM", "OLX_EXP_KGRP"}) { const char* e = getenv(name); env += e ? e : ""; env += '|'; }
         const bool same = c->planned && !c->uploaded && !c->hetero && memcmp(&c->grid, g, sizeof *g) == 0 && c->slab.x_begin == s.x_begin &&
                           c->slab.x_count == s.x_count && c->plan_foci == n_foci && c->freq == freq && c->c == cs && c->rho == rho &&
                           c->p0_pa == p0_pa && c->flags == flags && c->plan_absorb == c->absorb_np_m && c->nbuf == (c->comm_active() ? olx_ctx::NBUF : 1) && c->plan_env == env;

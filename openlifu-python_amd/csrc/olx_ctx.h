@@ -90,7 +90,7 @@ struct olx_ctx {
     std::vector<CosetBlock> up_blocks; std::vector<int> up_jobs, up_slot;   // host copies of what d_cpblocks / d_jobs / d_slot hold (re-uploaded only when they change)
     std::vector<int> up_perm, up_colinfo, up_targets;                      // ... and of d_perm / d_colinfo / d_targets (a new target of the same pattern changes none of them)
     bool use_cosetp = false;   // kernel 2g: 2e's NT = 2 shape with the planes in the MFMA rows (no output staging)
-    bool use_toep = false; int toep_nsa = 0, toep_saw = 16; unsigned toep_ksmask = 0; bool toep_m2 = false;   /* super-block columns, their width, non-zero K-steps */ int toep_targets[4] = {-1, -1, -1, -1};
+    bool use_toep = false; int toep_nsa = 0, toep_saw = 16; unsigned toep_ksmask = 0; int toep_nm = 1;   /* row tiles per block (ToepShape) */   /* super-block columns, their width, non-zero K-steps */ int toep_targets[4] = {-1, -1, -1, -1};
     int* d_cell = nullptr; size_t cell_cap = 0; uint4* d_afrag = nullptr; size_t afrag_cap = 0;
     static constexpr int NBUF = 2;
     float* d_pmag[NBUF] = {nullptr, nullptr};

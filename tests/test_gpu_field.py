@@ -897,7 +897,7 @@ def test_lattice_without_mirror_folds_and_in_slabs(ctx):
                   slab=(13, 14), expect="field_coset")
 
 
-@pytest.mark.parametrize("case", ["16x16", "16x16_e4m3", "32x32_e4m3_opted_out", "padded20x12", "32x32_parts", "widths_18_28_40", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e"])
+@pytest.mark.parametrize("case", ["16x16", "16x16_e4m3", "32x32_e4m3_opted_out", "padded20x12", "32x32_parts", "widths_18_28_40", "ragged_planes", "y_slab_fold_only", "apodized_pinned_2e", "three_row_tiles"])
 def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
     """Kernel 2f (one steering column: an on-axis focus on a mirror-symmetric lattice array; Toeplitz weights stationary, 16
     planes per MFMA tile) against the fp64 oracle, full volume: element counts that pad the 16 x 8 super-blocks, arrays of
@@ -924,6 +924,15 @@ def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
                 _lattice_case(ctx, nax, nay, (1.5, 1.5), grid, (0.5, 0.5, 0.5), foci=[[0, 0, zf]], expect="field_toep_k<mx2,my2,flat,noclamp", solve=True, fp8=opt)
     elif case == "ragged_planes":
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 44, 21), (1.0, 1.0, 1.0), z0=3e-3, expect="field_toep")
+    elif case == "three_row_tiles":   # arrays wider than 17 elements with 17 - 24 positions of a coset along x and >= 256 blocks (round 6: BASELINE configs[3]'s shape):
+        # 24 x <= 11 positions per block on 48-word table rows, one block per CU; 32 = 24 + 8 (the last column of super-blocks fills one K-step), 28 = 24 + 4,
+        # 40 = 24 + 16 (both), ragged parts along x and y, a ragged last plane block, a grid through the element plane (clamp), e4m3 and fp16 corrections
+        t3 = "3 row tile(s) x 11 y positions"
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (264, 264, 52), (0.25, 0.25, 0.5), foci=[[0, 0, 12e-3]], expect=t3, solve=True)
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (258, 250, 70), (0.25, 0.25, 0.5), foci=[[0, 0, 15e-3]], expect=t3, solve=True, fp8=False)
+        _lattice_case(ctx, 28, 10, (1.5, 1.5), (120, 40, 470), (0.5, 0.5, 0.25), foci=[[0, 0, 30e-3]], expect=t3, solve=True)
+        _lattice_case(ctx, 40, 8, (1.5, 1.5), (124, 36, 470), (0.5, 0.5, 0.25), foci=[[0, 0, 30e-3]], expect=t3, solve=True, fp8=False)
+        _lattice_case(ctx, 32, 32, (1.5, 1.5), (130, 132, 250), (0.5, 0.5, 0.5), z0=-2e-3, foci=[[0, 0, 40e-3]], expect=t3, solve=True)
     elif case == "y_slab_fold_only":
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[0, 0, 30e-3]], slab=(13, 14), expect="_k<mx1,my2")
     else:

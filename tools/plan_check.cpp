@@ -180,12 +180,12 @@ static void check_shape(const Shape& S, std::mt19937_64& rng, int nt_force) {
         for (int e = 0; e < n; e += 3) bad[e] += 1e-7 * (1 + e % 5);
         CHECK(!infer_foci(true, n, F, pos.data(), bad.data(), c0, origin[2], got), "scrambled delays accepted");
     }
-    // ---- block records of every shape the kernels use: (kxw, zb, limit) = 2g / 2e NT = 2 (3, 16, 40), 2e NT = 1 (6, 16, 0), 2e NT = 4 (2, 16, 0), 2f (8 | 16, 16, 0; positions one pitch apart),
+    // ---- block records of every shape the kernels use: (kxw, zb, limit) = 2g / 2e NT = 2 (3, 16, 40), 2e NT = 1 (6, 16, 0), 2e NT = 4 (2, 16, 0), 2f (8 | 16 | 24, 16, 0; positions one pitch apart),
     // each in every order of the records over the XCDs the host may choose (grp plane blocks -- or plane blocks x y cosets -- in a row on one XCD)
     struct Form { const char* name; int kxw, zb; unsigned grp; int max_pos; int xs; };
     std::vector<Form> forms;
     for (unsigned grp : {1u, 2u, 4u, 16u, 48u, 192u})
-        for (const Form& f0 : {Form{"2g", 3, 16, 2, 40, 2}, Form{"2e nt1", 6, 16, 2, 0, 2}, Form{"2e nt4", 2, 16, 2, 0, 2}, Form{"2f", 8, 16, 2, 0, 1}, Form{"2f m2", 16, 16, 2, 0, 1}}) {
+        for (const Form& f0 : {Form{"2g", 3, 16, 2, 40, 2}, Form{"2e nt1", 6, 16, 2, 0, 2}, Form{"2e nt4", 2, 16, 2, 0, 2}, Form{"2f", 8, 16, 2, 0, 1}, Form{"2f m2", 16, 16, 2, 0, 1}, Form{"2f m3", 24, 16, 2, 0, 1}}) {
             Form f = f0; f.grp = grp; forms.push_back(f);
         }
     for (const Form& fm : forms) {
