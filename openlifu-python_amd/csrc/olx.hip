@@ -763,6 +763,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     if (c->toep_nsa > 16) return fail(c, OLX_ESTATE, "kernel 2f: more than 16 super-block columns");      // (ks_mask holds 2 bits per column)
                     c->toep_ksmask = 0;
                     int ksteps_total = 0;       // non-zero K-steps over the super-block columns
+                    int e4_units = 0;           // matrix units of the e4m3 instructions per element row and y position, over the columns
                     for (int sa = 0; sa < c->toep_nsa; ++sa) {
                         const int wdt = std::min(c->toep_saw, A.ax - sa * c->toep_saw);      // elements of this column
                         // table columns with weights: ud' = xs kx - al + (saw - 1), al < wdt, kx < KXW  ->  [saw - wdt, saw - 1 + xs (KXW - 1)]
@@ -772,6 +773,7 @@ static int configure_variant_impl(olx_ctx* c) {
                         if (hi_c >= 16) m |= 2u;
                         c->toep_ksmask |= m << (2 * sa);
                         ksteps_total += (int)(m & 1u) + (int)(m >> 1);
+                        e4_units += (c->toep_nm == 3 && m == 2u) ? 1 : 2;      // (three row tiles: a column with K-step 1 only takes its element rows in pairs, k_toep.hip)
                     }
                     for (int q = 0; q < 4; ++q) c->toep_targets[q] = tiles[0][0].tgt[q];
                     if (c->cell_cap < A.cell.size()) {
@@ -794,7 +796,7 @@ static int configure_variant_impl(olx_ctx* c) {
                     long long n_mfma = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     // per element row and y position: 3 fp16 products per non-zero K-step, or 1 per non-zero K-step + one e4m3 instruction (2 units) per column
-                    const double per_row = far_frac * ((double)ksteps_total + 2.0 * c->toep_nsa) + (1.0 - far_frac) * 3.0 * ksteps_total;
+                    const double per_row = far_frac * ((double)ksteps_total + (double)e4_units) + (1.0 - far_frac) * 3.0 * ksteps_total;
                     for (int rx = 0; rx < Q.xs * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry) {
                             const int kxa = rx < wx ? (wx - 1 - rx) / (Q.xs * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
