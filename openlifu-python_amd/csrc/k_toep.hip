@@ -18,7 +18,8 @@ namespace olx {
 //     acc_ky[(kx, o), plane] += A_b . B_{ky - b}          v_mfma_f32_16x16x32_f16, fp16 hi/lo split, 3 products.
 // M = 8 positions x (re, im) = 16/16 rows, N = 16 planes = 16/16 columns, K = 30 offsets x (re, im) -> 64 (47 - 81 % dense,
 // the Toeplitz band): ~2.6 x fewer matrix instructions than 2e's NT = 1 shape on BASELINE's grids.
-//   * Block = (coset, x part <= 8 positions, y part <= 11 positions, 16 planes), 4 waves.  Elements are walked in
+//   * Block = (coset, x part <= 8 NM positions -- NM = 1, 2, 3 row tiles that share tables and weights: ToepShape, k_toep.hip.h --, y part <= 11 positions,
+//     16 planes), 8 waves = 4 y-position groups x 2 halves of the contraction.  Elements are walked in
 //     super-blocks of 16 (a) x 8 (b); per super-block the block evaluates ONE table of 18 x <= 30 offsets for each of its 16
 //     planes -- shared by all waves, (row, offset) pairs across the threads, the 16 planes in a register loop so that dx^2 +
 //     dy^2 is formed once per pair -- as fp16 (re, im) hi and lo words in LDS.
