@@ -316,6 +316,66 @@ __global__ __launch_bounds__(ToepShape<NM>::WAVES * 64, ToepShape<NM>::MINW) voi
                 }
                 return;
             }
+            if constexpr (NMM == 2 && FP8) {
+                // Arrays up to 17 elements wide: a row of 8 positions meets at most 7 table offsets in K-step 1 (ud' = kx - al + sa_w - 1 <= 23), i.e. 14 of its 32 K
+                // slots.  Two element rows b, b + 1 share ONE K-step-1 operand instead: k-groups 0, 1 hold row b's offsets 16 .. 23 against ITS table row (this
+                // diagonal's), k-groups 2, 3 row b + 1's against the previous diagonal's -- a per-lane row in the fragment address, the weights packed to match
+                // (toep_pack_k, pair_k1).  Per y position and FOUR element rows: 4 + 2 fp16 products and THREE e4m3 instructions whose halves are
+                //   [K0 b0 | K1 (b0, b1)]   [K0 b1 | K0 b2]   [K0 b3 | K1 (b2, b3)]
+                // (a half's bytes follow the same order in both operands, whichever rows it holds) = 12 matrix units instead of 16; every half meets fragments of this
+                // diagonal or the previous one, whose e4m3 piece stays in four registers.  Fragment reads per diagonal as before (four 16-byte pieces).
+                static_assert(NB == 4 && NKY == 3, "rows in quads, three y positions per wave");
+                const unsigned pofs = (unsigned)(n16 * TOEP_PSZ + 16 + 4 * (g & 1));
+                const bool odd_row = g >= 2;
+                struct BF2 { uint4 h0, q0, ph, pq; };        // this diagonal's K-step-0 pieces (hi fp16 | e4m3), the paired K-step-1 pieces of (this | previous) diagonal
+                auto load2 = [&](const int step) __attribute__((always_inline)) {
+                    const int m = step / ND, d = step - m * ND - (NB - 1);
+                    int prow = p0 + d, prow1 = p0 + d - 1;   // physical rows of the ring (scalar arithmetic: wave-uniform)
+                    prow = prow >= 2 * TOEP_ROWS ? prow - 2 * TOEP_ROWS : (prow >= TOEP_ROWS ? prow - TOEP_ROWS : prow);
+                    prow1 = prow1 >= 2 * TOEP_ROWS ? prow1 - 2 * TOEP_ROWS : (prow1 >= TOEP_ROWS ? prow1 - TOEP_ROWS : prow1);
+                    const unsigned wm = bbase + (unsigned)(prow * TOEP_TW) + 8u * (unsigned)m;
+                    BF2 f;
+                    f.h0 = *reinterpret_cast<const uint4*>(s_hi + wm); f.q0 = *reinterpret_cast<const uint4*>(s_lo + wm);
+                    if (d >= -(NB - 2)) {                    // (compile-time: the first diagonal holds the last row of a quad only)
+                        const unsigned wp = pofs + (unsigned)((odd_row ? prow1 : prow) * TOEP_TW) + 8u * (unsigned)m;
+                        f.ph = *reinterpret_cast<const uint4*>(s_hi + wp); f.pq = *reinterpret_cast<const uint4*>(s_lo + wp);
+                    } else { f.ph = make_uint4(0u, 0u, 0u, 0u); f.pq = f.ph; }
+                    return f;
+                };
+                auto e4 = [&](floatx4_t c, const uint4 a_lo, const uint4 a_hi, const uint4 b_lo, const uint4 b_hi) __attribute__((always_inline)) {
+                    intx8_t a8, b8;
+                    a8[0] = (int)a_lo.x; a8[1] = (int)a_lo.y; a8[2] = (int)a_lo.z; a8[3] = (int)a_lo.w; a8[4] = (int)a_hi.x; a8[5] = (int)a_hi.y; a8[6] = (int)a_hi.z; a8[7] = (int)a_hi.w;
+                    b8[0] = (int)b_lo.x; b8[1] = (int)b_lo.y; b8[2] = (int)b_lo.z; b8[3] = (int)b_lo.w; b8[4] = (int)b_hi.x; b8[5] = (int)b_hi.y; b8[6] = (int)b_hi.z; b8[7] = (int)b_hi.w;
+                    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 0, 0, 0, 128, 0, 127);      // (E8M0 scales as below)
+                };
+                BF2 cur = load2(0);
+                uint4 qprev = make_uint4(0u, 0u, 0u, 0u);    // the previous diagonal's K-step-0 e4m3 piece
+#pragma unroll
+                for (int step = 0; step < NSTEP; ++step) {
+                    const int m = step / ND, d = step - m * ND - (NB - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < NKY; ++t) {
+                        const int bi = t - d;                // element row of the quad: (t, bi) on the diagonal d
+                        if (bi < 0 || bi >= NB) continue;    // (compile-time)
+                        Half8Bits a0, b0;
+                        a0.u = afr[bi][0]; b0.u = cur.h0;
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0.h, b0.h, acc[m][t], 0, 0, 0);          // K-step 0, hi x hi
+                        if (bi == 0 || bi == 2) {            // K-step 1 of the pair (bi, bi + 1), hi x hi
+                            Half8Bits a1, b1;
+                            a1.u = afr[bi][1]; b1.u = cur.ph;
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1.h, b1.h, acc[m][t], 0, 0, 0);
+                        }
+                        if (bi == 0) acc[m][t] = e4(acc[m][t], afr[0][2], afr[0][3], cur.q0, cur.pq);
+                        else if (bi == 1) acc[m][t] = e4(acc[m][t], afr[1][2], afr[2][2], cur.q0, qprev);
+                        else if (bi == 2) acc[m][t] = e4(acc[m][t], afr[3][2], afr[2][3], qprev, cur.pq);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    qprev = cur.q0;
+                    if (step + 1 < NSTEP) cur = load2(step + 1);
+                }
+                return;
+            }
             // B fragments of one diagonal: hi of this wave's K-step(s) and -- FP8 -- the 32 e4m3 bytes of the table row's two pieces
             struct BF { uint4 h0, h1, q0, q1; };
             auto load = [&](const int step) __attribute__((always_inline)) {
@@ -462,7 +522,8 @@ __global__ __launch_bounds__(ToepShape<NM>::WAVES * 64, ToepShape<NM>::MINW) voi
 __global__ void toep_pack_k(const double* __restrict__ area, int n, const double* __restrict__ delays, const double* __restrict__ apod,
                             const int* __restrict__ perm, double freq, double w_scale, int n_foci,
                             const int* __restrict__ colinfo /*[tiles][32][2]*/, const int* __restrict__ cell /*[ax][ay] -> element*/,
-                            int ax, int ay, int ay_pad, int fp8corr /*1: the two lo pieces hold the row's e4m3 bytes instead*/, int sa_w, int xs, uint4* __restrict__ afrag) {
+                            int ax, int ay, int ay_pad, int fp8corr /*1: the two lo pieces hold the row's e4m3 bytes instead*/, int sa_w, int xs,
+                            int pair_k1 /*1: the K-step-1 pieces of an EVEN row hold rows (b | b + 1), offsets 16 .. 23, in k-groups (0, 1 | 2, 3)*/, uint4* __restrict__ afrag) {
     const int lane = threadIdx.x, tile = blockIdx.y;
     const int sa = blockIdx.x / ay_pad, b = blockIdx.x - sa * ay_pad;
     const int m = lane & 15, g = lane >> 4, kx = m >> 1, o = m & 1;
@@ -472,11 +533,14 @@ __global__ void toep_pack_k(const double* __restrict__ area, int n, const double
         Half8Bits hi, lo;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const int k = 32 * s + 8 * g + jj, udp = k >> 1, c = k & 1;
+            const int k = 32 * s + 8 * g + jj, c = k & 1;
+            const bool paired = pair_k1 && s == 1;       // (odd rows' K-step-1 pieces are not read in that layout: zeros)
+            const int udp = paired ? 16 + 4 * (g & 1) + (jj >> 1) : (k >> 1);
+            const int bb = paired ? b + (g >> 1) : b;
             const int al = xs * kx - (udp - (sa_w - 1)), a = sa_w * sa + al;
             double val = 0.0;
-            if (al >= 0 && al < sa_w && a < ax && b < ay && f >= 0 && f < n_foci) {
-                const int e = cell[(size_t)a * ay + b];
+            if (al >= 0 && al < sa_w && a < ax && bb < ay && f >= 0 && f < n_foci && !(paired && (b & 1))) {
+                const int e = cell[(size_t)a * ay + bb];
                 if (e >= 0) {
                     const int es = perm[mirror * n + e];
                     const size_t off = (size_t)f * n + es;
@@ -522,7 +586,8 @@ void olx_pack_toep(olx_ctx* c) {
     const olx_ctx::Lattice& A = c->lat;
     dim3 g(c->toep_nsa * 8 * A.nsb, c->mp.n_tiles);
     hipLaunchKernelGGL(toep_pack_k, g, dim3(64), 0, c->stream, c->d_area, c->n_el, c->d_delays, c->d_apod, c->d_perm, c->freq,
-                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->fp8corr ? 1 : 0, c->toep_saw, c->cp.xs, c->d_afrag);
+                       c->mfma_wscale, c->plan_foci, c->d_colinfo, c->d_cell, A.ax, A.ay, 8 * A.nsb, c->fp8corr ? 1 : 0, c->toep_saw, c->cp.xs,
+                       (c->fp8corr && c->toep_nm == 2) ? 1 : 0, c->d_afrag);
 }
 
 template <int MX, int MY>

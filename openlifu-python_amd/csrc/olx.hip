@@ -796,7 +796,9 @@ static int configure_variant_impl(olx_ctx* c) {
                     long long n_mfma = 0;
                     const int wx = P.nx - L.x_lo, wy = P.ny - L.y_lo;
                     // per element row and y position: 3 fp16 products per non-zero K-step, or 1 per non-zero K-step + one e4m3 instruction (2 units) per column
-                    const double per_row = far_frac * ((double)ksteps_total + (double)e4_units) + (1.0 - far_frac) * 3.0 * ksteps_total;
+                    // (two row tiles, e4m3: rows in quads with paired K-step-1 operands -- 6 fp16 products + 3 e4m3 instructions per four rows: 3 units per row, k_toep.hip)
+                    const double units_e4m3 = c->toep_nm == 2 ? 3.0 : (double)ksteps_total + (double)e4_units;
+                    const double per_row = far_frac * units_e4m3 + (1.0 - far_frac) * 3.0 * ksteps_total;
                     for (int rx = 0; rx < Q.xs * A.mx; ++rx)
                         for (int ry = 0; ry < A.my; ++ry) {
                             const int kxa = rx < wx ? (wx - 1 - rx) / (Q.xs * A.mx) + 1 : 0, kya = ry < wy ? (wy - 1 - ry) / A.my + 1 : 0;
