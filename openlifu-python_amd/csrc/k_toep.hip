@@ -503,7 +503,13 @@ __global__ __launch_bounds__(ToepShape<NM>::WAVES * 64, ToepShape<NM>::MINW) voi
                 const unsigned oy = (unsigned)((fy ? (P.ny - 1 - j) : j) * P.nz);                 // scalar
                 float* dst = vol + (long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy);      // (32-bit offset within the focus volume)
                 if (!OLX_IN((long long)(code >> 2) * P.vox + ((fx ? ox1 : ox0) + oy) + (FULL4 ? 3 : 0), (long long)P.n_foci * P.vox, 5)) continue;
-                if constexpr (FULL4) *reinterpret_cast<floatx4u_t*>(dst) = floatx4u_t{v[0], v[1], v[2], v[3]};
+                if constexpr (FULL4) {
+                    // the walking shape stores non-temporally: its blocks overflow the XCD's L2 between the two halves of a 128-byte line (19.6 M instead of 16.8 M
+                    // write requests per launch on configs[3]) -- 1.263 -> 1.215 ms, same box, alternating.  The two-tile shapes keep plain stores: non-temporal ones
+                    // gain 1.5 % at 128^3 and LOSE 5 % at 256^3, where the lines do meet in L2 (profiles/r06_toep_phases.txt (11)).
+                    if constexpr (NM == 3) __builtin_nontemporal_store(floatx4u_t{v[0], v[1], v[2], v[3]}, reinterpret_cast<floatx4u_t*>(dst));
+                    else *reinterpret_cast<floatx4u_t*>(dst) = floatx4u_t{v[0], v[1], v[2], v[3]};
+                }
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (kz + e < P.nz) dst[e] = v[e];
