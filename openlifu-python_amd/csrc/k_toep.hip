@@ -44,8 +44,8 @@ namespace olx {
 // M2 (round 5; arrays up to 17 elements wide, i.e. every 16 x 16 array): TWO row tiles per block -- positions kx = 0 .. 7 and 8 .. 15 of the coset, the
 // whole half axis on BASELINE's grids -- that share the block's tables AND its Toeplitz weights: A[(kx + 8, o), ud'] = A[(kx, o), ud' - 8], so the
 // second tile is the same A fragment against the table row read 8 columns further on (32 bytes: the fragment reads stay aligned and
-// conflict-free; what they overrun -- the first columns of the next row, the plane's pad -- meets zero weights and is finite because the whole
-// arena is cleared at block entry).  Same matrix instructions as two blocks of <= 8 positions; one table of <= 31 columns instead of two of
+// conflict-free; what they overrun -- the first columns of the next row, the plane's pad -- meets zero weights and is finite because every
+// word no generation round writes is cleared at block entry).  Same matrix instructions as two blocks of <= 8 positions; one table of <= 31 columns instead of two of
 // <= 23, half the block prologues, barriers and weight loads per position.
 // NM = 3 (round 6; arrays wider than 17 elements, e.g. BASELINE configs[3]): THREE row tiles -- 24 positions along x -- on 48-word table rows, one block per CU
 // (ToepShape<3>, k_toep.hip.h): a table entry then serves 2.1 positions along x instead of one in four.
