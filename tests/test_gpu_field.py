@@ -956,6 +956,66 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
     _lattice_case(ctx, 16, 20, (3.0, 2.0), (40, 44, 24), (1.0, 1.0, 1.0), foci=foci[:1], expect="field_coset_k<nt1")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp8", [None, False])
+def test_single_column_kernel_wide_arrays_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
+    """Kernel 2f's three-row-tile shape (round 6: arrays wider than 17 elements, 24 positions per block on 48-word table rows, one block per CU walking
+    the block records, element rows in pairs where a column of super-blocks fills one K-step) through randomised corners -- widths 18 .. 40 (one or two
+    columns of super-blocks, the last one narrow or not), 4 .. 18 rows, pitches of 2 .. 4 voxels, 17 .. 24 positions of a coset along x in ragged parts,
+    ragged y parts and last plane blocks, grids from above and through the element plane -- each compared with kernel 2a (exact per pair) on the same
+    inputs, with the e4m3 correction products where the planner allows them and opted out."""
+    rng = np.random.default_rng(2718)
+    seen3 = 0
+    for case in range(10):
+        nax, nay = int(rng.integers(18, 41)), int(rng.integers(4, 19))
+        mxv, myv = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+        h = 0.5
+        kx = int(rng.integers(17, 25))                                   # positions of a coset along the half axis
+        nx = 2 * (mxv * (kx - 1) + int(rng.integers(1, mxv + 1)))        # even or odd counts both fold: centred grid
+        nx += int(rng.integers(0, 2))
+        ny = int(rng.integers(20, 60))
+        # enough plane blocks for a record per CU: cosets x parts x plane blocks >= 256
+        ky = (ny - ny // 2 - 1) // myv + 1
+        per_pb = mxv * myv * ((ky + 10) // 11)
+        nz = 16 * ((256 + per_pb - 1) // per_pb) + int(rng.integers(-5, 6))
+        z0 = -2.0 if case % 4 == 3 else 4.0
+        a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+        pos = np.stack([(a.ravel() - (nax - 1) / 2) * mxv * h, (b.ravel() - (nay - 1) / 2) * myv * h, np.zeros(nax * nay)], axis=1)
+        foci = np.array([[0.0, 0.0, (z0 + 0.5 * nz * h) * 1e-3]])
+        size = np.tile([0.9 * mxv * h, 0.9 * myv * h], (nax * nay, 1))
+        pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, apod=("maxangle", 70.0, 0.0), solve=True)
+        xs = (np.arange(nx) - (nx - 1) / 2) * h * 1e-3
+        ys = (np.arange(ny) - (ny - 1) / 2) * h * 1e-3
+        zs = (z0 + np.arange(nz) * h) * 1e-3
+        got = {}
+        for fam in ("auto", "general"):
+            if fam == "auto":
+                monkeypatch.delenv("OLX_FIELD_VARIANT", raising=False)
+            else:
+                monkeypatch.setenv("OLX_FIELD_VARIANT", fam)
+            ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, (nx, ny, nz), F0, C, RHO, P0,
+                           flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.FIELD_FP16_CORRECTION if fp8 is False else 0))
+            ctx.field_launch()
+            got[fam] = (ctx.field_variant(), ctx.field_fetch(0)["pmag"], ctx.field_fetch(0)["intensity"])
+        name = got["auto"][0]
+        assert "field_accum" in got["general"][0], got["general"][0]
+        if "field_toep_k" not in name:      # (arrays whose padding to 8 x 8 super-blocks would more than double their K slots are not taken as lattices: kernel 2b)
+            assert "field_shared_k" in name or "field_mfma_k" in name, name
+        seen3 += "3 row tile(s)" in name
+        ref_p, ref_i = got["general"][1], got["general"][2]
+        # (kernel 2a is itself an fp32 evaluation -- 1 - 2e-6 of the maximum on these deep grids -- hence 5e-6 as in the lattice fuzz above; the gate is 1e-5.
+        # The e4m3 bound is stated against the focal peak, which lies inside these volumes.)
+        tol = FP8_BOUND if "fp8corr" in name else 5e-6
+        err = np.abs(got["auto"][1] - ref_p).max() / ref_p.max()
+        if err > tol:       # which of the two fp32 evaluations is off?  (a grid through the element plane has its maximum beside an element: the fp64 oracle decides)
+            ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], ap[0], F0, C, P0, dmin=0.5 * h * 1e-3))
+            e_auto, e_2a = np.abs(got["auto"][1] - ref).max() / ref.max(), np.abs(ref_p - ref).max() / ref.max()
+            assert e_auto <= tol, (case, name, nax, nay, mxv, myv, (nx, ny, nz), "vs 2a", err, "vs oracle", e_auto, "2a vs oracle", e_2a)
+            ref_i = fo.intensity_wcm2(ref, RHO, C)
+        assert np.abs(got["auto"][2] - ref_i).max() <= 2 * tol * ref_i.max(), (case, name)
+    assert seen3 >= 5, seen3
+
+
 @pytest.mark.parametrize("case", ["2g_nt2", "2g_ragged_nz", "2e_nt1", "2f"])
 def test_one_output_only_equals_the_two_output_launch(ctx, case):
     """|p| alone and intensity alone (OLX_OUT_PMAG / OLX_OUT_INTENSITY) give the bits of the launch that writes both: kernel 2g has its own
