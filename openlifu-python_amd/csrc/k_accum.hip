@@ -25,7 +25,9 @@ namespace olx {
 // ------------------------------------------------------------------------------------
 
 
-template <int ZPL, bool FLAT, bool CLAMP>
+//   NEAR : some voxel comes within a quarter wavelength of an element (host: min_dist) -- coordinates as (voxel index, residual), see below; else absolute fp32
+//          coordinates (one subtraction per axis: the split form costs 5 % of the launch -- jittered array, single focus, 256^3: 1.074 -> 1.128 ms).
+template <int ZPL, bool FLAT, bool CLAMP, bool NEAR>
 __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
     const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
     float* __restrict__ cplx, const FieldParams P) {
@@ -38,22 +40,30 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
     const int chunk = (int)(lane_id - row * cpr);
     const int i = (int)(row / P.ny), j = (int)(row - (long long)i * P.ny);
     const int k0 = chunk * ZPL;
-    const float x = (float)(i + P.x_begin) * P.hx;
-    const float y = (float)j * P.hy;
+    // Coordinates as (voxel index, residual): an element is { nearest voxel index, offset from that voxel } per axis (steer_pack_k, split), so that
+    // x_v - x_e = (i - i_e) h - f_e with an EXACT index difference -- formed from absolute fp32 coordinates the difference carried the rounding of a
+    // coordinate of ~ 10 wavelengths (1e-6) into distances of a fraction of a wavelength: 1.07e-5 of the volume maximum on a 72 mm wide 0.5 mm grid
+    // through the element plane (round 6, tools/probe/kernel2a_near_plane.py; the lattice kernels always worked from index differences).
+    // Away from the elements (every distance >= a quarter wavelength) the rounding is <= 1e-6 of a term and the kernel keeps its absolute coordinates.
+    const float xi = NEAR ? (float)(i + P.x_begin) : (float)(i + P.x_begin) * P.hx, yj = NEAR ? (float)j : (float)j * P.hy;
+    // (the spacings in VECTOR registers: an fma reads ONE scalar operand on this part -- with h and f_e both scalar the compiler copies one per element)
+    float hxv = P.hx, hyv = P.hy, hzv = P.hz;
+    asm volatile("" : "+v"(hxv), "+v"(hyv), "+v"(hzv));
     float z[ZPL], re[ZPL], im[ZPL];
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
-        z[q] = (float)(k0 + q) * P.hz;
-        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+        z[q] = NEAR ? (float)(k0 + q) : (float)(k0 + q) * P.hz;  // plane index | coordinate
+        if (FLAT) { const float dz = NEAR ? fmaf(z[q] - P.flat_kz, P.hz, -P.flat_fz) : z[q] - P.flat_ez; z[q] = dz * dz; }
         re[q] = 0.f; im[q] = 0.f;
     }
     const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
 #pragma unroll 2
     for (int e = 0; e < P.n_el; ++e) {
-        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
+        const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];      // voxel indices of the element (integers) ...
         const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
         const float phi = t[e * TAB_STRIDE + 4];
-        const float dx = x - ex, dy = y - ey;
+        const float fx = t[e * TAB_STRIDE + 5], fy = t[e * TAB_STRIDE + 6], fz = t[e * TAB_STRIDE + 7];      // ... and its offsets from them [wavelengths]
+        const float dx = NEAR ? fmaf(xi - ex, hxv, -fx) : xi - ex, dy = NEAR ? fmaf(yj - ey, hyv, -fy) : yj - ey;
         const float r2 = fmaf(dy, dy, dx * dx);
         // Two voxels per packed fp32 instruction (v_pk_add / v_pk_fma / v_pk_mul: the five plain operations of a pair; the three transcendentals
         // stay scalar) -- same bits; jittered array, single focus, 256^3: 1.154 -> 1.080 ms (same box, alternating: round 6)
@@ -62,7 +72,11 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
             for (int q = 0; q < ZPL; q += 2) {
                 float2_t d2;
                 if (FLAT) d2 = float2_t{r2, r2} + float2_t{z[q], z[q + 1]};
-                else { const float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez}; d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2}); }
+                else {
+                    float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez};
+                    if constexpr (NEAR) dz = __builtin_elementwise_fma(dz, float2_t{hzv, hzv}, float2_t{-fz, -fz});
+                    d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2});
+                }
                 if (CLAMP) { d2.x = fmaxf(d2.x, P.dmin2); d2.y = fmaxf(d2.y, P.dmin2); }
                 const float2_t ri = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
                 const float2_t ph = __builtin_elementwise_fma(d2, ri, float2_t{phi, phi});
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_k(
             if (FLAT) {
                 d2 = r2 + z[q];
             } else {
-                const float dz = z[q] - ez;
+                const float dz = NEAR ? fmaf(z[q] - ez, hzv, -fz) : z[q] - ez;
                 d2 = fmaf(dz, dz, r2);
             }
             if (CLAMP) d2 = fmaxf(d2, P.dmin2);
@@ -143,24 +157,24 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_dir_k(
     const int chunk = (int)(lane_id - row * cpr);
     const int i = (int)(row / P.ny), j = (int)(row - (long long)i * P.ny);
     const int k0 = chunk * ZPL;
-    const float x = (float)(i + P.x_begin) * P.hx;
-    const float y = (float)j * P.hy;
+    const float xi = (float)(i + P.x_begin), yj = (float)j;      // (index, residual) coordinates as in field_accum_k
     float z[ZPL], re[ZPL], im[ZPL];
 #pragma unroll
-    for (int q = 0; q < ZPL; ++q) { z[q] = (float)(k0 + q) * P.hz; re[q] = 0.f; im[q] = 0.f; }
+    for (int q = 0; q < ZPL; ++q) { z[q] = (float)(k0 + q); re[q] = 0.f; im[q] = 0.f; }
     const float* t = tab + (size_t)f * P.n_el * TAB_STRIDE;
     constexpr float TWO_PI = 6.283185307179586f;
     for (int e = 0; e < P.n_el; ++e) {
         const float ex = t[e * TAB_STRIDE + 0], ey = t[e * TAB_STRIDE + 1];
         const float ez = t[e * TAB_STRIDE + 2], w = t[e * TAB_STRIDE + 3];
         const float phi = t[e * TAB_STRIDE + 4];
+        const float fx = t[e * TAB_STRIDE + 5], fy = t[e * TAB_STRIDE + 6], fz = t[e * TAB_STRIDE + 7];
         const float* a = tab2 ? tab2 + (size_t)e * 8 : t;      // (no frames: never read)
-        const float dx = x - ex, dy = y - ey;
+        const float dx = fmaf(xi - ex, P.hx, -fx), dy = fmaf(yj - ey, P.hy, -fy);
         const float r2 = fmaf(dy, dy, dx * dx);
         const float px = tab2 ? fmaf(dy, a[1], dx * a[0]) : 0.f, py = tab2 ? fmaf(dy, a[5], dx * a[4]) : 0.f;   // lateral part of r . ex, r . ey
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
-            const float dz = z[q] - ez;
+            const float dz = fmaf(z[q] - ez, P.hz, -fz);
             float d2 = fmaf(dz, dz, r2);
             if (CLAMP) d2 = fmaxf(d2, P.dmin2);
             const float ri = __builtin_amdgcn_rsqf(d2);
@@ -205,7 +219,8 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_accum_dir_k(
 // (lanes cover only the upper half of that axis and also write the mirrored voxel),
 // NF = foci per tile (blockIdx.y = tile).  Exact: no approximation is involved, only
 // re-association of which (voxel, element) pair is evaluated where.
-// Table entry (tile, e) = { x_e, y_e, z_e, 0, (wr_k, wi_k) k < NOUT },  k = f_local*NM + cx + DX*cy,
+// Table entry (tile, e) = { kx, ky, kz, 0 | fx, fy, fz, 0 | (wr_k, wi_k) k < NOUT },  k = f_local*NM + cx + DX*cy: the element as (index of the nearest
+// coordinate step, offset from it [wavelengths]) per axis -- round 6, as kernel 2a: x_v - x_e = (k_v - k_e) s - f_e with an exact index difference,
 // NM = DX*DY distinct mirror columns (perm[m] passed to the pack kernel lists exactly those).
 // Coordinates on a mirrored axis are taken relative to the grid centre and formed as
 // (2 i - (n-1)) * h/2 so that x(n-1-i) == -x(i) bit for bit.
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
     const float* __restrict__ tab, float* __restrict__ pmag, float* __restrict__ inten,
     float* __restrict__ cplx, const SharedParams P) {
     static_assert(DX <= MX && DY <= MY, "distinct columns cannot exceed the fold");
-    constexpr int NM = DX * DY, NOUT = NM * NF, STRIDE = 4 + 2 * NOUT;
+    constexpr int NM = DX * DY, NOUT = NM * NF, STRIDE = SH_HEAD + 2 * NOUT;
     const int tile = blockIdx.y;
     const unsigned cpr = (unsigned)(P.nz + ZPL - 1) / ZPL;
     const unsigned lane_id = blockIdx.x * FIELD_THREADS + threadIdx.x;
@@ -232,21 +247,27 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
     const int ii = (int)(row / hyn);
     const int i = ii + x_lo, j = (int)(row - (unsigned)ii * hyn) + y_lo;
     const int k0 = chunk * ZPL;
-    const float x = (MX == 2) ? (float)(2 * i - (P.nx - 1)) * (0.5f * P.hx) : (float)(i + P.x_begin) * P.hx;
-    const float y = (MY == 2) ? (float)(2 * j - (P.ny - 1)) * (0.5f * P.hy) : (float)j * P.hy;
+    // NEAR (= the CLAMP instantiations: the host launches them wherever a voxel comes within a quarter wavelength of an element): coordinates as (index, residual);
+    // coordinate steps: half a voxel on a folded axis (x = (2 i - (n - 1)) h / 2 about the grid centre), a voxel otherwise; indices are exact in fp32.
+    // Elsewhere absolute fp32 coordinates as before (the split form costs the tilted array's single focus 9 %: one fma per pair for dz).
+    constexpr bool NEAR = CLAMP;
+    float sxv = (MX == 2) ? 0.5f * P.hx : P.hx, syv = (MY == 2) ? 0.5f * P.hy : P.hy, hzv = P.hz;
+    const float x = ((MX == 2) ? (float)(2 * i - (P.nx - 1)) : (float)(i + P.x_begin)) * (NEAR ? 1.0f : sxv);
+    const float y = ((MY == 2) ? (float)(2 * j - (P.ny - 1)) : (float)j) * (NEAR ? 1.0f : syv);
+    asm volatile("" : "+v"(sxv), "+v"(syv), "+v"(hzv));      // (vector registers: an fma reads one scalar operand)
     float z[ZPL], re[ZPL][NOUT], im[ZPL][NOUT];
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
-        z[q] = (float)(k0 + q) * P.hz;
-        if (FLAT) { const float dz = z[q] - P.flat_ez; z[q] = dz * dz; }
+        z[q] = NEAR ? (float)(k0 + q) : (float)(k0 + q) * P.hz;
+        if (FLAT) { const float dz = NEAR ? fmaf(z[q] - P.flat_kz, P.hz, -P.flat_fz) : z[q] - P.flat_ez; z[q] = dz * dz; }
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) { re[q][k] = 0.f; im[q][k] = 0.f; }
     }
     const float* t = tab + (size_t)tile * P.n_el * STRIDE;
     for (int e = 0; e < P.n_el; ++e) {
         const float* te = t + (size_t)e * STRIDE;
-        const float dx = x - te[0], dy = y - te[1];
-        const float ez = te[2];
+        const float dx = NEAR ? fmaf(x - te[0], sxv, -te[4]) : x - te[0], dy = NEAR ? fmaf(y - te[1], syv, -te[5]) : y - te[1];
+        const float ez = te[2], fz = te[6];
         const float r2 = fmaf(dy, dy, dx * dx);
         float gr[ZPL], gi[ZPL];
         if constexpr (ZPL % 2 == 0) {      // two voxels per packed fp32 instruction, as kernel 2a (same bits): tilted array, single focus 0.372 -> 0.348 ms
@@ -254,7 +275,11 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
             for (int q = 0; q < ZPL; q += 2) {
                 float2_t d2;
                 if (FLAT) d2 = float2_t{r2, r2} + float2_t{z[q], z[q + 1]};
-                else { const float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez}; d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2}); }
+                else {
+                    float2_t dz = float2_t{z[q], z[q + 1]} - float2_t{ez, ez};
+                    if constexpr (NEAR) dz = __builtin_elementwise_fma(dz, float2_t{hzv, hzv}, float2_t{-fz, -fz});
+                    d2 = __builtin_elementwise_fma(dz, dz, float2_t{r2, r2});
+                }
                 if (CLAMP) { d2.x = fmaxf(d2.x, P.dmin2); d2.y = fmaxf(d2.y, P.dmin2); }
                 const float2_t ri = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
                 const float2_t ph = d2 * ri;
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
             }
 #pragma unroll
             for (int k = 0; k < NOUT; ++k) {
-                const float wr = te[4 + 2 * k], wi = te[5 + 2 * k];
+                const float wr = te[SH_HEAD + 2 * k], wi = te[SH_HEAD + 1 + 2 * k];
 #pragma unroll
                 for (int q = 0; q < ZPL; q += 2) {
                     const float2_t g0 = {gr[q], gr[q + 1]}, g1 = {gi[q], gi[q + 1]};
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
             if (FLAT) {
                 d2 = r2 + z[q];
             } else {
-                const float dz = z[q] - ez;
+                const float dz = NEAR ? fmaf(z[q] - ez, hzv, -fz) : z[q] - ez;
                 d2 = fmaf(dz, dz, r2);
             }
             if (CLAMP) d2 = fmaxf(d2, P.dmin2);
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_shared_k(
         }
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
-            const float wr = te[4 + 2 * k], wi = te[5 + 2 * k];
+            const float wr = te[SH_HEAD + 2 * k], wi = te[SH_HEAD + 1 + 2 * k];
 #pragma unroll
             for (int q = 0; q < ZPL; ++q) {
                 re[q][k] = fmaf(gr[q], wr, re[q][k]);
@@ -359,10 +384,10 @@ static void launch_shared(olx_ctx* c, float* pm) {
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), (c->plan_foci + NF - 1) / NF);
     dim3 blk(FIELD_THREADS);
     if (c->flat) {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        if (c->near) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
         else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, true, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
     } else {
-        if (c->clamp) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
+        if (c->near) hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, true>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
         else          hipLaunchKernelGGL((field_shared_k<ZPL, MX, MY, DX, DY, NF, false, false>), grid, blk, 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, S);
     }
 }
@@ -393,8 +418,9 @@ static void launch_field(olx_ctx* c, float* pm) {
     const long long cpr = (P.nz + ZPL - 1) / ZPL;
     const long long lanes = (long long)P.nx * P.ny * cpr;
     dim3 grid((unsigned)((lanes + FIELD_THREADS - 1) / FIELD_THREADS), c->plan_foci);
-    hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm,
-                       c->d_inten, c->d_cplx, P);
+    // (the table carries split coordinates where a voxel comes within a quarter wavelength of an element: olx.hip, steer_pack_k)
+    if (CLAMP || c->near) hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP, true>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, P);
+    else hipLaunchKernelGGL((field_accum_k<ZPL, FLAT, CLAMP, CLAMP>), grid, dim3(FIELD_THREADS), 0, c->stream, c->d_tab, pm, c->d_inten, c->d_cplx, P);
 }
 
 bool olx_launch_shared(olx_ctx* c, float* pm) { return dispatch_shared(c, pm); }

@@ -30,12 +30,12 @@ namespace olx {
 
 template <int MT, int NT, int MX, int MY, bool FLAT, bool CLAMP>
 __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
-    const float4* __restrict__ coords /*[n_el_pad]*/, const uint4* __restrict__ bfrag /*[tiles][ks][NT][2][64]*/,
+    const float4* __restrict__ coords /*[n_el_pad][2]: { kx, ky, kz, 0 }, { fx, fy, fz, 0 } -- the element as (index of the nearest coordinate step, offset from it [wavelengths])*/, const uint4* __restrict__ bfrag /*[tiles][ks][NT][2][64]*/,
     float* __restrict__ pmag, float* __restrict__ inten, float* __restrict__ cplx,
     const int* __restrict__ targets /*[tiles][32][4]: focus*4 + image of every store target of a column, -1 = none*/,
     const MfmaParams P) {
     constexpr int CH = MFMA_ELEMS_LDS / NT;              // elements per LDS chunk
-    __shared__ float4 s_xyz[CH];
+    __shared__ float4 s_xyz[CH][2];
     __shared__ uint4 s_B[CH / 16][NT][2][64];
     const int tile = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,13 +52,18 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
     const int zb = (int)(run - row * rpr) * RUN;
     const int ii = (int)(rowc / hyn);
     const int i = ii + x_lo, j = (int)(rowc - (unsigned)ii * hyn) + y_lo;
-    const float x = (MX == 2) ? (float)(2 * i - (P.nx - 1)) * (0.5f * P.hx) : (float)(i + P.x_begin) * P.hx;
-    const float y = (MY == 2) ? (float)(2 * j - (P.ny - 1)) * (0.5f * P.hy) : (float)j * P.hy;
+    // Coordinates as (index, residual), round 6 (as kernels 2a / 2b: x_v - x_e = (k_v - k_e) s - f_e with an exact index difference -- absolute fp32 coordinates
+    // lose 1e-6 wavelengths, which is 1e-5 of a term a tenth of a wavelength from its element); steps: half a voxel on a folded axis, a voxel otherwise
+    // NEAR = the CLAMP instantiations (the host launches them wherever a voxel comes within a quarter wavelength of an element); elsewhere absolute coordinates as before
+    constexpr bool NEAR = CLAMP;
+    const float sx = (MX == 2) ? 0.5f * P.hx : P.hx, sy = (MY == 2) ? 0.5f * P.hy : P.hy;
+    const float x = ((MX == 2) ? (float)(2 * i - (P.nx - 1)) : (float)(i + P.x_begin)) * (NEAR ? 1.0f : sx);
+    const float y = ((MY == 2) ? (float)(2 * j - (P.ny - 1)) : (float)j) * (NEAR ? 1.0f : sy);
     float zz[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        zz[t] = (float)(zb + 16 * t + r16) * P.hz;
-        if (FLAT) { const float dz = zz[t] - P.flat_ez; zz[t] = dz * dz; }
+        zz[t] = NEAR ? (float)(zb + 16 * t + r16) : (float)(zb + 16 * t + r16) * P.hz;
+        if (FLAT) { const float dz = NEAR ? fmaf(zz[t] - P.flat_kz, P.hz, -P.flat_fz) : zz[t] - P.flat_ez; zz[t] = dz * dz; }
     }
     floatx4_t acc[MT][NT];
 #pragma unroll
@@ -70,19 +75,19 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
     for (int chunk = 0; chunk < P.n_el_pad; chunk += CH) {
         const int n_here = min(CH, P.n_el_pad - chunk), nks = n_here / 16;
         __syncthreads();
-        if (tid < n_here) s_xyz[tid] = coords[chunk + tid];
+        for (int q = tid; q < 2 * n_here; q += FIELD_THREADS) (&s_xyz[0][0])[q] = coords[2 * chunk + q];
         const uint4* src = bfrag + ((size_t)tile * ks_total + chunk / 16) * (NT * 128);
         for (int q = tid; q < nks * NT * 128; q += FIELD_THREADS) (&s_B[0][0][0][0])[q] = src[q];
         __syncthreads();
         if (!active) continue;
         for (int ks = 0; ks < nks; ++ks) {
-            float r2[4], ez[4];
+            float r2[4], ez[4], fz[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 e = s_xyz[16 * ks + 4 * g + q];
-                const float dx = x - e.x, dy = y - e.y;
+                const float4 e = s_xyz[16 * ks + 4 * g + q][0], f = s_xyz[16 * ks + 4 * g + q][1];
+                const float dx = NEAR ? fmaf(x - e.x, sx, -f.x) : x - e.x, dy = NEAR ? fmaf(y - e.y, sy, -f.y) : y - e.y;
                 r2[q] = fmaf(dy, dy, dx * dx);
-                ez[q] = e.z;
+                ez[q] = e.z; fz[q] = f.z;
             }
             // B fragments of this K-step stay in registers and are reused by all MT voxel tiles.
             Half8Bits bh[NT], bl[NT];
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_mfma_k(
                     if (FLAT) {
                         d2 = r2[q] + zz[t];
                     } else {
-                        const float dz = zz[t] - ez[q];
+                        const float dz = NEAR ? fmaf(zz[t] - ez[q], P.hz, -fz[q]) : zz[t] - ez[q];
                         d2 = fmaf(dz, dz, r2[q]);
                     }
                     if (CLAMP) d2 = fmaxf(d2, P.dmin2);
@@ -201,8 +206,8 @@ static void launch_mfma(olx_ctx* c, float* pm) {
     const long long runs = (long long)(M.nx - (MX == 2 ? M.nx / 2 : 0)) * (M.ny - (MY == 2 ? M.ny / 2 : 0)) * rpr;
     dim3 grid((unsigned)((runs + 3) / 4), M.n_tiles), blk(FIELD_THREADS);
 #define OLX_MF(FL, CL) hipLaunchKernelGGL((field_mfma_k<MT, NT, MX, MY, FL, CL>), grid, blk, 0, c->stream, c->d_coords, c->d_bfrag, pm, c->d_inten, c->d_cplx, c->d_targets, M)
-    if (c->flat) { if (c->clamp) OLX_MF(true, true); else OLX_MF(true, false); }
-    else         { if (c->clamp) OLX_MF(false, true); else OLX_MF(false, false); }
+    if (c->flat) { if (c->near) OLX_MF(true, true); else OLX_MF(true, false); }      // (near: a voxel within a quarter wavelength of an element -- the clamp instantiations carry the split coordinates)
+    else         { if (c->near) OLX_MF(false, true); else OLX_MF(false, false); }
 #undef OLX_MF
 }
 

@@ -140,6 +140,7 @@ __global__ void steer_pack_k(const double* __restrict__ pos, const double* __res
                              const double* __restrict__ delays, const double* __restrict__ apod,
                              double ox, double oy, double oz, double freq, double p0_over_lambda,
                              double rev, const int* __restrict__ kfirst, const int* __restrict__ klast,
+                             double hx_m, double hy_m, double hz_m /* spacing [m]: > 0 = SPLIT coordinates (kernel 2a) */,
                              float* __restrict__ tab) {
     const int f = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,11 +148,22 @@ __global__ void steer_pack_k(const double* __restrict__ pos, const double* __res
     const size_t o = ((size_t)f * n + e);
     const double cyc = freq * delays[o];
     float* t = tab + o * TAB_STRIDE;
+    t[3] = (float)(apod[o] * area[e] * p0_over_lambda * rev);
+    t[4] = (float)(cyc - floor(cyc));
+    if (hx_m > 0.0) {
+        // kernel 2a: { voxel index nearest the element (an integer, exact in fp32), ... } and { offset from that voxel [wavelengths] }: the kernel forms
+        // x_v - x_e = (i - i_e) h - f_e from an exact index difference instead of subtracting two rounded coordinates of ~ 10 wavelengths
+        const double q[3] = {pos[e] - ox, pos[n + e] - oy, pos[2 * n + e] - oz}, h[3] = {hx_m, hy_m, hz_m};
+        for (int a = 0; a < 3; ++a) {
+            const double k = rint(q[a] / h[a]);
+            t[a] = (float)k;
+            t[5 + a] = (float)((q[a] - k * h[a]) * rev);
+        }
+        return;
+    }
     t[0] = (float)((pos[e] - ox) * rev);
     t[1] = (float)((pos[n + e] - oy) * rev);
     t[2] = (float)((pos[2 * n + e] - oz) * rev);
-    t[3] = (float)(apod[o] * area[e] * p0_over_lambda * rev);
-    t[4] = (float)(cyc - floor(cyc));
     t[5] = kfirst ? __int_as_float(kfirst[e]) : 0.f;  // kernel 2h: planes strictly above / below the element
     t[6] = klast ? __int_as_float(klast[e]) : 0.f;
     t[7] = 0.f;
@@ -163,16 +175,21 @@ __global__ void steer_pack_shared_k(const double* __restrict__ pos, const double
                                     const double* __restrict__ delays, const double* __restrict__ apod,
                                     const int* __restrict__ perm, double ox, double oy, double oz, double freq,
                                     double p0_over_lambda, double rev, int n_foci, int nf, int nm,
+                                    double sx_m, double sy_m, double sz_m /* coordinate steps [m]: half a voxel on a folded axis, a voxel otherwise */,
                                     float* __restrict__ tab) {
     const int tile = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const int nout = nf * nm, stride = 4 + 2 * nout;
+    const int nout = nf * nm, stride = SH_HEAD + 2 * nout;
     float* t = tab + ((size_t)tile * n + e) * stride;
-    t[0] = (float)((pos[e] - ox) * rev);
-    t[1] = (float)((pos[n + e] - oy) * rev);
-    t[2] = (float)((pos[2 * n + e] - oz) * rev);
-    t[3] = 0.f;
+    {   // the element as (index of the nearest coordinate step -- exact in fp32 --, offset from it [wavelengths]) per axis
+        const double q[3] = {pos[e] - ox, pos[n + e] - oy, pos[2 * n + e] - oz}, st[3] = {sx_m, sy_m, sz_m};
+        for (int a = 0; a < 3; ++a) {
+            if (sx_m > 0.0) { const double k = rint(q[a] / st[a]); t[a] = (float)k; t[4 + a] = (float)((q[a] - k * st[a]) * rev); }
+            else { t[a] = (float)(q[a] * rev); t[4 + a] = 0.f; }      // (absolute coordinates [wavelengths]: no voxel within a wavelength of an element)
+        }
+        t[3] = 0.f; t[7] = 0.f;
+    }
     for (int k = 0; k < nout; ++k) {
         const int f = tile * nf + k / nm, m = k % nm;
         float wr = 0.f, wi = 0.f;
@@ -185,8 +202,8 @@ __global__ void steer_pack_shared_k(const double* __restrict__ pos, const double
             wr = (float)(w * cos(ph));
             wi = (float)(w * sin(ph));
         }
-        t[4 + 2 * k] = wr;
-        t[5 + 2 * k] = wi;
+        t[SH_HEAD + 2 * k] = wr;
+        t[SH_HEAD + 1 + 2 * k] = wi;
     }
 }
 
@@ -202,13 +219,22 @@ __global__ void mfma_pack_k(const double* __restrict__ pos, const double* __rest
                             int fp8corr /*1 = kernel 2e / 2g, NT <= 2: the second fragment holds e4m3 [hi(k0), hi(k1), lo(k0), lo(k1)] per element*/,
                             int split_reim /*1 = kernel 2g (NT = 2): matrix column c of column tile 0 is Re, of column tile 1 Im of steering column c --
                                              a lane's accumulators then hold both parts of its voxels; 0 = (Re, Im) in adjacent matrix columns*/,
-                            float4* __restrict__ coords, uint4* __restrict__ bfrag) {
+                            double sx_m, double sy_m, double sz_m /* kernel 2c: coordinate steps [m] (half a voxel on a folded axis, a voxel otherwise) */,
+                            float4* __restrict__ coords /*[n_pad][2], kernel 2c*/, uint4* __restrict__ bfrag) {
     const int ks = blockIdx.x, tile = blockIdx.y, nt = blockIdx.z, NT = gridDim.z, lane = threadIdx.x;
     if (!slot_elem && tile == 0 && nt == 0 && lane < 16) {
+        // the element as (index of the nearest coordinate step -- exact in fp32 --, offset from it [wavelengths]) per axis: field_mfma_k
         const int e = 16 * ks + lane;
-        coords[e] = (e < n) ? make_float4((float)((pos[e] - ox) * rev), (float)((pos[n + e] - oy) * rev),
-                                          (float)((pos[2 * n + e] - oz) * rev), 0.f)
-                            : make_float4(1.0e4f, 1.0e4f, 1.0e4f, 0.f);  // padding: far away, zero weight
+        float kf[3] = {1.0e5f, 1.0e5f, 1.0e5f}, ff[3] = {0.f, 0.f, 0.f};      // padding: far away (steps or wavelengths), zero weight
+        if (e < n) {
+            const double q[3] = {pos[e] - ox, pos[n + e] - oy, pos[2 * n + e] - oz}, st[3] = {sx_m, sy_m, sz_m};
+            for (int a = 0; a < 3; ++a) {
+                if (sx_m > 0.0) { const double k = rint(q[a] / st[a]); kf[a] = (float)k; ff[a] = (float)((q[a] - k * st[a]) * rev); }
+                else { kf[a] = (float)(q[a] * rev); ff[a] = 0.f; }      // (absolute coordinates: no voxel within a wavelength of an element)
+            }
+        }
+        coords[2 * e] = make_float4(kf[0], kf[1], kf[2], 0.f);
+        coords[2 * e + 1] = make_float4(ff[0], ff[1], ff[2], 0.f);
     }
     const int g = lane >> 4, c = lane & 15, o = split_reim ? c : nt * 8 + (c >> 1), part_c = split_reim ? nt : c & 1;
     const int col_focus = colinfo[((size_t)tile * (MFMA_COLS * MFMA_MAX_NT) + o) * 2];

@@ -568,7 +568,7 @@ static int configure_variant_impl(olx_ctx* c) {
         if (c->coords_cap < (size_t)n_pad) {
             if (c->d_coords) hipFree(c->d_coords);
             c->d_coords = nullptr; c->coords_cap = 0;
-            HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * n_pad));
+            HIPCHK(c, hipMalloc((void**)&c->d_coords, sizeof(float4) * 2 * n_pad));      // (index, residual) per element: kernel 2c
             c->coords_cap = n_pad;
         }
         c->bfrag_half = (size_t)ntiles * (n_pad / 16) * 128 * c->nt;      // uint4 per K-step and column tile: hi, lo of the 64 lanes
@@ -604,7 +604,7 @@ static int configure_variant_impl(olx_ctx* c) {
         const FieldParams& P = c->fp;
         MfmaParams& M = c->mp;
         M.nx = P.nx; M.ny = P.ny; M.nz = P.nz; M.n_el_pad = n_pad; M.x_begin = P.x_begin; M.n_tiles = ntiles;
-        M.hx = P.hx; M.hy = P.hy; M.hz = P.hz; M.dmin2 = P.dmin2; M.flat_ez = P.flat_ez;
+        M.hx = P.hx; M.hy = P.hy; M.hz = P.hz; M.dmin2 = P.dmin2; M.flat_ez = P.flat_ez; M.flat_kz = P.flat_kz; M.flat_fz = P.flat_fz;
         M.g_scale = (float)sg; M.out_scale = (float)(1.0 / (sg * sw)); M.inten_scale = P.inten_scale;
         M.vox = P.vox; M.flags = P.flags;
         c->mfma_wscale = c->p0_pa / lambda * rev * sw;
@@ -835,13 +835,13 @@ static int configure_variant_impl(olx_ctx* c) {
             }
         } else {
             snprintf(nmbuf, sizeof nmbuf, "field_mfma_k<mt%d,nt%d,mx%d,my%d,%s,%s> %d columns for %d foci x %d images in %d tile(s)",
-                     P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp", total_cols, F,
+                     P.nz >= 48 ? 4 : 1, c->nt, c->mx, c->my, c->flat ? "flat" : "general", c->clamp ? "clamp" : (c->near ? "near" : "noclamp"), total_cols, F,
                      n_img, ntiles);
         }
     } else if (c->mx * c->my * c->nf == 1) {
         if (c->modifier()) snprintf(nmbuf, sizeof nmbuf, "field_accum_dir_k<4,%s> (%s%s%s)", c->clamp ? "clamp" : "noclamp", c->directivity ? "piston directivity" : "",
                                     (c->directivity && c->absorb_np_m > 0) ? ", " : "", c->absorb_np_m > 0 ? "uniform absorption" : "");
-        else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+        else snprintf(nmbuf, sizeof nmbuf, "field_accum_k<4,%s,%s>", c->flat ? "flat" : "general", c->clamp ? "clamp" : (c->near ? "near" : "noclamp"));
     } else {
         std::vector<int> perm((size_t)nm * n);
         for (int m = 0; m < nm; ++m)
@@ -855,7 +855,7 @@ static int configure_variant_impl(olx_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->d_perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // perm is a stack vector
         c->up_perm.clear();                          // (the lattice / matrix path's remembered copy no longer describes d_perm)
-        const size_t need = (size_t)((F + c->nf - 1) / c->nf) * n * (4 + 2 * nm * c->nf);  // never trust the plan-time bound
+        const size_t need = (size_t)((F + c->nf - 1) / c->nf) * n * (SH_HEAD + 2 * nm * c->nf);  // never trust the plan-time bound
         if (c->tab_cap < need) {
             if (c->d_tab) hipFree(c->d_tab);
             c->d_tab = nullptr; c->tab_cap = 0;
@@ -863,7 +863,7 @@ static int configure_variant_impl(olx_ctx* c) {
             c->tab_cap = need;
         }
         snprintf(nmbuf, sizeof nmbuf, "field_shared_k<4,mx%d,my%d,dx%d,dy%d,nf%d,%s,%s>", c->mx, c->my, c->dx, c->dy, c->nf,
-                 c->flat ? "flat" : "general", c->clamp ? "clamp" : "noclamp");
+                 c->flat ? "flat" : "general", c->clamp ? "clamp" : (c->near ? "near" : "noclamp"));
     }
     if (c->modifier() && c->use_mfma && !(c->use_lattice && c->use_coset)) {   // only the coset kernels (2e / 2f / 2g) carry per-term factors: fall back to 2a-d
         c->dir_lattice = false; c->allow_shared = false;
@@ -888,19 +888,22 @@ static int pack_if_needed(olx_ctx* c) {
         hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
                            c->plan_foci, c->d_colinfo, c->use_lattice ? c->d_slot : nullptr,
-                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, (c->use_lattice && c->use_cosetp) ? 1 : 0, c->d_coords, c->d_bfrag);
+                           (c->use_lattice && c->use_coset && c->fp8corr) ? 1 : 0, (c->use_lattice && c->use_cosetp) ? 1 : 0,
+                           c->near ? (c->mx == 2 ? 0.5 : 1.0) * c->grid.spacing[0] : 0.0, (c->my == 2 ? 0.5 : 1.0) * c->grid.spacing[1], c->grid.spacing[2], c->d_coords, c->d_bfrag);
         if (c->use_lattice && c->use_toep) olx_pack_toep(c);
         if (c->use_lattice && c->use_coset && c->fp8corr && c->cp_nfar < c->cp_nblocks) {   // a launch split at fp8_kcut: the fp16 operands of the plane blocks below the cut
             hipLaunchKernelGGL(mfma_pack_k, g, dim3(64), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->mp.n_el_pad, c->d_delays,
                                c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->mfma_wscale, c->freq / c->c,
-                               c->plan_foci, c->d_colinfo, c->d_slot, 0, c->use_cosetp ? 1 : 0, c->d_coords, c->d_bfrag + c->bfrag_half);
+                               c->plan_foci, c->d_colinfo, c->d_slot, 0, c->use_cosetp ? 1 : 0, 1.0, 1.0, 1.0, c->d_coords, c->d_bfrag + c->bfrag_half);
             if (c->use_toep) { c->fp8corr = false; c->d_afrag += c->afrag_half; olx_pack_toep(c); c->d_afrag -= c->afrag_half; c->fp8corr = true; }
         }
     } else if (c->mx * c->my * c->nf == 1) {
         dim3 g((c->n_el + 127) / 128, c->plan_foci);
+        // split coordinates where a voxel comes within a wavelength of an element (always with the clamp), and for the modifier kernel (field_accum_dir_k)
+        c->tab_split = c->near || c->modifier();
         hipLaunchKernelGGL(steer_pack_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq,
-                           c->p0_pa / lambda, c->freq / c->c, nullptr, nullptr, c->d_tab);
+                           c->p0_pa / lambda, c->freq / c->c, nullptr, nullptr, c->tab_split ? c->grid.spacing[0] : 0.0, c->grid.spacing[1], c->grid.spacing[2], c->d_tab);
         if (c->directivity) {   // frame table: { ex, pi w / lambda (as revolutions: w / (2 lambda)) | ey = n x ex, l / (2 lambda) } per element
             const int n = c->n_el;
             std::vector<float> t2((size_t)n * 8);
@@ -928,7 +931,7 @@ static int pack_if_needed(olx_ctx* c) {
         dim3 g((c->n_el + 127) / 128, tiles);
         hipLaunchKernelGGL(steer_pack_shared_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays,
                            c->d_apod, c->d_perm, ox, oy, c->grid.origin[2], c->freq, c->p0_pa / lambda, c->freq / c->c,
-                           c->plan_foci, c->nf, c->dx * c->dy, c->d_tab);
+                           c->plan_foci, c->nf, c->dx * c->dy, c->near ? (c->mx == 2 ? 0.5 : 1.0) * c->grid.spacing[0] : 0.0, (c->my == 2 ? 0.5 : 1.0) * c->grid.spacing[1], c->grid.spacing[2], c->d_tab);
     }
     HIPCHK(c, hipGetLastError());
     c->packed_version = c->steer_version;
@@ -1012,6 +1015,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     c->flat = true;
     for (int e = 1; e < n; ++e) if (hz[e] != hz[0]) { c->flat = false; break; }
     P.flat_ez = (float)((hz[0] - g->origin[2]) * rev);
+    { const double kz = std::rint((hz[0] - g->origin[2]) / g->spacing[2]); P.flat_kz = (float)kz; P.flat_fz = (float)(((hz[0] - g->origin[2]) - kz * g->spacing[2]) * rev); }
     // clamp needed iff some element lies within dmin (+ fp32 slack) of the slab's bounding box
     double lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
@@ -1034,6 +1038,9 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
         if (d2 < guard * guard) c->clamp = true;
     }
     c->min_dist = c->clamp ? dmin : std::sqrt(min_d2);  // lower bound of any voxel-element distance [m]
+    // a voxel within a QUARTER wavelength of an element: the general kernels (2a / 2b / 2c) then work from index differences (k_accum.hip) -- absolute fp32
+    // coordinates of ~ 10 wavelengths lose 1e-6 wavelengths, i.e. up to 4e-6 of a term at a quarter wavelength and 1.5e-5 at the clamp distance of a 0.25 mm grid
+    c->near = c->clamp || c->min_dist < 0.25 * cs / freq;
     detect_lattice(c, lo, hi, dmin);
     c->nf_s2.clear();     // near-field sums of the e4m3 error bound: derived lazily by configure_variant (fp8_eligible)
     // ---- shared-geometry variant: mirror folds (element set symmetric about the grid centre planes)
@@ -1096,7 +1103,7 @@ int olx_field_plan(olx_ctx* c, const olx_grid* g, const olx_slab* slab, int n_fo
     SharedParams& S = c->sp;
     S.nx = P.nx; S.ny = P.ny; S.nz = P.nz; S.n_el = n; S.x_begin = s.x_begin; S.n_foci = n_foci;
     S.hx = P.hx; S.hy = P.hy; S.hz = P.hz; S.dmin2 = P.dmin2;
-    S.inten_scale = P.inten_scale; S.flat_ez = P.flat_ez; S.vox = P.vox; S.flags = P.flags;
+    S.inten_scale = P.inten_scale; S.flat_ez = P.flat_ez; S.flat_kz = P.flat_kz; S.flat_fz = P.flat_fz; S.vox = P.vox; S.flags = P.flags;
     c->dx = c->mx; c->dy = c->my; c->nf = 1;
     char nm[96] = "(steering-dependent)";
     c->variant = nm;

@@ -38,6 +38,8 @@ struct P2PState;    // olx_p2p.hip: direct peer-to-peer reassembly (OLX_GATHER=p
 struct olx_ctx {
     int device = 0;
     FetchLane* fetch_lanes = nullptr;          // per context, created on the first staged fetch
+    bool near = false;                         // a voxel comes within a quarter wavelength of an element: kernels 2a / 2b / 2c take their coordinates as (index, residual)
+    bool tab_split = false;                    // kernel 2a's table holds such coordinates (near, or the modifier kernel)
     int n_cu = 0;                              // compute units of the device (persistent kernels size their grids by it)
     hipStream_t stream = nullptr;
     std::string err;

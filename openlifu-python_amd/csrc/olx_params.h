@@ -9,6 +9,7 @@
 namespace olx {
 
 constexpr int BF_THREADS = 256;
+constexpr int SH_HEAD = 8;                 // floats of a kernel-2b table entry before its (wr, wi) pairs: { kx, ky, kz, 0, fx, fy, fz, 0 }
 constexpr int TAB_STRIDE = 8;              // floats per packed kernel-2a table entry (one s_load_dwordx8)
 constexpr int FIELD_THREADS = 256;
 
@@ -21,6 +22,7 @@ struct FieldParams {
     float dmin2;           // dmin^2 [wavelengths^2]
     float inten_scale;     // 1e-4 / (2 rho c)
     float flat_ez;         // common element z (FLAT only), relative to table origin [wavelengths]
+    float flat_kz, flat_fz; // ... as (plane index nearest it, offset from that plane [wavelengths]): kernel 2a's split coordinates
     float absorb_l2;       // uniform absorption (kernel 2a-d): log2(e) Np per wavelength; 0 = lossless
     long long vox;         // voxels per focus volume (nx*ny*nz)
     unsigned flags;        // OLX_OUT_*
@@ -31,6 +33,7 @@ struct SharedParams {
     int x_begin, n_foci;
     float hx, hy, hz;                     // [wavelengths]
     float dmin2, inten_scale, flat_ez;
+    float flat_kz, flat_fz;               // the common element z as (plane index, offset): FieldParams
     long long vox;
     unsigned flags;
 };
@@ -44,6 +47,7 @@ struct MfmaParams {
     int x_begin, n_tiles;
     float hx, hy, hz;              // [wavelengths]
     float dmin2, flat_ez, g_scale; // g_scale = S_G
+    float flat_kz, flat_fz;        // the common element z as (plane index, offset [wavelengths]): kernel 2c's split coordinates (FieldParams)
     float out_scale;               // 1 / (S_G S_W)
     float inten_scale;
     long long vox;

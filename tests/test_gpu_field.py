@@ -957,6 +957,42 @@ def test_pair_tables_with_an_odd_number_of_super_block_rows(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["general", "shared", "mfma"])
+@pytest.mark.parametrize("array", ["grid_aligned", "jittered", "tilted"])
+def test_general_kernels_next_to_the_elements_on_a_wide_grid(ctx, monkeypatch, family, array):
+    """Kernels 2a / 2b / 2c on a 72 mm wide 0.5 mm grid THROUGH the element plane (the reference's default SimSetup starts at z = -4 mm): voxels a
+    clamp distance (0.067 wavelengths) from an element, at lateral coordinates of ~ 10 wavelengths.  From absolute fp32 coordinates the difference
+    x_v - x_e loses 1e-6 wavelengths -- 1.07e-5 of the volume maximum in kernel 2a, 9.8e-6 in 2b on the grid-aligned array (round 6,
+    tools/probe/kernel2a_near_plane.py, found by the wide-array fuzz below); the kernels now take their coordinates as (index, residual) wherever a
+    voxel comes within a quarter wavelength of an element.  Full volume against the fp64 oracle; the gate is 1e-5, the kernels sit at ~ 2e-6."""
+    nax, nay, h = 36, 13, 0.5
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * 2.0, (b.ravel() - (nay - 1) / 2) * 1.5, np.zeros(nax * nay)], axis=1)
+    ori = np.zeros_like(pos)
+    if array == "jittered":        # no lattice, no mirror symmetry
+        pos[:, :2] += np.random.default_rng(5).uniform(-0.12, 0.12, (nax * nay, 2))
+    elif array == "tilted":        # elements on a cylinder about y (roc 60 mm), symmetric about both centre planes: z_e and the normals vary
+        pos[:, 2] = 60.0 - np.sqrt(60.0 ** 2 - pos[:, 0] ** 2)
+        ori[:, 1] = -np.arcsin(pos[:, 0] / 60.0)
+    size = np.tile([1.8, 1.35], (nax * nay, 1))
+    nx, ny, nz, z0 = 144, 57, 48, -2.0
+    foci = np.array([[0.0, 0.0, 15e-3]])
+    if array == "jittered" and family == "shared":
+        pytest.skip("kernel 2b needs a mirror symmetry or several foci per tile")
+    pos_m, area, d, ap = setup_ctx(ctx, pos, ori, size, foci, apod=("maxangle", 70.0, 0.0))
+    xs = (np.arange(nx) - (nx - 1) / 2) * h * 1e-3; ys = (np.arange(ny) - (ny - 1) / 2) * h * 1e-3; zs = (z0 + np.arange(nz) * h) * 1e-3
+    monkeypatch.setenv("OLX_FIELD_VARIANT", family)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, (nx, ny, nz), F0, C, RHO, P0)
+    name = ctx.field_variant()
+    assert {"general": "field_accum_k", "shared": "field_shared_k", "mfma": "field_mfma_k"}[family] in name and "clamp" in name, name
+    ctx.field_launch()
+    got = ctx.field_fetch(0)["pmag"]
+    ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], ap[0], F0, C, P0, dmin=0.5 * h * 1e-3))
+    err = np.abs(got - ref).max() / ref.max()
+    assert err <= 5e-6, (name, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fp8", [None, False])
 def test_single_column_kernel_wide_arrays_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
     """Kernel 2f's three-row-tile shape (round 6: arrays wider than 17 elements, 24 positions per block on 48-word table rows, one block per CU walking
