@@ -916,6 +916,10 @@ def config_legs(ol, nat, od, eng, sf, timed, ramp, out_flags):
     run("default_extents_f8", "the reference's default SimSetup extents at 0.25 mm (241 x 241 x 257, z from -4 mm: the grid passes through the element plane), 16 x 16 array, "
         "the 8-focus shard", m16, gdef, shard, steps=100, check=(0, 3), covered_by="tests/test_gpu_field.py::test_e4m3_rule_near_the_array (full volumes)")
     run("default_extents_f1", "the same grid, single on-axis focus", m16, gdef, focus, steps=200, covered_by="tests/test_gpu_field.py::test_e4m3_rule_near_the_array (full volumes)")
+    # ... and the jittered (non-lattice) array on it: kernel 2a's clamp variant, coordinates as (index, residual) -- voxels of the element plane lie a clamp
+    # distance (0.033 wavelengths) from elements at lateral coordinates of ~ 8 wavelengths, where absolute fp32 coordinates lost up to 3e-5 of such a term
+    run("default_extents_jitter_f1", "the jittered 16 x 16 array on the reference's default SimSetup extents at 0.25 mm, single focus (kernel 2a, split coordinates)", jit, gdef, focus, steps=50,
+        covered_by="tests/test_gpu_field.py::test_general_kernels_next_to_the_elements_on_a_wide_grid (full volumes, 0.5 mm)")
     run("jitter_sweep64", "the same array, configs[2]'s whole 64-focus sweep on one GPU (64 steering columns in two launch tiles of 32: kernel 2c's NT = 4 shape)", jit, g256, sweep, steps=20, check=(0, 17, 63), covered_by="tests/test_gpu_field.py::test_many_foci_without_symmetry_uses_wide_mfma_tiles (full volumes, smaller grids)")
     skull = skull_slab_volumes(*g256[3])
     skull["model"] = "marched"

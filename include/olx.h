@@ -142,7 +142,9 @@ int olx_bf_quantize(olx_ctx *ctx, double bf_clk_hz, int width_bits, uint16_t *ti
  *   volume into caller-owned host arrays [nx*ny*nz] (cplx: 2 floats per voxel); any
  *   pointer may be NULL.
  * accuracy: fp32 results within 1e-5 of the volume's maximum |p| against the fp64 definition (north_star's gate; the
- *   per-pair and fp16-split kernels measure 0.8e-6 ... 1.9e-6).  Matrix arrays on a commensurate grid (the lattice
+ *   per-pair and fp16-split kernels measure 0.8e-6 ... 2.1e-6, also on grids through the element plane: wherever a voxel comes
+ *   within a quarter wavelength of an element they form voxel - element differences from exact index differences, not from
+ *   rounded absolute coordinates).  Matrix arrays on a commensurate grid (the lattice
  *   kernels 2e / 2g and the single-column kernel 2f) compute the two small correction products of their fp16 hi/lo
  *   operand split in fp8 (e4m3) BY DEFAULT -- ~20 % faster, error <= 7.5e-6 of the VOLUME MAXIMUM (measured 4.1e-6 ...
  *   6.2e-6 on full 256^3 volumes) -- but only where the planner can bound it (olx_plan.h, FP8_ERR_K / FP8_ERR_BOUND):
