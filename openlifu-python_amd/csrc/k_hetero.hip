@@ -69,12 +69,12 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
     const int k0 = (zb * 4 + wave) * ZPL;
     const bool live = i < P.nx && j < P.ny && k0 < P.nz;
     const int ic = min(i, P.nx - 1), jc = min(j, P.ny - 1);
-    const float x = (float)(ic + P.x_begin) * P.hx, y = (float)jc * P.hy;
+    const float xi = (float)(ic + P.x_begin), yj = (float)jc;      // voxel indices: differences to an element from exact index differences (table slots 5 .. 10)
     float z[ZPL], re[ZPL][NF], im[ZPL][NF], sv[ZPL], av[ZPL];
 #pragma unroll
     for (int q = 0; q < ZPL; ++q) {
         const int kq = min(k0 + q, P.nz - 1);
-        z[q] = (float)kq * P.hz;
+        z[q] = (float)kq;                                   // plane index
 #pragma unroll
         for (int f = 0; f < NF; ++f) { re[q][f] = 0.f; im[q][f] = 0.f; }
         const int pq = plane_of_k[kq];                   // the voxel's own half layer
@@ -89,14 +89,15 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
         const float* te = t + (size_t)e * STRIDE;
         const float ex = te[0], ey = te[1], ez = te[2];
         const int kfirst = __float_as_int(te[3]), klast = __float_as_int(te[4]);
-        const float dx = x - ex, dy = y - ey;
+        const float kez = te[7], fez = te[10];
+        const float dx = fmaf(xi - te[5], P.hx, -te[8]), dy = fmaf(yj - te[6], P.hy, -te[9]);
         const float r2 = fmaf(dy, dy, dx * dx);
         const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid index space
         const float dxu = dx * H.inv_hx, dyv = dy * H.inv_hy;
         float dz[ZPL], idz[ZPL], ss[ZPL], as[ZPL];
 #pragma unroll
         for (int q = 0; q < ZPL; ++q) {
-            dz[q] = z[q] - ez;
+            dz[q] = fmaf(z[q] - kez, P.hz, -fez);
             idz[q] = dz[q] != 0.f ? __builtin_amdgcn_rcpf(dz[q]) : 0.f;
             ss[q] = sv[q]; as[q] = av[q];
         }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
             for (int g = 0; g < H.n_layers; ++g) {
                 const int lo = layer_lo[g], hi = layer_hi[g];
                 if ((hi < kfirst || lo >= k0 + ZPL - 1) && (lo > klast || hi <= k0)) continue;   // no plane of it is between for any q
-                const float zg = 0.5f * (float)(lo + hi) * P.hz - ez;
+                const float zg = fmaf(0.5f * (float)(lo + hi) - kez, P.hz, -fez);
                 bool part = false;
 #pragma unroll
                 for (int q = 0; q < ZPL; ++q) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
                 }
                 if (!part) continue;
                 for (int k = lo; k <= hi; ++k) {          // the layer the voxels sit in (or an element plane cuts): plane by plane
-                    const float zk = (float)k * P.hz - ez;
+                    const float zk = fmaf((float)k - kez, P.hz, -fez);
                     const float4* plane = med + (size_t)plane_of_k[k] * plane_sz;
 #pragma unroll
                     for (int q = 0; q < ZPL; ++q) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
                 const int k = plane_k[p];                    // wave-uniform
                 const bool any_above = k >= kfirst && k < k0 + ZPL - 1, any_below = k <= klast && k > k0;
                 if (!any_above && !any_below) continue;
-                const float zk = (float)k * P.hz - ez;
+                const float zk = fmaf((float)k - kez, P.hz, -fez);
                 const float4* plane = med + (size_t)p * plane_sz;
 #pragma unroll
                 for (int q = 0; q < ZPL; ++q) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
 __global__ void steer_pack_hetero_k(const double* __restrict__ pos, const double* __restrict__ area, int n,
                                     const double* __restrict__ delays, const double* __restrict__ apod, double ox, double oy,
                                     double oz, double freq, double p0_over_lambda, double rev, const int* __restrict__ kfirst,
-                                    const int* __restrict__ klast, int n_foci, int nf, float* __restrict__ tab) {
+                                    const int* __restrict__ klast, int n_foci, int nf, double hx_m, double hy_m, double hz_m /* spacing [m] */, float* __restrict__ tab) {
     const int tile = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -196,7 +197,12 @@ __global__ void steer_pack_hetero_k(const double* __restrict__ pos, const double
     t[2] = (float)((pos[2 * n + e] - oz) * rev);
     t[3] = __int_as_float(kfirst[e]);
     t[4] = __int_as_float(klast[e]);
-    t[5] = 0.f; t[6] = 0.f; t[7] = 0.f;
+    {   // the element as (voxel index, offset from that voxel): voxel - element differences from exact index differences next to the elements (round 6: kernel 2h
+        // throughout, kernel 2m in the planes below the medium; as kernels 2a - 2c)
+        const double q[3] = {pos[e] - ox, pos[n + e] - oy, pos[2 * n + e] - oz}, h[3] = {hx_m, hy_m, hz_m};
+        for (int a = 0; a < 3; ++a) { const double k = rint(q[a] / h[a]); t[5 + a] = (float)k; t[8 + a] = (float)((q[a] - k * h[a]) * rev); }
+        t[11] = 0.f;
+    }
     for (int fl = 0; fl < nf; ++fl) {
         const int f = tile * nf + fl;
         float w = 0.f, ph = 0.f;
@@ -221,7 +227,7 @@ void olx_pack_hetero(olx_ctx* c) {
     dim3 g((c->n_el + 127) / 128, tiles);
     hipLaunchKernelGGL(steer_pack_hetero_k, g, dim3(128), 0, c->stream, c->d_pos, c->d_area, c->n_el, c->d_delays, c->d_apod,
                        c->grid.origin[0], c->grid.origin[1], c->grid.origin[2], c->freq, c->p0_pa / lambda, c->freq / c->c,
-                       c->d_kfirst, c->d_klast, c->plan_foci, c->nf, c->d_tab);
+                       c->d_kfirst, c->d_klast, c->plan_foci, c->nf, c->grid.spacing[0], c->grid.spacing[1], c->grid.spacing[2], c->d_tab);
 }
 
 template <int NF>

@@ -135,12 +135,16 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
             for (int q = lane; q < n_ch; q += 64) {          // ray table of this chunk: one element per lane
                 const float* te = t + (size_t)(es + ES * (c0 + q)) * STRIDE;
                 const float ex = te[0], ey = te[1], ez = te[2];
-                const float dz = z - ez;
+                // Planes WITHOUT source sums (!SRC: at or below the first non-trivial plane -- the only planes that come near the elements, which all lie
+                // below the medium): voxel - element differences from exact index differences, the element as (voxel index, offset) in table slots
+                // 5 .. 10 (round 6, as kernels 2a - 2c: absolute fp32 coordinates of ~ 10 wavelengths lose 1e-6 wavelengths, 1.5e-5 of a term at the clamp
+                // distance of a fine grid).  The crossing coefficients of the look-up (r0.y, r0.z) are not needed there: the slots carry the offsets.
+                const float dz = SRC ? z - ez : fmaf((float)kc - te[7], P.hz, -te[10]);
                 const float idz = dz != 0.f ? 1.0f / dz : 0.f;
                 const float tt = SRC ? (zsrc - ez) * idz : 0.f;
                 const float eu = fmaf(ex, H.inv_hx, H.u0), ev = fmaf(ey, H.inv_hy, H.v0);   // element in grid cells
-                s_ray[wave][q][0] = make_float4(tt, eu - tt * eu, ev - tt * ev, P.hz * fabsf(idz));
-                s_ray[wave][q][1] = make_float4(dz * dz, ex, ey, 0.f);
+                s_ray[wave][q][0] = SRC ? make_float4(tt, eu - tt * eu, ev - tt * ev, P.hz * fabsf(idz)) : make_float4(0.f, te[8], te[9], P.hz * fabsf(idz));
+                s_ray[wave][q][1] = SRC ? make_float4(dz * dz, ex, ey, 0.f) : make_float4(dz * dz, te[5], te[6], 0.f);
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     const bool two = 2 * r + 1 < NF;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(64 * hm_waves<ES>()) void field_hmarch_k(
                 for (int s = 0; s < E; ++s) {                // phase 2: interpolate, (write,) accumulate
                     const int e = es + ES * (c0 + q0 + s);
                     const float4 r0 = s_ray[wave][q0 + s][0], r1 = s_ray[wave][q0 + s][1];
-                    const float dx = x - r1.y, dy = y - r1.z;
+                    const float dx = SRC ? x - r1.y : fmaf(igf - r1.y, P.hx, -r0.y), dy = SRC ? y - r1.z : fmaf(jgf - r1.z, P.hy, -r0.z);
                     float2u_t sa = {0.f, 0.f};               // { sum sig, sum a' } at the crossing: (s, a) pairs in packed fp32
                     if constexpr (SRC) {
                         if constexpr (ONE) {

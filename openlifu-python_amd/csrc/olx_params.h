@@ -126,7 +126,8 @@ constexpr int cos_kxw(int nt) { return nt >= 4 ? 2 : (nt >= 2 ? 3 : 6); }
 constexpr bool cos_fp8(int nt) { return nt <= 2; }
 constexpr float COS_F8_LO = 32.0f, COS_F8_HI = 1.0f / 64.0f;
 
-constexpr int HET_TAB_HEAD = 8;            // floats of a kernel-2h table entry before its (w, phi) pairs
+constexpr int HET_TAB_HEAD = 12;           // floats of a kernel-2h / 2m table entry before its (w, phi) pairs: { x, y, z [wavelengths], kfirst, klast,
+                                           //   kx, ky, kz (voxel index nearest the element), fx, fy, fz (offset from that voxel [wavelengths]), 0 }
 
 struct HeteroParams {
     int n_planes;          // non-trivial planes

@@ -444,6 +444,36 @@ def test_heterogeneous_medium_layered_ray_model(ctx, model, monkeypatch):
     assert np.array_equal(ctx.field_fetch(0, want=("complex",))["complex"], p0)
 
 
+@pytest.mark.parametrize("model", ["sampled", "auto"])
+def test_heterogeneous_kernels_next_to_the_elements_on_a_wide_grid(ctx, model):
+    """The skull-slab phantom on a 72 mm wide 0.5 mm grid THROUGH the element plane (the reference's default SimSetup starts at z = -4 mm): the
+    voxels a clamp distance from an element lie in the water below the medium.  Kernels 2h and 2m formed voxel - element differences from absolute
+    fp32 coordinates there as kernels 2a - 2c did (test_general_kernels_next_to_the_elements_on_a_wide_grid); round 6: from exact index
+    differences -- kernel 2h throughout, kernel 2m in the planes without source sums (every element lies below the medium).  Full volume against
+    each kernel's own fp64 definition, asserted at half the gate."""
+    nax, nay, h = 24, 9, 0.5
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * 3.0, (b.ravel() - (nay - 1) / 2) * 3.0, np.zeros(nax * nay)], axis=1)
+    pos[:, :2] += np.random.default_rng(9).uniform(-0.2, 0.2, (nax * nay, 2))
+    size = np.tile([2.7, 2.7], (nax * nay, 1))
+    nx, ny, nz, z0 = 144, 57, 44, -2.0
+    foci = np.array([[0.0, 0.0, 16e-3]])
+    pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, apod=("maxangle", 70.0, 0.0))
+    xs = (np.arange(nx) - (nx - 1) / 2) * h * 1e-3; ys = (np.arange(ny) - (ny - 1) / 2) * h * 1e-3; zs = (z0 + np.arange(nz) * h) * 1e-3
+    cvol, avol, rvol = _skull_medium(xs, ys, zs)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, (nx, ny, nz), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY)
+    ctx.field_set_medium(cvol, avol, rvol, model=model)
+    name = ctx.field_variant()
+    assert ("field_hetero_k" if model == "sampled" else "field_hmarch_k") in name and "clamp" in name, name
+    ctx.field_launch()
+    sig, ab = co.medium_terms(cvol, avol, C, F0)
+    oracle = co.field_on_grid_hetero if model == "sampled" else co.field_hetero_march
+    ref = np.abs(oracle(xs, ys, zs, sig, ab, pos_m, area, d[0], ap[0], F0, C, P0, dmin=0.5 * h * 1e-3))
+    err = np.abs(ctx.field_fetch(0)["pmag"] - ref).max() / ref.max()
+    print(f"hetero next to the elements ({model}): {err:.2e}")
+    assert err <= 5e-6, (name, err)
+
+
 def test_heterogeneous_foci_share_ray_integrals_and_layers(ctx):
     """Kernel 2h evaluates the ray integrals of a (voxel, element) pair once for up to 8 foci of a launch tile (nf1/2/4/8
     shapes, last tile partly empty), optionally with the two-level layered quadrature (olx_field_medium_layering, G = 3 and
