@@ -1020,6 +1020,11 @@ def test_general_kernels_next_to_the_elements_on_a_wide_grid(ctx, monkeypatch, f
     ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[0], ap[0], F0, C, P0, dmin=0.5 * h * 1e-3))
     err = np.abs(got - ref).max() / ref.max()
     assert err <= 5e-6, (name, err)
+    # ... and in an x-slab (GLOBAL voxel indices in the index differences; the x fold is gone, the slab holds its own maximum next to other elements)
+    ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, (nx, ny, nz), F0, C, RHO, P0, slab=(41, 37))
+    ctx.field_launch()
+    gs = ctx.field_fetch(0)["pmag"]
+    assert gs.shape == (37, ny, nz) and np.abs(gs - ref[41:78]).max() / ref[41:78].max() <= 5e-6, ctx.field_variant()
 
 
 @pytest.mark.gpu
