@@ -1028,6 +1028,39 @@ def test_general_kernels_next_to_the_elements_on_a_wide_grid(ctx, monkeypatch, f
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one_off_axis", "four_foci", "ten_foci", "complex_output"])
+def test_lattice_kernels_next_to_the_elements_on_a_wide_grid(ctx, case):
+    """The multi-column lattice kernels (2e NT = 1 / 2g / 2e NT = 4, and 2d for complex output) on the grid of
+    test_general_kernels_next_to_the_elements_on_a_wide_grid: 36 x 13 elements at 2.0 x 1.5 mm on a 72 mm wide 0.5 mm grid through the element plane.
+    They always formed their tables from index differences; the planner's e4m3 rule must refuse the plane blocks next to the array (or the whole
+    launch).  Full volume against the fp64 oracle: three fp16 products <= 5e-6, e4m3 blocks within the bound include/olx.h states."""
+    nax, nay, h = 36, 13, 0.5
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * 2.0, (b.ravel() - (nay - 1) / 2) * 1.5, np.zeros(nax * nay)], axis=1)
+    size = np.tile([1.8, 1.35], (nax * nay, 1))
+    nx, ny, nz, z0 = 144, 57, 48, -2.0
+    foci = {"one_off_axis": [[2e-3, 1e-3, 15e-3]], "complex_output": [[2e-3, 1e-3, 15e-3]],
+            "four_foci": [[2e-3, 1e-3, 15e-3], [-3e-3, 0.5e-3, 14e-3], [1e-3, -2e-3, 16e-3], [0, 0, 15e-3]],
+            "ten_foci": bo.wheel_targets([0.5, 0.25, 15.0], True, 9, 3.0) * 1e-3}[case]
+    foci = np.asarray(foci)
+    pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, apod=("maxangle", 70.0, 0.0), solve=True)
+    xs = (np.arange(nx) - (nx - 1) / 2) * h * 1e-3; ys = (np.arange(ny) - (ny - 1) / 2) * h * 1e-3; zs = (z0 + np.arange(nz) * h) * 1e-3
+    cplx = case == "complex_output"
+    ctx.field_plan((xs[0], ys[0], zs[0]), (h * 1e-3,) * 3, (nx, ny, nz), F0, C, RHO, P0, flags=nat.OUT_PMAG | nat.OUT_INTENSITY | (nat.OUT_COMPLEX if cplx else 0))
+    name = ctx.field_variant()
+    assert {"one_off_axis": "field_coset_k<nt1", "four_foci": "field_cosetp_k<nt2", "ten_foci": "field_coset", "complex_output": "field_lattice_k"}[case] in name and "clamp" in name, name
+    ctx.field_launch()
+    tol = FP8_BOUND if "fp8corr" in name else 5e-6
+    for f in range(len(foci)):
+        ref = co.field_on_grid(xs, ys, zs, pos_m, area, d[f], ap[f], F0, C, P0, dmin=0.5 * h * 1e-3)
+        out = ctx.field_fetch(f, want=("pmag", "complex") if cplx else ("pmag",))
+        mx = np.abs(ref).max()
+        assert np.abs(out["pmag"] - np.abs(ref)).max() / mx <= tol, (name, f, np.abs(out["pmag"] - np.abs(ref)).max() / mx)
+        if cplx:
+            assert np.abs(out["complex"] - ref).max() / mx <= 3 * tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fp8", [None, False])
 def test_single_column_kernel_wide_arrays_fuzz_against_general_kernel(ctx, monkeypatch, fp8):
     """Kernel 2f's three-row-tile shape (round 6: arrays wider than 17 elements, 24 positions per block on 48-word table rows, one block per CU walking
