@@ -87,7 +87,7 @@ __global__ __launch_bounds__(FIELD_THREADS) void field_hetero_k(
     const float* t = tab + (size_t)ftile * P.n_el * STRIDE;
     for (int e = 0; e < P.n_el; ++e) {
         const float* te = t + (size_t)e * STRIDE;
-        const float ex = te[0], ey = te[1], ez = te[2];
+        const float ex = te[0], ey = te[1];
         const int kfirst = __float_as_int(te[3]), klast = __float_as_int(te[4]);
         const float kez = te[7], fez = te[10];
         const float dx = fmaf(xi - te[5], P.hx, -te[8]), dy = fmaf(yj - te[6], P.hy, -te[9]);

@@ -601,7 +601,6 @@ static void launch_toep(olx_ctx* c, float* pm) {
     ToepParams T;
     T.q = c->cp; T.nsa = c->toep_nsa; T.sa_w = c->toep_saw; T.ax = c->lat.ax; T.ks_mask = c->toep_ksmask; T.ay_pad = 8 * c->lat.nsb;
     for (int q = 0; q < 4; ++q) T.targets[q] = c->toep_targets[q];
-    const CosetParams& Q = T.q;
     const int nm = c->toep_nm;                          // row tiles per block (the planner's choice: olx.hip)
     T.n_rec = c->cp_nblocks;
     // (three row tiles: one block per CU walks the records; a multiple of 8 blocks so that a block's records stay on its XCD)
