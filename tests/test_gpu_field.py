@@ -963,6 +963,10 @@ def test_single_column_toeplitz_kernel(ctx, case, monkeypatch):
         _lattice_case(ctx, 28, 10, (1.5, 1.5), (120, 40, 470), (0.5, 0.5, 0.25), foci=[[0, 0, 30e-3]], expect=t3, solve=True)
         _lattice_case(ctx, 40, 8, (1.5, 1.5), (124, 36, 470), (0.5, 0.5, 0.25), foci=[[0, 0, 30e-3]], expect=t3, solve=True, fp8=False)
         _lattice_case(ctx, 32, 32, (1.5, 1.5), (130, 132, 250), (0.5, 0.5, 0.5), z0=-2e-3, foci=[[0, 0, 40e-3]], expect=t3, solve=True)
+        # ... and as a SPLIT launch (e4m3 corrections from plane 16 on, three fp16 products below: two walks over two record lists and operand sets)
+        for z0 in (-2e-3, 1e-3):
+            _lattice_case(ctx, 20, 20, (1.5, 1.5), (206, 206, 320), (0.25, 0.25, 0.25), z0=z0, foci=[[0, 0, 30e-3]], expect="fp8corr from plane 16", solve=True)
+            assert t3 in ctx.field_variant(), ctx.field_variant()
     elif case == "y_slab_fold_only":
         _lattice_case(ctx, 16, 16, (3.0, 3.0), (40, 36, 40), (1.0, 1.0, 0.5), foci=[[0, 0, 30e-3]], slab=(13, 14), expect="_k<mx1,my2")
     else:
