@@ -127,6 +127,30 @@ def test_calc_solution_on_the_untouched_default_simsetup(pattern):
         assert np.abs(sol.simulation_result["p_min"].data[i] - p).max() / p.max() <= 1e-5, (i, name)
 
 
+@pytest.mark.parametrize("pattern", ["single", "wheel"])
+def test_calc_solution_concave_array_on_the_default_extents(pattern):
+    """A two-module TransducerArray on an 80 mm cylinder (no lattice: kernels 2b / 2c) on the reference's default SimSetup EXTENTS at 0.5 mm: the grid
+    passes through the element plane, voxels of it lie a clamp distance from elements at lateral coordinates of ~ 8 wavelengths.  Round 6: these kernels
+    form voxel - element differences from index differences there; full-volume parity of every focus through the product API, asserted at half
+    of north_star's gate."""
+    half = ol.Transducer.gen_matrix_array(nx=8, ny=16, pitch=3.0, kerf=0.3, units="mm", sensitivity=1e5)
+    arr = ol.TransducerArray.get_concave_cylinder(half, rows=1, cols=2, width=24.0, gap=0.6, roc=80.0, units="mm").to_transducer()
+    setup = ol.SimSetup(spacing=0.5)
+    fp = ol.focal_patterns.SinglePoint(target_pressure=1.0e6) if pattern == "single" else \
+        ol.focal_patterns.Wheel(center=True, num_spokes=3, spoke_radius=4.0, target_pressure=1.0e6)
+    proto = ol.Protocol(pulse=ol.Pulse(frequency=400e3, duration=2e-5), sequence=ol.Sequence(pulse_count=8, pulse_train_interval=0),
+                        focal_pattern=fp, sim_setup=setup)
+    sol, agg, an = proto.calc_solution(ol.Point(position=(0, 0, 40), units="mm", id="t"), arr, simulate=True, scale=False)
+    name = ol.get_engine().ctx.field_variant()
+    assert ("field_shared_k" in name or "field_mfma_k" in name) and ("clamp" in name or "near" in name), name
+    xs, ys, zs = (np.asarray(c.data) * 1e-3 for c in setup.get_coords().values())
+    assert (len(xs), len(ys), len(zs)) == (121, 121, 129) and zs[0] == -4e-3
+    ref = _oracle_solution(arr, sol.foci, xs, ys, zs, 400e3, ("uniform", 1.0, 0.0), 1e5)
+    for i, (d, a, p) in enumerate(ref):
+        err = np.abs(sol.simulation_result["p_min"].data[i] - p).max() / p.max()
+        assert err <= 5e-6, (i, name, err)
+
+
 def test_calc_solution_without_simulation_and_scale_guard():
     arr = ol.Transducer.gen_matrix_array(nx=8, ny=8, pitch=4.0, kerf=0.4, units="mm")
     proto = ol.Protocol()
