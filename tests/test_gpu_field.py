@@ -1032,6 +1032,32 @@ def test_general_kernels_next_to_the_elements_on_a_wide_grid(ctx, monkeypatch, f
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["general", "mfma"])
+def test_general_kernels_next_to_the_elements_off_centre_anisotropic(ctx, monkeypatch, family):
+    """... and with a grid that is NOT centred on the array (no folds), three different spacings (0.5 / 0.4 / 0.3 mm) and an origin that is no multiple of
+    them away from any element: the (index, residual) coordinates are per axis and relative to the grid's own origin.  Two foci, full volume, <= 5e-6."""
+    nax, nay = 30, 10
+    a, b = np.meshgrid(np.arange(nax), np.arange(nay), indexing="ij")
+    pos = np.stack([(a.ravel() - (nax - 1) / 2) * 2.0, (b.ravel() - (nay - 1) / 2) * 1.6, np.zeros(nax * nay)], axis=1)
+    pos[:, :2] += np.random.default_rng(11).uniform(-0.15, 0.15, (nax * nay, 2))
+    size = np.tile([1.8, 1.4], (nax * nay, 1))
+    foci = np.array([[3e-3, -2e-3, 14e-3], [-6e-3, 1e-3, 18e-3]])
+    pos_m, area, d, ap = setup_ctx(ctx, pos, np.zeros_like(pos), size, foci, apod=("maxangle", 70.0, 0.0))
+    h = (0.5e-3, 0.4e-3, 0.3e-3)
+    nx, ny, nz = 150, 70, 60
+    xs = -41.37e-3 + np.arange(nx) * h[0]; ys = -9.21e-3 + np.arange(ny) * h[1]; zs = -1.93e-3 + np.arange(nz) * h[2]
+    monkeypatch.setenv("OLX_FIELD_VARIANT", family)
+    ctx.field_plan((xs[0], ys[0], zs[0]), h, (nx, ny, nz), F0, C, RHO, P0)
+    name = ctx.field_variant()
+    assert {"general": "field_accum_k", "mfma": "field_mfma_k"}[family] in name and "clamp" in name and "mx1,my1" in name + ("mx1,my1" if family == "general" else ""), name
+    ctx.field_launch()
+    for f in range(2):
+        ref = np.abs(co.field_on_grid(xs, ys, zs, pos_m, area, d[f], ap[f], F0, C, P0, dmin=0.5 * min(h)))
+        err = np.abs(ctx.field_fetch(f)["pmag"] - ref).max() / ref.max()
+        assert err <= 5e-6, (name, f, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["one_off_axis", "four_foci", "ten_foci", "complex_output"])
 def test_lattice_kernels_next_to_the_elements_on_a_wide_grid(ctx, case):
     """The multi-column lattice kernels (2e NT = 1 / 2g / 2e NT = 4, and 2d for complex output) on the grid of
